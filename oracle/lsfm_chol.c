@@ -1,0 +1,193 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Sparse SPD direct solve standing where the reference calls CHOLMOD (cholmod_analyze[_p] / cholmod_factorize /
+ * cholmod_solve(CHOLMOD_A), Imp.cpp:2380-2449, 7043-7121).  CHOLMOD itself (SuiteSparse; Windows tree pins
+ * 1.6.0 headers only, no source) is not available in this image, so this is NOT the reference's arithmetic:
+ * it is an up-looking sparse LL^T (the textbook algorithm: elimination tree, row pattern by tree reach,
+ * one sparse triangular solve per row) on the same upper-triangular CSC input with a fill-reducing block
+ * ordering.  The solution of an SPD system is unique, so only rounding differs.
+ */
+#include "lsfm_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void* xm(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
+
+/* pattern of row k of L: nodes reachable in the elimination tree from the entries of column k of C (upper) */
+static int ereach(const int* Cp, const int* Ci, int k, const int* parent, int* s, int* w, int n)
+{
+	int top = n, p, i, len;
+	w[k] = k;
+	for (p = Cp[k]; p < Cp[k + 1]; p++)
+	{
+		i = Ci[p];
+		if (i > k) continue;
+		for (len = 0; w[i] != k; i = parent[i]) { s[len++] = i; w[i] = k; }
+		while (len > 0) s[--top] = s[--len];
+	}
+	return top;
+}
+
+static long symbolic_lnz(int n, const int* Cp, const int* Ci, int* parent, int* colcount)
+{
+	int *anc = xm(n * sizeof(int)), *s = xm(n * sizeof(int)), *w = xm(n * sizeof(int));
+	int k, p, i, inext, top;
+	long lnz = 0;
+	for (k = 0; k < n; k++)
+	{
+		parent[k] = -1; anc[k] = -1;
+		for (p = Cp[k]; p < Cp[k + 1]; p++)
+		{
+			i = Ci[p];
+			while (i != -1 && i < k) { inext = anc[i]; anc[i] = k; if (inext == -1) parent[i] = k; i = inext; }
+		}
+	}
+	for (k = 0; k < n; k++) { w[k] = -1; colcount[k] = 1; }
+	for (k = 0; k < n; k++)
+	{
+		top = ereach(Cp, Ci, k, parent, s, w, n);
+		for (; top < n; top++) colcount[s[top]]++;
+	}
+	for (k = 0; k < n; k++) lnz += colcount[k];
+	free(anc); free(s); free(w);
+	return lnz;
+}
+
+/* C = P A P^T, upper part, CSC.  pinv[old] = new */
+static void symperm(int n, const int* Ap, const int* Ai, const double* Ax, const int* pinv, int** Cp_o, int** Ci_o, double** Cx_o)
+{
+	int *Cp = xm((n + 1) * sizeof(int)), *w = calloc(n + 1, sizeof(int)), *Ci;
+	double* Cx;
+	int j, p, i, i2, j2, q;
+	for (j = 0; j < n; j++)
+		for (p = Ap[j]; p < Ap[j + 1]; p++)
+		{
+			i = Ai[p];
+			if (i > j) continue;
+			i2 = pinv ? pinv[i] : i; j2 = pinv ? pinv[j] : j;
+			w[i2 > j2 ? i2 : j2]++;
+		}
+	Cp[0] = 0;
+	for (j = 0; j < n; j++) { Cp[j + 1] = Cp[j] + w[j]; w[j] = Cp[j]; }
+	Ci = xm((Cp[n] + 1) * sizeof(int));
+	Cx = Ax ? xm((Cp[n] + 1) * sizeof(double)) : NULL;
+	for (j = 0; j < n; j++)
+		for (p = Ap[j]; p < Ap[j + 1]; p++)
+		{
+			i = Ai[p];
+			if (i > j) continue;
+			i2 = pinv ? pinv[i] : i; j2 = pinv ? pinv[j] : j;
+			q = w[i2 > j2 ? i2 : j2]++;
+			Ci[q] = i2 < j2 ? i2 : j2;
+			if (Cx) Cx[q] = Ax[p];
+		}
+	free(w);
+	*Cp_o = Cp; *Ci_o = Ci; *Cx_o = Cx;
+}
+
+int orc_chol_solve(int n, const int* Ap, const int* Ai, const double* Ax, const int* perm, const double* b, double* x, long* lnz_out)
+{
+	int *pinv = NULL, *Cp, *Ci, *parent, *cc, *Lp, *Li, *c, *s, *w;
+	double *Cx, *Lx, *y, *xw;
+	int k, p, i, top, rc = 0;
+	long lnz;
+	if (n == 0) { if (lnz_out) *lnz_out = 0; return 0; }
+	if (perm)
+	{
+		pinv = xm(n * sizeof(int));
+		for (k = 0; k < n; k++) pinv[perm[k]] = k;
+	}
+	symperm(n, Ap, Ai, Ax, pinv, &Cp, &Ci, &Cx);
+	parent = xm(n * sizeof(int)); cc = xm(n * sizeof(int));
+	lnz = symbolic_lnz(n, Cp, Ci, parent, cc);
+	if (lnz_out) *lnz_out = lnz;
+	Lp = xm((n + 1) * sizeof(int)); c = xm(n * sizeof(int));
+	Lp[0] = 0;
+	for (k = 0; k < n; k++) { Lp[k + 1] = Lp[k] + cc[k]; c[k] = Lp[k]; }
+	Li = xm((size_t)lnz * sizeof(int)); Lx = xm((size_t)lnz * sizeof(double));
+	s = xm(n * sizeof(int)); w = xm(n * sizeof(int)); xw = xm(n * sizeof(double));
+	for (k = 0; k < n; k++) { w[k] = -1; xw[k] = 0; }
+	for (k = 0; k < n; k++)
+	{
+		double d, lki;
+		top = ereach(Cp, Ci, k, parent, s, w, n);
+		xw[k] = 0;
+		for (p = Cp[k]; p < Cp[k + 1]; p++)
+			if (Ci[p] <= k) xw[Ci[p]] += Cx[p];   /* += : duplicate entries are summed */
+		d = xw[k]; xw[k] = 0;
+		for (; top < n; top++)
+		{
+			i = s[top];
+			lki = xw[i] / Lx[Lp[i]];
+			xw[i] = 0;
+			for (p = Lp[i] + 1; p < c[i]; p++) xw[Li[p]] -= Lx[p] * lki;
+			d -= lki * lki;
+			p = c[i]++;
+			Li[p] = k; Lx[p] = lki;
+		}
+		if (!(d > 0)) { rc = k + 1; break; }
+		p = c[k]++;
+		Li[p] = k; Lx[p] = sqrt(d);
+	}
+	if (rc == 0)
+	{
+		y = xm(n * sizeof(double));
+		for (k = 0; k < n; k++) y[k] = b[perm ? perm[k] : k];
+		for (k = 0; k < n; k++) /* L y = b */
+		{
+			y[k] /= Lx[Lp[k]];
+			for (p = Lp[k] + 1; p < Lp[k + 1]; p++) y[Li[p]] -= Lx[p] * y[k];
+		}
+		for (k = n - 1; k >= 0; k--) /* L^T x = y */
+		{
+			for (p = Lp[k] + 1; p < Lp[k + 1]; p++) y[k] -= Lx[p] * y[Li[p]];
+			y[k] /= Lx[Lp[k]];
+		}
+		for (k = 0; k < n; k++) x[perm ? perm[k] : k] = y[k];
+		free(y);
+	}
+	else
+		for (k = 0; k < n; k++) x[k] = 0;
+	free(pinv); free(Cp); free(Ci); free(Cx); free(parent); free(cc); free(Lp); free(c); free(Li); free(Lx);
+	free(s); free(w); free(xw);
+	return rc;
+}
+
+/* Fill-reducing ordering of the block graph.  The Schur matrices of this path are "chain + hubs": every
+ * transform makes one pose adjacent to its whole sub-map.  Eliminating by ascending initial degree (ties in
+ * natural order) keeps the chain banded and pushes the hubs -- the separators of the join tree -- to the end.
+ * It is compared with the natural order by symbolic fill and the better one is returned. */
+typedef struct { int deg, idx; } degidx;
+static int cmp_degidx(const void* a, const void* b)
+{
+	const degidx* x = a; const degidx* y = b;
+	if (x->deg != y->deg) return x->deg < y->deg ? -1 : 1;
+	return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm)
+{
+	degidx* d = xm(nb * sizeof *d);
+	int *pinv = xm(nb * sizeof(int)), *Cp, *Ci, *parent = xm(nb * sizeof(int)), *cc = xm(nb * sizeof(int));
+	double* Cx;
+	int j, p;
+	long fill_nat, fill_deg;
+	for (j = 0; j < nb; j++) { d[j].deg = 0; d[j].idx = j; }
+	for (j = 0; j < nb; j++)
+		for (p = Ap[j]; p < Ap[j + 1]; p++)
+			if (Ai[p] != j) { d[j].deg++; d[Ai[p]].deg++; }
+	qsort(d, nb, sizeof *d, cmp_degidx);
+	for (j = 0; j < nb; j++) { perm[j] = d[j].idx; pinv[d[j].idx] = j; }
+	symperm(nb, Ap, Ai, NULL, NULL, &Cp, &Ci, &Cx);
+	fill_nat = symbolic_lnz(nb, Cp, Ci, parent, cc);
+	free(Cp); free(Ci);
+	symperm(nb, Ap, Ai, NULL, pinv, &Cp, &Ci, &Cx);
+	fill_deg = symbolic_lnz(nb, Cp, Ci, parent, cc);
+	free(Cp); free(Ci);
+	if (fill_nat <= fill_deg)
+		for (j = 0; j < nb; j++) perm[j] = j;
+	free(d); free(pinv); free(parent); free(cc);
+}

@@ -1,0 +1,1657 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see lsfm_oracle.h for scope and parity-pin status).
+ *
+ * CPU restatement of /root/reference/linux/src/LinearSFMImp/LinearSFMImp.cpp ("Imp.cpp").  The reference
+ * hand-unrolls every 6x6 / 6x3 / 3x3 product; here the same sums are written with small generic block
+ * helpers, in the same loop order and with the same output slot layout, so the arrays can be compared
+ * entry by entry with the real code (oracle/_ref/ref_dump).
+ */
+#include "lsfm_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define ORC_PI 3.1415926 /* Imp.h:57 -- the truncated literal is part of the reference's behaviour */
+
+static int g_match_hash = 0;
+void orc_set_match_hash(int on) { g_match_hash = on; }
+
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
+static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+void orc_map_free(orc_map* g)
+{
+	free(g->stno); free(g->stVal); free(g->U); free(g->Ui); free(g->Uj); free(g->W); free(g->photo);
+	free(g->feature); free(g->V); free(g->FBlock);
+	memset(g, 0, sizeof *g);
+}
+
+static void* dup_mem(const void* p, size_t n) { void* q = xmalloc(n); if (n) memcpy(q, p, n); return q; }
+
+void orc_map_copy(orc_map* d, const orc_map* s)
+{
+	*d = *s;
+	int r = 6 * s->m + 3 * s->n;
+	d->stno = dup_mem(s->stno, r * sizeof(int));
+	d->stVal = dup_mem(s->stVal, r * sizeof(double));
+	d->U = dup_mem(s->U, (size_t)s->nU * 36 * sizeof(double));
+	d->Ui = dup_mem(s->Ui, s->nU * sizeof(int));
+	d->Uj = dup_mem(s->Uj, s->nU * sizeof(int));
+	d->W = dup_mem(s->W, (size_t)s->nW * 18 * sizeof(double));
+	d->photo = dup_mem(s->photo, s->nW * sizeof(int));
+	d->feature = dup_mem(s->feature, s->nW * sizeof(int));
+	d->V = dup_mem(s->V, (size_t)s->n * 9 * sizeof(double));
+	d->FBlock = dup_mem(s->FBlock, s->n * sizeof(int));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * I/O   (Imp.cpp:3044-3132, 6660-6754)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_read_map(const char* path, int mono, orc_map* g)
+{
+	FILE* f = fopen(path, "r");
+	int i, ok = 1;
+	if (!f) return -1;
+	memset(g, 0, sizeof *g);
+	ok &= fscanf(f, "%d", &g->Ref) == 1;
+	g->FRef = g->Ref;
+	if (mono)
+	{
+		ok &= fscanf(f, "%d", &g->ScaP) == 1; g->FScaP = g->ScaP;
+		ok &= fscanf(f, "%d", &g->Fix) == 1;  g->FFix = g->Fix;
+		ok &= fscanf(f, "%d", &g->Sign) == 1;
+	}
+	ok &= fscanf(f, "%d", &g->r) == 1;
+	if (!ok || g->r < 0) { fclose(f); return -2; }
+	g->stno = xmalloc(g->r * sizeof(int));
+	g->stVal = xmalloc(g->r * sizeof(double));
+	for (i = 0; i < g->r; i++) ok &= fscanf(f, "%d %lf", &g->stno[i], &g->stVal[i]) == 2;
+	ok &= fscanf(f, "%d", &g->m) == 1;
+	ok &= fscanf(f, "%d", &g->n) == 1;
+	ok &= fscanf(f, "%d", &g->nU) == 1;
+	if (!ok) { fclose(f); return -2; }
+	g->U = xmalloc((size_t)g->nU * 36 * sizeof(double));
+	g->Ui = xmalloc(g->nU * sizeof(int));
+	g->Uj = xmalloc(g->nU * sizeof(int));
+	for (i = 0; i < 36 * g->nU; i++) ok &= fscanf(f, "%lf", &g->U[i]) == 1;
+	for (i = 0; i < g->nU; i++) ok &= fscanf(f, "%d", &g->Ui[i]) == 1;
+	for (i = 0; i < g->nU; i++) ok &= fscanf(f, "%d", &g->Uj[i]) == 1;
+	ok &= fscanf(f, "%d", &g->nW) == 1;
+	if (!ok) { fclose(f); return -2; }
+	g->W = xmalloc((size_t)g->nW * 18 * sizeof(double));
+	g->photo = xmalloc(g->nW * sizeof(int));
+	g->feature = xmalloc(g->nW * sizeof(int));
+	for (i = 0; i < 18 * g->nW; i++) ok &= fscanf(f, "%lf", &g->W[i]) == 1;
+	for (i = 0; i < g->nW; i++) ok &= fscanf(f, "%d", &g->photo[i]) == 1;
+	for (i = 0; i < g->nW; i++) ok &= fscanf(f, "%d", &g->feature[i]) == 1;
+	g->V = xmalloc((size_t)g->n * 9 * sizeof(double));
+	for (i = 0; i < 9 * g->n; i++) ok &= fscanf(f, "%lf", &g->V[i]) == 1;
+	g->FBlock = xmalloc(g->n * sizeof(int));
+	for (i = 0; i < g->n; i++) ok &= fscanf(f, "%d", &g->FBlock[i]) == 1;
+	fclose(f);
+	return ok ? 0 : -2;
+}
+
+int orc_write_map(const char* path, int mono, const orc_map* g)
+{
+	FILE* f = fopen(path, "w");
+	int i, r = 6 * g->m + 3 * g->n;
+	if (!f) return -1;
+	fprintf(f, "%d\n", g->Ref);
+	if (mono) fprintf(f, "%d\n%d\n%d\n", g->ScaP, g->Fix, g->Sign);
+	fprintf(f, "%d\n", r);
+	for (i = 0; i < r; i++) fprintf(f, "%d %.17g\n", g->stno[i], g->stVal[i]);
+	fprintf(f, "%d\n%d\n%d\n", g->m, g->n, g->nU);
+	for (i = 0; i < 36 * g->nU; i++) fprintf(f, "%.17g%c", g->U[i], (i % 36 == 35) ? '\n' : ' ');
+	for (i = 0; i < g->nU; i++) fprintf(f, "%d ", g->Ui[i]);
+	fprintf(f, "\n");
+	for (i = 0; i < g->nU; i++) fprintf(f, "%d ", g->Uj[i]);
+	fprintf(f, "\n%d\n", g->nW);
+	for (i = 0; i < 18 * g->nW; i++) fprintf(f, "%.17g%c", g->W[i], (i % 18 == 17) ? '\n' : ' ');
+	for (i = 0; i < g->nW; i++) fprintf(f, "%d ", g->photo[i]);
+	fprintf(f, "\n");
+	for (i = 0; i < g->nW; i++) fprintf(f, "%d ", g->feature[i]);
+	fprintf(f, "\n");
+	for (i = 0; i < 9 * g->n; i++) fprintf(f, "%.17g%c", g->V[i], (i % 9 == 8) ? '\n' : ' ');
+	for (i = 0; i < g->n; i++) fprintf(f, "%d ", g->FBlock[i]);
+	fprintf(f, "\n");
+	fclose(f);
+	return 0;
+}
+
+/* Imp.cpp:2102-2117 */
+int orc_save_state(const char* path, const double* st, const int* stno, int n)
+{
+	FILE* fp = fopen(path, "w");
+	int i;
+	if (!fp) { printf("Please Input Path to Save Final State Vector!"); return -1; }
+	for (i = 0; i < n; i++) fprintf(fp, "%d %lf\n", stno[i], st[i]);
+	fclose(fp);
+	return 0;
+}
+
+typedef struct { int id, idx; } id_idx;
+static int cmp_id_idx(const void* a, const void* b)
+{
+	const id_idx* x = a; const id_idx* y = b;
+	if (x->id != y->id) return x->id < y->id ? -1 : 1;
+	return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+/* Imp.cpp:7876-7967: poses / features sorted by id (std::set order); a repeated id keeps the LAST occurrence
+ * (std::map overwrite at 7907/7925). */
+int orc_save_poses(const char* pose_path, const char* feat_path, const int* stno, const double* st, int n)
+{
+	int i, np = 0, nf = 0;
+	id_idx *P, *F;
+	FILE *fp = NULL, *ff = NULL;
+	if (!pose_path && !feat_path) return 0;
+	P = xmalloc(n * sizeof *P); F = xmalloc(n * sizeof *F);
+	for (i = 0; i < n; i++)
+	{
+		if (stno[i] <= 0) { P[np].id = -stno[i]; P[np].idx = i; np++; i += 5; }
+		else { F[nf].id = stno[i]; F[nf].idx = i; nf++; i += 2; }
+	}
+	qsort(P, np, sizeof *P, cmp_id_idx);
+	qsort(F, nf, sizeof *F, cmp_id_idx);
+	if (pose_path) fp = fopen(pose_path, "w");
+	if (feat_path) ff = fopen(feat_path, "w");
+	if (fp)
+	{
+		for (i = 0; i < np; i++)
+		{
+			const double* p;
+			if (i + 1 < np && P[i + 1].id == P[i].id) continue;
+			p = st + P[i].idx;
+			fprintf(fp, "%d  %lf  %lf  %lf %lf  %lf  %lf\n", P[i].id, p[0], p[1], p[2], p[3], p[4], p[5]);
+		}
+		fclose(fp);
+	}
+	if (ff)
+	{
+		for (i = 0; i < nf; i++)
+		{
+			const double* p;
+			if (i + 1 < nf && F[i + 1].id == F[i].id) continue;
+			p = st + F[i].idx;
+			fprintf(ff, "%d  %lf  %lf %lf\n", F[i].id, p[0], p[1], p[2]);
+		}
+		fclose(ff);
+	}
+	free(P); free(F);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * rotation helpers   (Imp.cpp:132-347)
+ * ---------------------------------------------------------------------------------------------- */
+static void mul33(const double* A, const double* B, double* C) /* C = A*B */
+{
+	int i, j;
+	for (i = 0; i < 3; i++)
+		for (j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+/* Imp.cpp:132-143 */
+static void rmat_ypr(double* R, double Alpha, double Beta, double Gamma)
+{
+	R[0] = cos(Beta) * cos(Alpha);
+	R[1] = cos(Beta) * sin(Alpha);
+	R[2] = -sin(Beta);
+	R[3] = sin(Gamma) * sin(Beta) * cos(Alpha) - cos(Gamma) * sin(Alpha);
+	R[4] = sin(Gamma) * sin(Beta) * sin(Alpha) + cos(Gamma) * cos(Alpha);
+	R[5] = sin(Gamma) * cos(Beta);
+	R[6] = cos(Gamma) * sin(Beta) * cos(Alpha) + sin(Gamma) * sin(Alpha);
+	R[7] = cos(Gamma) * sin(Beta) * sin(Alpha) - sin(Gamma) * cos(Alpha);
+	R[8] = cos(Gamma) * cos(Beta);
+}
+
+/* Imp.cpp:145-160 (angles of R^T) */
+static void inv_rmat_ypr_T(const double* R, double* alpha, double* beta, double* gamma)
+{
+	*beta = atan2(-R[6], sqrt(R[0] * R[0] + R[3] * R[3]));
+	if (cos(*beta) == 0) { *alpha = 0; *beta = ORC_PI / 2; *gamma = atan2(R[3], R[4]); }
+	else { *alpha = atan2(R[3] / cos(*beta), R[0] / cos(*beta)); *gamma = atan2(R[7] / cos(*beta), R[8] / cos(*beta)); }
+}
+
+/* Imp.cpp:162-177 */
+static void inv_rmat_ypr(const double* R, double* alpha, double* beta, double* gamma)
+{
+	*beta = atan2(-R[2], sqrt(R[0] * R[0] + R[1] * R[1]));
+	if (cos(*beta) == 0) { *alpha = 0; *beta = ORC_PI / 2; *gamma = atan2(R[1], R[4]); }
+	else { *alpha = atan2(R[1] / cos(*beta), R[0] / cos(*beta)); *gamma = atan2(R[5] / cos(*beta), R[8] / cos(*beta)); }
+}
+
+/* Imp.cpp:179-280: R and dR/dAlpha, dR/dBeta, dR/dGamma as products of the elementary factors */
+static void r_derivation(double Alpha, double Beta, double Gamma, double* matR, double* dRA, double* dRB, double* dRG)
+{
+	double RG[9] = { 1, 0, 0, 0, cos(Gamma), sin(Gamma), 0, -sin(Gamma), cos(Gamma) };
+	double RB[9] = { cos(Beta), 0, -sin(Beta), 0, 1, 0, sin(Beta), 0, cos(Beta) };
+	double RA[9] = { cos(Alpha), sin(Alpha), 0, -sin(Alpha), cos(Alpha), 0, 0, 0, 1 };
+	double DG[9] = { 0, 0, 0, 0, -sin(Gamma), cos(Gamma), 0, -cos(Gamma), -sin(Gamma) };
+	double DB[9] = { -sin(Beta), 0, -cos(Beta), 0, 0, 0, cos(Beta), 0, -sin(Beta) };
+	double DA[9] = { -sin(Alpha), cos(Alpha), 0, -cos(Alpha), -sin(Alpha), 0, 0, 0, 0 };
+	double tmp[9];
+	rmat_ypr(matR, Alpha, Beta, Gamma);
+	mul33(DG, RB, tmp); mul33(tmp, RA, dRG);
+	mul33(RG, DB, tmp); mul33(tmp, RA, dRB);
+	mul33(RG, RB, tmp); mul33(tmp, DA, dRA);
+}
+
+/* Imp.cpp:282-307: derivative of the YPR angles of Ri along dRi */
+static void d_ri(double* dRid, const double* dRi, const double* Ri)
+{
+	double F1, F2, F3, F4, F5, dAdF1, dBdF2, dGdF3, dF1d, dF2d, dF3d, dF4d, dF5d, dF4dF5;
+	F1 = Ri[1] / Ri[0];
+	F3 = Ri[5] / Ri[8];
+	F5 = Ri[0] * Ri[0] + Ri[1] * Ri[1];
+	F4 = sqrt(F5);
+	F2 = -Ri[2] / F4;
+	dAdF1 = 1.0 / (1 + F1 * F1);
+	dBdF2 = 1.0 / (1 + F2 * F2);
+	dGdF3 = 1.0 / (1 + F3 * F3);
+	dF1d = (dRi[1] * Ri[0] - Ri[1] * dRi[0]) / (Ri[0] * Ri[0]);
+	dF3d = (dRi[5] * Ri[8] - Ri[5] * dRi[8]) / (Ri[8] * Ri[8]);
+	dF4dF5 = 1.0 / (2 * sqrt(F5));
+	dF5d = 2 * Ri[0] * dRi[0] + 2 * Ri[1] * dRi[1];
+	dF4d = dF4dF5 * dF5d;
+	dF2d = (-dRi[2] * F4 + Ri[2] * dF4d) / F5;
+	dRid[0] = dAdF1 * dF1d;
+	dRid[1] = dBdF2 * dF2d;
+	dRid[2] = dGdF3 * dF3d;
+}
+
+/* Imp.cpp:309-334: same for the transposed matrix */
+static void d_ri_tt(double* dRid, const double* dRi, const double* Ri)
+{
+	double F1, F2, F3, F4, F5, dAdF1, dBdF2, dGdF3, dF1d, dF2d, dF3d, dF4d, dF5d, dF4dF5;
+	F1 = Ri[3] / Ri[0];
+	F3 = Ri[7] / Ri[8];
+	F5 = Ri[0] * Ri[0] + Ri[3] * Ri[3];
+	F4 = sqrt(F5);
+	F2 = -Ri[6] / F4;
+	dAdF1 = 1.0 / (1 + F1 * F1);
+	dBdF2 = 1.0 / (1 + F2 * F2);
+	dGdF3 = 1.0 / (1 + F3 * F3);
+	dF1d = (dRi[3] * Ri[0] - Ri[3] * dRi[0]) / (Ri[0] * Ri[0]);
+	dF3d = (dRi[7] * Ri[8] - Ri[7] * dRi[8]) / (Ri[8] * Ri[8]);
+	dF4dF5 = 1.0 / (2 * sqrt(F5));
+	dF5d = 2 * Ri[0] * dRi[0] + 2 * Ri[3] * dRi[3];
+	dF4d = dF4dF5 * dF5d;
+	dF2d = (-dRi[6] * F4 + Ri[6] * dF4d) / F5;
+	dRid[0] = dAdF1 * dF1d;
+	dRid[1] = dBdF2 * dF2d;
+	dRid[2] = dGdF3 * dF3d;
+}
+
+/* Imp.cpp:336-347: R3 = R1 * R2^T */
+static void times_rrt(double* R3, const double* R1, const double* R2)
+{
+	int i, j;
+	for (i = 0; i < 3; i++)
+		for (j = 0; j < 3; j++) R3[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];
+}
+
+static void mv3(const double* R, const double* v, double* o) /* o = R v */
+{
+	o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+	o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+	o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * small block helpers for I' = J^T I J
+ * ---------------------------------------------------------------------------------------------- */
+/* T[ca x cb] = JA^T * B * JB with JA [ra x ca], B [ra x rb], JB [rb x cb], all row-major.
+ * (the reference's "tmp = JA^T*B" then "ttmp = tmp*JB", e.g. Imp.cpp:735-817) */
+static void jt_b_j(const double* JA, int ra, int ca, const double* B, int rb, const double* JB, int cb, double* T)
+{
+	double tmp[36];
+	int i, j, k;
+	for (i = 0; i < ca; i++)
+		for (j = 0; j < rb; j++)
+		{
+			double s = 0;
+			for (k = 0; k < ra; k++) s += JA[k * ca + i] * B[k * rb + j];
+			tmp[i * rb + j] = s;
+		}
+	for (i = 0; i < ca; i++)
+		for (j = 0; j < cb; j++)
+		{
+			double s = 0;
+			for (k = 0; k < rb; k++) s += tmp[i * rb + k] * JB[k * cb + j];
+			T[i * cb + j] = s;
+		}
+}
+
+/* dst[rows x cols] += T   or, transposed, dst[cols x rows] += T^T */
+static void add_blk(double* dst, const double* T, int rows, int cols, int transpose)
+{
+	int r, c;
+	if (!transpose)
+		for (r = 0; r < rows * cols; r++) dst[r] += T[r];
+	else
+		for (r = 0; r < rows; r++)
+			for (c = 0; c < cols; c++) dst[c * rows + r] += T[r * cols + c];
+}
+
+/* A 6x6 contribution T to the new information block I'(r,c) (pose-pose).  The map stores one orientation of
+ * every off-diagonal block (row index <= col index) and diagonal blocks in full, so T lands in `slot` only
+ * when r<=c, and its mirror T^T (contribution to I'(c,r), present when the SOURCE block was off-diagonal)
+ * only when c<=r.  This is the rule behind every "if ( .. >= posID ) / if ( .. <= posID && Ui != Uj )" pair
+ * in the reference (Imp.cpp:819-901, 948-1033, 1079-1138, 1183-1265 and the Mono analogues 3863-4983). */
+static void place_pp(double* newU, int slot, const double* T, int r, int c, int src_offdiag)
+{
+	double* d = newU + (size_t)slot * 36;
+	if (r <= c) add_blk(d, T, 6, 6, 0);
+	if (src_offdiag && c <= r) add_blk(d, T, 6, 6, 1);
+}
+
+static int find_label(const int* stno, int N, int label)
+{
+	int i;
+	for (i = 0; i < N; i++)
+		if (stno[i] == label) return i;
+	return N;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lmj_Transform_PF3DStereo   (Imp.cpp:349-1924)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_transform_stereo(const orc_map* in, int Ref, orc_map* out)
+{
+	int pos, i, j, N, m = in->m, n = in->n, posID, n_newU, n_newW, a, b;
+	double t[3], Alpha, Beta, Gamma, R[9], R2[9], R3[9], dRA[9], dRB[9], dRG[9], dA[3], dB[3], dG[3];
+	const double* ptr1 = in->stVal;
+	double *ptr2, *J1, *J2, *newU, *newW, *newV;
+	const int* stno = in->stno;
+
+	if (in->Ref == Ref) { orc_map_copy(out, in); return; } /* Imp.cpp:352-355 (shallow alias there) */
+
+	N = 6 * m + 3 * n;
+	memset(out, 0, sizeof *out);
+	pos = find_label(stno, N, -Ref); /* Imp.cpp:389-390 */
+	if (pos >= N) { fprintf(stderr, "oracle: transform_stereo: pose %d not in map\n", Ref); exit(1); }
+	t[0] = ptr1[pos]; t[1] = ptr1[pos + 1]; t[2] = ptr1[pos + 2];
+	Alpha = ptr1[pos + 3]; Beta = ptr1[pos + 4]; Gamma = ptr1[pos + 5];
+	rmat_ypr(R, Alpha, Beta, Gamma);
+
+	out->r = in->r; out->m = m; out->n = n; out->Ref = Ref; out->FRef = in->FRef;
+	out->stno = xmalloc(N * sizeof(int));
+	out->stVal = xmalloc(N * sizeof(double));
+	out->FBlock = xmalloc(n * sizeof(int));
+	ptr2 = out->stVal;
+	memcpy(out->stno, stno, N * sizeof(int));
+	for (i = 0; i < 6; i++) out->stno[pos + i] = -in->Ref; /* Imp.cpp:416-417 */
+
+	/* new state, Imp.cpp:421-455 */
+	for (i = 0; i < N; i++)
+	{
+		double d[3] = { ptr1[i] - t[0], ptr1[i + 1] - t[1], ptr1[i + 2] - t[2] };
+		if (stno[i] <= 0)
+		{
+			if (i == pos)
+			{
+				ptr2[i] = -(R[0] * t[0] + R[1] * t[1] + R[2] * t[2]);
+				ptr2[i + 1] = -(R[3] * t[0] + R[4] * t[1] + R[5] * t[2]);
+				ptr2[i + 2] = -(R[6] * t[0] + R[7] * t[1] + R[8] * t[2]);
+				inv_rmat_ypr_T(R, &ptr2[i + 3], &ptr2[i + 4], &ptr2[i + 5]);
+			}
+			else
+			{
+				mv3(R, d, ptr2 + i);
+				rmat_ypr(R2, ptr1[i + 3], ptr1[i + 4], ptr1[i + 5]);
+				times_rrt(R3, R2, R);
+				inv_rmat_ypr(R3, &ptr2[i + 3], &ptr2[i + 4], &ptr2[i + 5]);
+			}
+			i += 5;
+		}
+		else { mv3(R, d, ptr2 + i); i += 2; }
+	}
+
+	/* Imp.cpp:459-471 */
+	t[0] = ptr2[pos]; t[1] = ptr2[pos + 1]; t[2] = ptr2[pos + 2];
+	Alpha = ptr2[pos + 3]; Beta = ptr2[pos + 4]; Gamma = ptr2[pos + 5];
+	r_derivation(Alpha, Beta, Gamma, R, dRA, dRB, dRG);
+	d_ri_tt(dA, dRA, R); d_ri_tt(dB, dRB, R); d_ri_tt(dG, dRG, R);
+
+	/* Jacobian of the OLD state w.r.t. the NEW state: J = blkdiag(J1) + J2 e_posID^T, Imp.cpp:475-683 */
+	J1 = xcalloc((size_t)m * 36 + (size_t)n * 9, sizeof(double));
+	J2 = xcalloc((size_t)m * 36 + (size_t)n * 18, sizeof(double));
+	for (i = 0; i < N; i++)
+	{
+		double tmp1[3], tmp2[3], tmp3[3];
+		int r;
+		if (out->stno[i] <= 0)
+		{
+			double* pJ1 = J1 + (size_t)(i / 6) * 36;
+			double* pJ2 = J2 + (size_t)(i / 6) * 36;
+			if (i == pos)
+			{
+				mv3(dRA, t, tmp1); mv3(dRB, t, tmp2); mv3(dRG, t, tmp3);
+				for (r = 0; r < 3; r++)
+				{
+					pJ1[6 * r + 0] += -R[3 * r]; pJ1[6 * r + 1] += -R[3 * r + 1]; pJ1[6 * r + 2] += -R[3 * r + 2];
+					pJ1[6 * r + 3] += -tmp1[r]; pJ1[6 * r + 4] += -tmp2[r]; pJ1[6 * r + 5] += -tmp3[r];
+					pJ1[6 * (3 + r) + 3] += dA[r]; pJ1[6 * (3 + r) + 4] += dB[r]; pJ1[6 * (3 + r) + 5] += dG[r];
+				}
+			}
+			else
+			{
+				double t2[3] = { ptr2[i], ptr2[i + 1], ptr2[i + 2] }, d[3], Ri[9], dRA2[9], dRB2[9], dRG2[9];
+				double dRidA2[9], dRidB2[9], dRidG2[9], dRidA[9], dRidB[9], dRidG[9];
+				double ddA2[3], ddB2[3], ddG2[3], ddA[3], ddB[3], ddG[3];
+				r_derivation(ptr2[i + 3], ptr2[i + 4], ptr2[i + 5], R2, dRA2, dRB2, dRG2);
+				times_rrt(Ri, R2, R);
+				times_rrt(dRidA2, dRA2, R); times_rrt(dRidB2, dRB2, R); times_rrt(dRidG2, dRG2, R);
+				times_rrt(dRidA, R2, dRA); times_rrt(dRidB, R2, dRB); times_rrt(dRidG, R2, dRG);
+				d_ri(ddA2, dRidA2, Ri); d_ri(ddB2, dRidB2, Ri); d_ri(ddG2, dRidG2, Ri);
+				d_ri(ddA, dRidA, Ri); d_ri(ddB, dRidB, Ri); d_ri(ddG, dRidG, Ri);
+				d[0] = t2[0] - t[0]; d[1] = t2[1] - t[1]; d[2] = t2[2] - t[2];
+				mv3(dRA, d, tmp1); mv3(dRB, d, tmp2); mv3(dRG, d, tmp3);
+				for (r = 0; r < 3; r++)
+				{
+					pJ2[6 * r + 0] += -R[3 * r]; pJ2[6 * r + 1] += -R[3 * r + 1]; pJ2[6 * r + 2] += -R[3 * r + 2];
+					pJ2[6 * r + 3] += tmp1[r]; pJ2[6 * r + 4] += tmp2[r]; pJ2[6 * r + 5] += tmp3[r];
+					pJ2[6 * (3 + r) + 3] += ddA[r]; pJ2[6 * (3 + r) + 4] += ddB[r]; pJ2[6 * (3 + r) + 5] += ddG[r];
+					pJ1[6 * r + 0] += R[3 * r]; pJ1[6 * r + 1] += R[3 * r + 1]; pJ1[6 * r + 2] += R[3 * r + 2];
+					pJ1[6 * (3 + r) + 3] += ddA2[r]; pJ1[6 * (3 + r) + 4] += ddB2[r]; pJ1[6 * (3 + r) + 5] += ddG2[r];
+				}
+			}
+			i += 5;
+		}
+		else
+		{
+			int Id = (i - m * 6) / 3;
+			double d[3] = { ptr2[i] - t[0], ptr2[i + 1] - t[1], ptr2[i + 2] - t[2] };
+			double* pJ2 = J2 + (size_t)m * 36 + (size_t)Id * 18;
+			double* pJ1 = J1 + (size_t)m * 36 + (size_t)Id * 9;
+			mv3(dRA, d, tmp1); mv3(dRB, d, tmp2); mv3(dRG, d, tmp3);
+			for (r = 0; r < 3; r++)
+			{
+				pJ2[6 * r + 0] += -R[3 * r]; pJ2[6 * r + 1] += -R[3 * r + 1]; pJ2[6 * r + 2] += -R[3 * r + 2];
+				pJ2[6 * r + 3] += tmp1[r]; pJ2[6 * r + 4] += tmp2[r]; pJ2[6 * r + 5] += tmp3[r];
+				pJ1[3 * r + 0] += R[3 * r]; pJ1[3 * r + 1] += R[3 * r + 1]; pJ1[3 * r + 2] += R[3 * r + 2];
+			}
+			i += 2;
+		}
+	}
+
+	/* new U, Imp.cpp:686-1268.  Slots 0..m-1 are the pairs (k,posID); other blocks are appended. */
+	posID = pos / 6;
+	newU = xcalloc((size_t)(in->nU + m) * 36, sizeof(double));
+	out->U = newU;
+	out->Ui = xmalloc((in->nU + m) * sizeof(int));
+	out->Uj = xmalloc((in->nU + m) * sizeof(int));
+	n_newU = m;
+	for (i = 0; i < m; i++)
+	{
+		if (i <= posID) { out->Ui[i] = i; out->Uj[i] = posID; }
+		else { out->Ui[i] = posID; out->Uj[i] = i; }
+	}
+	for (i = 0; i < in->nU; i++)
+	{
+		const double* Ub = in->U + (size_t)i * 36;
+		const double* Ja[2], *Jb[2];
+		double T[36];
+		int al, be, slot11, off;
+		a = in->Ui[i]; b = in->Uj[i]; off = (a != b);
+		Ja[0] = J1 + (size_t)a * 36; Ja[1] = J2 + (size_t)a * 36;
+		Jb[0] = J1 + (size_t)b * 36; Jb[1] = J2 + (size_t)b * 36;
+		if (a == posID) slot11 = b;                 /* Imp.cpp:1079-1094 */
+		else if (b == posID) slot11 = a;
+		else { slot11 = n_newU; out->Ui[n_newU] = a; out->Uj[n_newU] = b; n_newU++; }
+		for (al = 0; al < 2; al++)
+			for (be = 0; be < 2; be++)
+			{
+				int r = al ? posID : a, c = be ? posID : b, slot;
+				if (!al && !be) slot = slot11;       /* Line 3: J1^T U J1 */
+				else if (al && be) slot = posID;     /* Line 4: J2^T U J2 */
+				else if (al) slot = b;               /* Line 5: J2^T U J1 -> pair (posID,b) */
+				else slot = a;                       /* Line 6: J1^T U J2 -> pair (a,posID) */
+				jt_b_j(Ja[al], 6, 6, Ub, 6, Jb[be], 6, T);
+				place_pp(newU, slot, T, r, c, off);
+			}
+	}
+	out->nU = n_newU;
+
+	/* new W and V, Imp.cpp:1270-1917.  Every feature gets a first W block to posID. */
+	newW = xcalloc((size_t)(in->nW + n) * 18, sizeof(double));
+	newV = xcalloc((size_t)n * 9, sizeof(double));
+	out->W = newW; out->V = newV;
+	out->feature = xmalloc((in->nW + n) * sizeof(int));
+	out->photo = xmalloc((in->nW + n) * sizeof(int));
+	n_newW = 0; j = 0;
+	for (i = 0; i < n; i++)
+	{
+		double* ptrPID = newW + (size_t)n_newW * 18;
+		const double* Vb = in->V + (size_t)i * 9;
+		const double* J1f = J1 + (size_t)m * 36 + (size_t)i * 9;
+		const double* J2f = J2 + (size_t)m * 36 + (size_t)i * 18;
+		double T[36];
+		out->FBlock[i] = n_newW;
+		out->feature[n_newW] = i; out->photo[n_newW] = posID; n_newW++;
+		/* the feature's own V block (diagonal source): Line 4 -> (posID,posID), Line 5 -> W(posID,i), Line 3 -> V' */
+		jt_b_j(J2f, 3, 6, Vb, 3, J2f, 6, T); place_pp(newU, posID, T, posID, posID, 0);
+		jt_b_j(J2f, 3, 6, Vb, 3, J1f, 3, T); add_blk(ptrPID, T, 6, 3, 0);
+		jt_b_j(J1f, 3, 3, Vb, 3, J1f, 3, T); add_blk(newV + (size_t)i * 9, T, 3, 3, 0);
+		while (j < in->nW && in->feature[j] == i)
+		{
+			const double* Wb = in->W + (size_t)j * 18;
+			int k = in->photo[j];
+			const double* J1p = J1 + (size_t)k * 36;
+			const double* J2p = J2 + (size_t)k * 36;
+			double* dst;
+			/* Line 4: J2p^T W J2f -> (posID,posID), both orientations (source is off-diagonal) */
+			jt_b_j(J2p, 6, 6, Wb, 3, J2f, 6, T); place_pp(newU, posID, T, posID, posID, 1);
+			/* Line 5: J2p^T W J1f -> W'(posID,i) */
+			jt_b_j(J2p, 6, 6, Wb, 3, J1f, 3, T); add_blk(ptrPID, T, 6, 3, 0);
+			/* Line 3: J1p^T W J1f -> W'(k,i)   (Imp.cpp:1759-1769) */
+			if (k == posID) dst = ptrPID;
+			else { dst = newW + (size_t)n_newW * 18; out->feature[n_newW] = i; out->photo[n_newW] = k; n_newW++; }
+			jt_b_j(J1p, 6, 6, Wb, 3, J1f, 3, T); add_blk(dst, T, 6, 3, 0);
+			/* Line 6: J1p^T W J2f -> pair (k,posID) */
+			jt_b_j(J1p, 6, 6, Wb, 3, J2f, 6, T); place_pp(newU, k, T, k, posID, 1);
+			j++;
+		}
+	}
+	out->nW = n_newW;
+	free(J1); free(J2);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lmj_Transform_PF3DMono   (Imp.cpp:3173-6509)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_transform_mono(const orc_map* in, int Ref, int ScaP, int Fix, orc_map* out)
+{
+	int pos1, pos2, pos3, pos4, i, j, N, m = in->m, n = in->n, mFix, posID, posID2, posID3, posID4, n_newU, n_newW, r;
+	double t[3], t2[3], ts[3], d[3], Scale, Scale2, Sign, Alpha, Beta, Gamma, R[9], R2[9], R3[9], dRA[9], dRB[9], dRG[9];
+	double dA[3], dB[3], dG[3], dSdt[9], dSdA[3], dSdB[3], dSdG[3], dSdtt[9];
+	const double* ptr1 = in->stVal;
+	double *ptr2, *J1, *J2, *J3, *newU, *newW, *newV;
+	const int* stno = in->stno;
+	size_t size1, size2;
+
+	if (in->Ref == Ref && in->ScaP == ScaP) { orc_map_copy(out, in); return; } /* Imp.cpp:3176-3179 */
+
+	N = 6 * m + 3 * n;
+	memset(out, 0, sizeof *out);
+	pos1 = find_label(stno, N, -Ref);
+	pos2 = find_label(stno, N, -ScaP);
+	if (pos1 >= N || pos2 >= N) { fprintf(stderr, "oracle: transform_mono: pose %d/%d not in map\n", Ref, ScaP); exit(1); }
+	t[0] = ptr1[pos1]; t[1] = ptr1[pos1 + 1]; t[2] = ptr1[pos1 + 2];
+	rmat_ypr(R, ptr1[pos1 + 3], ptr1[pos1 + 4], ptr1[pos1 + 5]);
+	d[0] = ptr1[pos2] - t[0]; d[1] = ptr1[pos2 + 1] - t[1]; d[2] = ptr1[pos2 + 2] - t[2];
+	mv3(R, d, ts);
+	Scale = fabs(ts[Fix]);                      /* Imp.cpp:3239 */
+	out->Sign = (ts[Fix] >= 0) ? 1 : -1;
+
+	out->r = in->r; out->m = m; out->n = n; out->Ref = Ref; out->ScaP = ScaP; out->Fix = Fix;
+	out->FRef = in->FRef; out->FScaP = in->FScaP; out->FFix = in->FFix;
+	out->stno = xmalloc(N * sizeof(int));
+	out->stVal = xmalloc(N * sizeof(double));
+	out->FBlock = xmalloc(n * sizeof(int));
+	ptr2 = out->stVal;
+	memcpy(out->stno, stno, N * sizeof(int));
+
+	/* new state, Imp.cpp:3268-3306 */
+	for (i = 0; i < N; i++)
+	{
+		double dd[3] = { ptr1[i] - t[0], ptr1[i + 1] - t[1], ptr1[i + 2] - t[2] }, o[3];
+		mv3(R, dd, o);
+		ptr2[i] = o[0] / Scale; ptr2[i + 1] = o[1] / Scale; ptr2[i + 2] = o[2] / Scale;
+		if (stno[i] <= 0)
+		{
+			rmat_ypr(R2, ptr1[i + 3], ptr1[i + 4], ptr1[i + 5]);
+			times_rrt(R3, R2, R);
+			inv_rmat_ypr(R3, &ptr2[i + 3], &ptr2[i + 4], &ptr2[i + 5]);
+			if (i == pos1) for (r = 0; r < 6; r++) ptr2[i + r] = 0;
+			if (i == pos2) ptr2[i + Fix] = out->Sign;
+			i += 5;
+		}
+		else i += 2;
+	}
+
+	/* Imp.cpp:3311-3365: the OLD reference / scale pose as seen in the new state */
+	pos3 = find_label(out->stno, N, -in->Ref);
+	pos4 = find_label(out->stno, N, -in->ScaP);
+	t[0] = ptr2[pos3]; t[1] = ptr2[pos3 + 1]; t[2] = ptr2[pos3 + 2];
+	Alpha = ptr2[pos3 + 3]; Beta = ptr2[pos3 + 4]; Gamma = ptr2[pos3 + 5];
+	r_derivation(Alpha, Beta, Gamma, R, dRA, dRB, dRG);
+	d_ri_tt(dA, dRA, R); d_ri_tt(dB, dRB, R); d_ri_tt(dG, dRG, R);
+	t2[0] = ptr2[pos4]; t2[1] = ptr2[pos4 + 1]; t2[2] = ptr2[pos4 + 2];
+	d[0] = t2[0] - t[0]; d[1] = t2[1] - t[1]; d[2] = t2[2] - t[2];
+	mv3(R, d, ts);
+	mFix = in->Fix;
+	Scale = fabs(ts[mFix]);
+	Scale2 = Scale * Scale;
+	Sign = (ts[mFix] >= 0) ? 1 : -1;
+	for (r = 0; r < 9; r++) { dSdt[r] = -R[r] * Sign; dSdtt[r] = R[r] * Sign; }
+	mv3(dRA, d, dSdA); mv3(dRB, d, dSdB); mv3(dRG, d, dSdG);
+	for (r = 0; r < 3; r++) { dSdA[r] *= Sign; dSdB[r] *= Sign; dSdG[r] *= Sign; }
+
+	/* J = blkdiag(J1) + J2 e_posID^T + J3 e_posID2^T, Imp.cpp:3371-3688 */
+	size1 = (size_t)m * 36 + (size_t)n * 9;
+	size2 = (size_t)m * 36 + (size_t)n * 18;
+	J1 = xcalloc(size1, sizeof(double));
+	J2 = xcalloc(size2, sizeof(double));
+	J3 = xcalloc(size2, sizeof(double));
+	for (i = 0; i < N; i++)
+	{
+		double t222[3], t22[3], tmp1[3], tmp2[3], tmp3[3], dt2dt22[9], dt2dt[9], dt2dtt[9], v[3];
+		int ispose = out->stno[i] <= 0, c;
+		t222[0] = ptr2[i] - t[0]; t222[1] = ptr2[i + 1] - t[1]; t222[2] = ptr2[i + 2] - t[2];
+		mv3(R, t222, t22);
+		mv3(dRA, t222, v); for (r = 0; r < 3; r++) tmp1[r] = (v[r] * Scale - t22[r] * dSdA[mFix]) / Scale2;
+		mv3(dRB, t222, v); for (r = 0; r < 3; r++) tmp2[r] = (v[r] * Scale - t22[r] * dSdB[mFix]) / Scale2;
+		mv3(dRG, t222, v); for (r = 0; r < 3; r++) tmp3[r] = (v[r] * Scale - t22[r] * dSdG[mFix]) / Scale2;
+		for (r = 0; r < 3; r++)
+			for (c = 0; c < 3; c++)
+			{
+				dt2dt22[3 * r + c] = R[3 * r + c] / Scale;
+				dt2dt[3 * r + c] = (-R[3 * r + c] * Scale - t22[r] * dSdt[3 * mFix + c]) / Scale2;
+				dt2dtt[3 * r + c] = (-t22[r] * dSdtt[3 * mFix + c]) / Scale2;
+			}
+		if (ispose)
+		{
+			double Ri[9], dRA2[9], dRB2[9], dRG2[9], dRidA2[9], dRidB2[9], dRidG2[9], dRidA[9], dRidB[9], dRidG[9];
+			double ddA2[3], ddB2[3], ddG2[3], ddA[3], ddB[3], ddG[3];
+			double* pJ1 = J1 + (size_t)(i / 6) * 36;
+			double* pJ2 = J2 + (size_t)(i / 6) * 36;
+			double* pJ3 = J3 + (size_t)(i / 6) * 36;
+			double* q;
+			r_derivation(ptr2[i + 3], ptr2[i + 4], ptr2[i + 5], R2, dRA2, dRB2, dRG2);
+			times_rrt(Ri, R2, R);
+			times_rrt(dRidA2, dRA2, R); times_rrt(dRidB2, dRB2, R); times_rrt(dRidG2, dRG2, R);
+			times_rrt(dRidA, R2, dRA); times_rrt(dRidB, R2, dRB); times_rrt(dRidG, R2, dRG);
+			d_ri(ddA2, dRidA2, Ri); d_ri(ddB2, dRidB2, Ri); d_ri(ddG2, dRidG2, Ri);
+			d_ri(ddA, dRidA, Ri); d_ri(ddB, dRidB, Ri); d_ri(ddG, dRidG, Ri);
+			for (r = 0; r < 3; r++)
+			{
+				for (c = 0; c < 3; c++) pJ1[6 * r + c] += dt2dt22[3 * r + c];
+				pJ1[6 * (3 + r) + 3] += ddA2[r]; pJ1[6 * (3 + r) + 4] += ddB2[r]; pJ1[6 * (3 + r) + 5] += ddG2[r];
+			}
+			q = (i == pos3) ? pJ1 : pJ2;            /* Imp.cpp:3495-3556 */
+			for (r = 0; r < 3; r++)
+			{
+				for (c = 0; c < 3; c++) q[6 * r + c] += dt2dt[3 * r + c];
+				q[6 * (3 + r) + 3] += ddA[r]; q[6 * (3 + r) + 4] += ddB[r]; q[6 * (3 + r) + 5] += ddG[r];
+				q[6 * r + 3] += tmp1[r]; q[6 * r + 4] += tmp2[r]; q[6 * r + 5] += tmp3[r];
+			}
+			q = (i == pos4) ? pJ1 : pJ3;            /* Imp.cpp:3558-3581 */
+			for (r = 0; r < 3; r++)
+				for (c = 0; c < 3; c++) q[6 * r + c] += dt2dtt[3 * r + c];
+			i += 5;
+		}
+		else
+		{
+			int Id = (i - m * 6) / 3;
+			double* pJ1 = J1 + (size_t)m * 36 + (size_t)Id * 9;
+			double* pJ2 = J2 + (size_t)m * 36 + (size_t)Id * 18;
+			double* pJ3 = J3 + (size_t)m * 36 + (size_t)Id * 18;
+			for (r = 0; r < 3; r++)
+			{
+				for (c = 0; c < 3; c++)
+				{
+					pJ1[3 * r + c] += dt2dt22[3 * r + c];
+					pJ2[6 * r + c] += dt2dt[3 * r + c];
+					pJ3[6 * r + c] += dt2dtt[3 * r + c];
+				}
+				pJ2[6 * r + 3] += tmp1[r]; pJ2[6 * r + 4] += tmp2[r]; pJ2[6 * r + 5] += tmp3[r];
+			}
+			i += 2;
+		}
+	}
+	/* gauge: Imp.cpp:3691-3710 */
+	posID3 = pos1 / 6; posID4 = pos2 / 6;
+	memset(J1 + (size_t)posID3 * 36, 0, 36 * sizeof(double));
+	for (i = 0; i < 6; i++) J1[(size_t)posID4 * 36 + 6 * i + Fix] = 0;
+	if (pos3 == pos2) for (i = 0; i < 6 * m + 3 * n; i++) J2[(size_t)6 * i + Fix] = 0;
+	if (pos4 == pos1) memset(J3, 0, size2 * sizeof(double));
+
+	/* new U: slots 0..m-1 pairs with posID, m..2m-1 pairs with posID2, Imp.cpp:3713-4986 */
+	posID = pos3 / 6; posID2 = pos4 / 6;
+	newU = xcalloc((size_t)(in->nU + 2 * m) * 36, sizeof(double));
+	out->U = newU;
+	out->Ui = xmalloc((in->nU + 2 * m) * sizeof(int));
+	out->Uj = xmalloc((in->nU + 2 * m) * sizeof(int));
+	n_newU = 2 * m;
+	for (i = 0; i < m; i++)
+	{
+		if (i <= posID) { out->Ui[i] = i; out->Uj[i] = posID; } else { out->Ui[i] = posID; out->Uj[i] = i; }
+		/* the reference compares against posID (not posID2) here too, Imp.cpp:3753-3765 */
+		if (i <= posID) { out->Ui[i + m] = i; out->Uj[i + m] = posID2; } else { out->Ui[i + m] = posID2; out->Uj[i + m] = i; }
+	}
+	for (i = 0; i < in->nU; i++)
+	{
+		const double* Ub = in->U + (size_t)i * 36;
+		const double *Ja[3], *Jb[3];
+		double T[36];
+		int a = in->Ui[i], b = in->Uj[i], off = (a != b), al, be, slot11;
+		Ja[0] = J1 + (size_t)a * 36; Ja[1] = J2 + (size_t)a * 36; Ja[2] = J3 + (size_t)a * 36;
+		Jb[0] = J1 + (size_t)b * 36; Jb[1] = J2 + (size_t)b * 36; Jb[2] = J3 + (size_t)b * 36;
+		if (a == posID) slot11 = b;                  /* Imp.cpp:4249-4271 */
+		else if (b == posID) slot11 = a;
+		else if (a == posID2) slot11 = m + b;
+		else if (b == posID2) slot11 = m + a;
+		else { slot11 = n_newU; out->Ui[n_newU] = a; out->Uj[n_newU] = b; n_newU++; }
+		for (al = 0; al < 3; al++)
+			for (be = 0; be < 3; be++)
+			{
+				int rr = al == 0 ? a : (al == 1 ? posID : posID2);
+				int cc = be == 0 ? b : (be == 1 ? posID : posID2);
+				int slot;
+				if (al == 0 && be == 0) slot = slot11;
+				else if (al == 1 && be == 1) slot = posID;          /* 3863 */
+				else if (al == 1 && be == 0) slot = b;              /* 3992 */
+				else if (al == 0 && be == 1) slot = a;              /* 4360 */
+				else if (al == 0 && be == 2) slot = m + a;          /* 4488 */
+				else if (al == 2 && be == 0) slot = m + b;          /* 4778 */
+				else if (al == 2 && be == 2) slot = m + posID2;     /* 4653 */
+				else slot = posID2;                                 /* J2^T I J3 / J3^T I J2: 4124, 4904 */
+				jt_b_j(Ja[al], 6, 6, Ub, 6, Jb[be], 6, T);
+				place_pp(newU, slot, T, rr, cc, off);
+			}
+	}
+	out->nU = n_newU;
+
+	/* new W / V: two leading W blocks per feature (posID, posID2), Imp.cpp:4989-6503 */
+	newW = xcalloc((size_t)(in->nW + 2 * n) * 18, sizeof(double));
+	newV = xcalloc((size_t)n * 9, sizeof(double));
+	out->W = newW; out->V = newV;
+	out->feature = xmalloc((in->nW + 2 * n) * sizeof(int));
+	out->photo = xmalloc((in->nW + 2 * n) * sizeof(int));
+	n_newW = 0; j = 0;
+	for (i = 0; i < n; i++)
+	{
+		double *ptrPID, *ptrPID2;
+		const double* Vb = in->V + (size_t)i * 9;
+		const double* Jf[3];
+		int fc[3] = { 3, 6, 6 };
+		double T[36];
+		int al, be;
+		Jf[0] = J1 + (size_t)m * 36 + (size_t)i * 9;
+		Jf[1] = J2 + (size_t)m * 36 + (size_t)i * 18;
+		Jf[2] = J3 + (size_t)m * 36 + (size_t)i * 18;
+		out->FBlock[i] = n_newW;
+		ptrPID = newW + (size_t)n_newW * 18; out->feature[n_newW] = i; out->photo[n_newW] = posID; n_newW++;
+		ptrPID2 = newW + (size_t)n_newW * 18; out->feature[n_newW] = i; out->photo[n_newW] = posID2; n_newW++;
+		/* V block (diagonal source) */
+		jt_b_j(Jf[0], 3, 3, Vb, 3, Jf[0], 3, T); add_blk(newV + (size_t)i * 9, T, 3, 3, 0);     /* 5323-5349 */
+		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[0], 3, T); add_blk(ptrPID, T, 6, 3, 0);                   /* 5149-5175 */
+		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[0], 3, T); add_blk(ptrPID2, T, 6, 3, 0);                  /* 5470-5496 */
+		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[1], 6, T); place_pp(newU, posID, T, posID, posID, 0);     /* 5041-5110 */
+		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[2], 6, T); place_pp(newU, m + posID2, T, posID2, posID2, 0); /* 5362-5431 */
+		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[2], 6, T); place_pp(newU, posID2, T, posID, posID2, 0);   /* 5197-5320 */
+		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[1], 6, T); place_pp(newU, posID2, T, posID2, posID, 0);
+		while (j < in->nW && in->feature[j] == i)
+		{
+			const double* Wb = in->W + (size_t)j * 18;
+			int k = in->photo[j];
+			const double* Jp[3];
+			double* dst;
+			Jp[0] = J1 + (size_t)k * 36; Jp[1] = J2 + (size_t)k * 36; Jp[2] = J3 + (size_t)k * 36;
+			if (k == posID) dst = ptrPID;               /* Imp.cpp:5898-5912 */
+			else if (k == posID2) dst = ptrPID2;
+			else { dst = newW + (size_t)n_newW * 18; out->feature[n_newW] = i; out->photo[n_newW] = k; n_newW++; }
+			for (al = 0; al < 3; al++)
+				for (be = 0; be < 3; be++)
+				{
+					int rr = al == 0 ? k : (al == 1 ? posID : posID2);
+					jt_b_j(Jp[al], 6, 6, Wb, 3, Jf[be], fc[be], T);
+					if (be == 0)
+					{	/* pose-feature block W'(rr, i) */
+						double* wd = al == 0 ? dst : (al == 1 ? ptrPID : ptrPID2);
+						add_blk(wd, T, 6, 3, 0);
+					}
+					else
+					{
+						int cc = be == 1 ? posID : posID2, slot;
+						if (al == 0) slot = be == 1 ? k : m + k;                 /* 5977, 6099 */
+						else if (al == 1 && be == 1) slot = posID;               /* 5598 */
+						else if (al == 2 && be == 2) slot = m + posID2;          /* 6248 */
+						else slot = posID2;                                      /* 5718, 6366 */
+						place_pp(newU, slot, T, rr, cc, 1);
+					}
+				}
+			j++;
+		}
+	}
+	out->nW = n_newW;
+	free(J1); free(J2); free(J3);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * join assembly
+ * ---------------------------------------------------------------------------------------------- */
+static void mv66(const double* A, const double* x, double* y, int transpose) /* y += A x  or  y += A^T x */
+{
+	int r, c;
+	for (r = 0; r < 6; r++)
+		for (c = 0; c < 6; c++) y[r] += (transpose ? A[6 * c + r] : A[6 * r + c]) * x[c];
+}
+static void mv63(const double* W, const double* x3, double* y6) /* y6 += W x3 */
+{
+	int r;
+	for (r = 0; r < 6; r++) y6[r] += W[3 * r] * x3[0] + W[3 * r + 1] * x3[1] + W[3 * r + 2] * x3[2];
+}
+static void mv63t(const double* W, const double* x6, double* y3) /* y3 += W^T x6 */
+{
+	int r, c;
+	for (c = 0; c < 3; c++)
+		for (r = 0; r < 6; r++) y3[c] += W[3 * r + c] * x6[r];
+}
+static void mv33(const double* V, const double* x, double* y) /* y += V x */
+{
+	int r;
+	for (r = 0; r < 3; r++) y[r] += V[3 * r] * x[0] + V[3 * r + 1] * x[1] + V[3 * r + 2] * x[2];
+}
+
+/* common-feature search, Imp.cpp:2575-2599 / 7316-7340: for each End feature the FIRST Cur feature with the
+ * same label.  The sort-based variant gives the same answer (labels are unique inside a map). */
+static int match_features(const orc_map* End, const orc_map* Cur, int* comM1, int* comM2, int* Curfeature2)
+{
+	int n1 = End->n, n2 = Cur->n, m1 = End->m, m2 = Cur->m, i, ncom = 0;
+	const int* p2 = Cur->stno + m2 * 6;
+	for (i = 0; i < n2; i++) Curfeature2[i] = -1;
+	if (!g_match_hash)
+	{
+		int* findTmp = xmalloc(n2 * sizeof(int));
+		for (i = 0; i < n2; i++) findTmp[i] = p2[i * 3];
+		for (i = 0; i < n1; i++)
+		{
+			int stno1 = End->stno[6 * m1 + i * 3], FID = 0;
+			while (FID < n2 && findTmp[FID] != stno1) FID++;
+			if (FID < n2) { comM1[ncom] = i; comM2[ncom] = FID; Curfeature2[FID] = i; ncom++; }
+		}
+		free(findTmp);
+	}
+	else
+	{
+		id_idx* S = xmalloc(n2 * sizeof *S);
+		for (i = 0; i < n2; i++) { S[i].id = p2[i * 3]; S[i].idx = i; }
+		qsort(S, n2, sizeof *S, cmp_id_idx);
+		for (i = 0; i < n1; i++)
+		{
+			int stno1 = End->stno[6 * m1 + i * 3], lo = 0, hi = n2;
+			while (lo < hi) { int mid = (lo + hi) >> 1; if (S[mid].id < stno1) lo = mid + 1; else hi = mid; }
+			if (lo < n2 && S[lo].id == stno1) { comM1[ncom] = i; comM2[ncom] = S[lo].idx; Curfeature2[S[lo].idx] = i; ncom++; }
+		}
+		free(S);
+	}
+	return ncom;
+}
+
+/* Imp.cpp:2551-2965 */
+void orc_join_assemble_stereo(const orc_map* End, const orc_map* Cur, orc_map* J, double** ePo, double** eFo)
+{
+	int m1 = End->m, m2 = Cur->m, n1 = End->n, n2 = Cur->n, m, n, ncom, i, j, l, a, b, cnt, id, k;
+	int* comM1 = xmalloc((n1 + 1) * sizeof(int));
+	int* comM2 = xmalloc((n2 + 1) * sizeof(int));
+	int* Curfeature2 = xmalloc((n2 + 1) * sizeof(int));
+	double *eP, *eF, *ptr3, *ptr5;
+
+	memset(J, 0, sizeof *J);
+	ncom = match_features(End, Cur, comM1, comM2, Curfeature2);
+	n = J->n = n1 + n2 - ncom;
+	m = J->m = m1 + m2;
+	J->nU = End->nU + Cur->nU;
+	J->nW = End->nW + Cur->nW;
+	J->U = xmalloc((size_t)J->nU * 36 * sizeof(double));
+	J->W = xmalloc((size_t)J->nW * 18 * sizeof(double));
+	J->V = xmalloc((size_t)n * 9 * sizeof(double));
+	J->Ui = xmalloc(J->nU * sizeof(int));
+	J->Uj = xmalloc(J->nU * sizeof(int));
+	J->feature = xmalloc(J->nW * sizeof(int));
+	J->photo = xmalloc(J->nW * sizeof(int));
+	J->stno = xmalloc((6 * m + 3 * n) * sizeof(int));
+	J->stVal = xcalloc(6 * m + 3 * n, sizeof(double));
+	J->FBlock = xmalloc(n * sizeof(int));
+	for (i = 0; i < n; i++) J->FBlock[i] = -1;
+	J->FRef = End->FRef; J->Ref = Cur->Ref; J->r = 6 * m + 3 * n;
+
+	memcpy(J->stno, End->stno, 6 * m1 * sizeof(int));
+	memcpy(J->stno + 6 * m1, Cur->stno, 6 * m2 * sizeof(int));
+	memcpy(J->stno + m * 6, End->stno + m1 * 6, n1 * 3 * sizeof(int));
+	id = 0;
+	for (i = 0; i < n2; i++)
+		if (Curfeature2[i] == -1)
+		{
+			for (k = 0; k < 3; k++) J->stno[6 * m + n1 * 3 + id * 3 + k] = Cur->stno[6 * m2 + i * 3 + k];
+			Curfeature2[i] = n1 + id;
+			id++;
+		}
+	eP = xcalloc(6 * m, sizeof(double));
+	eF = xcalloc(3 * n, sizeof(double));
+
+	/* U blocks of End then Cur (offset m1), eP += U x, eP += U^T x for off-diagonals: Imp.cpp:2654-2735 */
+	for (i = 0; i < End->nU; i++)
+	{
+		const double* u = End->U + (size_t)i * 36;
+		memcpy(J->U + (size_t)i * 36, u, 36 * sizeof(double));
+		J->Ui[i] = End->Ui[i]; J->Uj[i] = End->Uj[i];
+		mv66(u, End->stVal + End->Uj[i] * 6, eP + J->Ui[i] * 6, 0);
+		if (End->Ui[i] != End->Uj[i]) mv66(u, End->stVal + End->Ui[i] * 6, eP + J->Uj[i] * 6, 1);
+	}
+	for (i = 0; i < Cur->nU; i++)
+	{
+		const double* u = Cur->U + (size_t)i * 36;
+		int o = End->nU + i;
+		memcpy(J->U + (size_t)o * 36, u, 36 * sizeof(double));
+		J->Ui[o] = Cur->Ui[i] + m1; J->Uj[o] = Cur->Uj[i] + m1;
+		mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + J->Ui[o] * 6, 0);
+		if (Cur->Ui[i] != Cur->Uj[i]) mv66(u, Cur->stVal + Cur->Ui[i] * 6, eP + J->Uj[o] * 6, 1);
+	}
+
+	/* features of End (with the matching Cur run appended), Imp.cpp:2747-2860 */
+	ptr3 = J->W; ptr5 = J->V;
+	j = 0; l = 0; a = 0;
+	for (i = 0; i < n1; i++)
+	{
+		const double* v = End->V + (size_t)i * 9;
+		const double* xf = End->stVal + 6 * m1 + i * 3;
+		memcpy(ptr5, v, 9 * sizeof(double));
+		mv33(v, xf, eF + i * 3);
+		cnt = 0;
+		while (j < End->nW && End->feature[j] == i)
+		{
+			const double* w = End->W + (size_t)j * 18;
+			memcpy(ptr3, w, 18 * sizeof(double));
+			J->feature[l] = i; J->photo[l] = End->photo[j];
+			mv63(w, xf, eP + J->photo[l] * 6);
+			mv63t(w, End->stVal + End->photo[j] * 6, eF + i * 3);
+			ptr3 += 18; l++; j++; cnt++;
+		}
+		if (a < ncom && i == comM1[a])
+		{
+			const double* v2 = Cur->V + (size_t)comM2[a] * 9;
+			const double* xf2 = Cur->stVal + 6 * m2 + comM2[a] * 3;
+			for (k = 0; k < 9; k++) ptr5[k] += v2[k];
+			mv33(v2, xf2, eF + i * 3);
+			b = Cur->FBlock[comM2[a]];
+			if (b != -1)
+				while (b < Cur->nW && Cur->feature[b] == comM2[a])
+				{
+					const double* w = Cur->W + (size_t)b * 18;
+					memcpy(ptr3, w, 18 * sizeof(double));
+					J->feature[l] = i; J->photo[l] = Cur->photo[b] + m1;
+					mv63(w, xf2, eP + J->photo[l] * 6);
+					mv63t(w, Cur->stVal + Cur->photo[b] * 6, eF + i * 3);
+					ptr3 += 18; l++; b++; cnt++;
+				}
+			a++;
+		}
+		ptr5 += 9;
+		J->FBlock[i] = cnt == 0 ? -1 : l - cnt;
+	}
+	/* new features of Cur, Imp.cpp:2862-2930 */
+	j = 0;
+	for (i = 0; i < n2; i++)
+	{
+		if (Curfeature2[i] >= n1)
+		{
+			const double* v = Cur->V + (size_t)i * 9;
+			const double* xf = Cur->stVal + 6 * m2 + i * 3;
+			int f = Curfeature2[i];
+			memcpy(ptr5, v, 9 * sizeof(double));
+			ptr5 += 9;
+			mv33(v, xf, eF + f * 3);
+			cnt = 0;
+			while (j < Cur->nW && Cur->feature[j] == i)
+			{
+				const double* w = Cur->W + (size_t)j * 18;
+				memcpy(ptr3, w, 18 * sizeof(double));
+				J->feature[l] = f; J->photo[l] = Cur->photo[j] + m1;
+				mv63(w, xf, eP + J->photo[l] * 6);
+				mv63t(w, Cur->stVal + Cur->photo[j] * 6, eF + f * 3);
+				ptr3 += 18; l++; j++; cnt++;
+			}
+			J->FBlock[f] = cnt == 0 ? -1 : l - cnt;
+		}
+		else
+			while (j < Cur->nW && Cur->feature[j] == i) j++;
+	}
+	free(comM1); free(comM2); free(Curfeature2);
+	*ePo = eP; *eFo = eF;
+}
+
+/* Imp.cpp:7427-7465 */
+static void wrap_angles(double* wrp1, double* wrp2)
+{
+	int i, tmpwrp;
+	double Errwrp;
+	for (i = 0; i < 3; i++)
+	{
+		if (wrp1[i] > ORC_PI) { tmpwrp = (int)(wrp1[i] / (2 * ORC_PI)); wrp1[i] -= (tmpwrp + 1) * (2 * ORC_PI); }
+		if (wrp1[i] < -ORC_PI) { tmpwrp = (int)(wrp1[i] / (2 * ORC_PI)); wrp1[i] -= (tmpwrp - 1) * (2 * ORC_PI); }
+		if (wrp2[i] > ORC_PI) { tmpwrp = (int)(wrp2[i] / (2 * ORC_PI)); wrp2[i] -= (tmpwrp + 1) * (2 * ORC_PI); }
+		if (wrp2[i] < -ORC_PI) { tmpwrp = (int)(wrp2[i] / (2 * ORC_PI)); wrp2[i] -= (tmpwrp - 1) * (2 * ORC_PI); }
+		Errwrp = wrp2[i] - wrp1[i];
+		if (Errwrp > ORC_PI) wrp2[i] -= 2 * ORC_PI;
+		else if (Errwrp < -ORC_PI) wrp2[i] += 2 * ORC_PI;
+	}
+}
+
+/* Imp.cpp:7282-7864 */
+void orc_join_assemble_mono(orc_map* End, orc_map* Cur, orc_map* J, double** ePo, double** eFo, int solve_args[5])
+{
+	int m1 = End->m, m2 = Cur->m, n1 = End->n, n2 = Cur->n, m, n, ncom, i, j, l, a, b, cnt, id, k, ul;
+	int pos1, pos2, posID1, posID2, pos12 = 0, pos22 = 0, Fl = 0;
+	int* comM1 = xmalloc((n1 + 1) * sizeof(int));
+	int* comM2 = xmalloc((n2 + 1) * sizeof(int));
+	int* Curfeature2 = xmalloc((n2 + 1) * sizeof(int));
+	int* CurPose2 = xmalloc((m2 + 1) * sizeof(int));
+	double *eP, *eF, *ptr2, *ptr3, *ptr5, *FlA = NULL;
+
+	memset(J, 0, sizeof *J);
+	for (i = 0; i < m2; i++) CurPose2[i] = -1;
+	pos1 = find_label(End->stno, End->r, -End->Ref); posID1 = pos1 / 6;
+	pos2 = find_label(End->stno, End->r, -End->ScaP); posID2 = pos2 / 6;
+	ncom = match_features(End, Cur, comM1, comM2, Curfeature2);
+	n = J->n = n1 + n2 - ncom;
+	m = J->m = m1 + m2 - 2;
+	J->U = xmalloc((size_t)(End->nU + Cur->nU) * 36 * sizeof(double));
+	J->W = xmalloc((size_t)(End->nW + Cur->nW) * 18 * sizeof(double));
+	J->V = xmalloc((size_t)n * 9 * sizeof(double));
+	J->Ui = xmalloc((End->nU + Cur->nU) * sizeof(int));
+	J->Uj = xmalloc((End->nU + Cur->nU) * sizeof(int));
+	J->feature = xmalloc((End->nW + Cur->nW) * sizeof(int));
+	J->photo = xmalloc((End->nW + Cur->nW) * sizeof(int));
+	J->stno = xmalloc((6 * m + 3 * n) * sizeof(int));
+	J->stVal = xcalloc(6 * m + 3 * n, sizeof(double));
+	J->FBlock = xmalloc(n * sizeof(int));
+	for (i = 0; i < n; i++) J->FBlock[i] = -1;
+	J->Ref = Cur->Ref; J->r = 6 * m + 3 * n; J->ScaP = Cur->ScaP; J->Fix = Cur->Fix; J->Sign = Cur->Sign;
+	J->FRef = End->FRef; J->FScaP = End->FScaP; J->FFix = End->FFix;
+	eP = xcalloc(6 * m, sizeof(double));
+	eF = xcalloc(3 * n, sizeof(double));
+
+	memcpy(J->stno, End->stno, 6 * m1 * sizeof(int));
+	id = 0;
+	for (i = 0; i < m2; i++) /* Imp.cpp:7383-7409 */
+	{
+		if (Cur->stno[6 * i] == -Cur->Ref) { CurPose2[i] = posID1; pos12 = 6 * i; }
+		else if (Cur->stno[6 * i] == -Cur->ScaP) { CurPose2[i] = posID2; pos22 = 6 * i; }
+		else
+		{
+			for (k = 0; k < 6; k++) J->stno[6 * m1 + id * 6 + k] = Cur->stno[i * 6 + k];
+			CurPose2[i] = m1 + id;
+			id++;
+		}
+	}
+	(void)pos12;
+	memcpy(J->stno + m * 6, End->stno + m1 * 6, n1 * 3 * sizeof(int));
+	id = 0;
+	for (i = 0; i < n2; i++)
+		if (Curfeature2[i] == -1)
+		{
+			for (k = 0; k < 3; k++) J->stno[6 * m + n1 * 3 + id * 3 + k] = Cur->stno[6 * m2 + i * 3 + k];
+			Curfeature2[i] = n1 + id;
+			id++;
+		}
+
+	wrap_angles(End->stVal + pos2 + 3, Cur->stVal + pos22 + 3);
+
+	/* U, Imp.cpp:7470-7590: blocks touching the Ref pose are dropped; Cur's (ScaP,ScaP) block is summed into End's */
+	ptr2 = J->U; ul = 0;
+	for (i = 0; i < End->nU; i++)
+	{
+		const double* u = End->U + (size_t)i * 36;
+		if (End->Ui[i] != posID1 && End->Uj[i] != posID1)
+		{
+			if (End->Ui[i] == posID2 && End->Uj[i] == posID2) { Fl = 1; FlA = ptr2; }
+			memcpy(ptr2, u, 36 * sizeof(double));
+			J->Ui[ul] = End->Ui[i]; J->Uj[ul] = End->Uj[i];
+			mv66(u, End->stVal + End->Uj[i] * 6, eP + J->Ui[ul] * 6, 0);
+			if (End->Ui[i] != End->Uj[i]) mv66(u, End->stVal + End->Ui[i] * 6, eP + J->Uj[ul] * 6, 1);
+			ptr2 += 36; ul++;
+		}
+	}
+	for (i = 0; i < Cur->nU; i++)
+	{
+		const double* u = Cur->U + (size_t)i * 36;
+		int ci = CurPose2[Cur->Ui[i]], cj = CurPose2[Cur->Uj[i]];
+		if (ci != posID1 && cj != posID1)
+		{
+			if (ci == posID2 && cj == posID2 && Fl == 1)
+			{
+				for (k = 0; k < 36; k++) FlA[k] += u[k];
+				mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + posID2 * 6, 0);
+			}
+			else
+			{
+				memcpy(ptr2, u, 36 * sizeof(double));
+				J->Ui[ul] = ci; J->Uj[ul] = cj;
+				mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + ci * 6, 0);
+				if (Cur->Ui[i] != Cur->Uj[i]) mv66(u, Cur->stVal + Cur->Ui[i] * 6, eP + cj * 6, 1);
+				ptr2 += 36; ul++;
+			}
+		}
+	}
+	J->nU = ul;
+
+	/* W / V, Imp.cpp:7592-7823 */
+	ptr3 = J->W; ptr5 = J->V;
+	j = 0; l = 0; a = 0;
+	for (i = 0; i < n1; i++)
+	{
+		const double* v = End->V + (size_t)i * 9;
+		const double* xf = End->stVal + 6 * m1 + i * 3;
+		memcpy(ptr5, v, 9 * sizeof(double));
+		mv33(v, xf, eF + i * 3);
+		cnt = 0; Fl = 0;
+		while (j < End->nW && End->feature[j] == i)
+		{
+			if (End->photo[j] != posID1)
+			{
+				const double* w = End->W + (size_t)j * 18;
+				if (End->photo[j] == posID2) { Fl = 1; FlA = ptr3; }
+				memcpy(ptr3, w, 18 * sizeof(double));
+				J->feature[l] = i; J->photo[l] = End->photo[j];
+				mv63(w, xf, eP + J->photo[l] * 6);
+				mv63t(w, End->stVal + End->photo[j] * 6, eF + i * 3);
+				ptr3 += 18; l++; cnt++;
+			}
+			j++;
+		}
+		if (a < ncom && i == comM1[a])
+		{
+			const double* v2 = Cur->V + (size_t)comM2[a] * 9;
+			const double* xf2 = Cur->stVal + 6 * m2 + comM2[a] * 3;
+			for (k = 0; k < 9; k++) ptr5[k] += v2[k];
+			mv33(v2, xf2, eF + i * 3);
+			b = Cur->FBlock[comM2[a]];
+			if (b != -1)
+				while (b < Cur->nW && Cur->feature[b] == comM2[a])
+				{
+					const double* w = Cur->W + (size_t)b * 18;
+					int cp = CurPose2[Cur->photo[b]];
+					if (cp != posID1)
+					{
+						if (cp == posID2 && Fl == 1)
+						{
+							for (k = 0; k < 18; k++) FlA[k] += w[k];
+							mv63(w, xf2, eP + posID2 * 6);
+							mv63t(w, Cur->stVal + Cur->photo[b] * 6, eF + i * 3);
+						}
+						else
+						{
+							memcpy(ptr3, w, 18 * sizeof(double));
+							J->feature[l] = i; J->photo[l] = cp;
+							mv63(w, xf2, eP + cp * 6);
+							mv63t(w, Cur->stVal + Cur->photo[b] * 6, eF + i * 3);
+							ptr3 += 18; l++; cnt++;
+						}
+					}
+					b++;
+				}
+			a++;
+		}
+		ptr5 += 9;
+		J->FBlock[i] = cnt == 0 ? -1 : l - cnt;
+	}
+	j = 0;
+	for (i = 0; i < n2; i++)
+	{
+		if (Curfeature2[i] >= n1)
+		{
+			const double* v = Cur->V + (size_t)i * 9;
+			const double* xf = Cur->stVal + 6 * m2 + i * 3;
+			int f = Curfeature2[i];
+			memcpy(ptr5, v, 9 * sizeof(double));
+			ptr5 += 9;
+			mv33(v, xf, eF + f * 3);
+			cnt = 0;
+			while (j < Cur->nW && Cur->feature[j] == i)
+			{
+				int cp = CurPose2[Cur->photo[j]];
+				if (cp != posID1)
+				{
+					const double* w = Cur->W + (size_t)j * 18;
+					memcpy(ptr3, w, 18 * sizeof(double));
+					J->feature[l] = f; J->photo[l] = cp;
+					mv63(w, xf, eP + cp * 6);
+					mv63t(w, Cur->stVal + Cur->photo[j] * 6, eF + f * 3);
+					ptr3 += 18; l++; cnt++;
+				}
+				j++;
+			}
+			J->FBlock[f] = cnt == 0 ? -1 : l - cnt;
+		}
+		else
+			while (j < Cur->nW && Cur->feature[j] == i) j++;
+	}
+	J->nW = l;
+	/* call-site argument mapping, Imp.cpp:7860-7864 */
+	solve_args[0] = posID1; solve_args[1] = pos1; solve_args[2] = pos2 + End->Fix; solve_args[3] = End->Sign;
+	solve_args[4] = posID2 - 1;
+	free(comM1); free(comM2); free(Curfeature2); free(CurPose2);
+	*ePo = eP; *eFo = eF;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Schur complement + solve + back-substitution  (Imp.cpp:2119-2378, 6756-7041, 2980-3042)
+ * ---------------------------------------------------------------------------------------------- */
+/* Imp.cpp:3022-3042: V^-1, written back symmetrised from the upper triangle of the inverse */
+static void inverse_v(const double* V, double* IV, int n)
+{
+	int i;
+	for (i = 0; i < n; i++)
+	{
+		const double* a = V + (size_t)i * 9;
+		double* o = IV + (size_t)i * 9;
+		double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+		double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+		/* inverse = adj/det; (0,1) (0,2) (1,2) entries of the inverse */
+		double i00 = c00 * id, i11 = (a[0] * a[8] - a[2] * a[6]) * id, i22 = (a[0] * a[4] - a[1] * a[3]) * id;
+		double i01 = (a[2] * a[7] - a[1] * a[8]) * id, i02 = (a[1] * a[5] - a[2] * a[4]) * id, i12 = (a[2] * a[3] - a[0] * a[5]) * id;
+		o[0] = i00; o[4] = i11; o[8] = i22;
+		o[1] = o[3] = i01; o[2] = o[6] = i02; o[5] = o[7] = i12;
+	}
+}
+
+static int cmp_int(const void* a, const void* b) { int x = *(const int*)a, y = *(const int*)b; return x < y ? -1 : x > y; }
+
+/* returns index of column j in row i of the block-CRS pattern (sba_crsm_elmidx, Imp.cpp:55-76) */
+static int crs_find(const int* rowptr, const int* colidx, int i, int j)
+{
+	int low = rowptr[i], high = rowptr[i + 1] - 1;
+	while (low <= high)
+	{
+		int mid = (low + high) >> 1, diff = j - colidx[mid];
+		if (diff < 0) high = mid - 1; else if (diff > 0) low = mid + 1; else return mid;
+	}
+	return -1;
+}
+
+void orc_schur(const double* eb, const double* ea, const double* U, const double* W, const double* V,
+               const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
+               int accumulate_u, int** rowptr_o, int** colidx_o, double** S_o, double** E_o, double** IV_o)
+{
+	int *mapPhoto, *rowptr, *colidx, *pcnt, *pptr, *plist, *mark, *fstart;
+	int i, j, k, ii, jj, l, pos, nuis, p;
+	double *S, *E, *IV, WV[18], sum;
+
+	/* run length of each feature in feature[] (mapPhoto, Imp.cpp:2134-2153) */
+	mapPhoto = xcalloc(n, sizeof(int));
+	fstart = xmalloc((n + 1) * sizeof(int));
+	{
+		int id = 0, nBase, nBaseNum = 1;
+		if (nW > 0)
+		{
+			nBase = feature[0];
+			for (i = 1; i < nW; i++)
+			{
+				if (feature[i] == nBase) nBaseNum++;
+				else { mapPhoto[id++] = nBaseNum; nBaseNum = 1; nBase = feature[i]; }
+			}
+			mapPhoto[n - 1] = nBaseNum;
+		}
+		fstart[0] = 0;
+		for (i = 0; i < n; i++) fstart[i + 1] = fstart[i] + mapPhoto[i];
+	}
+	/* block pattern of S (upper): pose pairs sharing a feature + U pattern.  The reference sets a dense m x m
+	 * byte mask (Imp.cpp:2131-2205); the same set is built here row by row from a pose->entries index. */
+	pcnt = xcalloc(m + 1, sizeof(int));
+	for (i = 0; i < nW; i++) pcnt[photo[i] + 1]++;
+	pptr = xmalloc((m + 1) * sizeof(int));
+	pptr[0] = 0;
+	for (i = 0; i < m; i++) pptr[i + 1] = pptr[i] + pcnt[i + 1];
+	plist = xmalloc((nW + 1) * sizeof(int));
+	memset(pcnt, 0, (m + 1) * sizeof(int));
+	for (i = 0; i < n; i++)
+		for (j = fstart[i]; j < fstart[i + 1]; j++) { p = photo[j]; plist[pptr[p] + pcnt[p]++] = i; }
+	/* U pattern per row */
+	{
+		int* ucnt = xcalloc(m + 1, sizeof(int));
+		int *uptr = xmalloc((m + 1) * sizeof(int)), *ulist = xmalloc((nU + 1) * sizeof(int));
+		int cap = 1024, cnt;
+		int* tmpcols = xmalloc(m * sizeof(int));
+		for (i = 0; i < nU; i++) { int a = Ui[i] < Uj[i] ? Ui[i] : Uj[i]; ucnt[a + 1]++; }
+		uptr[0] = 0;
+		for (i = 0; i < m; i++) uptr[i + 1] = uptr[i] + ucnt[i + 1];
+		memset(ucnt, 0, (m + 1) * sizeof(int));
+		for (i = 0; i < nU; i++)
+		{
+			int a = Ui[i] < Uj[i] ? Ui[i] : Uj[i], b = Ui[i] < Uj[i] ? Uj[i] : Ui[i];
+			ulist[uptr[a] + ucnt[a]++] = b;
+		}
+		mark = xmalloc(m * sizeof(int));
+		for (i = 0; i < m; i++) mark[i] = -1;
+		rowptr = xmalloc((m + 1) * sizeof(int));
+		colidx = xmalloc(cap * sizeof(int));
+		nuis = 0;
+		for (p = 0; p < m; p++)
+		{
+			rowptr[p] = nuis;
+			cnt = 0;
+			for (j = pptr[p]; j < pptr[p + 1]; j++)
+			{
+				int f = plist[j];
+				for (k = fstart[f]; k < fstart[f + 1]; k++)
+				{
+					int q = photo[k];
+					if (q >= p && mark[q] != p) { mark[q] = p; tmpcols[cnt++] = q; }
+				}
+			}
+			for (j = uptr[p]; j < uptr[p + 1]; j++)
+			{
+				int q = ulist[j];
+				if (mark[q] != p) { mark[q] = p; tmpcols[cnt++] = q; }
+			}
+			qsort(tmpcols, cnt, sizeof(int), cmp_int);
+			if (nuis + cnt > cap) { while (nuis + cnt > cap) cap *= 2; colidx = realloc(colidx, cap * sizeof(int)); }
+			memcpy(colidx + nuis, tmpcols, cnt * sizeof(int));
+			nuis += cnt;
+		}
+		rowptr[m] = nuis;
+		free(ucnt); free(uptr); free(ulist); free(tmpcols); free(mark);
+	}
+	free(pcnt); free(pptr); free(plist);
+
+	S = xcalloc((size_t)nuis * 36, sizeof(double));
+	E = xmalloc((size_t)6 * m * sizeof(double));
+	IV = xmalloc((size_t)9 * n * sizeof(double));
+	inverse_v(V, IV, n);
+	/* copy U into S, Imp.cpp:2214-2238 (Stereo '=') / 6854-6878 (Mono '+='); diagonal blocks: upper triangle only */
+	for (i = 0; i < nU; i++)
+	{
+		int a = Ui[i], b = Uj[i];
+		int pos1 = crs_find(rowptr, colidx, a, b);
+		double* ptr2 = S + (size_t)pos1 * 36;
+		const double* ptr1 = U + (size_t)i * 36;
+		if (pos1 < 0) { fprintf(stderr, "oracle: U block (%d,%d) not upper-ordered\n", a, b); exit(1); }
+		for (ii = 0; ii < 6; ii++)
+			for (jj = (a == b ? ii : 0); jj < 6; jj++)
+			{
+				if (accumulate_u) ptr2[ii * 6 + jj] += ptr1[ii * 6 + jj]; else ptr2[ii * 6 + jj] = ptr1[ii * 6 + jj];
+			}
+	}
+	for (i = 0; i < 6 * m; i++) E[i] = ea[i];
+	/* S -= W V^-1 W^T, E -= W V^-1 eb: Imp.cpp:2244-2332 */
+	pos = 0;
+	for (i = 0; i < n; i++)
+	{
+		int numfea = mapPhoto[i];
+		for (j = 0; j < numfea; j++)
+		{
+			int nF1 = feature[pos + j], nP1 = photo[pos + j];
+			const double* ptr1 = W + (size_t)(pos + j) * 18;
+			const double* ptr2 = IV + (size_t)nF1 * 9;
+			double* ptrE = E + nP1 * 6;
+			for (ii = 0; ii < 6; ii++)
+				for (jj = 0; jj < 3; jj++)
+				{
+					for (k = 0, sum = 0.0; k < 3; k++) sum += ptr1[ii * 3 + k] * ptr2[jj * 3 + k]; /* Imp.cpp:2269-2271 */
+					WV[ii * 3 + jj] = sum;
+				}
+			for (k = 0; k < numfea; k++)
+			{
+				int nP2 = photo[pos + k];
+				const double* ptr3 = W + (size_t)(pos + k) * 18;
+				if (nP1 <= nP2)
+				{
+					int pos1 = crs_find(rowptr, colidx, nP1, nP2);
+					double* ptrS = S + (size_t)pos1 * 36;
+					for (ii = 0; ii < 6; ii++)
+						for (jj = (nP1 == nP2 ? ii : 0); jj < 6; jj++)
+						{
+							for (l = 0, sum = 0.0; l < 3; l++) sum += WV[ii * 3 + l] * ptr3[jj * 3 + l];
+							ptrS[ii * 6 + jj] -= sum;
+						}
+				}
+			}
+			{
+				const double* ptr5 = eb + nF1 * 3;
+				for (ii = 0; ii < 6; ii++)
+				{
+					for (jj = 0, sum = 0.0; jj < 3; jj++) sum += WV[ii * 3 + jj] * ptr5[jj];
+					ptrE[ii] -= sum;
+				}
+			}
+		}
+		pos += numfea;
+	}
+	free(mapPhoto); free(fstart);
+	*rowptr_o = rowptr; *colidx_o = colidx; *S_o = S; *E_o = E; *IV_o = IV;
+}
+
+/* Imp.cpp:2980-3020 */
+static void solve_features(const double* W, const double* IV, const double* eb, const double* dpa, double* dpb,
+                           int n, const int* photo, const int* feature, int nW)
+{
+	int i, pos = 0, ii, jj;
+	for (i = 0; i < n; i++)
+	{
+		double eb2[3] = { 0, 0, 0 };
+		const double* ptr2 = IV + (size_t)i * 9;
+		while (pos < nW && feature[pos] == i)
+		{
+			const double* ptr3 = W + (size_t)pos * 18;
+			const double* ptr4 = dpa + photo[pos] * 6;
+			for (ii = 0; ii < 3; ii++)
+			{
+				double sum = 0;
+				for (jj = 0; jj < 6; jj++) sum += ptr3[jj * 3 + ii] * ptr4[jj];
+				eb2[ii] += sum;
+			}
+			pos++;
+		}
+		for (ii = 0; ii < 3; ii++)
+		{
+			double sum = 0;
+			for (jj = 0; jj < 3; jj++) sum += ptr2[ii * 3 + jj] * (eb[i * 3 + jj] - eb2[jj]);
+			dpb[i * 3 + ii] = sum;
+		}
+	}
+}
+
+/* shared by Stereo (skipblk=-1, skipfix=-1) and Mono (the 6 scalars of block skipblk and scalar skipfix are
+ * removed from the system: pba_constructCSSGN, Imp.cpp:7123-7200) */
+static int solve_common(double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                        const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature,
+                        int m, int n, int nU, int nW, int accumulate_u, int skipblk, int skipfix, long* stats)
+{
+	int *rowptr, *colidx, *cptr, *crow, *cpos, *newidx, *Sp, *Si, *bperm, *sperm, *bAp, *bAi;
+	double *S, *E, *IV, *Sx, *rhs, *sol;
+	int i, k, ii, jj, jjj, nuis, ns, nz, rc, nb;
+	long lnz = 0;
+
+	orc_schur(eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, accumulate_u, &rowptr, &colidx, &S, &E, &IV);
+	nuis = rowptr[m];
+	/* column access to the upper block pattern */
+	cptr = xcalloc(m + 2, sizeof(int));
+	for (i = 0; i < nuis; i++) cptr[colidx[i] + 1]++;
+	for (i = 0; i < m; i++) cptr[i + 1] += cptr[i];
+	crow = xmalloc((nuis + 1) * sizeof(int));
+	cpos = xmalloc((nuis + 1) * sizeof(int));
+	{
+		int* fill = xcalloc(m + 1, sizeof(int));
+		for (i = 0; i < m; i++)
+			for (k = rowptr[i]; k < rowptr[i + 1]; k++)
+			{
+				int c = colidx[k];
+				crow[cptr[c] + fill[c]] = i; cpos[cptr[c] + fill[c]] = k; fill[c]++;
+			}
+		free(fill);
+	}
+	/* scalar renumbering with the removed DOFs skipped */
+	newidx = xmalloc(6 * m * sizeof(int));
+	ns = 0;
+	for (i = 0; i < 6 * m; i++)
+	{
+		if ((skipblk >= 0 && i / 6 == skipblk) || i == skipfix) newidx[i] = -1; else newidx[i] = ns++;
+	}
+	/* CSC upper (stype=1) as handed to CHOLMOD: pba_constructCSSLM / GN, Imp.cpp:2451-2498 / 7123-7200 */
+	Sp = xmalloc((ns + 1) * sizeof(int));
+	Si = xmalloc(((size_t)nuis * 36 + 1) * sizeof(int));
+	Sx = xmalloc(((size_t)nuis * 36 + 1) * sizeof(double));
+	nz = 0;
+	for (ii = 0; ii < m; ii++)
+		for (k = 0; k < 6; k++)
+		{
+			if (newidx[ii * 6 + k] < 0) continue;
+			Sp[newidx[ii * 6 + k]] = nz;
+			for (i = cptr[ii]; i < cptr[ii + 1]; i++)
+			{
+				const double* ptr5 = S + (size_t)cpos[i] * 36;
+				jj = crow[i];
+				for (jjj = 0; jjj < (ii == jj ? k + 1 : 6); jjj++)
+				{
+					if (newidx[jj * 6 + jjj] < 0) continue;
+					Si[nz] = newidx[jj * 6 + jjj];
+					Sx[nz] = ptr5[jjj * 6 + k];
+					nz++;
+				}
+			}
+		}
+	Sp[ns] = nz;
+	/* ordering: block minimum degree (reference: CHOLMOD block AMD for Stereo, scalar AMD for Mono) */
+	nb = m;
+	bAp = xmalloc((nb + 1) * sizeof(int));
+	bAi = xmalloc((nuis + 1) * sizeof(int));
+	for (i = 0; i <= nb; i++) bAp[i] = cptr[i];
+	for (i = 0; i < nuis; i++) bAi[i] = crow[i];
+	bperm = xmalloc(nb * sizeof(int));
+	orc_min_degree(nb, bAp, bAi, bperm);
+	sperm = xmalloc((ns + 1) * sizeof(int));
+	k = 0;
+	for (i = 0; i < nb; i++)
+		for (jj = 0; jj < 6; jj++)
+			if (newidx[bperm[i] * 6 + jj] >= 0) sperm[k++] = newidx[bperm[i] * 6 + jj];
+	rhs = xmalloc((ns + 1) * sizeof(double));
+	sol = xmalloc((ns + 1) * sizeof(double));
+	for (i = 0; i < 6 * m; i++) if (newidx[i] >= 0) rhs[newidx[i]] = E[i];
+	rc = orc_chol_solve(ns, Sp, Si, Sx, sperm, rhs, sol, &lnz);
+	for (i = 0; i < 6 * m; i++) stVal[i] = newidx[i] >= 0 ? sol[newidx[i]] : 0.0; /* Imp.cpp:7010-7021 */
+	solve_features(W, IV, eb, stVal, stVal + 6 * m, n, photo, feature, nW);
+	if (stats) { stats[0] = nuis; stats[1] = lnz; }
+	free(rowptr); free(colidx); free(S); free(E); free(IV); free(cptr); free(crow); free(cpos); free(newidx);
+	free(Sp); free(Si); free(Sx); free(bAp); free(bAi); free(bperm); free(sperm); free(rhs); free(sol);
+	return rc;
+}
+
+int orc_solve_stereo(double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                     const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature,
+                     int m, int n, int nU, int nW, long* stats)
+{
+	return solve_common(stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, 0, -1, -1, stats);
+}
+
+/* Imp.cpp:6756-7041.  Ref = BLOCK index of the reference pose; ScaP = SCALAR offset of that same pose (sic,
+ * see the call site Imp.cpp:7864); Fix = scalar index of the gauge-fixed translation of the scale pose. */
+int orc_solve_mono(double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                   const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature,
+                   int m, int n, int nU, int nW, int Ref, int ScaP, int Fix, int Sign, int FixBlk, long* stats)
+{
+	int rc;
+	(void)FixBlk;
+	if (ScaP != Ref * 6) { fprintf(stderr, "oracle: solve_mono: ScaP (%d) must be 6*Ref (%d)\n", ScaP, Ref); return -1; }
+	rc = solve_common(stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, 1, Ref, Fix, stats);
+	stVal[Fix] = Sign; /* Imp.cpp:7026 */
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * full joins and the divide & conquer driver
+ * ---------------------------------------------------------------------------------------------- */
+static double g_t_asm = 0, g_t_solve = 0, g_t_trans = 0;
+
+int orc_join_stereo(orc_map* End, orc_map* Cur, orc_map* joint)
+{
+	double *eP, *eF, t0 = now_s(), t1;
+	int rc;
+	orc_join_assemble_stereo(End, Cur, joint, &eP, &eF);
+	orc_map_free(End); orc_map_free(Cur);
+	t1 = now_s(); g_t_asm += t1 - t0;
+	rc = orc_solve_stereo(joint->stVal, eF, eP, joint->U, joint->W, joint->V, joint->Ui, joint->Uj, joint->photo,
+	                      joint->feature, joint->m, joint->n, joint->nU, joint->nW, NULL);
+	g_t_solve += now_s() - t1;
+	free(eP); free(eF);
+	return rc;
+}
+
+int orc_join_mono(orc_map* End, orc_map* Cur, orc_map* joint)
+{
+	double *eP, *eF, t0 = now_s(), t1;
+	int rc, sa[5];
+	orc_join_assemble_mono(End, Cur, joint, &eP, &eF, sa);
+	orc_map_free(End); orc_map_free(Cur);
+	t1 = now_s(); g_t_asm += t1 - t0;
+	rc = orc_solve_mono(joint->stVal, eF, eP, joint->U, joint->W, joint->V, joint->Ui, joint->Uj, joint->photo,
+	                    joint->feature, joint->m, joint->n, joint->nU, joint->nW, sa[0], sa[1], sa[2], sa[3], sa[4], NULL);
+	g_t_solve += now_s() - t1;
+	free(eP); free(eF);
+	return rc;
+}
+
+static void transform_any(const orc_map* in, int mono, int Ref, int ScaP, int Fix, orc_map* out)
+{
+	double t0 = now_s();
+	if (mono) orc_transform_mono(in, Ref, ScaP, Fix, out); else orc_transform_stereo(in, Ref, out);
+	g_t_trans += now_s() - t0;
+}
+
+/* Imp.cpp:1926-2063 / 6511-6630 */
+int orc_divide_conquer(orc_map* LM, int nLocalMapCount, int mono, orc_map* out, int verbose, double* timing)
+{
+	int L = 0, rc = 0, i, j;
+	orc_map G;
+	double t0 = now_s();
+	g_t_asm = g_t_solve = g_t_trans = 0;
+	memset(&G, 0, sizeof G);
+	if (nLocalMapCount == 1) { G = LM[0]; memset(&LM[0], 0, sizeof LM[0]); }
+	while (nLocalMapCount > 1)
+	{
+		int N2 = nLocalMapCount % 2;
+		nLocalMapCount = (int)(nLocalMapCount / 2.0 + 0.5);
+		for (i = 0; i < nLocalMapCount; i++)
+		{
+			int NumLM = (i < nLocalMapCount - 1 || N2 == 0) ? 2 : 1;
+			for (j = 0; j < NumLM; j++)
+			{
+				if (verbose) printf("Join Level %d Local Map %d\n", L, 2 * i + j + 1);
+				if (j == 0) { G = LM[2 * i]; memset(&LM[2 * i], 0, sizeof G); }
+				else
+				{
+					orc_map End, Joint, *Cur = &LM[2 * i + j];
+					transform_any(&G, mono, Cur->Ref, Cur->ScaP, Cur->Fix, &End);
+					orc_map_free(&G);
+					rc |= mono ? orc_join_mono(&End, Cur, &Joint) : orc_join_stereo(&End, Cur, &Joint);
+					G = Joint;
+				}
+			}
+			if (verbose) printf("Generate Level %d Local Map %d\n\n", L + 1, i + 1);
+			if ((i + 1) % 2 == 0 && G.Ref > G.FRef)
+			{
+				orc_map Tmp;
+				transform_any(&G, mono, G.FRef, G.FScaP, G.FFix, &Tmp);
+				orc_map_free(&G);
+				G = Tmp;
+			}
+			LM[i] = G;
+			memset(&G, 0, sizeof G);
+		}
+		L++;
+		if (nLocalMapCount == 1) { G = LM[0]; memset(&LM[0], 0, sizeof G); }
+	}
+	if (G.Ref > G.FRef)
+	{
+		orc_map Tmp;
+		transform_any(&G, mono, G.FRef, G.FScaP, G.FFix, &Tmp);
+		orc_map_free(&G);
+		G = Tmp;
+	}
+	*out = G;
+	if (timing) { timing[0] = now_s() - t0; timing[1] = g_t_trans; timing[2] = g_t_asm; timing[3] = g_t_solve; }
+	return rc;
+}

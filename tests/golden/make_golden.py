@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ by running the REAL reference code
+(oracle/_ref/ref_dump = /root/reference's LinearSFMImp.cpp compiled where it lies, CHOLMOD-free entry points
+only, see oracle/ref_harness.cpp) on small synthetic local-map sets.  Runs only in the authoring container
+(needs /root/reference); the fixtures it writes are plain data (inputs + the reference's outputs).
+
+For every join of the reference's binary tree (lmj_PF3D_Divide_Conquer*, LinearSFMImp.cpp:1926-2063 / 6511-6630)
+the fixture stores
+    A, B            the two maps handed to the join (A before its transform)
+    end.*           lmj_Transform_PF3D*(A -> B's frame)               [reference output]
+    solve.*         what lmj_LinearLS_PF3D* assembled and passed to lmj_solveLinearSFM* (joint U/W/V, index
+                    arrays, ea=eP, eb=eF, Mono: Ref/ScaP/Fix/Sign/FixBlk)   [reference output]
+    joint.stno/FBlock
+and for every re-anchoring transform (LinearSFMImp.cpp:1997-2025, 2039-2063) the input map and the reference's
+output.  The solve itself (Schur + CHOLMOD) cannot be run from the reference here (CHOLMOD absent, no stand-in),
+so the state that flows to the next tree level is the ORACLE's solution (oracle/lsfm_oracle.c); the fixture also
+stores that state ("sol") so that other implementations can be compared with the oracle on identical inputs.
+
+Usage:  python tests/golden/make_golden.py        (from the repo root)
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from linearsfm_amd import synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from refdump import read_dump, sub  # noqa: E402
+
+REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+MAPKEYS = ("Ref", "FRef", "m", "n", "ScaP", "Fix", "Sign", "FScaP", "FFix", "stno", "stVal", "U", "Ui", "Uj", "W",
+           "photo", "feature", "V", "FBlock")
+
+
+def write_map(path, d, mono):
+    g = po.dict_to_map(d)
+    po.lib().orc_write_map(path.encode(), int(mono), C.byref(g))
+    po.lib().orc_map_free(C.byref(g))
+
+
+def put(store, prefix, d, keys=None):
+    for k, v in d.items():
+        if keys is None or k in keys:
+            store[f"{prefix}.{k}"] = np.asarray(v)
+
+
+def check_close(a, b, what, tol=1e-12):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    err = float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+    assert err < tol, (what, err)
+    return err
+
+
+def run(typ, maps, out_path, tmp):
+    mono = typ == "Monocular"
+    store = {"type": np.array(typ), "N": np.array(len(maps))}
+    LM = [po.localmap_to_dict(m) for m in maps]
+    for k, d in enumerate(LM):
+        put(store, f"in{k}", d, MAPKEYS)
+    count = len(LM)
+    L = 0
+    step = 0
+    worst = 0.0
+    while count > 1:
+        N2 = count % 2
+        count = int(count / 2.0 + 0.5)
+        for i in range(count):
+            num = 2 if (i < count - 1 or N2 == 0) else 1
+            G = LM[2 * i]
+            if num == 2:
+                A, B = G, LM[2 * i + 1]
+                fa, fb, fo = (os.path.join(tmp, x) for x in ("A.txt", "B.txt", "o.bin"))
+                write_map(fa, A, mono)
+                write_map(fb, B, mono)
+                subprocess.check_call([REF_DUMP, "pair", typ, fa, fb, fo])
+                D = read_dump(fo)
+                tag = f"join{step}"
+                store[f"{tag}.level"] = np.array(L)
+                put(store, f"{tag}.A", A, MAPKEYS)
+                put(store, f"{tag}.B", B, MAPKEYS)
+                for k, v in D.items():
+                    store[f"{tag}.{k}"] = v
+                # oracle on the same inputs, checked against the reference right here
+                E = po.transform(A, mono, B["Ref"], B["ScaP"], B["Fix"])
+                er = sub(D, "end")
+                for k in ("stno", "Ui", "Uj", "photo", "feature", "FBlock"):
+                    assert np.array_equal(np.asarray(E[k]).ravel(), er[k].ravel()), (tag, k)
+                for k in ("stVal", "U", "W", "V"):
+                    worst = max(worst, check_close(E[k], er[k], f"{tag}.end.{k}"))
+                J, eP, eF, sa, Ew, Bw = po.join_assemble(E, B, mono)
+                sr = sub(D, "solve")
+                for k in ("Ui", "Uj", "photo", "feature"):
+                    assert np.array_equal(J[k], sr[k]), (tag, k)
+                assert np.array_equal(J["stno"], D["joint.stno"]) and np.array_equal(J["FBlock"], D["joint.FBlock"])
+                for k, x in (("U", J["U"]), ("W", J["W"]), ("V", J["V"]), ("ea", eP), ("eb", eF)):
+                    worst = max(worst, check_close(x, sr[k], f"{tag}.solve.{k}"))
+                if mono:
+                    assert sa == [sr["Ref"], sr["ScaP"], sr["Fix"], sr["Sign"], sr["FixBlk"]], (sa, sr)
+                st, rc, stats = po.solve(J, eP, eF, mono, sa)
+                assert rc == 0
+                J["stVal"] = st
+                store[f"{tag}.sol"] = st
+                G = J
+                step += 1
+            if (i + 1) % 2 == 0 and G["Ref"] > G["FRef"]:
+                G = reanchor(typ, mono, G, store, f"re{L}_{i}", tmp)
+            LM[i] = G
+        L += 1
+    G = LM[0]
+    if G["Ref"] > G["FRef"]:
+        G = reanchor(typ, mono, G, store, "final", tmp)
+    put(store, "result", G, MAPKEYS)
+    store["njoins"] = np.array(step)
+    np.savez_compressed(out_path, **store)
+    print(f"{out_path}: {step} joins, worst oracle-vs-reference rel err {worst:.2e}, "
+          f"{os.path.getsize(out_path) / 1024:.0f} KiB")
+
+
+def reanchor(typ, mono, G, store, tag, tmp):
+    fa, fo = os.path.join(tmp, "A.txt"), os.path.join(tmp, "o.bin")
+    write_map(fa, G, mono)
+    args = [REF_DUMP, "trans", typ, fa, str(G["FRef"])]
+    if mono:
+        args += [str(G["FScaP"]), str(G["FFix"])]
+    subprocess.check_call(args + [fo])
+    D = read_dump(fo)
+    put(store, f"{tag}.A", G, MAPKEYS)
+    for k, v in D.items():
+        if k.startswith("out."):
+            store[f"{tag}.{k}"] = v
+    T = po.transform(G, mono, G["FRef"], G["FScaP"], G["FFix"])
+    o = sub(D, "out")
+    for k in ("stno", "Ui", "Uj", "photo", "feature", "FBlock"):
+        assert np.array_equal(np.asarray(T[k]).ravel(), o[k].ravel()), (tag, k)
+    for k in ("stVal", "U", "W", "V"):
+        check_close(T[k], o[k], f"{tag}.{k}")
+    return T
+
+
+def main():
+    po.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    out = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        run("Stereo", synth.make_stereo_set(5, new_per_frame=4, vis=4, seed=11), os.path.join(out, "stereo_n5.npz"), tmp)
+        run("Stereo", synth.make_stereo_set(8, new_per_frame=3, vis=5, seed=12), os.path.join(out, "stereo_n8.npz"), tmp)
+        run("Monocular", synth.make_mono_set(5, new_per_frame=6, vis=4, seed=13), os.path.join(out, "mono_n5.npz"), tmp)
+        run("Monocular", synth.make_mono_set(8, new_per_frame=5, vis=5, seed=14), os.path.join(out, "mono_n8.npz"), tmp)
+
+
+if __name__ == "__main__":
+    main()

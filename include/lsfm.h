@@ -1,0 +1,146 @@
+/* lsfm.h -- C ABI of the MI355X-native LinearSFM hot path (liblsfm_hip.so).
+ *
+ * Every entry point replaces one public method of the reference's CLinearSFMImp
+ * (/root/reference/linux/src/LinearSFMImp/LinearSFMImp.h, "Imp.h"; bodies in LinearSFMImp.cpp, "Imp.cpp").
+ * Plain pointers and sizes only; all arrays are HOST arrays in the reference's own layout unless the name
+ * says "dev".  Every function returns an int status: 0 ok, <0 invalid input / runtime failure, >0 numerical
+ * (PCG not converged / not positive definite).  The reference's methods are void and ignore CHOLMOD's
+ * status (Imp.cpp:2356, 7006).  There is NO CPU fallback: without a usable HIP device every call fails with
+ * LSFM_ERR_NO_DEVICE.
+ *
+ * Map layout (= LocalMapInfoStereo / LocalMapInfo, Imp.h:75-178):
+ *   stno[6m+3n]   labels: <=0 pose id (-stno, x6), >0 feature id (x3)
+ *   stVal[6m+3n]  poses (tx ty tz alpha beta gamma) then features (x y z)
+ *   U[nU*36]      6x6 row-major pose-pose information blocks, (Ui,Uj) block coordinates, Ui<=Uj, diagonal
+ *                 blocks stored full; several entries with the same coordinates add up
+ *   W[nW*18]      6x3 row-major pose-feature blocks, (photo, feature), sorted by feature, >=1 per feature
+ *   V[n*9]        3x3 feature blocks;  FBlock[n] first W index of each feature
+ *   Mono only:    ScaP (id of the scale pose), Fix (0..2 fixed translation axis of ScaP), Sign (+-1),
+ *                 FScaP / FFix (those of the map's first frame)
+ */
+#ifndef LSFM_H
+#define LSFM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSFM_OK 0
+#define LSFM_ERR_ARG (-1)
+#define LSFM_ERR_NO_DEVICE (-2)
+#define LSFM_ERR_HIP (-3)
+#define LSFM_ERR_OOM (-4)
+#define LSFM_ERR_INTERNAL (-5)
+#define LSFM_ERR_IO (-6)
+#define LSFM_NOT_CONVERGED 1
+
+typedef struct lsfm_context lsfm_context; /* one per GPU / stream; thread-compatible, not thread-safe */
+
+/* mirrors LocalMapInfoStereo / LocalMapInfo (Imp.h:75-178); arrays owned by whoever filled the struct */
+typedef struct lsfm_map {
+	int Ref, FRef, m, n, nU, nW;
+	int ScaP, Fix, Sign, FScaP, FFix; /* Mono only */
+	int* stno;
+	double* stVal;
+	double* U;
+	int *Ui, *Uj;
+	double* W;
+	int *photo, *feature;
+	double* V;
+	int* FBlock;
+} lsfm_map;
+
+typedef struct lsfm_stats {
+	/* whole run */
+	double t_total_ms;      /* region the reference times: Imp.cpp:1929 -> 2068 (all transforms + joins) */
+	double t_transform_ms, t_join_ms, t_schur_ms, t_pcg_ms, t_backsub_ms;
+	long pcg_iterations;    /* sum over levels of the iterations run (batched systems iterate together) */
+	long spmv_launches;
+	double spmv_ms;         /* HIP-event time of all SpMV launches, measured on the context's stream */
+	double spmv_bytes;      /* algorithmic bytes of all SpMV launches ("K10a") */
+	long spmv_nnzb_upper_last, spmv_rows_last; /* upper blocks / block rows of the last (top) system */
+	double max_rel_residual;/* max over systems of ||E - S x|| / ||E|| at exit */
+	int levels, joins, transforms;
+	int not_converged;      /* number of systems that hit the iteration cap */
+} lsfm_stats;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* device: HIP device ordinal.  arena_bytes: device memory reserved for maps and work space (0 = size on
+ * demand from the inputs of the first call).  Fails with LSFM_ERR_NO_DEVICE when no GPU is usable. */
+int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out);
+void lsfm_context_destroy(lsfm_context* ctx);
+/* PCG controls: relative tolerance on the preconditioned residual (default 1e-10), iteration cap per system
+ * = max_it_factor * (6m) + 200 (default factor 4). */
+int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor);
+const char* lsfm_last_error(lsfm_context* ctx);
+void* lsfm_stream(lsfm_context* ctx); /* hipStream_t the library launches on */
+
+/* frees the arrays of a map that the LIBRARY allocated (outputs of the functions below) */
+void lsfm_map_release(lsfm_map* g);
+
+/* ---- the three methods the reference's scheduler calls ------------------------------------------ */
+/* replaces CLinearSFMImp::lmj_Transform_PF3DStereo (Imp.h:206, Imp.cpp:349-1924): `in` expressed in the frame
+ * of its pose `Ref`.  out: library-allocated. */
+int lsfm_transform_stereo(lsfm_context* ctx, const lsfm_map* in, int Ref, lsfm_map* out);
+/* replaces lmj_Transform_PF3DMono (Imp.h:218, Imp.cpp:3173-6509) */
+int lsfm_transform_mono(lsfm_context* ctx, const lsfm_map* in, int Ref, int ScaP, int Fix, lsfm_map* out);
+
+/* replaces lmj_LinearLS_PF3DStereo (Imp.h:207, Imp.cpp:2551-2978): joins End (already in Cur's frame) with Cur
+ * and solves.  Unlike the reference (which frees both inputs, Imp.cpp:2937-2958, and publishes the result in
+ * the member m_GMapS) inputs are left untouched and the joint map is returned in `joint`.
+ * eP_out[6m] / eF_out[3n] (optional, may be NULL) receive the assembled right-hand sides. */
+int lsfm_join_stereo(lsfm_context* ctx, const lsfm_map* End, const lsfm_map* Cur, lsfm_map* joint,
+                     double* eP_out, double* eF_out);
+/* replaces lmj_LinearLS_PF3DMono (Imp.h:221, Imp.cpp:7282-7874).  The reference unwraps the scale-pose angles of
+ * both inputs in place (Imp.cpp:7427-7465); here the inputs stay const and the unwrapped values are used inside. */
+int lsfm_join_mono(lsfm_context* ctx, const lsfm_map* End, const lsfm_map* Cur, lsfm_map* joint,
+                   double* eP_out, double* eF_out);
+
+/* replaces lmj_solveLinearSFMStereo (Imp.h:209, Imp.cpp:2119-2378), same argument list + context.
+ * Schur complement on the features, preconditioned CG on the camera system (instead of CHOLMOD),
+ * back-substitution.  Writes stVal[0..6m+3n).  x0 (optional, may be NULL): initial guess for the 6m pose
+ * scalars.  V is read only (the reference inverts it in place and restores it). */
+int lsfm_solve_stereo(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U,
+                      const double* W, const double* V, const int* Ui, const int* Uj, const int* photo,
+                      const int* feature, int m, int n, int nU, int nW, const double* x0);
+/* replaces lmj_solveLinearSFMMono (Imp.h:223, Imp.cpp:6756-7041); Ref/ScaP/Fix/Sign/FixBlk as at the reference's
+ * call site Imp.cpp:7860-7864 (Ref = block index of the reference pose, ScaP = its scalar offset, Fix = scalar
+ * index of the gauge-fixed translation). */
+int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U,
+                    const double* W, const double* V, const int* Ui, const int* Uj, const int* photo,
+                    const int* feature, int m, int n, int nU, int nW, int Ref, int ScaP, int Fix, int Sign,
+                    int FixBlk, const double* x0);
+
+/* ---- the scheduler itself ------------------------------------------------------------------------ */
+/* replaces lmj_PF3D_Divide_Conquer{Stereo,Mono} (Imp.h:205/220, Imp.cpp:1926-2063 / 6511-6630): hierarchical
+ * join of maps[0..N) with the reference's binary-tree order; all joins of one tree level run as ONE batch on
+ * the device.  maps are read only.  mono: 0 Stereo, 1 Monocular.  out: library-allocated final map.
+ * Two phases so that a caller (bench) can time the device part with inputs resident in HBM:
+ *   lsfm_tree_upload   copies the N maps to the device (PCIe), returns a handle
+ *   lsfm_tree_run      runs the whole tree on the device (this is the region the reference times)
+ *   lsfm_tree_download copies the final map back;  lsfm_tree_free releases the handle. */
+typedef struct lsfm_tree lsfm_tree;
+int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_tree** out);
+int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* tree, lsfm_stats* stats);
+int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
+void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* tree);
+/* convenience: upload + run + download */
+int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_map* out, lsfm_stats* stats);
+
+/* ---- file formats (Imp.cpp:3044-3132, 6660-6754, 2102-2117, 7876-7967) ---------------------------- */
+int lsfm_read_localmap(const char* path, int mono, lsfm_map* out); /* out: library-allocated */
+int lsfm_save_state(const char* path, const double* st, const int* stno, int n);
+int lsfm_save_poses(const char* pose_path, const char* feat_path, const int* stno, const double* st, int n);
+
+/* ---- stand-alone kernel entry for measurement: y = S x on a symmetric 6x6-block matrix given as upper block
+ * CSR (rowptr[m+1], colidx[nnzb], val[nnzb*36], diagonal blocks full); runs `reps` launches and returns the
+ * average launch time in ms measured with HIP events on the context's stream. */
+int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val,
+                    const double* x, double* y, int reps, double* avg_ms, double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,263 @@
+"""ctypes binding of liblsfm_hip.so (C ABI: include/lsfm.h).
+
+This module is plumbing only: every numerical step runs in the hand-written HIP library.  There is no CPU
+fallback -- importing works anywhere, but creating a Context without a usable MI355X (or without the built
+library) raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsfm_hip.so")
+_LIB = None
+
+LSFM_OK = 0
+LSFM_NOT_CONVERGED = 1
+
+
+class LsfmMap(C.Structure):
+    _fields_ = [("Ref", C.c_int), ("FRef", C.c_int), ("m", C.c_int), ("n", C.c_int), ("nU", C.c_int), ("nW", C.c_int),
+                ("ScaP", C.c_int), ("Fix", C.c_int), ("Sign", C.c_int), ("FScaP", C.c_int), ("FFix", C.c_int),
+                ("stno", C.POINTER(C.c_int)), ("stVal", C.POINTER(C.c_double)),
+                ("U", C.POINTER(C.c_double)), ("Ui", C.POINTER(C.c_int)), ("Uj", C.POINTER(C.c_int)),
+                ("W", C.POINTER(C.c_double)), ("photo", C.POINTER(C.c_int)), ("feature", C.POINTER(C.c_int)),
+                ("V", C.POINTER(C.c_double)), ("FBlock", C.POINTER(C.c_int))]
+
+
+class LsfmStats(C.Structure):
+    _fields_ = [("t_total_ms", C.c_double), ("t_transform_ms", C.c_double), ("t_join_ms", C.c_double),
+                ("t_schur_ms", C.c_double), ("t_pcg_ms", C.c_double), ("t_backsub_ms", C.c_double),
+                ("pcg_iterations", C.c_long), ("spmv_launches", C.c_long), ("spmv_ms", C.c_double),
+                ("spmv_bytes", C.c_double), ("spmv_nnzb_upper_last", C.c_long), ("spmv_rows_last", C.c_long),
+                ("max_rel_residual", C.c_double), ("levels", C.c_int), ("joins", C.c_int), ("transforms", C.c_int),
+                ("not_converged", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class LsfmError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise LsfmError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        dp, ip, vp = P(C.c_double), P(C.c_int), C.c_void_p
+        L.lsfm_context_create.argtypes = [C.c_int, C.c_size_t, P(vp)]
+        L.lsfm_context_destroy.argtypes = [vp]
+        L.lsfm_context_destroy.restype = None
+        L.lsfm_set_pcg.argtypes = [vp, C.c_double, C.c_int]
+        L.lsfm_last_error.argtypes = [vp]
+        L.lsfm_last_error.restype = C.c_char_p
+        L.lsfm_stream.argtypes = [vp]
+        L.lsfm_stream.restype = vp
+        L.lsfm_map_release.argtypes = [P(LsfmMap)]
+        L.lsfm_map_release.restype = None
+        L.lsfm_transform_stereo.argtypes = [vp, P(LsfmMap), C.c_int, P(LsfmMap)]
+        L.lsfm_transform_mono.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, C.c_int, P(LsfmMap)]
+        L.lsfm_join_stereo.argtypes = [vp, P(LsfmMap), P(LsfmMap), P(LsfmMap), dp, dp]
+        L.lsfm_join_mono.argtypes = [vp, P(LsfmMap), P(LsfmMap), P(LsfmMap), dp, dp]
+        L.lsfm_solve_stereo.argtypes = [vp, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.lsfm_solve_mono.argtypes = [vp, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.lsfm_tree_upload.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(vp)]
+        L.lsfm_tree_run.argtypes = [vp, vp, P(LsfmStats)]
+        L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
+        L.lsfm_tree_free.argtypes = [vp, vp]
+        L.lsfm_tree_free.restype = None
+        L.lsfm_divide_conquer.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(LsfmMap), P(LsfmStats)]
+        L.lsfm_read_localmap.argtypes = [C.c_char_p, C.c_int, P(LsfmMap)]
+        L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
+        L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
+        L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
+        _LIB = L
+    return _LIB
+
+
+EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_last_error", "lsfm_stream",
+           "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
+           "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_download",
+           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_save_state", "lsfm_save_poses",
+           "lsfm_spmv_bench"]
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype).reshape(-1)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class HostMap:
+    """A map in the reference layout whose arrays are owned by numpy; `.c` is the lsfm_map view."""
+
+    def __init__(self, d):
+        g = d if isinstance(d, dict) else d.__dict__
+        self.stno = _c(g["stno"], np.int32); self.stVal = _c(g["stVal"], np.float64)
+        self.U = _c(g["U"], np.float64); self.Ui = _c(g["Ui"], np.int32); self.Uj = _c(g["Uj"], np.int32)
+        self.W = _c(g["W"], np.float64); self.photo = _c(g["photo"], np.int32); self.feature = _c(g["feature"], np.int32)
+        self.V = _c(g["V"], np.float64); self.FBlock = _c(g["FBlock"], np.int32)
+        c = LsfmMap()
+        c.Ref = int(g["Ref"]); c.FRef = int(g.get("FRef", g["Ref"])); c.m = int(g["m"]); c.n = int(g["n"])
+        c.nU = len(self.Ui); c.nW = len(self.photo)
+        c.ScaP = int(g.get("ScaP", 0)); c.Fix = int(g.get("Fix", 0)); c.Sign = int(g.get("Sign", 1))
+        c.FScaP = int(g.get("FScaP", c.ScaP)); c.FFix = int(g.get("FFix", c.Fix))
+        c.stno = _ptr(self.stno, C.c_int); c.stVal = _ptr(self.stVal, C.c_double)
+        c.U = _ptr(self.U, C.c_double); c.Ui = _ptr(self.Ui, C.c_int); c.Uj = _ptr(self.Uj, C.c_int)
+        c.W = _ptr(self.W, C.c_double); c.photo = _ptr(self.photo, C.c_int); c.feature = _ptr(self.feature, C.c_int)
+        c.V = _ptr(self.V, C.c_double); c.FBlock = _ptr(self.FBlock, C.c_int)
+        self.c = c
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def map_to_dict(g: LsfmMap, release=True):
+    r = 6 * g.m + 3 * g.n
+    d = dict(Ref=g.Ref, FRef=g.FRef, m=g.m, n=g.n, nU=g.nU, nW=g.nW, ScaP=g.ScaP, Fix=g.Fix, Sign=g.Sign,
+             FScaP=g.FScaP, FFix=g.FFix,
+             stno=_arr(g.stno, r, np.int32), stVal=_arr(g.stVal, r, np.float64),
+             U=_arr(g.U, 36 * g.nU, np.float64).reshape(-1, 36), Ui=_arr(g.Ui, g.nU, np.int32), Uj=_arr(g.Uj, g.nU, np.int32),
+             W=_arr(g.W, 18 * g.nW, np.float64).reshape(-1, 18), photo=_arr(g.photo, g.nW, np.int32),
+             feature=_arr(g.feature, g.nW, np.int32), V=_arr(g.V, 9 * g.n, np.float64).reshape(-1, 9),
+             FBlock=_arr(g.FBlock, g.n, np.int32))
+    if release:
+        lib().lsfm_map_release(C.byref(g))
+    return d
+
+
+class Context:
+    """One per GPU.  Raises LsfmError when no HIP device is usable (the library has no CPU path)."""
+
+    def __init__(self, device=0, arena_bytes=0):
+        self._h = C.c_void_p()
+        rc = lib().lsfm_context_create(int(device), int(arena_bytes), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise LsfmError(f"lsfm_context_create failed (rc={rc}): no usable HIP device -- there is no CPU fallback")
+
+    def close(self):
+        if self._h:
+            lib().lsfm_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise LsfmError(f"{what} failed (rc={rc}): {lib().lsfm_last_error(self._h).decode()}")
+        return rc
+
+    def set_pcg(self, rel_tol=1e-10, max_it_factor=4):
+        self._check(lib().lsfm_set_pcg(self._h, float(rel_tol), int(max_it_factor)), "lsfm_set_pcg")
+
+    def stream(self):
+        return lib().lsfm_stream(self._h)
+
+    # ---- the reference's three scheduler-facing methods -------------------------------------------------
+    def transform(self, d, mono, Ref, ScaP=0, Fix=0):
+        hm = HostMap(d)
+        out = LsfmMap()
+        if mono:
+            rc = lib().lsfm_transform_mono(self._h, C.byref(hm.c), int(Ref), int(ScaP), int(Fix), C.byref(out))
+        else:
+            rc = lib().lsfm_transform_stereo(self._h, C.byref(hm.c), int(Ref), C.byref(out))
+        self._check(rc, "lsfm_transform")
+        return map_to_dict(out)
+
+    def join(self, dEnd, dCur, mono):
+        """Returns (joint dict with solved state, eP, eF, rc)."""
+        he, hc = HostMap(dEnd), HostMap(dCur)
+        out = LsfmMap()
+        m = he.c.m + hc.c.m - (2 if mono else 0)
+        eP = np.zeros(6 * m)
+        eF = np.zeros(3 * (he.c.n + hc.c.n))
+        fn = lib().lsfm_join_mono if mono else lib().lsfm_join_stereo
+        rc = self._check(fn(self._h, C.byref(he.c), C.byref(hc.c), C.byref(out), _ptr(eP, C.c_double), _ptr(eF, C.c_double)),
+                         "lsfm_join")
+        j = map_to_dict(out)
+        return j, eP, eF[:3 * j["n"]], rc
+
+    def solve(self, j, eP, eF, mono, sa=None, x0=None):
+        m, n = int(j["m"]), int(j["n"])
+        st = np.zeros(6 * m + 3 * n)
+        U = _c(j["U"], np.float64); W = _c(j["W"], np.float64); V = _c(j["V"], np.float64)
+        Ui = _c(j["Ui"], np.int32); Uj = _c(j["Uj"], np.int32); ph = _c(j["photo"], np.int32); fe = _c(j["feature"], np.int32)
+        eP = _c(eP, np.float64); eF = _c(eF, np.float64)
+        x0p = _ptr(_c(x0, np.float64), C.c_double) if x0 is not None else None
+        d, i = C.c_double, C.c_int
+        if mono:
+            rc = lib().lsfm_solve_mono(self._h, _ptr(st, d), _ptr(eF, d), _ptr(eP, d), _ptr(U, d), _ptr(W, d), _ptr(V, d),
+                                       _ptr(Ui, i), _ptr(Uj, i), _ptr(ph, i), _ptr(fe, i), m, n, len(Ui), len(ph),
+                                       sa[0], sa[1], sa[2], sa[3], sa[4], x0p)
+        else:
+            rc = lib().lsfm_solve_stereo(self._h, _ptr(st, d), _ptr(eF, d), _ptr(eP, d), _ptr(U, d), _ptr(W, d), _ptr(V, d),
+                                         _ptr(Ui, i), _ptr(Uj, i), _ptr(ph, i), _ptr(fe, i), m, n, len(Ui), len(ph), x0p)
+        self._check(rc, "lsfm_solve")
+        return st, rc
+
+    # ---- the scheduler --------------------------------------------------------------------------------
+    def tree_upload(self, maps, mono):
+        hms = [HostMap(m) for m in maps]
+        arr = (LsfmMap * len(hms))(*[h.c for h in hms])
+        t = C.c_void_p()
+        self._check(lib().lsfm_tree_upload(self._h, arr, len(hms), int(mono), C.byref(t)), "lsfm_tree_upload")
+        return t
+
+    def tree_run(self, tree):
+        st = LsfmStats()
+        rc = self._check(lib().lsfm_tree_run(self._h, tree, C.byref(st)), "lsfm_tree_run")
+        return st.as_dict(), rc
+
+    def tree_download(self, tree):
+        out = LsfmMap()
+        self._check(lib().lsfm_tree_download(self._h, tree, C.byref(out)), "lsfm_tree_download")
+        return map_to_dict(out)
+
+    def tree_free(self, tree):
+        lib().lsfm_tree_free(self._h, tree)
+
+    def divide_conquer(self, maps, mono):
+        t = self.tree_upload(maps, mono)
+        try:
+            stats, rc = self.tree_run(t)
+            out = self.tree_download(t)
+        finally:
+            self.tree_free(t)
+        return out, stats, rc
+
+    def spmv_bench(self, rowptr, colidx, val, x, reps=20):
+        rowptr = _c(rowptr, np.int32); colidx = _c(colidx, np.int32); val = _c(val, np.float64); x = _c(x, np.float64)
+        m = len(rowptr) - 1
+        y = np.zeros(6 * m)
+        ms, by = C.c_double(), C.c_double()
+        self._check(lib().lsfm_spmv_bench(self._h, m, _ptr(rowptr, C.c_int), _ptr(colidx, C.c_int), _ptr(val, C.c_double),
+                                          _ptr(x, C.c_double), _ptr(y, C.c_double), int(reps), C.byref(ms), C.byref(by)),
+                    "lsfm_spmv_bench")
+        return y, ms.value, by.value
+
+
+def read_localmap(path, mono):
+    g = LsfmMap()
+    rc = lib().lsfm_read_localmap(str(path).encode(), int(mono), C.byref(g))
+    if rc:
+        raise LsfmError(f"lsfm_read_localmap({path}) failed (rc={rc})")
+    return map_to_dict(g)

@@ -1,0 +1,150 @@
+// Host maps (reference layout, Imp.h:75-178) <-> device batch (flat SoA with global indices).
+#include <cstdlib>
+
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+__global__ void k_fill_segment_ids(const int* __restrict__ off, int B, int* __restrict__ seg, int total)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total) return;
+	int lo = 0, hi = B; // largest b with off[b] <= i
+	while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+	seg[i] = lo;
+}
+
+void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b)
+{
+	b.d_pose_off = ar.alloc<int>(b.B + 1);
+	b.d_feat_off = ar.alloc<int>(b.B + 1);
+	h2d(ctx, b.d_pose_off, b.pose_off.data(), (b.B + 1) * sizeof(int));
+	h2d(ctx, b.d_feat_off, b.feat_off.data(), (b.B + 1) * sizeof(int));
+	b.pose_map = ar.alloc<int>(b.M);
+	b.feat_map = ar.alloc<int>(b.NF);
+	if (b.M) hipLaunchKernelGGL(k_fill_segment_ids, dim3((b.M + 255) / 256), dim3(256), 0, ctx->stream, b.d_pose_off, b.B, b.pose_map, b.M);
+	if (b.NF) hipLaunchKernelGGL(k_fill_segment_ids, dim3((b.NF + 255) / 256), dim3(256), 0, ctx->stream, b.d_feat_off, b.B, b.feat_map, b.NF);
+}
+
+void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, bool mono, DevBatch& o)
+{
+	o = DevBatch();
+	o.B = N;
+	o.pose_off.assign(N + 1, 0); o.feat_off.assign(N + 1, 0); o.u_off.assign(N + 1, 0); o.w_off.assign(N + 1, 0);
+	o.Ref.resize(N); o.FRef.resize(N); o.ScaP.assign(N, 0); o.Fix.assign(N, 0); o.Sign.assign(N, 1); o.FScaP.assign(N, 0); o.FFix.assign(N, 0);
+	for (int k = 0; k < N; k++)
+	{
+		const lsfm_map& g = maps[k];
+		if (g.m < 0 || g.n < 0 || g.nU < 0 || g.nW < 0) LSFM_FAIL(LSFM_ERR_ARG, "negative map size");
+		o.pose_off[k + 1] = o.pose_off[k] + g.m; o.feat_off[k + 1] = o.feat_off[k] + g.n;
+		o.u_off[k + 1] = o.u_off[k] + g.nU; o.w_off[k + 1] = o.w_off[k] + g.nW;
+		o.Ref[k] = g.Ref; o.FRef[k] = g.FRef;
+		if (mono) { o.ScaP[k] = g.ScaP; o.Fix[k] = g.Fix; o.Sign[k] = g.Sign; o.FScaP[k] = g.FScaP; o.FFix[k] = g.FFix; }
+	}
+	o.M = o.pose_off[N]; o.NF = o.feat_off[N]; o.NU = o.u_off[N]; o.NW = o.w_off[N];
+	std::vector<double> pose((size_t)o.M * 6), feat((size_t)o.NF * 3);
+	std::vector<int> pid(o.M), fid(o.NF), Ui(o.NU), Uj(o.NU), photo(o.NW), feature(o.NW), fptr(o.NF + 1);
+	for (int k = 0; k < N; k++)
+	{
+		const lsfm_map& g = maps[k];
+		int po = o.pose_off[k], fo = o.feat_off[k], uo = o.u_off[k], wo = o.w_off[k];
+		for (int i = 0; i < g.m; i++)
+		{
+			if (g.stno[6 * i] > 0) LSFM_FAIL(LSFM_ERR_ARG, "state label of a pose must be <= 0");
+			pid[po + i] = -g.stno[6 * i];
+			memcpy(&pose[(size_t)(po + i) * 6], g.stVal + 6 * i, 6 * sizeof(double));
+		}
+		for (int i = 0; i < g.n; i++)
+		{
+			if (g.stno[6 * g.m + 3 * i] <= 0) LSFM_FAIL(LSFM_ERR_ARG, "state label of a feature must be > 0");
+			fid[fo + i] = g.stno[6 * g.m + 3 * i];
+			memcpy(&feat[(size_t)(fo + i) * 3], g.stVal + 6 * g.m + 3 * i, 3 * sizeof(double));
+		}
+		for (int i = 0; i < g.nU; i++)
+		{
+			if (g.Ui[i] < 0 || g.Uj[i] >= g.m || g.Ui[i] > g.Uj[i]) LSFM_FAIL(LSFM_ERR_ARG, "U block coordinates must satisfy 0 <= Ui <= Uj < m");
+			Ui[uo + i] = g.Ui[i] + po; Uj[uo + i] = g.Uj[i] + po;
+		}
+		// W must be sorted by feature and every feature must own at least one block (the reference's solver
+		// derives the run lengths from feature[] under the same assumption, Imp.cpp:2134-2153)
+		int j = 0;
+		for (int f = 0; f < g.n; f++)
+		{
+			fptr[fo + f] = wo + j;
+			int j0 = j;
+			while (j < g.nW && g.feature[j] == f) j++;
+			if (j == j0) LSFM_FAIL(LSFM_ERR_ARG, "every feature needs at least one W block, W sorted by feature");
+		}
+		if (j != g.nW) LSFM_FAIL(LSFM_ERR_ARG, "W is not sorted by feature");
+		for (int i = 0; i < g.nW; i++)
+		{
+			if (g.photo[i] < 0 || g.photo[i] >= g.m) LSFM_FAIL(LSFM_ERR_ARG, "photo index out of range");
+			photo[wo + i] = g.photo[i] + po; feature[wo + i] = g.feature[i] + fo;
+		}
+	}
+	fptr[o.NF] = o.NW;
+	o.pose = ar.alloc<double>((size_t)o.M * 6); o.pose_id = ar.alloc<int>(o.M);
+	o.feat = ar.alloc<double>((size_t)o.NF * 3); o.feat_id = ar.alloc<int>(o.NF);
+	o.U = ar.alloc<double>((size_t)o.NU * 36); o.Ui = ar.alloc<int>(o.NU); o.Uj = ar.alloc<int>(o.NU);
+	o.W = ar.alloc<double>((size_t)o.NW * 18); o.photo = ar.alloc<int>(o.NW); o.feature = ar.alloc<int>(o.NW);
+	o.fptr = ar.alloc<int>(o.NF + 1); o.V = ar.alloc<double>((size_t)o.NF * 9);
+	h2d(ctx, o.pose, pose.data(), pose.size() * sizeof(double)); h2d(ctx, o.pose_id, pid.data(), pid.size() * sizeof(int));
+	h2d(ctx, o.feat, feat.data(), feat.size() * sizeof(double)); h2d(ctx, o.feat_id, fid.data(), fid.size() * sizeof(int));
+	h2d(ctx, o.Ui, Ui.data(), Ui.size() * sizeof(int)); h2d(ctx, o.Uj, Uj.data(), Uj.size() * sizeof(int));
+	h2d(ctx, o.photo, photo.data(), photo.size() * sizeof(int)); h2d(ctx, o.feature, feature.data(), feature.size() * sizeof(int));
+	h2d(ctx, o.fptr, fptr.data(), fptr.size() * sizeof(int));
+	// the big value arrays go map by map straight from the caller's buffers
+	for (int k = 0; k < N; k++)
+	{
+		const lsfm_map& g = maps[k];
+		if (g.nU) LSFM_CHECK_HIP(hipMemcpyAsync(o.U + (size_t)o.u_off[k] * 36, g.U, (size_t)g.nU * 36 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		if (g.nW) LSFM_CHECK_HIP(hipMemcpyAsync(o.W + (size_t)o.w_off[k] * 18, g.W, (size_t)g.nW * 18 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		if (g.n) LSFM_CHECK_HIP(hipMemcpyAsync(o.V + (size_t)o.feat_off[k] * 9, g.V, (size_t)g.n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	}
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+	batch_set_offsets(ctx, ar, o);
+}
+
+template <class T> static T* host_alloc(size_t n) { return static_cast<T*>(malloc((n ? n : 1) * sizeof(T))); }
+
+void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, lsfm_map* g)
+{
+	memset(g, 0, sizeof *g);
+	int po = b.pose_off[k], fo = b.feat_off[k];
+	int m = b.pose_off[k + 1] - po, n = b.feat_off[k + 1] - fo;
+	// u_off / w_off of the batch are kept on the host by every stage
+	int uo = b.u_off[k], wo = b.w_off[k], nU = b.u_off[k + 1] - uo, nW = b.w_off[k + 1] - wo;
+	g->m = m; g->n = n; g->nU = nU; g->nW = nW; g->Ref = b.Ref[k]; g->FRef = b.FRef[k];
+	if (mono) { g->ScaP = b.ScaP[k]; g->Fix = b.Fix[k]; g->Sign = b.Sign[k]; g->FScaP = b.FScaP[k]; g->FFix = b.FFix[k]; }
+	int r = 6 * m + 3 * n;
+	g->stno = host_alloc<int>(r); g->stVal = host_alloc<double>(r);
+	g->U = host_alloc<double>((size_t)nU * 36); g->Ui = host_alloc<int>(nU); g->Uj = host_alloc<int>(nU);
+	g->W = host_alloc<double>((size_t)nW * 18); g->photo = host_alloc<int>(nW); g->feature = host_alloc<int>(nW);
+	g->V = host_alloc<double>((size_t)n * 9); g->FBlock = host_alloc<int>(n);
+	std::vector<int> pid(m), fid(n), fptr(n + 1);
+	d2h(ctx, pid.data(), b.pose_id + po, m * sizeof(int));
+	d2h(ctx, fid.data(), b.feat_id + fo, n * sizeof(int));
+	d2h(ctx, g->stVal, b.pose + (size_t)po * 6, (size_t)m * 6 * sizeof(double));
+	d2h(ctx, g->stVal + 6 * m, b.feat + (size_t)fo * 3, (size_t)n * 3 * sizeof(double));
+	for (int i = 0; i < m; i++) for (int c = 0; c < 6; c++) g->stno[6 * i + c] = -pid[i];
+	for (int i = 0; i < n; i++) for (int c = 0; c < 3; c++) g->stno[6 * m + 3 * i + c] = fid[i];
+	d2h(ctx, g->U, b.U + (size_t)uo * 36, (size_t)nU * 36 * sizeof(double));
+	d2h(ctx, g->Ui, b.Ui + uo, nU * sizeof(int)); d2h(ctx, g->Uj, b.Uj + uo, nU * sizeof(int));
+	for (int i = 0; i < nU; i++) { g->Ui[i] -= po; g->Uj[i] -= po; }
+	d2h(ctx, g->W, b.W + (size_t)wo * 18, (size_t)nW * 18 * sizeof(double));
+	d2h(ctx, g->photo, b.photo + wo, nW * sizeof(int)); d2h(ctx, g->feature, b.feature + wo, nW * sizeof(int));
+	for (int i = 0; i < nW; i++) { g->photo[i] -= po; g->feature[i] -= fo; }
+	d2h(ctx, g->V, b.V + (size_t)fo * 9, (size_t)n * 9 * sizeof(double));
+	d2h(ctx, fptr.data(), b.fptr + fo, (n + 1) * sizeof(int));
+	for (int i = 0; i < n; i++) g->FBlock[i] = fptr[i] - wo;
+}
+
+} // namespace lsfm
+
+extern "C" void lsfm_map_release(lsfm_map* g)
+{
+	if (!g) return;
+	free(g->stno); free(g->stVal); free(g->U); free(g->Ui); free(g->Uj); free(g->W); free(g->photo); free(g->feature);
+	free(g->V); free(g->FBlock);
+	memset(g, 0, sizeof *g);
+}

@@ -1,0 +1,303 @@
+// C ABI (include/lsfm.h) and the tree scheduler that replaces lmj_PF3D_Divide_Conquer{Stereo,Mono}
+// (Imp.cpp:1926-2063 / 6511-6630): every level of the reference's binary join tree runs as ONE batch.
+#include <chrono>
+#include <cmath>
+
+#include "lsfm_internal.hpp"
+
+using namespace lsfm;
+
+struct lsfm_tree {
+	bool mono = false;
+	int N = 0;
+	DevBatch level;   // current level (lives in ctx->arena[slot])
+	int slot = 0;
+	bool done = false;
+};
+
+namespace {
+
+double now_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <class F> int guarded(lsfm_context* ctx, F&& f)
+{
+	if (!ctx) return LSFM_ERR_ARG;
+	try
+	{
+		if (hipSetDevice(ctx->device) != hipSuccess) return LSFM_ERR_NO_DEVICE;
+		return f();
+	}
+	catch (const Error& e)
+	{
+		ctx->last_error = e.msg;
+		fprintf(stderr, "liblsfm_hip: %s\n", e.msg.c_str());
+		(void)hipGetLastError();
+		return e.code;
+	}
+	catch (const std::exception& e)
+	{
+		ctx->last_error = e.what();
+		return LSFM_ERR_INTERNAL;
+	}
+}
+
+size_t estimate_arena(const lsfm_map* maps, int N, int levels)
+{
+	size_t nw = 0, nf = 0, nu = 0, m = 0;
+	for (int k = 0; k < N; k++) { nw += maps[k].nW; nf += maps[k].n; nu += maps[k].nU; m += maps[k].m; }
+	const size_t L = levels + 1;
+	size_t e = (nw + 2 * L * nf) * 160 * 3 + (nu + 3 * L * m) * 320 * 3 + nf * 400 + ((size_t)256 << 20);
+	return e;
+}
+
+int tree_levels(int N)
+{
+	int L = 0;
+	while (N > 1) { N = (N + 1) / 2; L++; }
+	return L;
+}
+
+// one level: transform the maps that need it, then join the pairs
+void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
+{
+	DevBatch& X = t->level;
+	const int B = X.B, npairs = B / 2;
+	std::vector<int> tref(B, -1), tscap(B, 0), tfix(B, 0);
+	int ntr = 0;
+	for (int i = 0; i < npairs; i++)
+	{
+		const int e = 2 * i, c = 2 * i + 1;
+		// odd outputs of the previous level go back to their first frame (Imp.cpp:1997-2025 / 6576-6602) ...
+		const bool re = X.Ref[c] > X.FRef[c];
+		int cref = X.Ref[c], cscap = X.ScaP[c], cfix = X.Fix[c];
+		if (re) { cref = X.FRef[c]; cscap = X.FScaP[c]; cfix = X.FFix[c]; tref[c] = cref; tscap[c] = cscap; tfix[c] = cfix; ntr++; }
+		// ... and End is expressed in Cur's frame (Imp.cpp:1964 / 6549)
+		tref[e] = cref; tscap[e] = cscap; tfix[e] = cfix; ntr++;
+	}
+	double t0 = now_ms();
+	Arena& other = ctx->arena[t->slot ^ 1];
+	other.reset();
+	DevBatch Xt;
+	transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt);
+	double t1 = now_ms();
+	Arena& mine = ctx->arena[t->slot];
+	mine.reset(); // X is dead from here on
+	DevBatch Y;
+	if (t->mono) LSFM_FAIL(LSFM_ERR_ARG, "Monocular joins are not implemented on the device yet");
+	join_batch_stereo(ctx, mine, Xt, Y, nullptr, nullptr);
+	double t2 = now_ms();
+	t->level = Y;
+	if (st)
+	{
+		st->t_transform_ms += t1 - t0;
+		st->t_join_ms += (t2 - t1);
+		st->levels++; st->joins += npairs; st->transforms += ntr;
+	}
+}
+
+void fill_host_map(const lsfm_map* src, lsfm_map* dst) { *dst = *src; }
+
+} // namespace
+
+extern "C" {
+
+int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_tree** out)
+{
+	if (!out || !maps || N <= 0) return LSFM_ERR_ARG;
+	*out = nullptr;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas(estimate_arena(maps, N, tree_levels(N)));
+		lsfm_tree* t = new lsfm_tree();
+		t->mono = mono != 0; t->N = N; t->slot = 0;
+		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
+		try { batch_upload(ctx, ctx->arena[0], maps, N, t->mono, t->level); }
+		catch (...) { delete t; throw; }
+		*out = t;
+		return LSFM_OK;
+	});
+}
+
+int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
+{
+	if (!t) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		lsfm_stats local;
+		memset(&local, 0, sizeof local);
+		lsfm_stats* st = stats ? stats : &local;
+		memset(st, 0, sizeof *st);
+		ctx->stats = st;
+		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		const double t0 = now_ms();
+		try
+		{
+			while (t->level.B > 1) run_level(ctx, t, st);
+			// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
+			DevBatch& X = t->level;
+			if (X.B == 1 && X.Ref[0] > X.FRef[0])
+			{
+				std::vector<int> tref(1, X.FRef[0]), tscap(1, X.FScaP[0]), tfix(1, X.FFix[0]);
+				Arena& other = ctx->arena[t->slot ^ 1];
+				other.reset();
+				DevBatch Xt;
+				const double a = now_ms();
+				transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt);
+				st->t_transform_ms += now_ms() - a;
+				st->transforms++;
+				t->level = Xt;
+				t->slot ^= 1;
+			}
+			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		}
+		catch (...) { ctx->stats = nullptr; throw; }
+		st->t_total_ms = now_ms() - t0;
+		ctx->stats = nullptr;
+		t->done = true;
+		return st->not_converged ? LSFM_NOT_CONVERGED : LSFM_OK;
+	});
+}
+
+int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)
+{
+	if (!t || !out) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		if (t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		batch_download_map(ctx, t->level, 0, t->mono, out);
+		return LSFM_OK;
+	});
+}
+
+void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* t)
+{
+	(void)ctx;
+	delete t;
+}
+
+int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_map* out, lsfm_stats* stats)
+{
+	lsfm_tree* t = nullptr;
+	int rc = lsfm_tree_upload(ctx, maps, N, mono, &t);
+	if (rc) return rc;
+	int rrc = lsfm_tree_run(ctx, t, stats);
+	if (rrc < 0) { lsfm_tree_free(ctx, t); return rrc; }
+	rc = lsfm_tree_download(ctx, t, out);
+	lsfm_tree_free(ctx, t);
+	return rc ? rc : rrc;
+}
+
+static int transform_one(lsfm_context* ctx, const lsfm_map* in, int Ref, int ScaP, int Fix, bool mono, lsfm_map* out)
+{
+	if (!in || !out) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas(estimate_arena(in, 1, 1));
+		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
+		DevBatch X, Y;
+		batch_upload(ctx, ctx->arena[0], in, 1, mono, X);
+		std::vector<int> tref(1, Ref), tscap(1, ScaP), tfix(1, Fix);
+		transform_batch(ctx, ctx->arena[1], X, tref, tscap, tfix, mono, Y);
+		batch_download_map(ctx, Y, 0, mono, out);
+		return LSFM_OK;
+	});
+}
+
+int lsfm_transform_stereo(lsfm_context* ctx, const lsfm_map* in, int Ref, lsfm_map* out) { return transform_one(ctx, in, Ref, 0, 0, false, out); }
+int lsfm_transform_mono(lsfm_context* ctx, const lsfm_map* in, int Ref, int ScaP, int Fix, lsfm_map* out)
+{
+	return transform_one(ctx, in, Ref, ScaP, Fix, true, out);
+}
+
+int lsfm_join_stereo(lsfm_context* ctx, const lsfm_map* End, const lsfm_map* Cur, lsfm_map* joint, double* eP_out, double* eF_out)
+{
+	if (!End || !Cur || !joint) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		lsfm_map two[2] = { *End, *Cur };
+		ctx->ensure_arenas(estimate_arena(two, 2, 1));
+		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
+		DevBatch X, Y;
+		batch_upload(ctx, ctx->arena[0], two, 2, false, X);
+		lsfm_stats st;
+		memset(&st, 0, sizeof st);
+		ctx->stats = &st;
+		try { join_batch_stereo(ctx, ctx->arena[1], X, Y, eP_out, eF_out); }
+		catch (...) { ctx->stats = nullptr; throw; }
+		ctx->stats = nullptr;
+		batch_download_map(ctx, Y, 0, false, joint);
+		return st.not_converged ? LSFM_NOT_CONVERGED : LSFM_OK;
+	});
+}
+
+int lsfm_join_mono(lsfm_context* ctx, const lsfm_map*, const lsfm_map*, lsfm_map*, double*, double*)
+{
+	if (ctx) ctx->last_error = "lsfm_join_mono: not implemented on the device yet";
+	return LSFM_ERR_ARG;
+}
+
+// raw-pointer solver with the reference's argument list (Imp.h:209)
+int lsfm_solve_stereo(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                      const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU,
+                      int nW, const double* x0)
+{
+	if (!stVal || m <= 0 || n < 0 || nU < 0 || nW < 0) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		size_t need = ((size_t)nW * 200 + (size_t)nU * 400 + (size_t)n * 300 + (size_t)m * 4000) * 3 + ((size_t)128 << 20);
+		ctx->ensure_arenas(need);
+		ctx->arena[0].reset(); ctx->scratch.reset();
+		Arena& ar = ctx->arena[0];
+		std::vector<int> fptr(n + 1);
+		{
+			int j = 0;
+			for (int f = 0; f < n; f++)
+			{
+				fptr[f] = j;
+				while (j < nW && feature[j] == f) j++;
+				if (j == fptr[f]) LSFM_FAIL(LSFM_ERR_ARG, "every feature needs at least one W block, W sorted by feature");
+			}
+			if (j != nW) LSFM_FAIL(LSFM_ERR_ARG, "W is not sorted by feature");
+			fptr[n] = nW;
+		}
+		double* dU = ar.alloc<double>((size_t)nU * 36); int* dUi = ar.alloc<int>(nU); int* dUj = ar.alloc<int>(nU);
+		double* dW = ar.alloc<double>((size_t)nW * 18); int* dph = ar.alloc<int>(nW); int* dfp = ar.alloc<int>(n + 1);
+		double* dV = ar.alloc<double>((size_t)n * 9); double* dea = ar.alloc<double>((size_t)m * 6); double* deb = ar.alloc<double>((size_t)n * 3);
+		double* dx0 = x0 ? ar.alloc<double>((size_t)m * 6) : nullptr;
+		double* dxp = ar.alloc<double>((size_t)m * 6); double* dxf = ar.alloc<double>((size_t)n * 3);
+		int* dseg = ar.alloc<int>(m + n + 1);
+		h2d(ctx, dU, U, (size_t)nU * 36 * sizeof(double)); h2d(ctx, dUi, Ui, nU * sizeof(int)); h2d(ctx, dUj, Uj, nU * sizeof(int));
+		h2d(ctx, dW, W, (size_t)nW * 18 * sizeof(double)); h2d(ctx, dph, photo, nW * sizeof(int)); h2d(ctx, dfp, fptr.data(), (n + 1) * sizeof(int));
+		h2d(ctx, dV, V, (size_t)n * 9 * sizeof(double)); h2d(ctx, dea, ea, (size_t)m * 6 * sizeof(double)); h2d(ctx, deb, eb, (size_t)n * 3 * sizeof(double));
+		if (x0) h2d(ctx, dx0, x0, (size_t)m * 6 * sizeof(double));
+		dev_zero(ctx, dseg, (m + n + 1) * sizeof(int));
+		SolveIO io;
+		io.M = m; io.NF = n; io.NU = nU; io.NW = nW; io.nseg = 1;
+		io.d_pose_seg = dseg; io.d_feat_seg = dseg + m; io.d_seg_active = nullptr;
+		io.U = dU; io.Ui = dUi; io.Uj = dUj; io.W = dW; io.photo = dph; io.fptr = dfp; io.V = dV;
+		io.ea = dea; io.eb = deb; io.x0 = dx0; io.x_pose = dxp; io.x_feat = dxf;
+		io.seg_rows.assign(1, m);
+		int rc = solve_batch(ctx, io);
+		d2h(ctx, stVal, dxp, (size_t)m * 6 * sizeof(double));
+		d2h(ctx, stVal + 6 * m, dxf, (size_t)n * 3 * sizeof(double));
+		return rc ? LSFM_NOT_CONVERGED : LSFM_OK;
+	});
+}
+
+int lsfm_solve_mono(lsfm_context* ctx, double*, const double*, const double*, const double*, const double*, const double*, const int*,
+                    const int*, const int*, const int*, int, int, int, int, int, int, int, int, int, const double*)
+{
+	if (ctx) ctx->last_error = "lsfm_solve_mono: not implemented on the device yet";
+	return LSFM_ERR_ARG;
+}
+
+int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y,
+                    int reps, double* avg_ms, double* algorithmic_bytes)
+{
+	if (!rowptr || !colidx || !val || !x || !y || m <= 0) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas(((size_t)rowptr[m] * 400 + (size_t)m * 1000) * 2 + ((size_t)64 << 20));
+		ctx->scratch.reset();
+		return spmv_external(ctx, m, rowptr, colidx, val, x, y, reps, avg_ms, algorithmic_bytes);
+	});
+}
+
+} // extern "C"

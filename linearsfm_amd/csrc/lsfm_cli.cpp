@@ -1,0 +1,112 @@
+// LinearSFM command line on top of liblsfm_hip: same flags, files and progress lines as the reference's console
+// program (main: linux/src/LinearSFM/LinearSFM.cpp:9-18, parser: LinearSFMImp.cpp:7989-8087, help: 8089-8105).
+//   LinearSFM -path <dir> -num <N> -type Monocular|Stereo [-p <poses>] [-f <features>] [-st <state>] [-help]
+// Extra flags that do not collide with the reference's: -gpu <ordinal>, -tol <pcg rel tol>, -full <file> (final state
+// at %.17g), -stats 1 (timing breakdown on stderr).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lsfm.h"
+
+static void print_help()
+{
+	printf("Linear SFM Solution General Options\n");
+	printf("\n");
+	printf("-path			Set Data Path.\n");
+	printf("-st            Set Path to Save Final State Vector\n");
+	printf("-p			Set Path to Save Poses\n");
+	printf("-f			Set Path to Save Features\n");
+	printf("-num			Number of Initial Recontruction\n");
+	printf("-type			Set Data Type.\n");
+	printf("Data Type Listed As Following:\n");
+	printf("			I  : Monocular\n");
+	printf("			II : Stereo\n");
+	printf("\n");
+}
+
+int main(int argc, char** argv)
+{
+	std::string path, st, pose, fea, full;
+	int num = 0, type = -1, gpu = 0, want_stats = 0;
+	bool has_path = false, has_num = false;
+	double tol = 0;
+	for (int i = 1; i < argc; i++)
+	{
+		std::string name = argv[i];
+		if (name[0] != '-') return 0; // each param has to start with at least one dash (Imp.cpp:8000-8002)
+		size_t d = name.find_first_not_of('-');
+		if (d != std::string::npos) name = name.substr(d);
+		if (name == "help") { print_help(); return 0; }
+		auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
+		if (name == "path") { path = next(); has_path = true; }
+		else if (name == "st") st = next();
+		else if (name == "p") pose = next();
+		else if (name == "f") fea = next();
+		else if (name == "num") { num = atoi(next()); has_num = true; }
+		else if (name == "type")
+		{
+			std::string v = next();
+			if (v == "Monocular") type = 1;
+			if (v == "Stereo") type = 0;
+		}
+		else if (name == "gpu") gpu = atoi(next());
+		else if (name == "tol") tol = atof(next());
+		else if (name == "full") full = next();
+		else if (name == "stats") want_stats = atoi(next());
+	}
+	if (!has_path) { printf("LinerSFM Error: Please Input Right File Path:\n"); return 0; }
+	if (!has_num) { printf("LinerSFM Error: Please Set Local Map Number:\n"); return 0; }
+	if (type < 0) { printf("LinerSFM Error: Please Set Data Type:\n"); return 0; }
+
+	std::vector<lsfm_map> maps(num);
+	for (int k = 0; k < num; k++)
+	{
+		char fn[4096];
+		snprintf(fn, sizeof fn, "%s/localmap_%d.txt", path.c_str(), k + 1); // Imp.cpp:125
+		if (lsfm_read_localmap(fn, type, &maps[k])) { fprintf(stderr, "LinearSFM: cannot read %s\n", fn); return 1; }
+	}
+	lsfm_context* ctx = nullptr;
+	int rc = lsfm_context_create(gpu, 0, &ctx);
+	if (rc) { fprintf(stderr, "LinearSFM: no HIP device (rc=%d); this build has no CPU path\n", rc); return 2; }
+	if (tol > 0) lsfm_set_pcg(ctx, tol, 4);
+	// progress lines of the reference (Imp.cpp:1952, 1995)
+	{
+		int cnt = num, L = 0;
+		while (cnt > 1)
+		{
+			int N2 = cnt % 2;
+			cnt = (int)(cnt / 2.0 + 0.5);
+			for (int i = 0; i < cnt; i++)
+			{
+				int NumLM = (i < cnt - 1 || N2 == 0) ? 2 : 1;
+				for (int j = 0; j < NumLM; j++) printf("Join Level %d Local Map %d\n", L, 2 * i + j + 1);
+				printf("Generate Level %d Local Map %d\n\n", L + 1, i + 1);
+			}
+			L++;
+		}
+	}
+	lsfm_map out;
+	lsfm_stats stats;
+	rc = lsfm_divide_conquer(ctx, maps.data(), num, type, &out, &stats);
+	if (rc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
+	printf("Total Used Time:  %lf  sec\n\n", stats.t_total_ms * 1e-3); // Imp.cpp:2072
+	if (want_stats)
+		fprintf(stderr, "lsfm: total %.3f ms (transform %.3f, join %.3f [schur %.3f, pcg %.3f, backsub %.3f]), pcg its %ld, max rel resid %.2e, not converged %d\n",
+		        stats.t_total_ms, stats.t_transform_ms, stats.t_join_ms, stats.t_schur_ms, stats.t_pcg_ms, stats.t_backsub_ms, stats.pcg_iterations,
+		        stats.max_rel_residual, stats.not_converged);
+	const int r = 6 * out.m + 3 * out.n;
+	if (!st.empty()) lsfm_save_state(st.c_str(), out.stVal, out.stno, r);
+	if (!pose.empty() && !fea.empty()) lsfm_save_poses(pose.c_str(), fea.c_str(), out.stno, out.stVal, r); // only together (Imp.cpp:2078)
+	if (!full.empty())
+	{
+		FILE* f = fopen(full.c_str(), "w");
+		if (f) { for (int i = 0; i < r; i++) fprintf(f, "%d %.17g\n", out.stno[i], out.stVal[i]); fclose(f); }
+	}
+	lsfm_map_release(&out);
+	for (auto& g : maps) lsfm_map_release(&g);
+	lsfm_context_destroy(ctx);
+	return 0;
+}

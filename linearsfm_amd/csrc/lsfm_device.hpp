@@ -1,0 +1,229 @@
+// Device-side helpers: small fixed-size block algebra in registers, rotation helpers, wave-level reductions.
+// gfx950 only: wavefront = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define LSFM_WAVE 64
+#define LSFM_PI_REF 3.1415926 /* the reference's truncated literal, Imp.h:57 */
+
+namespace lsfm {
+
+// ---------------------------------------------------------------------------------------------------------
+// block algebra (all row-major, sizes are compile-time so everything stays in registers)
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void ld(double* dst, const double* __restrict__ src)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) dst[i] = src[i];
+}
+template <int N>
+__device__ __forceinline__ void st(double* __restrict__ dst, const double* src)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) dst[i] = src[i];
+}
+template <int N>
+__device__ __forceinline__ void zero(double* a)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) a[i] = 0.0;
+}
+
+// C[RA x CB] (+)= A[RA x K] * B[K x CB]
+template <int RA, int K, int CB, bool ACC>
+__device__ __forceinline__ void mm(const double* A, const double* B, double* C)
+{
+#pragma unroll
+	for (int i = 0; i < RA; i++)
+#pragma unroll
+		for (int j = 0; j < CB; j++)
+		{
+			double s = ACC ? C[i * CB + j] : 0.0;
+#pragma unroll
+			for (int k = 0; k < K; k++) s = fma(A[i * K + k], B[k * CB + j], s);
+			C[i * CB + j] = s;
+		}
+}
+// C[CA x CB] (+)= A^T * B with A[K x CA], B[K x CB]
+template <int K, int CA, int CB, bool ACC>
+__device__ __forceinline__ void mtm(const double* A, const double* B, double* C)
+{
+#pragma unroll
+	for (int i = 0; i < CA; i++)
+#pragma unroll
+		for (int j = 0; j < CB; j++)
+		{
+			double s = ACC ? C[i * CB + j] : 0.0;
+#pragma unroll
+			for (int k = 0; k < K; k++) s = fma(A[k * CA + i], B[k * CB + j], s);
+			C[i * CB + j] = s;
+		}
+}
+// C[RA x RB] (+)= A * B^T with A[RA x K], B[RB x K]
+template <int RA, int K, int RB, bool ACC>
+__device__ __forceinline__ void mmt(const double* A, const double* B, double* C)
+{
+#pragma unroll
+	for (int i = 0; i < RA; i++)
+#pragma unroll
+		for (int j = 0; j < RB; j++)
+		{
+			double s = ACC ? C[i * RB + j] : 0.0;
+#pragma unroll
+			for (int k = 0; k < K; k++) s = fma(A[i * K + k], B[j * K + k], s);
+			C[i * RB + j] = s;
+		}
+}
+template <int R, int C>
+__device__ __forceinline__ void transpose(const double* A, double* AT)
+{
+#pragma unroll
+	for (int i = 0; i < R; i++)
+#pragma unroll
+		for (int j = 0; j < C; j++) AT[j * R + i] = A[i * C + j];
+}
+__device__ __forceinline__ void mv3(const double* R, const double* v, double* o)
+{
+	o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+	o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+	o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+
+// 3x3 symmetric inverse written back symmetrised from the upper triangle (pba_inverseV, Imp.cpp:3022-3042)
+__device__ __forceinline__ void inv3_sym(const double* a, double* o)
+{
+	double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+	double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+	double i01 = (a[2] * a[7] - a[1] * a[8]) * id, i02 = (a[1] * a[5] - a[2] * a[4]) * id, i12 = (a[2] * a[3] - a[0] * a[5]) * id;
+	o[0] = c00 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+	o[1] = o[3] = i01; o[2] = o[6] = i02; o[5] = o[7] = i12;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rotations (Imp.cpp:132-347)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mul33(const double* A, const double* B, double* C)
+{
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// R3 = R1 * R2^T (lmj_TimesRRT, Imp.cpp:336-347)
+__device__ __forceinline__ void times_rrt(double* R3, const double* R1, const double* R2)
+{
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int j = 0; j < 3; j++) R3[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];
+}
+// lmj_RMatrixYPR22, Imp.cpp:132-143
+__device__ __forceinline__ void rmat_ypr(double* R, double Alpha, double Beta, double Gamma)
+{
+	double ca = cos(Alpha), sa = sin(Alpha), cb = cos(Beta), sb = sin(Beta), cg = cos(Gamma), sg = sin(Gamma);
+	R[0] = cb * ca; R[1] = cb * sa; R[2] = -sb;
+	R[3] = sg * sb * ca - cg * sa; R[4] = sg * sb * sa + cg * ca; R[5] = sg * cb;
+	R[6] = cg * sb * ca + sg * sa; R[7] = cg * sb * sa - sg * ca; R[8] = cg * cb;
+}
+// lmj_InvRotMatrixYPR22, Imp.cpp:162-177
+__device__ __forceinline__ void inv_rmat_ypr(const double* R, double& alpha, double& beta, double& gamma)
+{
+	beta = atan2(-R[2], sqrt(R[0] * R[0] + R[1] * R[1]));
+	double cb = cos(beta);
+	if (cb == 0) { alpha = 0; beta = LSFM_PI_REF / 2; gamma = atan2(R[1], R[4]); }
+	else { alpha = atan2(R[1] / cb, R[0] / cb); gamma = atan2(R[5] / cb, R[8] / cb); }
+}
+// lmj_InvRotMatrixYPR22T, Imp.cpp:145-160
+__device__ __forceinline__ void inv_rmat_ypr_T(const double* R, double& alpha, double& beta, double& gamma)
+{
+	beta = atan2(-R[6], sqrt(R[0] * R[0] + R[3] * R[3]));
+	double cb = cos(beta);
+	if (cb == 0) { alpha = 0; beta = LSFM_PI_REF / 2; gamma = atan2(R[3], R[4]); }
+	else { alpha = atan2(R[3] / cb, R[0] / cb); gamma = atan2(R[7] / cb, R[8] / cb); }
+}
+// lmj_Rderivation, Imp.cpp:179-280
+__device__ __forceinline__ void r_derivation(double Alpha, double Beta, double Gamma, double* R, double* dRA, double* dRB, double* dRG)
+{
+	double ca = cos(Alpha), sa = sin(Alpha), cb = cos(Beta), sb = sin(Beta), cg = cos(Gamma), sg = sin(Gamma);
+	double RG[9] = { 1, 0, 0, 0, cg, sg, 0, -sg, cg };
+	double RB[9] = { cb, 0, -sb, 0, 1, 0, sb, 0, cb };
+	double RA[9] = { ca, sa, 0, -sa, ca, 0, 0, 0, 1 };
+	double DG[9] = { 0, 0, 0, 0, -sg, cg, 0, -cg, -sg };
+	double DB[9] = { -sb, 0, -cb, 0, 0, 0, cb, 0, -sb };
+	double DA[9] = { -sa, ca, 0, -ca, -sa, 0, 0, 0, 0 };
+	double tmp[9];
+	R[0] = cb * ca; R[1] = cb * sa; R[2] = -sb;
+	R[3] = sg * sb * ca - cg * sa; R[4] = sg * sb * sa + cg * ca; R[5] = sg * cb;
+	R[6] = cg * sb * ca + sg * sa; R[7] = cg * sb * sa - sg * ca; R[8] = cg * cb;
+	mul33(DG, RB, tmp); mul33(tmp, RA, dRG);
+	mul33(RG, DB, tmp); mul33(tmp, RA, dRB);
+	mul33(RG, RB, tmp); mul33(tmp, DA, dRA);
+}
+// lmj_dRi (Imp.cpp:282-307) when T==false, lmj_dRiTT (Imp.cpp:309-334) when T==true
+template <bool T>
+__device__ __forceinline__ void d_ri(double* dRid, const double* dRi, const double* Ri)
+{
+	const int i1 = T ? 3 : 1, i2 = T ? 6 : 2, i5 = T ? 7 : 5;
+	double F1 = Ri[i1] / Ri[0];
+	double F3 = Ri[i5] / Ri[8];
+	double F5 = Ri[0] * Ri[0] + Ri[i1] * Ri[i1];
+	double F4 = sqrt(F5);
+	double F2 = -Ri[i2] / F4;
+	double dAdF1 = 1.0 / (1 + F1 * F1), dBdF2 = 1.0 / (1 + F2 * F2), dGdF3 = 1.0 / (1 + F3 * F3);
+	double dF1d = (dRi[i1] * Ri[0] - Ri[i1] * dRi[0]) / (Ri[0] * Ri[0]);
+	double dF3d = (dRi[i5] * Ri[8] - Ri[i5] * dRi[8]) / (Ri[8] * Ri[8]);
+	double dF4dF5 = 1.0 / (2 * sqrt(F5));
+	double dF5d = 2 * Ri[0] * dRi[0] + 2 * Ri[i1] * dRi[i1];
+	double dF4d = dF4dF5 * dF5d;
+	double dF2d = (-dRi[i2] * F4 + Ri[i2] * dF4d) / F5;
+	dRid[0] = dAdF1 * dF1d; dRid[1] = dBdF2 * dF2d; dRid[2] = dGdF3 * dF3d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, LSFM_WAVE);
+	return v;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v)
+{
+	// hardware global_atomic_add_f64 (built with -munsafe-fp-atomics), agent scope, no return value used
+	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Adds vals[0..N) into dst[0..N) for every lane with valid==true.  When all valid lanes of the wave target the
+// SAME dst (the common case for hub rows: neighbouring features share their hub poses) the values are summed
+// across the wave first and one lane issues the atomics: 64x fewer atomics on the hot blocks.
+// Must be called by all 64 lanes (convergent).
+template <int N>
+__device__ __forceinline__ void wave_scatter_add(double* dst, const double* vals, bool valid)
+{
+	unsigned long long mask = __ballot(valid);
+	if (mask == 0ull) return;
+	int leader = __ffsll((long long)mask) - 1;
+	unsigned long long mine = (unsigned long long)(size_t)dst;
+	unsigned long long first = (unsigned long long)__shfl((long long)mine, leader, LSFM_WAVE);
+	bool uniform = __ballot(valid && mine != first) == 0ull;
+	if (uniform && __popcll(mask) > 1)
+	{
+		int lane = threadIdx.x & (LSFM_WAVE - 1);
+#pragma unroll
+		for (int i = 0; i < N; i++)
+		{
+			double s = wave_sum(valid ? vals[i] : 0.0);
+			if (lane == leader) atomic_add_f64(dst + i, s);
+		}
+	}
+	else if (valid)
+	{
+#pragma unroll
+		for (int i = 0; i < N; i++) atomic_add_f64(dst + i, vals[i]);
+	}
+}
+
+} // namespace lsfm

@@ -1,0 +1,135 @@
+// Host-side internals of liblsfm_hip: context, device arenas, the batched map container and stage entry points.
+//
+// Design: all maps of one tree level live in ONE flat structure-of-arrays container on the device
+// ("DevBatch"); pose / feature indices inside U and W are GLOBAL indices into that container, so a kernel
+// processes every map of the level in a single launch and a pairwise join is mostly a re-indexing of features.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lsfm.h"
+
+namespace lsfm {
+
+struct Error { int code; std::string msg; };
+
+#define LSFM_CHECK_HIP(expr)                                                                                   \
+	do {                                                                                                        \
+		hipError_t e__ = (expr);                                                                                \
+		if (e__ != hipSuccess)                                                                                  \
+			throw ::lsfm::Error{ LSFM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__) + " at " + __FILE__ + ":" + std::to_string(__LINE__) }; \
+	} while (0)
+#define LSFM_FAIL(code, m) throw ::lsfm::Error{ (code), std::string(m) + " at " + __FILE__ + ":" + std::to_string(__LINE__) }
+
+// bump allocator over one hipMalloc'ed slab: maps and work space of a level are carved out without any
+// hipMalloc/hipFree (both synchronise) inside the timed region.
+struct Arena {
+	char* base = nullptr;
+	size_t cap = 0, off = 0, high = 0;
+	void init(size_t bytes);
+	void destroy();
+	void* alloc_bytes(size_t bytes);
+	template <class T> T* alloc(size_t n) { return static_cast<T*>(alloc_bytes(n * sizeof(T))); }
+	void reset() { off = 0; }
+	size_t mark() const { return off; }
+	void release(size_t m) { off = m; }
+};
+
+// One tree level's maps, flat SoA on the device.  B maps; M poses, NF features, NU U blocks, NW W blocks in total.
+struct DevBatch {
+	int B = 0, M = 0, NF = 0, NU = 0, NW = 0;
+	// per map, host mirrors (offsets have B+1 entries)
+	std::vector<int> pose_off, feat_off, u_off, w_off;
+	std::vector<int> Ref, FRef, ScaP, Fix, Sign, FScaP, FFix;
+	// per map, device copies of the offsets
+	int *d_pose_off = nullptr, *d_feat_off = nullptr;
+	// poses
+	double* pose = nullptr; // [M*6]
+	int* pose_id = nullptr; // [M]  = -stno
+	int* pose_map = nullptr; // [M]
+	// features
+	double* feat = nullptr; // [NF*3]
+	int* feat_id = nullptr; // [NF]
+	int* feat_map = nullptr; // [NF]
+	// information blocks (global pose / feature indices)
+	double* U = nullptr; int *Ui = nullptr, *Uj = nullptr;
+	double* W = nullptr; int *photo = nullptr, *feature = nullptr;
+	int* fptr = nullptr;    // [NF+1] W run of each feature
+	double* V = nullptr;    // [NF*9]
+};
+
+struct PcgOptions { double rel_tol = 1e-10; int max_it_factor = 4; };
+
+} // namespace lsfm
+
+struct lsfm_context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	lsfm::Arena arena[2];   // ping-pong: level outputs / next level
+	lsfm::Arena scratch;    // per-stage work space
+	int cur = 0;
+	size_t arena_bytes = 0;
+	lsfm::PcgOptions pcg;
+	std::string last_error;
+	int* h_pinned = nullptr; // small pinned staging buffer for counters
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	lsfm_stats* stats = nullptr; // optional sink during a tree run
+	void ensure_arenas(size_t bytes_each);
+};
+
+namespace lsfm {
+
+// ---- primitives (lsfm_prims.hip; rocPRIM scan / radix sort on the context stream) ------------------------
+void dev_exclusive_scan(lsfm_context* ctx, const int* in, int* out, size_t n); // out[n] = total (n+1 entries written)
+void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, size_t n, int end_bit);
+int d2h_int(lsfm_context* ctx, const int* dptr);
+void d2h_ints(lsfm_context* ctx, const int* dptr, int* h, size_t n);
+void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes);
+void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes);
+void dev_zero(lsfm_context* ctx, void* d, size_t bytes);
+
+// ---- batches (lsfm_batch.hip) -------------------------------------------------------------------------------
+void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, bool mono, DevBatch& out);
+void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, lsfm_map* out);
+void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b); // uploads pose_off / feat_off, fills pose_map / feat_map
+
+// ---- transform (lsfm_transform.hip): K1-K4 ------------------------------------------------------------------
+// target_ref[b] < 0 ... map b is passed through unchanged; otherwise the pose id the map is re-expressed in
+// (Mono: target_scap / target_fix as well).  out is allocated from `ar`.
+void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
+                     const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out);
+
+// ---- join + solve (lsfm_join.hip, lsfm_solve.hip): K5-K11 ---------------------------------------------------
+struct JoinWork; // device work arrays shared between assembly and solve
+// groups: consecutive maps (2g, 2g+1) of `in` are joined, a trailing unpaired map is carried over unchanged.
+// Produces `out` (ceil(B/2) maps) with the solved state.  eP_out / eF_out (host, optional) receive the right-hand
+// sides of group 0 when B <= 2 (stage-level C ABI).
+void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out);
+
+struct SolveIO {
+	// system of `nseg` independent camera systems laid out back to back (block rows = poses of the batch)
+	int M = 0, NF = 0, NU = 0, NW = 0, nseg = 0;
+	const int* d_pose_seg = nullptr;   // [M] segment of each pose
+	const int* d_feat_seg = nullptr;   // [NF]
+	const unsigned char* d_seg_active = nullptr; // [nseg] 0 = carried map: state is not touched
+	const double* U = nullptr; const int *Ui = nullptr, *Uj = nullptr;
+	const double* W = nullptr; const int *photo = nullptr, *fptr = nullptr;
+	const double* V = nullptr;
+	const double* ea = nullptr;        // [M*6]
+	const double* eb = nullptr;        // [NF*3]
+	const double* x0 = nullptr;        // [M*6] initial guess (may be null -> zero)
+	const unsigned char* d_fixed = nullptr; // [M*6] optional: 1 = scalar removed from the system (Mono gauge)
+	double* x_pose = nullptr;          // [M*6] out
+	double* x_feat = nullptr;          // [NF*3] out
+	std::vector<int> seg_rows;         // host: block rows per segment
+};
+int solve_batch(lsfm_context* ctx, const SolveIO& io);
+int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,
+                  double* avg_ms, double* bytes);
+
+} // namespace lsfm

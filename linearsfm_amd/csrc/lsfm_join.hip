@@ -1,0 +1,305 @@
+// Batched pairwise join of the maps of one tree level (Stereo): feature matching, merge of the two information
+// matrices, right-hand side, then the batched solve.  Replaces lmj_LinearLS_PF3DStereo (Imp.cpp:2551-2978) for all
+// pairs (2g, 2g+1) of the level at once.
+//
+// Because U/W carry GLOBAL pose indices, the joint pose set of a pair is simply the two maps' poses back to back
+// (Imp.cpp:2626-2627 does the same copy), U is reused unchanged (Imp.cpp:2658-2735 only shifts Cur's indices by m1)
+// and the join reduces to renumbering features:  End's features keep their order, Cur's unmatched features are
+// appended (Imp.cpp:2630-2643), W runs of a shared feature are End's then Cur's (Imp.cpp:2761-2847), V is summed
+// (Imp.cpp:2796-2800).  The reference finds common features with std::find over all of Cur's labels per End
+// feature (O(n1*n2), Imp.cpp:2581-2599); here one radix sort of (pair, label, side) keys does it for the level.
+#include "lsfm_device.hpp"
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+struct JGroup {
+	int F0E, nE, F0C, nC; // feature ranges of End / Cur in the input batch (nC = 0: carried map)
+	int FY0;              // first joint feature
+	int rC0;              // rank offset of Cur's unmatched features
+};
+
+__global__ void k_join_keys(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, unsigned long long* __restrict__ keys,
+                            int* __restrict__ vals)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	int mp = feat_map[f];
+	keys[f] = ((unsigned long long)(mp >> 1) << 33) | ((unsigned long long)(unsigned)feat_id[f] << 1) | (unsigned long long)(mp & 1);
+	vals[f] = f;
+}
+
+// after the sort equal (pair,label) keys are adjacent, End (side 0) first
+__global__ void k_join_match(int NF, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int* __restrict__ match,
+                             int* __restrict__ unmatched)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NF) return;
+	unsigned long long k = keys[i];
+	int f = vals[i];
+	int mt = -1;
+	if ((k & 1ull) && i > 0 && keys[i - 1] == k - 1ull) mt = vals[i - 1];
+	match[f] = mt;
+	unmatched[f] = ((k & 1ull) && mt < 0) ? 1 : 0;
+	if (i == 0) unmatched[NF] = 0;
+}
+
+__global__ void k_gather_at(const int* __restrict__ src, const int* __restrict__ idx, int n, int* __restrict__ out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = src[idx[i]];
+}
+
+// new feature numbers, merged V, V-part of eF, run lengths
+__global__ void k_join_features(int NF, const int* __restrict__ feat_map, const int* __restrict__ feat_id, const double* __restrict__ feat,
+                                const double* __restrict__ V, const int* __restrict__ fptr, const int* __restrict__ match,
+                                const int* __restrict__ R, const JGroup* __restrict__ grp, int* __restrict__ newf, int* __restrict__ lenE,
+                                int* __restrict__ lenC, double* __restrict__ Vy, double* __restrict__ eF, int* __restrict__ fid_y,
+                                double* __restrict__ feat_y)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	int mp = feat_map[f];
+	const JGroup& g = grp[mp >> 1];
+	int nf;
+	const bool cur = mp & 1;
+	if (!cur) nf = g.FY0 + (f - g.F0E);
+	else if (match[f] >= 0) nf = g.FY0 + (match[f] - g.F0E);
+	else nf = g.FY0 + g.nE + (R[f] - g.rC0);
+	newf[f] = nf;
+	int len = fptr[f + 1] - fptr[f];
+	if (!cur) lenE[nf] = len; else lenC[nf] = len;
+	const double* v = V + (size_t)f * 9;
+	const double* x = feat + (size_t)f * 3;
+	for (int i = 0; i < 9; i++) atomic_add_f64(Vy + (size_t)nf * 9 + i, v[i]);
+	// eF += V x  with each map's own estimate (Imp.cpp:2752-2757, 2802-2807, 2874-2879)
+	for (int r = 0; r < 3; r++) atomic_add_f64(eF + (size_t)nf * 3 + r, v[3 * r] * x[0] + v[3 * r + 1] * x[1] + v[3 * r + 2] * x[2]);
+	if (!cur || match[f] < 0)
+	{
+		fid_y[nf] = feat_id[f];
+		feat_y[(size_t)nf * 3] = x[0]; feat_y[(size_t)nf * 3 + 1] = x[1]; feat_y[(size_t)nf * 3 + 2] = x[2];
+	}
+}
+
+__global__ void k_add_lens(int n, const int* __restrict__ a, const int* __restrict__ b, int* __restrict__ out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = a[i] + b[i];
+	if (i == 0) out[n] = 0;
+}
+
+__global__ void k_join_wcopy(int NW, const double* __restrict__ W, const int* __restrict__ photo, const int* __restrict__ feature,
+                             const int* __restrict__ fptr, const int* __restrict__ feat_map, const int* __restrict__ newf,
+                             const int* __restrict__ lenE, const int* __restrict__ fptr_y, double* __restrict__ Wy, int* __restrict__ photo_y,
+                             int* __restrict__ feature_y, int* __restrict__ srcf)
+{
+	int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NW) return;
+	int f = feature[j], nf = newf[f];
+	int dest = fptr_y[nf] + ((feat_map[f] & 1) ? lenE[nf] : 0) + (j - fptr[f]);
+	const double* w = W + (size_t)j * 18;
+	double* o = Wy + (size_t)dest * 18;
+	for (int i = 0; i < 18; i++) o[i] = w[i];
+	photo_y[dest] = photo[j];
+	feature_y[dest] = nf;
+	srcf[dest] = f;
+}
+
+// right-hand side: eF += W^T x_pose, eP += W x_feat (each block with the estimates of the map it came from),
+// Imp.cpp:2770-2786, 2822-2838, 2891-2906.  One lane per joint feature.
+__global__ void __launch_bounds__(256)
+k_join_rhs_w(int NFY, const int* __restrict__ fptr_y, const double* __restrict__ Wy, const int* __restrict__ photo_y,
+             const int* __restrict__ srcf, const double* __restrict__ pose, const double* __restrict__ feat, double* __restrict__ eP,
+             double* __restrict__ eF)
+{
+	int nf = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = nf < NFY;
+	int j0 = 0, len = 0;
+	if (inb) { j0 = fptr_y[nf]; len = fptr_y[nf + 1] - j0; }
+	int maxlen = len;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
+	double ef[3] = { 0, 0, 0 };
+	for (int it = 0; it < maxlen; it++)
+	{
+		const bool v = inb && it < len;
+		double y[6];
+		int k = 0;
+		if (v)
+		{
+			int j = j0 + it;
+			k = photo_y[j];
+			double W[18];
+			ld<18>(W, Wy + (size_t)j * 18);
+			const double* xp = pose + (size_t)k * 6;
+			const double* xf = feat + (size_t)srcf[j] * 3;
+#pragma unroll
+			for (int r = 0; r < 6; r++) y[r] = W[3 * r] * xf[0] + W[3 * r + 1] * xf[1] + W[3 * r + 2] * xf[2];
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+#pragma unroll
+				for (int r = 0; r < 6; r++) ef[c] = fma(W[3 * r + c], xp[r], ef[c]);
+		}
+		wave_scatter_add<6>(eP + (size_t)(v ? k : 0) * 6, y, v);
+	}
+	if (inb) { eF[(size_t)nf * 3] += ef[0]; eF[(size_t)nf * 3 + 1] += ef[1]; eF[(size_t)nf * 3 + 2] += ef[2]; }
+}
+
+// eP += U x, eP += U^T x for off-diagonal blocks, Imp.cpp:2666-2688
+__global__ void k_join_rhs_u(int NU, const double* __restrict__ U, const int* __restrict__ Ui, const int* __restrict__ Uj,
+                             const double* __restrict__ pose, double* __restrict__ eP)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NU) return;
+	int a = Ui[i], b = Uj[i];
+	double u[36];
+	ld<36>(u, U + (size_t)i * 36);
+	const double* xb = pose + (size_t)b * 6;
+	for (int r = 0; r < 6; r++)
+	{
+		double s = 0;
+		for (int c = 0; c < 6; c++) s = fma(u[6 * r + c], xb[c], s);
+		atomic_add_f64(eP + (size_t)a * 6 + r, s);
+	}
+	if (a != b)
+	{
+		const double* xa = pose + (size_t)a * 6;
+		for (int c = 0; c < 6; c++)
+		{
+			double s = 0;
+			for (int r = 0; r < 6; r++) s = fma(u[6 * r + c], xa[r], s);
+			atomic_add_f64(eP + (size_t)b * 6 + c, s);
+		}
+	}
+}
+
+__global__ void k_shift_segments(int n, const int* __restrict__ map_of, int* __restrict__ seg)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) seg[i] = map_of[i] >> 1;
+}
+
+void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out)
+{
+	hipStream_t s = ctx->stream;
+	const int B = in.B, G = (B + 1) / 2;
+	size_t smark = ctx->scratch.mark();
+	hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+	(void)e0; (void)e1;
+
+	// ---- common features (K5) ----
+	unsigned long long* keys = ctx->scratch.alloc<unsigned long long>(in.NF + 1);
+	int* vals = ctx->scratch.alloc<int>(in.NF + 1);
+	int* match = ctx->scratch.alloc<int>(in.NF + 1);
+	int* unm = ctx->scratch.alloc<int>(in.NF + 2);
+	int* R = ctx->scratch.alloc<int>(in.NF + 2);
+	const int nb = (in.NF + 255) / 256;
+	if (in.NF)
+	{
+		hipLaunchKernelGGL(k_join_keys, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, keys, vals);
+		int gbits = 1;
+		while ((1 << gbits) < G + 1) gbits++;
+		dev_sort_pairs_u64(ctx, keys, vals, in.NF, 33 + gbits);
+		hipLaunchKernelGGL(k_join_match, dim3(nb), dim3(256), 0, s, in.NF, keys, vals, match, unm);
+	}
+	else
+		dev_zero(ctx, unm, 2 * sizeof(int));
+	dev_exclusive_scan(ctx, unm, R, in.NF);
+	// unmatched counts per map -> joint feature offsets (host)
+	int* d_rb = ctx->scratch.alloc<int>(B + 1);
+	hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, R, in.d_feat_off, B + 1, d_rb);
+	std::vector<int> rb(B + 1);
+	d2h_ints(ctx, d_rb, rb.data(), B + 1);
+
+	out = DevBatch();
+	out.B = G; out.M = in.M; out.NU = in.NU; out.NW = in.NW;
+	out.pose_off.assign(G + 1, 0); out.feat_off.assign(G + 1, 0); out.u_off.assign(G + 1, 0); out.w_off.assign(G + 1, 0);
+	out.Ref.resize(G); out.FRef.resize(G); out.ScaP.assign(G, 0); out.Fix.assign(G, 0); out.Sign.assign(G, 1); out.FScaP.assign(G, 0); out.FFix.assign(G, 0);
+	std::vector<JGroup> grp(G);
+	std::vector<unsigned char> seg_active(G);
+	std::vector<int> seg_rows(G);
+	for (int g = 0; g < G; g++)
+	{
+		const int a = 2 * g, b = 2 * g + 1;
+		const bool pair = b < B;
+		JGroup& jg = grp[g];
+		jg.F0E = in.feat_off[a]; jg.nE = in.feat_off[a + 1] - jg.F0E;
+		jg.F0C = pair ? in.feat_off[b] : in.feat_off[a + 1]; jg.nC = pair ? in.feat_off[b + 1] - jg.F0C : 0;
+		jg.FY0 = out.feat_off[g];
+		jg.rC0 = pair ? rb[b] : 0;
+		const int nun = pair ? rb[b + 1] - rb[b] : 0;
+		out.feat_off[g + 1] = jg.FY0 + jg.nE + nun;
+		out.pose_off[g] = in.pose_off[a]; out.u_off[g] = in.u_off[a]; out.w_off[g] = in.w_off[a];
+		out.Ref[g] = pair ? in.Ref[b] : in.Ref[a];     // Imp.cpp:2974
+		out.FRef[g] = in.FRef[a];                      // Imp.cpp:2624
+		seg_active[g] = pair ? 1 : 0;
+		seg_rows[g] = (pair ? in.pose_off[b + 1] : in.pose_off[a + 1]) - in.pose_off[a];
+	}
+	out.pose_off[G] = in.M; out.u_off[G] = in.NU; out.w_off[G] = in.NW;
+	out.NF = out.feat_off[G];
+	const int NFY = out.NF;
+
+	JGroup* d_grp = ctx->scratch.alloc<JGroup>(G);
+	h2d(ctx, d_grp, grp.data(), sizeof(JGroup) * G);
+
+	// ---- joint arrays (K6) ----
+	out.pose = ar.alloc<double>((size_t)in.M * 6);
+	out.pose_id = ar.alloc<int>(in.M);
+	out.feat = ar.alloc<double>((size_t)NFY * 3);
+	out.feat_id = ar.alloc<int>(NFY);
+	out.U = ar.alloc<double>((size_t)in.NU * 36); out.Ui = ar.alloc<int>(in.NU); out.Uj = ar.alloc<int>(in.NU);
+	out.W = ar.alloc<double>((size_t)in.NW * 18); out.photo = ar.alloc<int>(in.NW); out.feature = ar.alloc<int>(in.NW);
+	out.fptr = ar.alloc<int>(NFY + 1);
+	out.V = ar.alloc<double>((size_t)NFY * 9);
+	batch_set_offsets(ctx, ar, out);
+	LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_id, in.pose_id, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
+	if (in.NU)
+	{
+		LSFM_CHECK_HIP(hipMemcpyAsync(out.U, in.U, (size_t)in.NU * 36 * sizeof(double), hipMemcpyDeviceToDevice, s));
+		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
+		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
+	}
+	int* newf = ctx->scratch.alloc<int>(in.NF + 1);
+	int* lenE = ctx->scratch.alloc<int>(NFY + 1);
+	int* lenC = ctx->scratch.alloc<int>(NFY + 1);
+	int* lens = ctx->scratch.alloc<int>(NFY + 2);
+	int* srcf = ctx->scratch.alloc<int>(in.NW + 1);
+	double* eP = ctx->scratch.alloc<double>((size_t)in.M * 6);
+	double* eF = ctx->scratch.alloc<double>((size_t)NFY * 3);
+	dev_zero(ctx, lenE, (NFY + 1) * sizeof(int)); dev_zero(ctx, lenC, (NFY + 1) * sizeof(int));
+	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
+	dev_zero(ctx, eP, (size_t)in.M * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
+	if (in.NF)
+		hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,
+		                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat);
+	hipLaunchKernelGGL(k_add_lens, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY, lenE, lenC, lens);
+	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
+	if (in.NW)
+		hipLaunchKernelGGL(k_join_wcopy, dim3((in.NW + 255) / 256), dim3(256), 0, s, in.NW, in.W, in.photo, in.feature, in.fptr, in.feat_map,
+		                   newf, lenE, out.fptr, out.W, out.photo, out.feature, srcf);
+	// ---- right-hand sides ----
+	if (NFY)
+		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + 255) / 256), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);
+	if (in.NU)
+		hipLaunchKernelGGL(k_join_rhs_u, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, in.U, in.Ui, in.Uj, in.pose, eP);
+	LSFM_CHECK_HIP(hipGetLastError());
+	if (eP_out) d2h(ctx, eP_out, eP, (size_t)in.M * 6 * sizeof(double));
+	if (eF_out) d2h(ctx, eF_out, eF, (size_t)NFY * 3 * sizeof(double));
+
+	// ---- solve (K7-K11) ----
+	unsigned char* d_act = ctx->scratch.alloc<unsigned char>(G);
+	h2d(ctx, d_act, seg_active.data(), G);
+	SolveIO io;
+	io.M = in.M; io.NF = NFY; io.NU = in.NU; io.NW = in.NW; io.nseg = G;
+	io.d_pose_seg = out.pose_map; io.d_feat_seg = out.feat_map; io.d_seg_active = d_act;
+	io.U = out.U; io.Ui = out.Ui; io.Uj = out.Uj; io.W = out.W; io.photo = out.photo; io.fptr = out.fptr; io.V = out.V;
+	io.ea = eP; io.eb = eF; io.x0 = in.pose; io.d_fixed = nullptr;
+	io.x_pose = out.pose; io.x_feat = out.feat;
+	io.seg_rows = seg_rows;
+	int rc = solve_batch(ctx, io);
+	LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	ctx->scratch.release(smark);
+	if (rc > 0 && ctx->stats) ctx->stats->not_converged += rc;
+}
+
+} // namespace lsfm

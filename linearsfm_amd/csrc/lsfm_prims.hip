@@ -1,0 +1,157 @@
+// Context, arenas and the two library primitives used off the hot path (prefix sum, radix sort: rocPRIM).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+void Arena::init(size_t bytes)
+{
+	destroy();
+	LSFM_CHECK_HIP(hipMalloc(&base, bytes));
+	cap = bytes; off = 0; high = 0;
+}
+void Arena::destroy()
+{
+	if (base) (void)hipFree(base);
+	base = nullptr; cap = off = 0;
+}
+void* Arena::alloc_bytes(size_t bytes)
+{
+	size_t a = (off + 255) & ~size_t(255);
+	if (bytes == 0) bytes = 8;
+	if (a + bytes > cap)
+		LSFM_FAIL(LSFM_ERR_OOM, "device arena exhausted (need " + std::to_string((a + bytes) >> 20) + " MiB of " + std::to_string(cap >> 20) +
+		                            " MiB); create the context with a larger arena_bytes");
+	off = a + bytes;
+	if (off > high) high = off;
+	return base + a;
+}
+
+void dev_exclusive_scan(lsfm_context* ctx, const int* in, int* out, size_t n)
+{
+	// scans n+1 entries (callers keep one trailing zero in `in`) so that out[n] is the total
+	size_t tb = 0;
+	LSFM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0, n + 1, rocprim::plus<int>(), ctx->stream));
+	size_t mk = ctx->scratch.mark();
+	void* tmp = ctx->scratch.alloc_bytes(tb);
+	LSFM_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, in, out, 0, n + 1, rocprim::plus<int>(), ctx->stream));
+	// the temporary may be reused by later allocations only after this launch is enqueued on the same stream
+	ctx->scratch.release(mk);
+}
+
+void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, size_t n, int end_bit)
+{
+	if (n == 0) return;
+	size_t mk = ctx->scratch.mark();
+	unsigned long long* k2 = ctx->scratch.alloc<unsigned long long>(n);
+	int* v2 = ctx->scratch.alloc<int>(n);
+	size_t tb = 0;
+	LSFM_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, k2, vals, v2, n, 0, end_bit, ctx->stream));
+	void* tmp = ctx->scratch.alloc_bytes(tb);
+	LSFM_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, k2, vals, v2, n, 0, end_bit, ctx->stream));
+	LSFM_CHECK_HIP(hipMemcpyAsync(keys, k2, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+	LSFM_CHECK_HIP(hipMemcpyAsync(vals, v2, n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+	ctx->scratch.release(mk);
+}
+
+int d2h_int(lsfm_context* ctx, const int* dptr)
+{
+	LSFM_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, dptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+	return ctx->h_pinned[0];
+}
+void d2h_ints(lsfm_context* ctx, const int* dptr, int* h, size_t n)
+{
+	LSFM_CHECK_HIP(hipMemcpyAsync(h, dptr, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+}
+void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes)
+{
+	if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+	// host buffers of callers are pageable and may go out of scope: make the copy complete before returning
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+}
+void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes)
+{
+	if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+}
+void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
+{
+	if (bytes) LSFM_CHECK_HIP(hipMemsetAsync(d, 0, bytes, ctx->stream));
+}
+
+} // namespace lsfm
+
+void lsfm_context::ensure_arenas(size_t bytes_each)
+{
+	if (arena_bytes >= bytes_each && arena[0].base) return;
+	LSFM_CHECK_HIP(hipStreamSynchronize(stream));
+	arena[0].init(bytes_each);
+	arena[1].init(bytes_each);
+	scratch.init(bytes_each);
+	arena_bytes = bytes_each;
+}
+
+extern "C" {
+
+int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
+{
+	if (!out) return LSFM_ERR_ARG;
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+	{
+		fprintf(stderr, "liblsfm_hip: no usable HIP device (count=%d, requested %d) -- this library has no CPU path\n", ndev, device);
+		return LSFM_ERR_NO_DEVICE;
+	}
+	lsfm_context* c = new lsfm_context();
+	try
+	{
+		c->device = device;
+		LSFM_CHECK_HIP(hipSetDevice(device));
+		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
+		LSFM_CHECK_HIP(hipEventCreate(&c->ev0));
+		LSFM_CHECK_HIP(hipEventCreate(&c->ev1));
+		if (arena_bytes) c->ensure_arenas(arena_bytes);
+	}
+	catch (const lsfm::Error& e)
+	{
+		fprintf(stderr, "liblsfm_hip: %s\n", e.msg.c_str());
+		int code = e.code;
+		delete c;
+		return code;
+	}
+	*out = c;
+	return LSFM_OK;
+}
+
+void lsfm_context_destroy(lsfm_context* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	c->arena[0].destroy(); c->arena[1].destroy(); c->scratch.destroy();
+	if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor)
+{
+	if (!ctx || !(rel_tol > 0) || max_it_factor <= 0) return LSFM_ERR_ARG;
+	ctx->pcg.rel_tol = rel_tol;
+	ctx->pcg.max_it_factor = max_it_factor;
+	return LSFM_OK;
+}
+
+const char* lsfm_last_error(lsfm_context* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+void* lsfm_stream(lsfm_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+} // extern "C"

@@ -1,0 +1,820 @@
+// Batched Schur complement + preconditioned CG + back-substitution for all joins of one tree level.
+// Replaces lmj_solveLinearSFM{Stereo,Mono} (Imp.cpp:2119-2378 / 6756-7041): the reference builds S = U - W V^-1 W^T
+// through a dense m x m byte mask and hands it to CHOLMOD; here
+//   K7  k_vinv            V^-1 per feature                                   (pba_inverseV, Imp.cpp:3022-3042)
+//   K8  k_pat_*           block pattern of S by hashing the pose pairs that share a feature + U's pattern
+//                         (replaces smask, Imp.cpp:2131-2205), sorted into block-CSR
+//   K9  k_schur_*         S(p,q) -= W_pf V_f^-1 W_qf^T, E_p -= W_pf V_f^-1 eb_f, one lane per feature, scatter-adds
+//                         pre-reduced over the wave (Imp.cpp:2244-2332)
+//   K10 k_spmv / k_pcg_*  block-Jacobi preconditioned CG on the symmetric 6x6-block system, all independent systems
+//                         of the level iterate together with per-system scalars (replaces Imp.cpp:2334-2361)
+//   K11 k_backsub         features: x_f = V_f^-1 (eb_f - sum W_pf^T x_p)     (pba_solveFeatures, Imp.cpp:2980-3020)
+// S is kept as its upper block triangle (diagonal blocks full); the SpMV walks a row-sorted index of both
+// orientations that points into the same 288-byte blocks (no second copy of the values).
+#include <algorithm>
+#include <cmath>
+
+#include "lsfm_device.hpp"
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+static const unsigned long long HEMPTY = ~0ull;
+#define SPMV_CHUNK 16
+
+__global__ void k_vinv(int NF, const double* __restrict__ V, double* __restrict__ IV)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	double a[9], o[9];
+	ld<9>(a, V + (size_t)f * 9);
+	inv3_sym(a, o);
+	st<9>(IV + (size_t)f * 9, o);
+}
+
+// ---- hash set of block coordinates ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+	return x;
+}
+__device__ __forceinline__ void hash_insert(unsigned long long* tab, unsigned long long mask, unsigned long long key, int* overflow)
+{
+	unsigned long long h = mix64(key) & mask;
+	for (int probe = 0; probe < 4096; probe++)
+	{
+		unsigned long long cur = tab[h];
+		if (cur == key) return;
+		if (cur == HEMPTY)
+		{
+			unsigned long long old = atomicCAS(&tab[h], HEMPTY, key);
+			if (old == HEMPTY || old == key) return;
+		}
+		h = (h + 1) & mask;
+	}
+	*overflow = 1;
+}
+__device__ __forceinline__ int hash_find(const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+                                         unsigned long long key)
+{
+	unsigned long long h = mix64(key) & mask;
+	for (int probe = 0; probe < 4096; probe++)
+	{
+		unsigned long long cur = tab[h];
+		if (cur == key) return val[h];
+		if (cur == HEMPTY) return -1;
+		h = (h + 1) & mask;
+	}
+	return -1;
+}
+__device__ __forceinline__ unsigned long long pair_key(int p, int q)
+{
+	return p <= q ? (((unsigned long long)(unsigned)p << 32) | (unsigned)q) : (((unsigned long long)(unsigned)q << 32) | (unsigned)p);
+}
+
+__global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+
+__global__ void k_pat_insert_u(int NU, int M, const int* __restrict__ Ui, const int* __restrict__ Uj, unsigned long long* tab,
+                               unsigned long long mask, int* overflow)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < NU) hash_insert(tab, mask, pair_key(Ui[i], Uj[i]), overflow);
+	if (i < M) hash_insert(tab, mask, pair_key(i, i), overflow); // every block row owns its diagonal block
+}
+
+// one lane per feature; all pose pairs of its W run (Imp.cpp:2155-2173).  When the whole wave asks for the same
+// pair (hub poses shared by neighbouring features) one lane inserts.
+__global__ void __launch_bounds__(256)
+k_pat_insert_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, unsigned long long* tab, unsigned long long mask,
+               int* overflow)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = f < NF;
+	int j0 = 0, len = 0;
+	if (inb) { j0 = fptr[f]; len = fptr[f + 1] - j0; }
+	int maxlen = len;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
+	const int lane = threadIdx.x & (LSFM_WAVE - 1);
+	for (int a = 0; a < maxlen; a++)
+	{
+		const int pa = (inb && a < len) ? photo[j0 + a] : -1;
+		for (int b = a + 1; b < maxlen; b++)
+		{
+			const bool v = inb && b < len;
+			unsigned long long key = v ? pair_key(pa, photo[j0 + b]) : 0ull;
+			unsigned long long m = __ballot(v);
+			if (m == 0ull) continue;
+			int leader = __ffsll((long long)m) - 1;
+			unsigned long long first = (unsigned long long)__shfl((long long)key, leader, LSFM_WAVE);
+			bool uniform = __ballot(v && key != first) == 0ull;
+			if (uniform) { if (lane == leader) hash_insert(tab, mask, key, overflow); }
+			else if (v) hash_insert(tab, mask, key, overflow);
+		}
+	}
+}
+
+__global__ void k_pat_compact(size_t cap, const unsigned long long* __restrict__ tab, unsigned long long* __restrict__ list, int* __restrict__ count)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= cap) return;
+	unsigned long long k = tab[i];
+	if (k != HEMPTY) list[atomicAdd(count, 1)] = k;
+}
+
+__global__ void k_pat_assign(int nnzb, const unsigned long long* __restrict__ sorted, const unsigned long long* __restrict__ tab,
+                             int* __restrict__ val, unsigned long long mask, int* __restrict__ colidx)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nnzb) return;
+	unsigned long long key = sorted[i];
+	unsigned long long h = mix64(key) & mask;
+	while (tab[h] != key) h = (h + 1) & mask;
+	val[h] = i;
+	colidx[i] = (int)(key & 0xffffffffull);
+}
+
+// rowptr[r] = first index whose key >= (r << 32)
+__global__ void k_rowptr_from_keys(int rows, int n, const unsigned long long* __restrict__ sorted, int shift, int* __restrict__ rowptr)
+{
+	int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > rows) return;
+	unsigned long long target = (unsigned long long)(unsigned)r << shift;
+	int lo = 0, hi = n;
+	while (lo < hi) { int mid = (lo + hi) >> 1; if (sorted[mid] < target) lo = mid + 1; else hi = mid; }
+	rowptr[r] = lo;
+}
+
+// ---- numeric Schur complement ------------------------------------------------------------------------------
+__global__ void k_schur_u(int NU, const double* __restrict__ U, const int* __restrict__ Ui, const int* __restrict__ Uj,
+                          const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask, double* __restrict__ S)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NU) return;
+	int a = Ui[i], b = Uj[i];
+	int slot = hash_find(tab, val, mask, pair_key(a, b));
+	const double* u = U + (size_t)i * 36;
+	double* s = S + (size_t)slot * 36;
+	if (a <= b) { for (int q = 0; q < 36; q++) atomic_add_f64(s + q, u[q]); }
+	else { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) atomic_add_f64(s + c * 6 + r, u[r * 6 + c]); }
+}
+
+__global__ void __launch_bounds__(256)
+k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
+          const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+          double* __restrict__ S, double* __restrict__ E)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = f < NF;
+	int j0 = 0, len = 0;
+	double iv[9], ebf[3];
+	if (inb)
+	{
+		j0 = fptr[f]; len = fptr[f + 1] - j0;
+		ld<9>(iv, IV + (size_t)f * 9);
+		ebf[0] = eb[(size_t)f * 3]; ebf[1] = eb[(size_t)f * 3 + 1]; ebf[2] = eb[(size_t)f * 3 + 2];
+	}
+	int maxlen = len;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
+	for (int a = 0; a < maxlen; a++)
+	{
+		const bool va = inb && a < len;
+		double WV[18];
+		int pa = 0;
+		if (va)
+		{
+			double Wa[18];
+			pa = photo[j0 + a];
+			ld<18>(Wa, W + (size_t)(j0 + a) * 18);
+			mm<6, 3, 3, false>(Wa, iv, WV); // W V^-1 (V^-1 symmetric), Imp.cpp:2260-2273
+		}
+		{
+			// E_p -= W V^-1 eb, Imp.cpp:2321-2328
+			double e[6];
+#pragma unroll
+			for (int r = 0; r < 6; r++) e[r] = va ? -(WV[3 * r] * ebf[0] + WV[3 * r + 1] * ebf[1] + WV[3 * r + 2] * ebf[2]) : 0.0;
+			wave_scatter_add<6>(E + (size_t)pa * 6, e, va);
+		}
+		for (int b = a; b < maxlen; b++)
+		{
+			const bool v = inb && b < len;
+			double X[36];
+			int slot = 0;
+			if (v)
+			{
+				double Wb[18], T[36];
+				const int pb = photo[j0 + b];
+				ld<18>(Wb, W + (size_t)(j0 + b) * 18);
+				mmt<6, 3, 6, false>(WV, Wb, T); // W_a V^-1 W_b^T = contribution to S(pa,pb)
+				slot = hash_find(tab, val, mask, pair_key(pa, pb));
+				if (a == b) { for (int q = 0; q < 36; q++) X[q] = -T[q]; }
+				else if (pa < pb) { for (int q = 0; q < 36; q++) X[q] = -T[q]; }
+				else if (pa > pb) { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) X[c * 6 + r] = -T[r * 6 + c]; }
+				else { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) X[r * 6 + c] = -(T[r * 6 + c] + T[c * 6 + r]); }
+			}
+			wave_scatter_add<36>(S + (size_t)slot * 36, X, v);
+		}
+	}
+}
+
+// ---- row-sorted index of both orientations -----------------------------------------------------------------
+__global__ void k_full_keys(int nnzb, const unsigned long long* __restrict__ sorted, unsigned long long* __restrict__ fkeys, int* __restrict__ fvals,
+                            int* __restrict__ count)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nnzb) return;
+	unsigned long long key = sorted[i];
+	unsigned p = (unsigned)(key >> 32), q = (unsigned)(key & 0xffffffffull);
+	fkeys[i] = key; fvals[i] = i << 1;
+	if (p != q)
+	{
+		int o = nnzb + atomicAdd(count, 1);
+		fkeys[o] = ((unsigned long long)q << 32) | p; fvals[o] = (i << 1) | 1;
+	}
+}
+__global__ void k_chunk_counts(int M, const int* __restrict__ frow, int* __restrict__ cnt)
+{
+	int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < M) cnt[r] = (frow[r + 1] - frow[r] + SPMV_CHUNK - 1) / SPMV_CHUNK;
+	if (r == 0) cnt[M] = 0;
+}
+__global__ void k_chunk_fill(int M, const int* __restrict__ frow, const int* __restrict__ cptr, int* __restrict__ chunk_row, int* __restrict__ chunk_beg)
+{
+	int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= M) return;
+	int c0 = cptr[r], n = cptr[r + 1] - c0, b = frow[r];
+	for (int c = 0; c < n; c++) { chunk_row[c0 + c] = r; chunk_beg[c0 + c] = b + c * SPMV_CHUNK; }
+}
+
+// ---- K10a: y = S x --------------------------------------------------------------------------------------
+// 8 lanes per chunk of <= SPMV_CHUNK blocks of one block row, lane r<6 owns scalar row r.  Rows with a single chunk
+// store, longer rows (hub poses) add atomically into the pre-zeroed y.  dotw != null: dot[seg] += w . y (fused p.Ap).
+__global__ void __launch_bounds__(256)
+k_spmv(int nchunks, const int* __restrict__ chunk_row, const int* __restrict__ chunk_beg, const int* __restrict__ frow,
+       const int* __restrict__ fcol, const int* __restrict__ fblk, const double* __restrict__ S, const double* __restrict__ x,
+       double* __restrict__ y, const unsigned char* __restrict__ fixed, const double* __restrict__ dotw, const int* __restrict__ pose_seg,
+       double* __restrict__ dot, int dot_stride)
+{
+	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int c = gid >> 3, r = gid & 7;
+	const bool v = c < nchunks && r < 6;
+	double sum = 0.0;
+	int row = 0;
+	bool single = true;
+	if (v)
+	{
+		row = chunk_row[c];
+		const int rb = frow[row], re = frow[row + 1];
+		const int b0 = chunk_beg[c], b1 = min(b0 + SPMV_CHUNK, re);
+		single = (re - rb) <= SPMV_CHUNK;
+		for (int k = b0; k < b1; k++)
+		{
+			const int col = fcol[k], bt = fblk[k];
+			const double* blk = S + (size_t)(bt >> 1) * 36;
+			const double* xv = x + (size_t)col * 6;
+			if (bt & 1)
+			{
+#pragma unroll
+				for (int j = 0; j < 6; j++) sum = fma(blk[j * 6 + r], xv[j], sum);
+			}
+			else
+			{
+#pragma unroll
+				for (int j = 0; j < 6; j++) sum = fma(blk[r * 6 + j], xv[j], sum);
+			}
+		}
+		if (fixed && fixed[(size_t)row * 6 + r]) sum = 0.0;
+		if (single) y[(size_t)row * 6 + r] = sum; else atomic_add_f64(y + (size_t)row * 6 + r, sum);
+	}
+	if (dotw)
+	{
+		double w = v ? dotw[(size_t)row * 6 + r] * sum : 0.0;
+		wave_scatter_add<1>(dot + (size_t)(v ? pose_seg[row] : 0) * dot_stride, &w, v);
+	}
+}
+
+// ---- block-Jacobi preconditioner: inverse of the diagonal blocks (6x6 SPD, Cholesky) -------------------------
+__global__ void k_diag_inverse(int M, const int* __restrict__ rowptr, const int* __restrict__ colidx, const double* __restrict__ S,
+                               const unsigned char* __restrict__ fixed, double* __restrict__ Minv, int* __restrict__ bad)
+{
+	int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= M) return;
+	// the diagonal block is the first entry of the row in the upper pattern
+	double A[36], L[36], Li[36];
+	ld<36>(A, S + (size_t)rowptr[p] * 36);
+	if (colidx[rowptr[p]] != p) { atomicExch(bad, 1 + p); return; }
+	for (int i = 0; i < 6; i++)
+	{
+		const bool fx = fixed && fixed[(size_t)p * 6 + i];
+		for (int j = 0; j < 6; j++)
+		{
+			const bool fj = fixed && fixed[(size_t)p * 6 + j];
+			if (fx || fj) A[i * 6 + j] = (i == j) ? 1.0 : 0.0;
+		}
+	}
+	zero<36>(L);
+	bool ok = true;
+	for (int j = 0; j < 6; j++)
+	{
+		double d = A[j * 6 + j];
+		for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
+		if (!(d > 0)) { ok = false; d = 1.0; }
+		L[j * 6 + j] = sqrt(d);
+		for (int i = j + 1; i < 6; i++)
+		{
+			double s = A[i * 6 + j];
+			for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+			L[i * 6 + j] = s / L[j * 6 + j];
+		}
+	}
+	if (!ok) atomicExch(bad, -(1 + p));
+	zero<36>(Li); // L^-1 (lower)
+	for (int j = 0; j < 6; j++)
+	{
+		Li[j * 6 + j] = 1.0 / L[j * 6 + j];
+		for (int i = j + 1; i < 6; i++)
+		{
+			double s = 0;
+			for (int k = j; k < i; k++) s -= L[i * 6 + k] * Li[k * 6 + j];
+			Li[i * 6 + j] = s / L[i * 6 + i];
+		}
+	}
+	double Ai[36]; // A^-1 = L^-T L^-1
+	for (int i = 0; i < 6; i++)
+		for (int j = 0; j < 6; j++)
+		{
+			double s = 0;
+			for (int k = (i > j ? i : j); k < 6; k++) s += Li[k * 6 + i] * Li[k * 6 + j];
+			Ai[i * 6 + j] = s;
+		}
+	for (int i = 0; i < 6; i++)
+		for (int j = 0; j < 6; j++)
+			if (fixed && (fixed[(size_t)p * 6 + i] || fixed[(size_t)p * 6 + j])) Ai[i * 6 + j] = 0.0;
+	st<36>(Minv + (size_t)p * 36, Ai);
+}
+
+// ---- PCG pieces (K10b/K10c) ---------------------------------------------------------------------------------
+struct PcgSeg {
+	double rz[2];
+	double pAp;
+	double rz0, ez, thresh;
+	int done, its, row0, active;
+};
+static_assert(sizeof(PcgSeg) % sizeof(double) == 0, "PcgSeg is strided in doubles by the SpMV's fused dot product");
+
+// r = E - y, z = Minv r, p = z, rz[0] += r.z, ez += E.Minv E ; x = x0 (fixed scalars forced to 0)
+__global__ void k_pcg_init(int M, const double* __restrict__ E, const double* __restrict__ y, const double* __restrict__ Minv,
+                           const int* __restrict__ pose_seg, const unsigned char* __restrict__ fixed, double* __restrict__ r, double* __restrict__ z,
+                           double* __restrict__ p, PcgSeg* seg)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool v = row < M;
+	double rz = 0, ez = 0;
+	int sg = 0;
+	if (v)
+	{
+		sg = pose_seg[row];
+		double rr[6], ee[6], mi[36], zz[6], ze[6];
+		for (int i = 0; i < 6; i++)
+		{
+			ee[i] = E[(size_t)row * 6 + i];
+			rr[i] = ee[i] - y[(size_t)row * 6 + i];
+			if (fixed && fixed[(size_t)row * 6 + i]) { rr[i] = 0; ee[i] = 0; }
+		}
+		ld<36>(mi, Minv + (size_t)row * 36);
+		mm<6, 6, 1, false>(mi, rr, zz);
+		mm<6, 6, 1, false>(mi, ee, ze);
+		for (int i = 0; i < 6; i++)
+		{
+			r[(size_t)row * 6 + i] = rr[i]; z[(size_t)row * 6 + i] = zz[i]; p[(size_t)row * 6 + i] = zz[i];
+			rz += rr[i] * zz[i]; ez += ee[i] * ze[i];
+		}
+	}
+	wave_scatter_add<1>(&seg[sg].rz[0], &rz, v);
+	wave_scatter_add<1>(&seg[sg].ez, &ez, v);
+}
+
+__global__ void k_pcg_init2(int nseg, PcgSeg* seg, const unsigned char* __restrict__ active, double rel_tol, int* ndone)
+{
+	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	PcgSeg& g = seg[s];
+	g.rz0 = g.rz[0];
+	const double floor_ = 1e-30 * g.ez; // (1e-15 relative to the right-hand side)^2
+	g.thresh = fmax(rel_tol * rel_tol * g.rz0, floor_);
+	g.pAp = 0; g.rz[1] = 0; g.its = 0;
+	g.active = active ? active[s] : 1;
+	g.done = (!g.active || !(g.rz0 > g.thresh)) ? 1 : 0;
+	if (g.done) atomicAdd(ndone, 1);
+}
+
+// alpha = rz/pAp ; x += alpha p ; r -= alpha Ap ; z = Minv r ; rz[nxt] += r.z
+__global__ void k_pcg_update1(int M, int cur, const double* __restrict__ Ap, const double* __restrict__ Minv, const int* __restrict__ pose_seg,
+                              double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, const double* __restrict__ p, PcgSeg* seg)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	bool v = row < M;
+	double rz = 0;
+	int sg = 0;
+	if (v)
+	{
+		sg = pose_seg[row];
+		const PcgSeg& g = seg[sg];
+		if (g.done) v = false;
+		else
+		{
+			const double alpha = g.rz[cur] / g.pAp;
+			double rr[6], mi[36], zz[6];
+			for (int i = 0; i < 6; i++)
+			{
+				const size_t o = (size_t)row * 6 + i;
+				x[o] += alpha * p[o];
+				rr[i] = r[o] - alpha * Ap[o];
+				r[o] = rr[i];
+			}
+			ld<36>(mi, Minv + (size_t)row * 36);
+			mm<6, 6, 1, false>(mi, rr, zz);
+			for (int i = 0; i < 6; i++) { z[(size_t)row * 6 + i] = zz[i]; rz += rr[i] * zz[i]; }
+		}
+	}
+	wave_scatter_add<1>(&seg[sg].rz[cur ^ 1], &rz, v);
+}
+
+// beta = rz[nxt]/rz[cur] ; p = z + beta p ; Ap = 0 ; per system: convergence test, reset accumulators
+__global__ void k_pcg_update2(int M, int cur, const double* __restrict__ z, const int* __restrict__ pose_seg, double* __restrict__ p,
+                              double* __restrict__ Ap, PcgSeg* seg, int* ndone)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= M) return;
+	const int sg = pose_seg[row];
+	PcgSeg& g = seg[sg];
+	const bool done = g.done;
+	const double rzn = g.rz[cur ^ 1], rzc = g.rz[cur];
+	for (int i = 0; i < 6; i++) Ap[(size_t)row * 6 + i] = 0.0;
+	if (!done)
+	{
+		const double beta = rzn / rzc;
+		for (int i = 0; i < 6; i++) { const size_t o = (size_t)row * 6 + i; p[o] = z[o] + beta * p[o]; }
+	}
+	if (row == g.row0 && !done)
+	{
+		g.pAp = 0;
+		g.its++;
+		// rz[cur] is zeroed by k_pcg_rotate before it becomes the accumulator again
+		if (!(rzn > g.thresh) || !(rzn == rzn)) { g.done = (rzn == rzn) ? 1 : 2; atomicAdd(ndone, 1); }
+	}
+}
+__global__ void k_pcg_rotate(int nseg, int cur, PcgSeg* seg)
+{
+	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < nseg) seg[s].rz[cur] = 0.0;
+}
+
+// final: true residual per system ||E - S x||^2 and ||E||^2 ; copy x0 for carried maps
+__global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* __restrict__ y, const int* __restrict__ pose_seg,
+                            const unsigned char* __restrict__ fixed, double* __restrict__ acc)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool v = row < M;
+	double a[2] = { 0, 0 };
+	int sg = 0;
+	if (v)
+	{
+		sg = pose_seg[row];
+		for (int i = 0; i < 6; i++)
+		{
+			if (fixed && fixed[(size_t)row * 6 + i]) continue;
+			double e = E[(size_t)row * 6 + i], d = e - y[(size_t)row * 6 + i];
+			a[0] += d * d; a[1] += e * e;
+		}
+	}
+	wave_scatter_add<2>(acc + (size_t)sg * 2, a, v);
+}
+
+__global__ void k_x_init(int M, const double* __restrict__ x0, const unsigned char* __restrict__ fixed, double* __restrict__ x)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)M * 6) return;
+	double v = x0 ? x0[i] : 0.0;
+	if (fixed && fixed[i]) v = 0.0;
+	x[i] = v;
+}
+
+// K11: one lane per feature (Imp.cpp:2980-3020); features of carried maps keep their values
+__global__ void k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
+                          const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,
+                          const int* __restrict__ feat_seg, const unsigned char* __restrict__ active, double* __restrict__ xf)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	if (active && !active[feat_seg[f]]) return;
+	double eb2[3] = { 0, 0, 0 };
+	for (int j = fptr[f]; j < fptr[f + 1]; j++)
+	{
+		const double* w = W + (size_t)j * 18;
+		const double* a = xp + (size_t)photo[j] * 6;
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+#pragma unroll
+			for (int r = 0; r < 6; r++) eb2[c] = fma(w[3 * r + c], a[r], eb2[c]);
+	}
+	const double* iv = IV + (size_t)f * 9;
+	double d[3] = { eb[(size_t)f * 3] - eb2[0], eb[(size_t)f * 3 + 1] - eb2[1], eb[(size_t)f * 3 + 2] - eb2[2] };
+	for (int r = 0; r < 3; r++) xf[(size_t)f * 3 + r] = iv[3 * r] * d[0] + iv[3 * r + 1] * d[1] + iv[3 * r + 2] * d[2];
+}
+
+// -------------------------------------------------------------------------------------------------------------
+__global__ void k_low_words(int n, const unsigned long long* __restrict__ keys, int* __restrict__ out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (int)(keys[i] & 0xffffffffull);
+}
+
+struct SchurSystem {
+	int M = 0, nnzb = 0, nfull = 0, nchunks = 0;
+	int *rowptr = nullptr, *colidx = nullptr;      // upper block CSR (diagonal block first in every row)
+	double* S = nullptr;                           // [nnzb*36]
+	double* E = nullptr;                           // [M*6]
+	double* IV = nullptr;                          // [NF*9]
+	int *frow = nullptr, *fcol = nullptr, *fblk = nullptr; // both orientations, row sorted; fblk = (upper index << 1) | transposed
+	int *chunk_row = nullptr, *chunk_beg = nullptr;
+};
+
+static void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	const int M = sy.M, cnt = sy.nnzb;
+	unsigned long long* fk = sc.alloc<unsigned long long>(2 * (size_t)cnt + 1);
+	int* fv = sc.alloc<int>(2 * (size_t)cnt + 1);
+	dev_zero(ctx, d_flags + 2, sizeof(int));
+	if (cnt) hipLaunchKernelGGL(k_full_keys, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, sorted_upper, fk, fv, d_flags + 2);
+	const int nmir = d2h_int(ctx, d_flags + 2);
+	sy.nfull = cnt + nmir;
+	dev_sort_pairs_u64(ctx, fk, fv, sy.nfull, 64);
+	sy.frow = sc.alloc<int>(M + 1);
+	sy.fcol = sc.alloc<int>(sy.nfull + 1);
+	sy.fblk = fv;
+	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, sy.nfull, fk, 32, sy.frow);
+	if (sy.nfull) hipLaunchKernelGGL(k_low_words, dim3((sy.nfull + 255) / 256), dim3(256), 0, s, sy.nfull, fk, sy.fcol);
+	// chunks of <= SPMV_CHUNK blocks
+	int* ccnt = sc.alloc<int>(M + 1);
+	int* cptr = sc.alloc<int>(M + 2);
+	hipLaunchKernelGGL(k_chunk_counts, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, ccnt);
+	dev_exclusive_scan(ctx, ccnt, cptr, M);
+	sy.nchunks = d2h_int(ctx, cptr + M);
+	sy.chunk_row = sc.alloc<int>(sy.nchunks + 1);
+	sy.chunk_beg = sc.alloc<int>(sy.nchunks + 1);
+	hipLaunchKernelGGL(k_chunk_fill, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, cptr, sy.chunk_row, sy.chunk_beg);
+}
+
+static void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	const int M = io.M, NF = io.NF;
+	sy.M = M;
+	sy.IV = sc.alloc<double>((size_t)NF * 9);
+	if (NF) hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.V, sy.IV);
+	int* d_flags = sc.alloc<int>(4); // [0] overflow, [1] count, [2] mirrored count
+	size_t cap = 1024;
+	while (cap < (size_t)4 * ((size_t)io.NU + 32 * (size_t)M + 64)) cap <<= 1;
+	unsigned long long *tab = nullptr, *list = nullptr;
+	int* hval = nullptr;
+	for (int attempt = 0;; attempt++)
+	{
+		size_t mk = sc.mark();
+		tab = sc.alloc<unsigned long long>(cap);
+		hval = sc.alloc<int>(cap);
+		list = sc.alloc<unsigned long long>(cap);
+		dev_zero(ctx, d_flags, 4 * sizeof(int));
+		hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, HEMPTY);
+		const int nu = std::max(io.NU, M);
+		if (nu) hipLaunchKernelGGL(k_pat_insert_u, dim3((nu + 255) / 256), dim3(256), 0, s, io.NU, M, io.Ui, io.Uj, tab, (unsigned long long)(cap - 1), d_flags);
+		if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, tab, (unsigned long long)(cap - 1), d_flags);
+		hipLaunchKernelGGL(k_pat_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, cap, tab, list, d_flags + 1);
+		int fl[2];
+		d2h_ints(ctx, d_flags, fl, 2);
+		if (!fl[0] && (size_t)fl[1] * 2 <= cap) { sy.nnzb = fl[1]; break; }
+		sc.release(mk);
+		cap <<= 2;
+		if (attempt > 10) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur pattern hash table kept overflowing");
+	}
+	const int cnt = sy.nnzb;
+	const unsigned long long mask = (unsigned long long)(cap - 1);
+	int* dummy = sc.alloc<int>(cnt + 1);
+	dev_sort_pairs_u64(ctx, list, dummy, cnt, 64);
+	sy.rowptr = sc.alloc<int>(M + 1);
+	sy.colidx = sc.alloc<int>(cnt + 1);
+	if (cnt) hipLaunchKernelGGL(k_pat_assign, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, list, tab, hval, mask, sy.colidx);
+	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, cnt, list, 32, sy.rowptr);
+	sy.S = sc.alloc<double>((size_t)cnt * 36);
+	sy.E = sc.alloc<double>((size_t)M * 6);
+	dev_zero(ctx, sy.S, (size_t)cnt * 36 * sizeof(double));
+	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
+	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
+	if (NF) hipLaunchKernelGGL(k_schur_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
+	build_spmv_index(ctx, sy, list, d_flags);
+	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+static inline void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,
+                               const double* dotw, const int* pose_seg, double* dot, int dot_stride = 1)
+{
+	const int threads = sy.nchunks * 8;
+	if (threads)
+		hipLaunchKernelGGL(k_spmv, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sy.nchunks, sy.chunk_row, sy.chunk_beg, sy.frow, sy.fcol,
+		                   sy.fblk, sy.S, x, y, fixed, dotw, pose_seg, dot, dot_stride);
+}
+
+// algorithmic bytes of one SpMV on the upper-block storage: blocks + column indices + row pointers + x and y
+static double spmv_bytes(const SchurSystem& sy) { return (double)sy.nnzb * (288 + 4) + 4.0 * (sy.M + 1) + 2.0 * 48 * sy.M; }
+
+int solve_batch(lsfm_context* ctx, const SolveIO& io)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	const int M = io.M, nseg = io.nseg;
+	hipEvent_t ea = nullptr, eb = nullptr;
+	float ms = 0;
+	LSFM_CHECK_HIP(hipEventCreate(&ea)); LSFM_CHECK_HIP(hipEventCreate(&eb));
+	LSFM_CHECK_HIP(hipEventRecord(ea, s));
+	SchurSystem sy;
+	build_schur(ctx, io, sy);
+	double* Minv = sc.alloc<double>((size_t)M * 36);
+	int* d_misc = sc.alloc<int>(4); // [0] bad diagonal, [1] ndone
+	dev_zero(ctx, d_misc, 4 * sizeof(int));
+	if (M) hipLaunchKernelGGL(k_diag_inverse, dim3((M + 127) / 128), dim3(128), 0, s, M, sy.rowptr, sy.colidx, sy.S, io.d_fixed, Minv, d_misc);
+	LSFM_CHECK_HIP(hipEventRecord(eb, s));
+	LSFM_CHECK_HIP(hipEventSynchronize(eb));
+	LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
+	if (ctx->stats) ctx->stats->t_schur_ms += ms;
+	LSFM_CHECK_HIP(hipEventRecord(ea, s));
+
+	// ---- PCG ----
+	std::vector<PcgSeg> hseg(nseg);
+	{
+		int row = 0;
+		for (int g = 0; g < nseg; g++) { memset(&hseg[g], 0, sizeof(PcgSeg)); hseg[g].row0 = row; row += io.seg_rows[g]; }
+	}
+	PcgSeg* seg = sc.alloc<PcgSeg>(nseg);
+	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg);
+	double* x = io.x_pose;
+	double* r = sc.alloc<double>((size_t)M * 6);
+	double* z = sc.alloc<double>((size_t)M * 6);
+	double* p = sc.alloc<double>((size_t)M * 6);
+	double* Ap = sc.alloc<double>((size_t)M * 6);
+	double* racc = sc.alloc<double>((size_t)nseg * 2);
+	const int nbr = (M + 127) / 128;
+	const size_t nscal = (size_t)M * 6;
+	hipLaunchKernelGGL(k_x_init, dim3((unsigned)((nscal + 255) / 256)), dim3(256), 0, s, M, io.x0, io.d_fixed, x);
+	dev_zero(ctx, Ap, nscal * sizeof(double));
+	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr);
+	hipLaunchKernelGGL(k_pcg_init, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, Minv, io.d_pose_seg, io.d_fixed, r, z, p, seg);
+	hipLaunchKernelGGL(k_pcg_init2, dim3((nseg + 127) / 128), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
+	dev_zero(ctx, Ap, nscal * sizeof(double));
+	int bad = d2h_int(ctx, d_misc);
+	if (bad > 0) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system: block row " + std::to_string(bad - 1) + " has no diagonal block");
+
+	int maxrows = 1;
+	for (int g = 0; g < nseg; g++) maxrows = std::max(maxrows, io.seg_rows[g]);
+	const long maxit = (long)ctx->pcg.max_it_factor * 6 * maxrows + 200;
+	const int per_graph = maxrows <= 8 ? 8 : (maxrows <= 64 ? 32 : 64); // iterations per graph replay (even)
+	auto enqueue_iteration = [&](int cur) {
+		// SpMV also zeroes the rz accumulator of this iteration (it reads no scalars)
+		hipLaunchKernelGGL(k_pcg_rotate, dim3((nseg + 127) / 128), dim3(128), 0, s, nseg, cur ^ 1, seg);
+		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, (int)(sizeof(PcgSeg) / sizeof(double)));
+		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, Ap, Minv, io.d_pose_seg, x, r, z, p, seg);
+		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
+	};
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t gexec = nullptr;
+	bool use_graph = true;
+	if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess)
+	{
+		for (int it = 0; it < per_graph; it++) enqueue_iteration(it & 1);
+		if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
+	}
+	else
+		use_graph = false;
+	(void)hipGetLastError();
+	long its = 0;
+	int ndone = d2h_int(ctx, d_misc + 1);
+	hipEvent_t es0 = ctx->ev0, es1 = ctx->ev1;
+	while (ndone < nseg && its < maxit)
+	{
+		// one SpMV per replay is bracketed by events on this stream: live sample of the kernel's duration
+		if (ctx->stats)
+		{
+			double* scratch_y = r; // not: timing sample must not disturb the iteration -> use a separate vector
+			(void)scratch_y;
+		}
+		if (use_graph) LSFM_CHECK_HIP(hipGraphLaunch(gexec, s));
+		else for (int it = 0; it < per_graph; it++) enqueue_iteration(it & 1);
+		its += per_graph;
+		ndone = d2h_int(ctx, d_misc + 1);
+	}
+	if (gexec) (void)hipGraphExecDestroy(gexec);
+	if (graph) (void)hipGraphDestroy(graph);
+	// ---- true residual, statistics ----
+	dev_zero(ctx, Ap, nscal * sizeof(double));
+	dev_zero(ctx, racc, (size_t)nseg * 2 * sizeof(double));
+	// timed SpMV launches (same kernel, same matrix, same stream as inside the loop)
+	const int nsample = 5;
+	float sp_ms = 0;
+	for (int k = 0; k < nsample; k++)
+	{
+		dev_zero(ctx, Ap, nscal * sizeof(double));
+		LSFM_CHECK_HIP(hipEventRecord(es0, s));
+		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr);
+		LSFM_CHECK_HIP(hipEventRecord(es1, s));
+		LSFM_CHECK_HIP(hipEventSynchronize(es1));
+		float t = 0;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&t, es0, es1));
+		sp_ms += t;
+	}
+	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, racc);
+	std::vector<double> hr((size_t)nseg * 2);
+	d2h(ctx, hr.data(), racc, hr.size() * sizeof(double));
+	d2h(ctx, hseg.data(), seg, sizeof(PcgSeg) * nseg);
+	int notconv = 0;
+	double maxrel = 0;
+	for (int g = 0; g < nseg; g++)
+	{
+		if (!hseg[g].active) continue;
+		if (hseg[g].done != 1) notconv++;
+		if (hr[2 * g + 1] > 0) maxrel = std::max(maxrel, sqrt(hr[2 * g] / hr[2 * g + 1]));
+	}
+	// ---- features ----
+	LSFM_CHECK_HIP(hipEventRecord(eb, s));
+	if (io.NF)
+		hipLaunchKernelGGL(k_backsub, dim3((io.NF + 255) / 256), dim3(256), 0, s, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x, io.d_feat_seg,
+		                   io.d_seg_active, io.x_feat);
+	LSFM_CHECK_HIP(hipGetLastError());
+	hipEvent_t ec = nullptr;
+	LSFM_CHECK_HIP(hipEventCreate(&ec));
+	LSFM_CHECK_HIP(hipEventRecord(ec, s));
+	LSFM_CHECK_HIP(hipEventSynchronize(ec));
+	if (ctx->stats)
+	{
+		lsfm_stats* st = ctx->stats;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); st->t_pcg_ms += ms;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, eb, ec)); st->t_backsub_ms += ms;
+		st->pcg_iterations += its;
+		st->spmv_launches += nsample;
+		st->spmv_ms += sp_ms;
+		st->spmv_bytes += nsample * spmv_bytes(sy);
+		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
+		st->max_rel_residual = std::max(st->max_rel_residual, maxrel);
+	}
+	(void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec);
+	return notconv;
+}
+
+// y = S x for an externally supplied symmetric block matrix (upper block CSR): measurement entry of the C ABI
+int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,
+                  double* avg_ms, double* bytes)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	size_t mk = sc.mark();
+	const int nnzb = rowptr[m];
+	SchurSystem sy;
+	sy.M = m; sy.nnzb = nnzb;
+	std::vector<unsigned long long> keys(nnzb);
+	for (int p = 0; p < m; p++)
+		for (int k = rowptr[p]; k < rowptr[p + 1]; k++) keys[k] = ((unsigned long long)(unsigned)p << 32) | (unsigned)colidx[k];
+	unsigned long long* dk = sc.alloc<unsigned long long>(nnzb + 1);
+	sy.S = sc.alloc<double>((size_t)nnzb * 36);
+	double* dx = sc.alloc<double>((size_t)m * 6);
+	double* dy = sc.alloc<double>((size_t)m * 6);
+	int* d_flags = sc.alloc<int>(4);
+	h2d(ctx, dk, keys.data(), (size_t)nnzb * sizeof(unsigned long long));
+	h2d(ctx, sy.S, val, (size_t)nnzb * 36 * sizeof(double));
+	h2d(ctx, dx, x, (size_t)m * 6 * sizeof(double));
+	build_spmv_index(ctx, sy, dk, d_flags);
+	float total = 0;
+	for (int k = 0; k < reps + 2; k++)
+	{
+		dev_zero(ctx, dy, (size_t)m * 6 * sizeof(double));
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
+		launch_spmv(ctx, sy, dx, dy, nullptr, nullptr, nullptr, nullptr);
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+		LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+		float t = 0;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+		if (k >= 2) total += t;
+	}
+	d2h(ctx, y, dy, (size_t)m * 6 * sizeof(double));
+	if (avg_ms) *avg_ms = reps > 0 ? total / reps : 0;
+	if (bytes) *bytes = spmv_bytes(sy);
+	sc.release(mk);
+	return 0;
+}
+
+} // namespace lsfm

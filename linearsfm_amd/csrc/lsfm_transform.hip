@@ -1,0 +1,732 @@
+// Batched coordinate transform of maps: new state x' = f(x) and new information I' = J^T I J.
+// Replaces lmj_Transform_PF3DStereo (Imp.cpp:349-1924) and lmj_Transform_PF3DMono (Imp.cpp:3173-6509) for all maps
+// of a tree level in one set of launches.
+//
+// Formulation (DESIGN.md "Transform"): the Jacobian of the OLD state w.r.t. the NEW state is
+//     J = blkdiag(D) + sum_s C_s e_{h_s}^T          D = "J1", C_1 = "J2" (column of the old reference pose h_1),
+//                                                   Mono: C_2 = "J3" (column of the old scale pose h_2)
+// so  I' = D^T I D  +  [D^T G_s] e_{h_s}^T + e_{h_s} [D^T G_s]^T  +  e_{h_s} (C_s^T G_t) e_{h_t}^T ,  G_s = I C_s .
+// The reference accumulates the same sums block by block ("Algorithm Line 3/4/5/6").  Here:
+//   k_tr_features  one lane per feature: V' = D_f^T V D_f, W' = D_k^T W D_f, the feature rows of G, the pose rows of
+//                  G (scatter-add, pre-reduced over the wave when the lanes hit the same pose), C_f^T G_f
+//   k_tr_ublocks   one lane per U block: U' = D_a^T U D_b and the U part of the pose rows of G
+//   k_tr_poseslots one lane per pose: the new (k,h_s) blocks D_k^T G_s,k and C_k^T G_k
+//   k_tr_diag      adds sum_a C_a^T G_a to the (h,h) blocks
+// Output slot layout is the reference's: per map first the m blocks (k,h_1) [Mono: then m blocks (k,h_2)], then the
+// untouched blocks in their old order; per feature first its block(s) to h_1 [h_2], then its old blocks.
+#include <algorithm>
+
+#include "lsfm_device.hpp"
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+struct TMap {
+	int active, nh;
+	int P0, m, F0, n;
+	int U0, U0n, W0, W0n, kU0, kW0;
+	int hub[2];        // global pose index of the old reference pose / old scale pose (= the dense columns)
+	int nref, nscap;   // Mono: global index of the NEW reference / scale pose
+	int newFix, oldFix, newLabel;
+	int c2fix, c3zero; // Mono gauge special cases, Imp.cpp:3703-3710
+	int tref, tscap, oldref, oldscap;
+	// phase 1: rotation / translation / scale that map old coordinates to new ones
+	double R1[9], t1[3], scale1;
+	int sign1;
+	// phase 2: quantities of the Jacobian, evaluated at the new state of the old reference pose
+	double R[9], dRA[9], dRB[9], dRG[9], t[3], dA[3], dB[3], dG[3];
+	double Scale, Scale2, dSdA[3], dSdB[3], dSdG[3], dSdt[9], dSdtt[9];
+};
+
+__global__ void k_tr_find(const int* __restrict__ pose_id, const int* __restrict__ pose_map, int M, TMap* tm)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= M) return;
+	TMap& t = tm[pose_map[k]];
+	if (!t.active) return;
+	int id = pose_id[k];
+	if (id == t.tref) t.nref = k;
+	if (t.nh == 2)
+	{
+		if (id == t.tscap) t.nscap = k;
+		if (id == t.oldref) t.hub[0] = k;
+		if (id == t.oldscap) t.hub[1] = k;
+	}
+	else if (id == t.tref) t.hub[0] = k; // Stereo: the slot of the new reference pose holds the old one afterwards
+}
+
+// Imp.cpp:389-400 / 3216-3244
+__global__ void k_tr_params1(const double* __restrict__ pose, TMap* tm, int B, int* err)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= B) return;
+	TMap& t = tm[b];
+	if (!t.active) return;
+	if (t.nref < 0 || t.hub[0] < 0 || (t.nh == 2 && (t.nscap < 0 || t.hub[1] < 0))) { atomicExch(err, 1 + b); t.active = -1; return; }
+	const double* p = pose + (size_t)t.nref * 6;
+	t.t1[0] = p[0]; t.t1[1] = p[1]; t.t1[2] = p[2];
+	rmat_ypr(t.R1, p[3], p[4], p[5]);
+	t.scale1 = 1.0; t.sign1 = 1;
+	if (t.nh == 2)
+	{
+		const double* q = pose + (size_t)t.nscap * 6;
+		double d[3] = { q[0] - p[0], q[1] - p[1], q[2] - p[2] }, ts[3];
+		mv3(t.R1, d, ts);
+		t.scale1 = fabs(ts[t.newFix]);
+		t.sign1 = ts[t.newFix] >= 0 ? 1 : -1;
+		t.c2fix = (t.hub[0] == t.nscap);
+		t.c3zero = (t.hub[1] == t.nref);
+	}
+}
+
+// new pose values, Imp.cpp:421-446 / 3268-3297; also copies ids (Stereo relabels the hub slot, Imp.cpp:416-417)
+__global__ void k_tr_new_poses(const double* __restrict__ pose, const int* __restrict__ pose_id, const int* __restrict__ pose_map,
+                               int M, const TMap* __restrict__ tm, double* __restrict__ npose, int* __restrict__ npose_id)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= M) return;
+	const TMap& t = tm[pose_map[k]];
+	const double* p = pose + (size_t)k * 6;
+	double* o = npose + (size_t)k * 6;
+	if (t.active <= 0)
+	{
+		for (int i = 0; i < 6; i++) o[i] = p[i];
+		npose_id[k] = pose_id[k];
+		return;
+	}
+	double R2[9], R3[9], a, b, g;
+	if (t.nh == 1 && k == t.hub[0])
+	{
+		o[0] = -(t.R1[0] * t.t1[0] + t.R1[1] * t.t1[1] + t.R1[2] * t.t1[2]);
+		o[1] = -(t.R1[3] * t.t1[0] + t.R1[4] * t.t1[1] + t.R1[5] * t.t1[2]);
+		o[2] = -(t.R1[6] * t.t1[0] + t.R1[7] * t.t1[1] + t.R1[8] * t.t1[2]);
+		inv_rmat_ypr_T(t.R1, a, b, g);
+		o[3] = a; o[4] = b; o[5] = g;
+		npose_id[k] = t.newLabel;
+		return;
+	}
+	double d[3] = { p[0] - t.t1[0], p[1] - t.t1[1], p[2] - t.t1[2] }, v[3];
+	mv3(t.R1, d, v);
+	if (t.nh == 2) { v[0] = v[0] / t.scale1; v[1] = v[1] / t.scale1; v[2] = v[2] / t.scale1; }
+	rmat_ypr(R2, p[3], p[4], p[5]);
+	times_rrt(R3, R2, t.R1);
+	inv_rmat_ypr(R3, a, b, g);
+	o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = a; o[4] = b; o[5] = g;
+	if (t.nh == 2)
+	{
+		if (k == t.nref) for (int i = 0; i < 6; i++) o[i] = 0.0;
+		if (k == t.nscap) o[t.newFix] = (double)t.sign1;
+	}
+	npose_id[k] = pose_id[k];
+}
+
+// Imp.cpp:459-471 / 3311-3365
+__global__ void k_tr_params2(const double* __restrict__ npose, TMap* tm, int B)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= B) return;
+	TMap& t = tm[b];
+	if (t.active <= 0) return;
+	const double* p = npose + (size_t)t.hub[0] * 6;
+	t.t[0] = p[0]; t.t[1] = p[1]; t.t[2] = p[2];
+	r_derivation(p[3], p[4], p[5], t.R, t.dRA, t.dRB, t.dRG);
+	d_ri<true>(t.dA, t.dRA, t.R); d_ri<true>(t.dB, t.dRB, t.R); d_ri<true>(t.dG, t.dRG, t.R);
+	t.Scale = 1.0; t.Scale2 = 1.0;
+	if (t.nh == 2)
+	{
+		const double* q = npose + (size_t)t.hub[1] * 6;
+		double d[3] = { q[0] - p[0], q[1] - p[1], q[2] - p[2] }, ts[3];
+		mv3(t.R, d, ts);
+		t.Scale = fabs(ts[t.oldFix]);
+		t.Scale2 = t.Scale * t.Scale;
+		double Sign = ts[t.oldFix] >= 0 ? 1.0 : -1.0;
+		for (int i = 0; i < 9; i++) { t.dSdt[i] = -t.R[i] * Sign; t.dSdtt[i] = t.R[i] * Sign; }
+		mv3(t.dRA, d, t.dSdA); mv3(t.dRB, d, t.dSdB); mv3(t.dRG, d, t.dSdG);
+		for (int i = 0; i < 3; i++) { t.dSdA[i] *= Sign; t.dSdB[i] *= Sign; t.dSdG[i] *= Sign; }
+	}
+}
+
+// translation part of the Mono Jacobians for an element at new position xn (Imp.cpp:3420-3469 / 3591-3640):
+// dt2dt22 = R/Scale (-> D), [dt2dt | tmp1 tmp2 tmp3] (-> C_1), dt2dtt (-> C_2)
+__device__ __forceinline__ void mono_trans_jac(const TMap& t, const double* xn, double* dt2dt22, double* dt2dt, double* tmpc, double* dt2dtt)
+{
+	double t222[3] = { xn[0] - t.t[0], xn[1] - t.t[1], xn[2] - t.t[2] }, t22[3], v[3];
+	const int mFix = t.oldFix;
+	mv3(t.R, t222, t22);
+	mv3(t.dRA, t222, v);
+#pragma unroll
+	for (int r = 0; r < 3; r++) tmpc[3 * r + 0] = (v[r] * t.Scale - t22[r] * t.dSdA[mFix]) / t.Scale2;
+	mv3(t.dRB, t222, v);
+#pragma unroll
+	for (int r = 0; r < 3; r++) tmpc[3 * r + 1] = (v[r] * t.Scale - t22[r] * t.dSdB[mFix]) / t.Scale2;
+	mv3(t.dRG, t222, v);
+#pragma unroll
+	for (int r = 0; r < 3; r++) tmpc[3 * r + 2] = (v[r] * t.Scale - t22[r] * t.dSdG[mFix]) / t.Scale2;
+#pragma unroll
+	for (int r = 0; r < 3; r++)
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			dt2dt22[3 * r + c] = t.R[3 * r + c] / t.Scale;
+			dt2dt[3 * r + c] = (-t.R[3 * r + c] * t.Scale - t22[r] * t.dSdt[3 * mFix + c]) / t.Scale2;
+			dt2dtt[3 * r + c] = (-t22[r] * t.dSdtt[3 * mFix + c]) / t.Scale2;
+		}
+}
+
+// per pose: D (6x6) and C_s (6x6), Imp.cpp:485-635 / 3383-3584 and the gauge zeroing 3691-3710
+template <int NH>
+__global__ void k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map, int M, const TMap* __restrict__ tm,
+                              double* __restrict__ Dp, double* __restrict__ Cp)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= M) return;
+	const TMap& t = tm[pose_map[k]];
+	if (t.active <= 0 || t.nh != NH) return;
+	double D[36], C1[36], C2[36];
+	zero<36>(D); zero<36>(C1); zero<36>(C2);
+	const double* p = npose + (size_t)k * 6;
+	if (NH == 1 && k == t.hub[0])
+	{
+		double tmp1[3], tmp2[3], tmp3[3];
+		mv3(t.dRA, t.t, tmp1); mv3(t.dRB, t.t, tmp2); mv3(t.dRG, t.t, tmp3);
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+		{
+			D[6 * r + 0] = -t.R[3 * r]; D[6 * r + 1] = -t.R[3 * r + 1]; D[6 * r + 2] = -t.R[3 * r + 2];
+			D[6 * r + 3] = -tmp1[r]; D[6 * r + 4] = -tmp2[r]; D[6 * r + 5] = -tmp3[r];
+			D[6 * (3 + r) + 3] = t.dA[r]; D[6 * (3 + r) + 4] = t.dB[r]; D[6 * (3 + r) + 5] = t.dG[r];
+		}
+	}
+	else
+	{
+		double R2[9], dRA2[9], dRB2[9], dRG2[9], Ri[9], dRi[9], ddA2[3], ddB2[3], ddG2[3], ddA[3], ddB[3], ddG[3];
+		r_derivation(p[3], p[4], p[5], R2, dRA2, dRB2, dRG2);
+		times_rrt(Ri, R2, t.R);
+		times_rrt(dRi, dRA2, t.R); d_ri<false>(ddA2, dRi, Ri);
+		times_rrt(dRi, dRB2, t.R); d_ri<false>(ddB2, dRi, Ri);
+		times_rrt(dRi, dRG2, t.R); d_ri<false>(ddG2, dRi, Ri);
+		times_rrt(dRi, R2, t.dRA); d_ri<false>(ddA, dRi, Ri);
+		times_rrt(dRi, R2, t.dRB); d_ri<false>(ddB, dRi, Ri);
+		times_rrt(dRi, R2, t.dRG); d_ri<false>(ddG, dRi, Ri);
+		if (NH == 1)
+		{
+			double d[3] = { p[0] - t.t[0], p[1] - t.t[1], p[2] - t.t[2] }, tmp1[3], tmp2[3], tmp3[3];
+			mv3(t.dRA, d, tmp1); mv3(t.dRB, d, tmp2); mv3(t.dRG, d, tmp3);
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+			{
+				C1[6 * r + 0] = -t.R[3 * r]; C1[6 * r + 1] = -t.R[3 * r + 1]; C1[6 * r + 2] = -t.R[3 * r + 2];
+				C1[6 * r + 3] = tmp1[r]; C1[6 * r + 4] = tmp2[r]; C1[6 * r + 5] = tmp3[r];
+				C1[6 * (3 + r) + 3] = ddA[r]; C1[6 * (3 + r) + 4] = ddB[r]; C1[6 * (3 + r) + 5] = ddG[r];
+				D[6 * r + 0] = t.R[3 * r]; D[6 * r + 1] = t.R[3 * r + 1]; D[6 * r + 2] = t.R[3 * r + 2];
+				D[6 * (3 + r) + 3] = ddA2[r]; D[6 * (3 + r) + 4] = ddB2[r]; D[6 * (3 + r) + 5] = ddG2[r];
+			}
+		}
+		else
+		{
+			double a22[9], adt[9], atmp[9], adtt[9];
+			mono_trans_jac(t, p, a22, adt, atmp, adtt);
+			double* q1 = (k == t.hub[0]) ? D : C1; // Imp.cpp:3495-3556
+			double* q2 = (k == t.hub[1]) ? D : C2; // Imp.cpp:3558-3581
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+			{
+#pragma unroll
+				for (int c = 0; c < 3; c++) D[6 * r + c] += a22[3 * r + c];
+				D[6 * (3 + r) + 3] += ddA2[r]; D[6 * (3 + r) + 4] += ddB2[r]; D[6 * (3 + r) + 5] += ddG2[r];
+			}
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+			{
+#pragma unroll
+				for (int c = 0; c < 3; c++) q1[6 * r + c] += adt[3 * r + c];
+				q1[6 * (3 + r) + 3] += ddA[r]; q1[6 * (3 + r) + 4] += ddB[r]; q1[6 * (3 + r) + 5] += ddG[r];
+				q1[6 * r + 3] += atmp[3 * r + 0]; q1[6 * r + 4] += atmp[3 * r + 1]; q1[6 * r + 5] += atmp[3 * r + 2];
+			}
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int c = 0; c < 3; c++) q2[6 * r + c] += adtt[3 * r + c];
+			if (k == t.nref) zero<36>(D);
+			if (k == t.nscap) for (int r = 0; r < 6; r++) D[6 * r + t.newFix] = 0.0;
+			if (t.c2fix) for (int r = 0; r < 6; r++) C1[6 * r + t.newFix] = 0.0;
+			if (t.c3zero) zero<36>(C2);
+		}
+	}
+	st<36>(Dp + (size_t)k * 36, D);
+	st<36>(Cp + (size_t)k * 36, C1);
+	if (NH == 2) st<36>(Cp + (size_t)M * 36 + (size_t)k * 36, C2);
+}
+
+__global__ void k_tr_flags(const int* __restrict__ Ui, const int* __restrict__ Uj, int NU, const int* __restrict__ photo, int NW,
+                           const int* __restrict__ pose_map, const TMap* __restrict__ tm, int* __restrict__ keepU, int* __restrict__ keepW)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < NU)
+	{
+		const TMap& t = tm[pose_map[Ui[i]]];
+		int a = Ui[i], b = Uj[i], keep = 1;
+		if (t.active > 0) keep = (a != t.hub[0] && b != t.hub[0] && (t.nh == 1 || (a != t.hub[1] && b != t.hub[1])));
+		keepU[i] = keep;
+	}
+	if (i < NW)
+	{
+		int k = photo[i];
+		const TMap& t = tm[pose_map[k]];
+		int keep = 1;
+		if (t.active > 0) keep = (k != t.hub[0] && (t.nh == 1 || k != t.hub[1]));
+		keepW[i] = keep;
+	}
+	if (i == 0) { keepU[NU] = 0; keepW[NW] = 0; }
+}
+
+__global__ void k_tr_gather_counts(const int* __restrict__ KU, const int* __restrict__ KW, const int* __restrict__ uoff, const int* __restrict__ woff,
+                                   int B, int* __restrict__ out)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > B) return;
+	out[b] = KU[uoff[b]];
+	out[B + 1 + b] = KW[woff[b]];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the feature kernel (K3/K4 of SURVEY 2a): Imp.cpp:1300-1915 / 5017-6501
+// ---------------------------------------------------------------------------------------------------------
+template <int NH>
+__global__ void __launch_bounds__(256)
+k_tr_features(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const double* __restrict__ feat,
+              const int* __restrict__ fptr, const double* __restrict__ Vold, const double* __restrict__ Wold, const int* __restrict__ photo,
+              const int* __restrict__ KW, const double* __restrict__ Dp, const double* __restrict__ Cp,
+              double* __restrict__ nfeat, int* __restrict__ nfptr, double* __restrict__ Vn, double* __restrict__ Wn_, int* __restrict__ nphoto,
+              int* __restrict__ nfeature, double* __restrict__ Gpose, double* __restrict__ PP)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = f < NF;
+	const TMap* t = inb ? &tm[feat_map[f]] : nullptr;
+	const bool act = inb && t->active > 0 && t->nh == NH;
+	int j0 = 0, len = 0, base = 0;
+	double Df[9], Cf[NH][18], G[NH][18], hubW[NH][18], xn[3];
+	int hub0 = -1, hub1 = -1;
+	if (inb)
+	{
+		j0 = fptr[f]; len = fptr[f + 1] - j0;
+		const double* x = feat + (size_t)f * 3;
+		if (!act)
+		{
+			// pass-through map: plain copy at the new offsets
+			base = t->W0n + (j0 - t->W0);
+			nfeat[3 * (size_t)f] = x[0]; nfeat[3 * (size_t)f + 1] = x[1]; nfeat[3 * (size_t)f + 2] = x[2];
+			for (int i = 0; i < 9; i++) Vn[(size_t)f * 9 + i] = Vold[(size_t)f * 9 + i];
+			nfptr[f] = base;
+			for (int j = 0; j < len; j++)
+			{
+				for (int i = 0; i < 18; i++) Wn_[(size_t)(base + j) * 18 + i] = Wold[(size_t)(j0 + j) * 18 + i];
+				nphoto[base + j] = photo[j0 + j];
+				nfeature[base + j] = f;
+			}
+		}
+		else
+		{
+			hub0 = t->hub[0]; hub1 = NH == 2 ? t->hub[1] : -1;
+			base = t->W0n + NH * (f - t->F0) + (KW[j0] - t->kW0);
+			nfptr[f] = base;
+			// new feature value, Imp.cpp:449-451 / 3300-3302
+			double d[3] = { x[0] - t->t1[0], x[1] - t->t1[1], x[2] - t->t1[2] };
+			mv3(t->R1, d, xn);
+			if (NH == 2) { xn[0] = xn[0] / t->scale1; xn[1] = xn[1] / t->scale1; xn[2] = xn[2] / t->scale1; }
+			nfeat[3 * (size_t)f] = xn[0]; nfeat[3 * (size_t)f + 1] = xn[1]; nfeat[3 * (size_t)f + 2] = xn[2];
+			// D_f, C_f: Imp.cpp:638-680 / 3587-3684
+			if (NH == 1)
+			{
+				double dd[3] = { xn[0] - t->t[0], xn[1] - t->t[1], xn[2] - t->t[2] }, tmp1[3], tmp2[3], tmp3[3];
+				mv3(t->dRA, dd, tmp1); mv3(t->dRB, dd, tmp2); mv3(t->dRG, dd, tmp3);
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+				{
+					Df[3 * r] = t->R[3 * r]; Df[3 * r + 1] = t->R[3 * r + 1]; Df[3 * r + 2] = t->R[3 * r + 2];
+					Cf[0][6 * r] = -t->R[3 * r]; Cf[0][6 * r + 1] = -t->R[3 * r + 1]; Cf[0][6 * r + 2] = -t->R[3 * r + 2];
+					Cf[0][6 * r + 3] = tmp1[r]; Cf[0][6 * r + 4] = tmp2[r]; Cf[0][6 * r + 5] = tmp3[r];
+				}
+			}
+			else
+			{
+				double adt[9], atmp[9], adtt[9];
+				mono_trans_jac(*t, xn, Df, adt, atmp, adtt);
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+				{
+#pragma unroll
+					for (int c = 0; c < 3; c++) { Cf[0][6 * r + c] = adt[3 * r + c]; Cf[NH - 1][6 * r + c] = adtt[3 * r + c]; Cf[NH - 1][6 * r + 3 + c] = 0.0; }
+					Cf[0][6 * r + 3] = atmp[3 * r]; Cf[0][6 * r + 4] = atmp[3 * r + 1]; Cf[0][6 * r + 5] = atmp[3 * r + 2];
+				}
+				if (t->c2fix) for (int r = 0; r < 3; r++) Cf[0][6 * r + t->newFix] = 0.0;
+				if (t->c3zero) zero<18>(Cf[NH - 1]);
+			}
+			// V' = D_f^T V D_f ; G_s = V C_s (feature row of I C_s)
+			double V[9], T[9];
+			ld<9>(V, Vold + (size_t)f * 9);
+			mtm<3, 3, 3, false>(Df, V, T);
+			double Vnew[9];
+			mm<3, 3, 3, false>(T, Df, Vnew);
+			st<9>(Vn + (size_t)f * 9, Vnew);
+#pragma unroll
+			for (int s = 0; s < NH; s++) { mm<3, 3, 6, false>(V, Cf[s], G[s]); zero<18>(hubW[s]); }
+		}
+	}
+	// run loop: all lanes of the wave iterate together (wave_scatter_add is a wave collective)
+	int maxlen = act ? len : 0;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
+	int kept = 0;
+	for (int it = 0; it < maxlen; it++)
+	{
+		const bool v = act && it < len;
+		double W[18];
+		int k = 0;
+		if (v)
+		{
+			const int j = j0 + it;
+			k = photo[j];
+			ld<18>(W, Wold + (size_t)j * 18);
+			double Dk[36], T[18], Wn[18];
+			ld<36>(Dk, Dp + (size_t)k * 36);
+			mtm<6, 6, 3, false>(Dk, W, T);      // D_k^T W        [6x3]
+			mm<6, 3, 3, false>(T, Df, Wn);      // ... D_f        [6x3]
+			if (k == hub0) { for (int i = 0; i < 18; i++) hubW[0][i] += Wn[i]; }
+			else if (NH == 2 && k == hub1) { for (int i = 0; i < 18; i++) hubW[NH - 1][i] += Wn[i]; }
+			else
+			{
+				const int pos = base + NH + kept;
+				st<18>(Wn_ + (size_t)pos * 18, Wn);
+				nphoto[pos] = k; nfeature[pos] = f;
+				kept++;
+			}
+		}
+#pragma unroll
+		for (int s = 0; s < NH; s++)
+		{
+			double Gp[36];
+			if (v)
+			{
+				double Ck[36];
+				ld<36>(Ck, Cp + (size_t)s * M * 36 + (size_t)k * 36);
+				mtm<6, 3, 6, true>(W, Ck, G[s]);    // G_s,f += W^T C_s,k     [3x6]
+				mm<6, 3, 6, false>(W, Cf[s], Gp);   // pose row: W C_s,f      [6x6]
+			}
+			wave_scatter_add<36>(Gpose + (size_t)s * M * 36 + (size_t)(v ? k : 0) * 36, Gp, v);
+		}
+	}
+	// leading hub block(s) of the feature: W'(h_s, f) = hubW_s + G_s^T D_f ; C_s^T G_t for the (h,h) blocks
+#pragma unroll
+	for (int s = 0; s < NH; s++)
+	{
+		if (act)
+		{
+			double Wh[18];
+			ld<18>(Wh, hubW[s]);
+			mtm<3, 6, 3, true>(G[s], Df, Wh);
+			st<18>(Wn_ + (size_t)(base + s) * 18, Wh);
+			nphoto[base + s] = s == 0 ? hub0 : hub1; nfeature[base + s] = f;
+		}
+#pragma unroll
+		for (int s2 = s; s2 < NH; s2++)
+		{
+			double P[36];
+			if (act) mtm<3, 6, 6, false>(Cf[s], G[s2], P);
+			const int idx = (s == 0 ? s2 : 2);
+			const int mp = act ? feat_map[f] : 0;
+			wave_scatter_add<36>(PP + ((size_t)mp * 3 + idx) * 36, P, act);
+		}
+	}
+}
+
+// one lane per U block: Imp.cpp:725-1266 / 3767-4984
+template <int NH>
+__global__ void k_tr_ublocks(int NU, int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Uold,
+                             const int* __restrict__ Ui, const int* __restrict__ Uj, const int* __restrict__ KU, const double* __restrict__ Dp,
+                             const double* __restrict__ Cp, double* __restrict__ Un, int* __restrict__ nUi, int* __restrict__ nUj,
+                             double* __restrict__ Gpose)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NU) return;
+	const int a = Ui[i], b = Uj[i];
+	const TMap& t = tm[pose_map[a]];
+	double U[36];
+	ld<36>(U, Uold + (size_t)i * 36);
+	if (t.active <= 0)
+	{
+		const int pos = t.U0n + (i - t.U0);
+		st<36>(Un + (size_t)pos * 36, U);
+		nUi[pos] = a; nUj[pos] = b;
+		return;
+	}
+	if (t.nh != NH) return;
+	double Da[36], Db[36], T1[36], T[36];
+	ld<36>(Da, Dp + (size_t)a * 36); ld<36>(Db, Dp + (size_t)b * 36);
+	mtm<6, 6, 6, false>(Da, U, T1);
+	mm<6, 6, 6, false>(T1, Db, T);            // D_a^T U D_b, block (a,b) with a<=b
+	int slot = -1;                            // Imp.cpp:1079-1094 / 4249-4271
+	if (a == t.hub[0]) slot = t.U0n + (b - t.P0);
+	else if (b == t.hub[0]) slot = t.U0n + (a - t.P0);
+	else if (NH == 2 && a == t.hub[1]) slot = t.U0n + t.m + (b - t.P0);
+	else if (NH == 2 && b == t.hub[1]) slot = t.U0n + t.m + (a - t.P0);
+	if (slot >= 0)
+	{
+		for (int q = 0; q < 36; q++) atomic_add_f64(Un + (size_t)slot * 36 + q, T[q]);
+	}
+	else
+	{
+		const int pos = t.U0n + NH * t.m + (KU[i] - t.kU0);
+		st<36>(Un + (size_t)pos * 36, T);
+		nUi[pos] = a; nUj[pos] = b;
+	}
+	// pose rows of G_s = I C_s : G_a += U C_b ; a != b: G_b += U^T C_a
+#pragma unroll
+	for (int s = 0; s < NH; s++)
+	{
+		double C[36], Y[36];
+		ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)b * 36);
+		mm<6, 6, 6, false>(U, C, Y);
+		for (int q = 0; q < 36; q++) atomic_add_f64(Gpose + (size_t)s * M * 36 + (size_t)a * 36 + q, Y[q]);
+		if (a != b)
+		{
+			ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)a * 36);
+			mtm<6, 6, 6, false>(U, C, Y);
+			for (int q = 0; q < 36; q++) atomic_add_f64(Gpose + (size_t)s * M * 36 + (size_t)b * 36 + q, Y[q]);
+		}
+	}
+}
+
+// adds X (a contribution to I'(r,c), r != c allowed in any order) to the stored upper-orientation block
+__device__ __forceinline__ void add_oriented(double* dst, const double* X, int r, int c)
+{
+	if (r < c) { for (int q = 0; q < 36; q++) dst[q] += X[q]; }
+	else if (r > c) { for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) dst[j * 6 + i] += X[i * 6 + j]; }
+	else { for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) dst[i * 6 + j] += X[i * 6 + j] + X[j * 6 + i]; }
+}
+
+// one lane per pose: new blocks (k,h_s) = D_k^T G_s,k (+ what k_tr_ublocks already put there) and C_k^T G_k
+template <int NH>
+__global__ void k_tr_poseslots(int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Dp,
+                               const double* __restrict__ Cp, const double* __restrict__ Gpose, double* __restrict__ Un, int* __restrict__ nUi,
+                               int* __restrict__ nUj, double* __restrict__ PP)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= M) return;
+	const int mp = pose_map[k];
+	const TMap& t = tm[mp];
+	if (t.active <= 0 || t.nh != NH) return;
+	double D[36];
+	ld<36>(D, Dp + (size_t)k * 36);
+	const int h0 = t.hub[0], h1 = NH == 2 ? t.hub[1] : -1;
+	const int slot1 = t.U0n + (k - t.P0), slot2 = t.U0n + t.m + (k - t.P0);
+	// labels, Imp.cpp:711-723 / 3739-3765 (the second set compares against posID as well -- reference quirk)
+	if (k <= h0) { nUi[slot1] = k; nUj[slot1] = h0; } else { nUi[slot1] = h0; nUj[slot1] = k; }
+	if (NH == 2) { if (k <= h0) { nUi[slot2] = k; nUj[slot2] = h1; } else { nUi[slot2] = h1; nUj[slot2] = k; } }
+#pragma unroll
+	for (int s = 0; s < NH; s++)
+	{
+		double G[36], X[36];
+		ld<36>(G, Gpose + (size_t)s * M * 36 + (size_t)k * 36);
+		mtm<6, 6, 6, false>(D, G, X); // contribution to I'(k, h_s)
+		const int hs = s == 0 ? h0 : h1;
+		if (NH == 2 && s == 1 && k == h0)
+		{
+			// pair (h_1,h_2): everything goes to the first-set slot of h_2 (the reference splits it over two slots with
+			// the same coordinates; only their sum is defined)
+			double* dst = Un + (size_t)(t.U0n + (h1 - t.P0)) * 36;
+			if (h0 < h1) { for (int q = 0; q < 36; q++) atomic_add_f64(dst + q, X[q]); }
+			else { for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) atomic_add_f64(dst + j * 6 + i, X[i * 6 + j]); }
+		}
+		else if (NH == 2 && s == 0 && k == h1)
+		{
+			double* dst = Un + (size_t)slot1 * 36; // block (min(h0,h1), max): X is I'(h1,h0)
+			if (h1 < h0) { for (int q = 0; q < 36; q++) atomic_add_f64(dst + q, X[q]); }
+			else { for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) atomic_add_f64(dst + j * 6 + i, X[i * 6 + j]); }
+		}
+		else
+		{
+			// only this lane touches the block in this kernel except the two cross cases above, which use atomics on
+			// slot1(h1); keep everything atomic on that one slot
+			double* dst = Un + (size_t)(s == 0 ? slot1 : slot2) * 36;
+			add_oriented(dst, X, k, hs);
+		}
+		// sum_a C_a^T G_a
+#pragma unroll
+		for (int s0 = 0; s0 <= s; s0++)
+		{
+			double C[36], P[36];
+			ld<36>(C, Cp + (size_t)s0 * M * 36 + (size_t)k * 36);
+			mtm<6, 6, 6, false>(C, G, P);
+			const int idx = (s0 == 0 ? s : 2);
+			for (int q = 0; q < 36; q++) atomic_add_f64(PP + ((size_t)mp * 3 + idx) * 36 + q, P[q]);
+		}
+	}
+}
+
+template <int NH>
+__global__ void k_tr_diag(int B, const TMap* __restrict__ tm, const double* __restrict__ PP, double* __restrict__ Un)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= B) return;
+	const TMap& t = tm[b];
+	if (t.active <= 0 || t.nh != NH) return;
+	const double* P = PP + (size_t)b * 3 * 36;
+	double* d0 = Un + (size_t)(t.U0n + (t.hub[0] - t.P0)) * 36;
+	for (int q = 0; q < 36; q++) d0[q] += P[q];
+	if (NH == 2)
+	{
+		double* d2 = Un + (size_t)(t.U0n + t.m + (t.hub[1] - t.P0)) * 36;
+		for (int q = 0; q < 36; q++) d2[q] += P[2 * 36 + q];
+		double* d1 = Un + (size_t)(t.U0n + (t.hub[1] - t.P0)) * 36; // block (h_1,h_2), upper orientation
+		const double* P01 = P + 36;                                  // C_1^T I C_2 = contribution to I'(h_1,h_2)
+		if (t.hub[0] < t.hub[1]) { for (int q = 0; q < 36; q++) d1[q] += P01[q]; }
+		else { for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) d1[j * 6 + i] += P01[i * 6 + j]; }
+	}
+}
+
+template <int NH>
+static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, const TMap* d_tm, const int* KU, const int* KW,
+                         double* Dp, double* Cp, double* Gpose, double* PP)
+{
+	hipStream_t s = ctx->stream;
+	const int M = in.M;
+	if (in.NF)
+		hipLaunchKernelGGL(k_tr_features<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.feat, in.fptr, in.V,
+		                   in.W, in.photo, KW, Dp, Cp, out.feat, out.fptr, out.V, out.W, out.photo, out.feature, Gpose, PP);
+	if (in.NU)
+		hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
+		                   Dp, Cp, out.U, out.Ui, out.Uj, Gpose);
+	if (M)
+		hipLaunchKernelGGL(k_tr_poseslots<NH>, dim3((M + 127) / 128), dim3(128), 0, s, M, d_tm, in.pose_map, Dp, Cp, Gpose, out.U, out.Ui,
+		                   out.Uj, PP);
+	hipLaunchKernelGGL(k_tr_diag<NH>, dim3((in.B + 127) / 128), dim3(128), 0, s, in.B, d_tm, PP, out.U);
+}
+
+__global__ void k_set_last(int* p, int idx, int v) { p[idx] = v; }
+
+void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
+                     const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out)
+{
+	hipStream_t s = ctx->stream;
+	const int B = in.B, nh = mono ? 2 : 1;
+	size_t smark = ctx->scratch.mark();
+	std::vector<TMap> tm(B);
+	bool any = false;
+	for (int b = 0; b < B; b++)
+	{
+		TMap& t = tm[b];
+		memset(&t, 0, sizeof t);
+		t.nh = nh;
+		t.P0 = in.pose_off[b]; t.m = in.pose_off[b + 1] - t.P0;
+		t.F0 = in.feat_off[b]; t.n = in.feat_off[b + 1] - t.F0;
+		t.U0 = in.u_off[b]; t.W0 = in.w_off[b];
+		t.hub[0] = t.hub[1] = t.nref = t.nscap = -1;
+		bool act = target_ref[b] >= 0 && !(in.Ref[b] == target_ref[b] && (!mono || in.ScaP[b] == target_scap[b])); // Imp.cpp:352 / 3176
+		t.active = act ? 1 : 0;
+		any |= act;
+		t.tref = target_ref[b]; t.tscap = mono ? target_scap[b] : 0; t.newFix = mono ? target_fix[b] : 0;
+		t.oldref = in.Ref[b]; t.oldscap = mono ? in.ScaP[b] : 0; t.oldFix = mono ? in.Fix[b] : 0;
+		t.newLabel = in.Ref[b];
+	}
+	TMap* d_tm = ctx->scratch.alloc<TMap>(B);
+	int* d_err = ctx->scratch.alloc<int>(1);
+	dev_zero(ctx, d_err, sizeof(int));
+	h2d(ctx, d_tm, tm.data(), sizeof(TMap) * B);
+
+	out = DevBatch();
+	out.B = B; out.M = in.M; out.NF = in.NF;
+	out.pose_off = in.pose_off; out.feat_off = in.feat_off;
+	out.Ref = in.Ref; out.FRef = in.FRef; out.ScaP = in.ScaP; out.Fix = in.Fix; out.Sign = in.Sign; out.FScaP = in.FScaP; out.FFix = in.FFix;
+	// nothing of `out` may alias `in`: the two live in different arenas with different lifetimes
+	batch_set_offsets(ctx, ar, out);
+	out.feat_id = ar.alloc<int>(in.NF);
+	if (in.NF) LSFM_CHECK_HIP(hipMemcpyAsync(out.feat_id, in.feat_id, (size_t)in.NF * sizeof(int), hipMemcpyDeviceToDevice, s));
+	out.pose = ar.alloc<double>((size_t)in.M * 6);
+	out.pose_id = ar.alloc<int>(in.M);
+	out.feat = ar.alloc<double>((size_t)in.NF * 3);
+	out.V = ar.alloc<double>((size_t)in.NF * 9);
+	out.fptr = ar.alloc<int>(in.NF + 1);
+
+	const int M = in.M;
+	if (M)
+	{
+		hipLaunchKernelGGL(k_tr_find, dim3((M + 255) / 256), dim3(256), 0, s, in.pose_id, in.pose_map, M, d_tm);
+		hipLaunchKernelGGL(k_tr_params1, dim3((B + 127) / 128), dim3(128), 0, s, in.pose, d_tm, B, d_err);
+		hipLaunchKernelGGL(k_tr_new_poses, dim3((M + 255) / 256), dim3(256), 0, s, in.pose, in.pose_id, in.pose_map, M, d_tm, out.pose, out.pose_id);
+		hipLaunchKernelGGL(k_tr_params2, dim3((B + 127) / 128), dim3(128), 0, s, out.pose, d_tm, B);
+	}
+	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
+	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
+	double* Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
+	double* PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);
+	dev_zero(ctx, Gpose, (size_t)M * 36 * nh * sizeof(double));
+	dev_zero(ctx, PP, (size_t)B * 3 * 36 * sizeof(double));
+	if (M)
+	{
+		if (mono) hipLaunchKernelGGL(k_tr_pose_jac<2>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);
+		else hipLaunchKernelGGL(k_tr_pose_jac<1>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);
+	}
+	// structure of the output: which blocks survive as they are, prefix sums, per-map offsets
+	int* keepU = ctx->scratch.alloc<int>(in.NU + 1);
+	int* keepW = ctx->scratch.alloc<int>(in.NW + 1);
+	int* KU = ctx->scratch.alloc<int>(in.NU + 2);
+	int* KW = ctx->scratch.alloc<int>(in.NW + 2);
+	{
+		int nmax = std::max(std::max(in.NU, in.NW), 1);
+		hipLaunchKernelGGL(k_tr_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, in.Ui, in.Uj, in.NU, in.photo, in.NW, in.pose_map, d_tm, keepU, keepW);
+	}
+	dev_exclusive_scan(ctx, keepU, KU, in.NU);
+	dev_exclusive_scan(ctx, keepW, KW, in.NW);
+	int* d_uoff = ctx->scratch.alloc<int>(B + 1);
+	int* d_woff = ctx->scratch.alloc<int>(B + 1);
+	int* d_cnt = ctx->scratch.alloc<int>(2 * (B + 1));
+	h2d(ctx, d_uoff, in.u_off.data(), (B + 1) * sizeof(int));
+	h2d(ctx, d_woff, in.w_off.data(), (B + 1) * sizeof(int));
+	hipLaunchKernelGGL(k_tr_gather_counts, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, d_uoff, d_woff, B, d_cnt);
+	std::vector<int> cnt(2 * (B + 1));
+	d2h_ints(ctx, d_cnt, cnt.data(), cnt.size());
+	int err = d2h_int(ctx, d_err);
+	if (err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(err - 1));
+	out.u_off.assign(B + 1, 0); out.w_off.assign(B + 1, 0);
+	for (int b = 0; b < B; b++)
+	{
+		TMap& t = tm[b];
+		t.kU0 = cnt[b]; t.kW0 = cnt[B + 1 + b];
+		int keptU = cnt[b + 1] - cnt[b], keptW = cnt[B + 1 + b + 1] - cnt[B + 1 + b];
+		t.U0n = out.u_off[b]; t.W0n = out.w_off[b];
+		out.u_off[b + 1] = t.U0n + (t.active ? nh * t.m : 0) + keptU;
+		out.w_off[b + 1] = t.W0n + (t.active ? nh * t.n : 0) + keptW;
+		if (t.active)
+		{
+			// Imp.cpp:409-411 / 3253-3259
+			out.Ref[b] = t.tref;
+			if (mono) { out.ScaP[b] = t.tscap; out.Fix[b] = t.newFix; }
+		}
+	}
+	out.NU = out.u_off[B]; out.NW = out.w_off[B];
+	// second upload keeps what the device computed (hub indices, parameters): patch only the offset fields
+	{
+		std::vector<TMap> dev(B);
+		d2h(ctx, dev.data(), d_tm, sizeof(TMap) * B);
+		for (int b = 0; b < B; b++)
+		{
+			dev[b].kU0 = tm[b].kU0; dev[b].kW0 = tm[b].kW0; dev[b].U0n = tm[b].U0n; dev[b].W0n = tm[b].W0n;
+			if (mono && dev[b].active > 0) out.Sign[b] = dev[b].sign1; // Imp.cpp:3241-3244
+		}
+		h2d(ctx, d_tm, dev.data(), sizeof(TMap) * B);
+	}
+	out.U = ar.alloc<double>((size_t)out.NU * 36); out.Ui = ar.alloc<int>(out.NU); out.Uj = ar.alloc<int>(out.NU);
+	out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW);
+	dev_zero(ctx, out.U, (size_t)out.NU * 36 * sizeof(double)); // the (k,h) slots are accumulated into
+	hipLaunchKernelGGL(k_set_last, dim3(1), dim3(1), 0, s, out.fptr, in.NF, out.NW);
+	if (mono) launch_stage<2>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP);
+	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP);
+	LSFM_CHECK_HIP(hipGetLastError());
+	(void)any;
+	// scratch is released by the caller's next stage only after these launches are ordered on the stream
+	LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	ctx->scratch.release(smark);
+}
+
+} // namespace lsfm

@@ -10,7 +10,9 @@ using namespace lsfm;
 struct lsfm_tree {
 	bool mono = false;
 	int N = 0;
-	DevBatch level;   // current level (lives in ctx->arena[slot])
+	Arena input_arena; // pristine copy of the N local maps, resident in HBM; lsfm_tree_run starts from a device copy of it
+	DevBatch input;
+	DevBatch level;    // current level (lives in ctx->arena[slot])
 	int slot = 0;
 	bool done = false;
 };
@@ -99,7 +101,24 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	}
 }
 
-void fill_host_map(const lsfm_map* src, lsfm_map* dst) { *dst = *src; }
+template <class T> void rebase(T*& p, ptrdiff_t delta)
+{
+	if (p) p = reinterpret_cast<T*>(reinterpret_cast<char*>(p) + delta);
+}
+DevBatch rebased(const DevBatch& b, ptrdiff_t d)
+{
+	DevBatch o = b;
+	rebase(o.d_pose_off, d); rebase(o.d_feat_off, d); rebase(o.pose, d); rebase(o.pose_id, d); rebase(o.pose_map, d);
+	rebase(o.feat, d); rebase(o.feat_id, d); rebase(o.feat_map, d); rebase(o.U, d); rebase(o.Ui, d); rebase(o.Uj, d);
+	rebase(o.W, d); rebase(o.photo, d); rebase(o.feature, d); rebase(o.fptr, d); rebase(o.V, d);
+	return o;
+}
+size_t input_bytes(const lsfm_map* maps, int N)
+{
+	size_t nw = 0, nf = 0, nu = 0, m = 0;
+	for (int k = 0; k < N; k++) { nw += maps[k].nW; nf += maps[k].n; nu += maps[k].nU; m += maps[k].m; }
+	return m * 64 + nf * 120 + nu * 300 + nw * 156 + (size_t)N * 16 + ((size_t)1 << 20);
+}
 
 } // namespace
 
@@ -114,8 +133,13 @@ int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, l
 		lsfm_tree* t = new lsfm_tree();
 		t->mono = mono != 0; t->N = N; t->slot = 0;
 		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
-		try { batch_upload(ctx, ctx->arena[0], maps, N, t->mono, t->level); }
-		catch (...) { delete t; throw; }
+		try
+		{
+			t->input_arena.init(input_bytes(maps, N));
+			batch_upload(ctx, t->input_arena, maps, N, t->mono, t->input);
+			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		}
+		catch (...) { t->input_arena.destroy(); delete t; throw; }
 		*out = t;
 		return LSFM_OK;
 	});
@@ -134,6 +158,13 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		const double t0 = now_ms();
 		try
 		{
+			// start from a device-to-device copy of the resident inputs, so that a tree can be run repeatedly
+			t->slot = 0;
+			ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
+			if (t->input_arena.off > ctx->arena[0].cap) LSFM_FAIL(LSFM_ERR_OOM, "inputs do not fit the level arena");
+			LSFM_CHECK_HIP(hipMemcpyAsync(ctx->arena[0].base, t->input_arena.base, t->input_arena.off, hipMemcpyDeviceToDevice, ctx->stream));
+			ctx->arena[0].off = t->input_arena.off;
+			t->level = rebased(t->input, ctx->arena[0].base - t->input_arena.base);
 			while (t->level.B > 1) run_level(ctx, t, st);
 			// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
 			DevBatch& X = t->level;
@@ -164,7 +195,7 @@ int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)
 {
 	if (!t || !out) return LSFM_ERR_ARG;
 	return guarded(ctx, [&]() {
-		if (t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (!t->done || t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
 		batch_download_map(ctx, t->level, 0, t->mono, out);
 		return LSFM_OK;
 	});
@@ -172,7 +203,9 @@ int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)
 
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* t)
 {
-	(void)ctx;
+	if (!t) return;
+	if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+	t->input_arena.destroy();
 	delete t;
 }
 

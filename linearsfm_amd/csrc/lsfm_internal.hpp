@@ -124,6 +124,7 @@ struct SolveIO {
 	const double* eb = nullptr;        // [NF*3]
 	const double* x0 = nullptr;        // [M*6] initial guess (may be null -> zero)
 	const unsigned char* d_fixed = nullptr; // [M*6] optional: 1 = scalar removed from the system (Mono gauge)
+	const int* d_pose_origin = nullptr;     // [M] optional: index of the local map that brought the pose (null: its position)
 	double* x_pose = nullptr;          // [M*6] out
 	double* x_feat = nullptr;          // [NF*3] out
 	std::vector<int> seg_rows;         // host: block rows per segment

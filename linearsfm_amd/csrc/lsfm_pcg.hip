@@ -1,0 +1,654 @@
+// K10: preconditioned conjugate gradients on the Schur-reduced camera system S x = E, all independent systems of one
+// tree level iterating together with per-system scalars.  Replaces cholmod_analyze / factorize / solve
+// (pba_solveCholmod{LM,GN}, Imp.cpp:2380-2449 / 7043-7121).
+//
+// Preconditioner.  Block-Jacobi needs O(10 m) iterations on these matrices (a pose chain of length m plus one dense
+// "hub" row per join of the tree; measured 84k iterations without convergence at m = 3499), so M is a sparse 6x6-block
+// Cholesky factorisation of S itself, made cheap by the structure of the join tree:
+//   * ordering: nested dissection along the tree.  The position of a pose in the level's pose array encodes the local
+//     map that brought it, so an edge (p,q) of S crosses the cut of tree level bitlen(origin_p ^ origin_q).  The
+//     endpoint of higher degree (the hub pose of that sub-map) goes into that level's separator; blocks are
+//     eliminated by ascending separator level.  Measured fill 1.5x nnz(S), elimination-tree height ~ 15 per level.
+//   * symbolic analysis (elimination tree, column patterns, level sets) on the host from the block pattern (a few
+//     hundred KB), numeric factorisation and triangular solves on the device, one launch per elimination-tree level,
+//     one work-group per block column; the narrow top of the tree runs inside a single launch.
+// With the exact factor CG is iterative refinement: 2-3 iterations to 1e-12.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "lsfm_device.hpp"
+#include "lsfm_internal.hpp"
+#include "lsfm_solve.hpp"
+
+namespace lsfm {
+
+struct PcgSeg {
+	double rz[2];
+	double pAp;
+	double rr, ee, thresh;
+	int done, its, row0, active;
+};
+static_assert(sizeof(PcgSeg) % sizeof(double) == 0, "PcgSeg is strided in doubles by the fused dot products");
+#define SEG_STRIDE ((int)(sizeof(PcgSeg) / sizeof(double)))
+
+// ---------------------------------------------------------------------------------------------------------------
+// sparse block Cholesky: device side
+// ---------------------------------------------------------------------------------------------------------------
+struct CholDev {
+	int M = 0, nnzL = 0, nlevels = 0, tail_begin = 0; // columns [tail_begin, M) (in level order) run in one launch
+	int* colptr = nullptr;  // [M+1]
+	int* rowidx = nullptr;  // [nnzL] ascending inside a column, diagonal first
+	int* perm = nullptr;    // [M] new -> old
+	int* pinv = nullptr;    // [M] old -> new
+	int* order = nullptr;   // [M] columns sorted by elimination-tree level
+	std::vector<int> level_ptr; // host: order[level_ptr[l] .. level_ptr[l+1]) = columns of level l (before the tail)
+	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
+	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
+	int* d_err = nullptr;
+};
+
+__device__ __forceinline__ int find_row(const int* __restrict__ rowidx, int lo, int hi, int target)
+{
+	while (lo < hi) { int mid = (lo + hi) >> 1; if (rowidx[mid] < target) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+// A (upper blocks of S, old numbering) -> lower blocks of P S P^T in L's storage
+__global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ keys, const double* __restrict__ S, const int* __restrict__ pinv,
+                               const int* __restrict__ colptr, const int* __restrict__ rowidx, const unsigned char* __restrict__ fixed,
+                               double* __restrict__ L)
+{
+	int e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= nnzb) return;
+	const unsigned long long key = keys[e];
+	const int p = (int)(key >> 32), q = (int)(key & 0xffffffffull);
+	int i = pinv[p], j = pinv[q];
+	bool tr = false; // stored block is S(p,q); the lower block L(i,j), i >= j, is S(perm i, perm j)
+	if (i < j) { int t = i; i = j; j = t; tr = true; }
+	const int pos = find_row(rowidx, colptr[j], colptr[j + 1], i);
+	const double* s = S + (size_t)e * 36;
+	double* d = L + (size_t)pos * 36;
+	const int rowp = tr ? q : p, colp = tr ? p : q; // old indices of the block's rows / columns
+	for (int r = 0; r < 6; r++)
+		for (int c = 0; c < 6; c++)
+		{
+			double v = tr ? s[c * 6 + r] : s[r * 6 + c];
+			if (fixed && (fixed[(size_t)rowp * 6 + r] || fixed[(size_t)colp * 6 + c])) v = (rowp == colp && r == c) ? 1.0 : 0.0;
+			d[r * 6 + c] = v;
+		}
+}
+
+// one work-group factors one block column: L_jj = chol(A_jj); L_ij = A_ij L_jj^-T; A_ik -= L_ij L_kj^T for the blocks
+// below (right-looking; targets in other columns are updated atomically because the columns of one level run together)
+__device__ void chol_factor_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
+                                   double* __restrict__ Dinv, int* err)
+{
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	__shared__ double sLi[36];
+	if (tid == 0)
+	{
+		double A[36], Lc[36], Li[36];
+		ld<36>(A, L + (size_t)c0 * 36);
+		zero<36>(Lc); zero<36>(Li);
+		bool ok = true;
+		for (int c = 0; c < 6; c++)
+		{
+			double d = A[c * 6 + c];
+			for (int k = 0; k < c; k++) d -= Lc[c * 6 + k] * Lc[c * 6 + k];
+			if (!(d > 0)) { ok = false; d = 1.0; }
+			Lc[c * 6 + c] = sqrt(d);
+			for (int i = c + 1; i < 6; i++)
+			{
+				double s = A[i * 6 + c];
+				for (int k = 0; k < c; k++) s -= Lc[i * 6 + k] * Lc[c * 6 + k];
+				Lc[i * 6 + c] = s / Lc[c * 6 + c];
+			}
+		}
+		if (!ok) atomicExch(err, 1 + j);
+		for (int c = 0; c < 6; c++)
+		{
+			Li[c * 6 + c] = 1.0 / Lc[c * 6 + c];
+			for (int i = c + 1; i < 6; i++)
+			{
+				double s = 0;
+				for (int k = c; k < i; k++) s -= Lc[i * 6 + k] * Li[k * 6 + c];
+				Li[i * 6 + c] = s / Lc[i * 6 + i];
+			}
+		}
+		st<36>(L + (size_t)c0 * 36, Lc);
+		st<36>(Dinv + (size_t)j * 36, Li);
+		for (int q = 0; q < 36; q++) sLi[q] = Li[q];
+	}
+	__syncthreads();
+	// L_ij = A_ij * Li^T : one thread per (block, row)
+	for (int w = tid; w < n * 6; w += nt)
+	{
+		double* blk = L + (size_t)(c0 + 1 + w / 6) * 36 + (w % 6) * 6;
+		double a[6], o[6];
+		for (int k = 0; k < 6; k++) a[k] = blk[k];
+		for (int c = 0; c < 6; c++)
+		{
+			double s = 0;
+			for (int k = 0; k <= c; k++) s = fma(a[k], sLi[c * 6 + k], s);
+			o[c] = s;
+		}
+		for (int k = 0; k < 6; k++) blk[k] = o[k];
+	}
+	__syncthreads();
+	// trailing updates: pairs a >= b of the blocks below the diagonal
+	const int npairs = n * (n + 1) / 2;
+	for (int pr = tid; pr < npairs; pr += nt)
+	{
+		// decode pr -> (a,b), a >= b, row-major over the lower triangle
+		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+		while (a * (a + 1) / 2 > pr) a--;
+		while ((a + 1) * (a + 2) / 2 <= pr) a++;
+		const int b = pr - a * (a + 1) / 2;
+		const int ra = rowidx[c0 + 1 + a], rb = rowidx[c0 + 1 + b];
+		double La[36], Lb[36], T[36];
+		ld<36>(La, L + (size_t)(c0 + 1 + a) * 36);
+		ld<36>(Lb, L + (size_t)(c0 + 1 + b) * 36);
+		mmt<6, 6, 6, false>(La, Lb, T); // L_a L_b^T = update of block (ra, rb)
+		const int pos = find_row(rowidx, colptr[rb], colptr[rb + 1], ra);
+		double* d = L + (size_t)pos * 36;
+		for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -T[q]);
+	}
+}
+
+__global__ void __launch_bounds__(64) k_chol_factor_level(const int* __restrict__ cols, const int* __restrict__ colptr,
+                                                           const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+{
+	chol_factor_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, err);
+}
+// the narrow top of the elimination tree: one work-group walks the remaining columns in index order
+__global__ void __launch_bounds__(256) k_chol_factor_tail(int ncols, const int* __restrict__ cols, const int* __restrict__ colptr,
+                                                           const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+{
+	for (int k = 0; k < ncols; k++)
+	{
+		chol_factor_column(cols[k], colptr, rowidx, L, Dinv, err);
+		__threadfence();
+		__syncthreads();
+	}
+}
+
+// forward substitution, right-looking: y_j = Li_j v_j ; v_i -= L_ij y_j
+__device__ void chol_fwd_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
+                                const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	__shared__ double sy[6];
+	if (tid < 6)
+	{
+		const double* Li = Dinv + (size_t)j * 36;
+		double s = 0;
+		for (int k = 0; k <= tid; k++) s = fma(Li[tid * 6 + k], v[(size_t)j * 6 + k], s);
+		sy[tid] = s;
+	}
+	__syncthreads();
+	if (tid < 6) v[(size_t)j * 6 + tid] = sy[tid];
+	for (int w = tid; w < n * 6; w += nt)
+	{
+		const int e = c0 + 1 + w / 6, r = w % 6;
+		const double* blk = L + (size_t)e * 36 + r * 6;
+		double s = 0;
+		for (int k = 0; k < 6; k++) s = fma(blk[k], sy[k], s);
+		atomic_add_f64(v + (size_t)rowidx[e] * 6 + r, -s);
+	}
+}
+// backward substitution: x_j = Li_j^T (y_j - sum_i L_ij^T x_i)   (all i > j are final)
+__device__ void chol_bwd_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
+                                const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	__shared__ double red[256];
+	__shared__ double ss[6];
+	const int c = tid % 6, g = tid / 6, ng = nt / 6;
+	double s = 0;
+	if (g < ng)
+		for (int e = g; e < n; e += ng)
+		{
+			const double* blk = L + (size_t)(c0 + 1 + e) * 36;
+			const double* xi = v + (size_t)rowidx[c0 + 1 + e] * 6;
+			for (int r = 0; r < 6; r++) s = fma(blk[r * 6 + c], xi[r], s);
+		}
+	red[tid] = (g < ng) ? s : 0.0;
+	__syncthreads();
+	if (tid < 6)
+	{
+		double t = v[(size_t)j * 6 + tid];
+		for (int k = 0; k < ng; k++) t -= red[k * 6 + tid];
+		ss[tid] = t;
+	}
+	__syncthreads();
+	if (tid < 6)
+	{
+		const double* Li = Dinv + (size_t)j * 36;
+		double t = 0;
+		for (int k = tid; k < 6; k++) t = fma(Li[k * 6 + tid], ss[k], t);
+		v[(size_t)j * 6 + tid] = t;
+	}
+}
+__global__ void __launch_bounds__(64) k_chol_fwd_level(const int* __restrict__ cols, const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                        const double* __restrict__ L, const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	chol_fwd_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, v);
+}
+__global__ void __launch_bounds__(64) k_chol_bwd_level(const int* __restrict__ cols, const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                        const double* __restrict__ L, const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	chol_bwd_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, v);
+}
+// tail: forward over the remaining columns in order, then straight back down over them
+__global__ void __launch_bounds__(256) k_chol_solve_tail(int ncols, const int* __restrict__ cols, const int* __restrict__ colptr,
+                                                          const int* __restrict__ rowidx, const double* __restrict__ L,
+                                                          const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	for (int k = 0; k < ncols; k++) { chol_fwd_column(cols[k], colptr, rowidx, L, Dinv, v); __threadfence(); __syncthreads(); }
+	for (int k = ncols - 1; k >= 0; k--) { chol_bwd_column(cols[k], colptr, rowidx, L, Dinv, v); __threadfence(); __syncthreads(); }
+}
+
+__global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
+                          double* __restrict__ v)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)M * 6) return;
+	const size_t src = (size_t)perm[i / 6] * 6 + i % 6;
+	v[i] = (fixed && fixed[src]) ? 0.0 : r[src];
+}
+// z = P^T v ; rz[nxt] += r . z
+__global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double* __restrict__ v, const double* __restrict__ r,
+                               const unsigned char* __restrict__ fixed, const int* __restrict__ pose_seg, double* __restrict__ z, double* dot,
+                               int dot_stride)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool ok = row < M;
+	double acc = 0;
+	int sg = 0;
+	if (ok)
+	{
+		sg = pose_seg[row];
+		const double* src = v + (size_t)pinv[row] * 6;
+		for (int i = 0; i < 6; i++)
+		{
+			double zz = src[i];
+			if (fixed && fixed[(size_t)row * 6 + i]) zz = 0.0;
+			z[(size_t)row * 6 + i] = zz;
+			acc = fma(zz, r[(size_t)row * 6 + i], acc);
+		}
+	}
+	wave_scatter_add<1>(dot + (size_t)sg * dot_stride, &acc, ok);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: ordering + symbolic factorisation
+// ---------------------------------------------------------------------------------------------------------------
+static int bitlen(unsigned x) { int l = 0; while (x) { l++; x >>= 1; } return l; }
+
+static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const int* d_origin, CholDev& ch)
+{
+	const int M = sy.M, nnzb = sy.nnzb;
+	Arena& sc = ctx->scratch;
+	std::vector<unsigned long long> keys(nnzb);
+	d2h(ctx, keys.data(), sy.upper_keys, (size_t)nnzb * sizeof(unsigned long long));
+	std::vector<int> origin(M);
+	if (d_origin) d2h(ctx, origin.data(), d_origin, (size_t)M * sizeof(int));
+	else std::iota(origin.begin(), origin.end(), 0);
+	std::vector<int> deg(M, 0), sep(M, 0);
+	for (int e = 0; e < nnzb; e++)
+	{
+		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+		if (p != q) { deg[p]++; deg[q]++; }
+	}
+	for (int e = 0; e < nnzb; e++)
+	{
+		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+		if (p == q) continue;
+		const int l = bitlen((unsigned)(origin[p] ^ origin[q]));
+		const int v = (deg[p] > deg[q] || (deg[p] == deg[q] && p > q)) ? p : q;
+		if (l > sep[v]) sep[v] = l;
+	}
+	std::vector<int> perm(M), pinv(M);
+	std::iota(perm.begin(), perm.end(), 0);
+	std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sep[a] < sep[b]; });
+	for (int i = 0; i < M; i++) pinv[perm[i]] = i;
+	// strict lower adjacency by row, new numbering
+	std::vector<int> rcnt(M + 1, 0);
+	for (int e = 0; e < nnzb; e++)
+	{
+		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+		if (p != q) rcnt[std::max(pinv[p], pinv[q]) + 1]++;
+	}
+	for (int i = 0; i < M; i++) rcnt[i + 1] += rcnt[i];
+	std::vector<int> radj(rcnt[M]), fill(M, 0);
+	for (int e = 0; e < nnzb; e++)
+	{
+		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+		if (p == q) continue;
+		const int a = std::min(pinv[p], pinv[q]), b = std::max(pinv[p], pinv[q]);
+		radj[rcnt[b] + fill[b]++] = a;
+	}
+	// elimination tree (ancestor path compression), column counts, column patterns by row sub-tree walks
+	std::vector<int> parent(M, -1), anc(M, -1);
+	for (int k = 0; k < M; k++)
+		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+		{
+			int i = radj[t];
+			while (i != -1 && i < k) { const int nx = anc[i]; anc[i] = k; if (nx == -1) parent[i] = k; i = nx; }
+		}
+	std::vector<int> mark(M, -1), ccount(M, 1);
+	for (int k = 0; k < M; k++)
+	{
+		mark[k] = k;
+		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+			for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
+	}
+	std::vector<int> colptr(M + 1, 0);
+	for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
+	const int nnzL = colptr[M];
+	std::vector<int> rowidx(nnzL), cfill(M, 1);
+	for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
+	std::fill(mark.begin(), mark.end(), -1);
+	for (int k = 0; k < M; k++)
+	{
+		mark[k] = k;
+		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+			for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + cfill[i]++] = k; mark[i] = k; }
+	}
+	// level sets (height above the leaves); the narrow top (<= 2 columns per level) becomes the tail
+	std::vector<int> lev(M, 0);
+	int nlev = 0;
+	for (int j = 0; j < M; j++)
+	{
+		if (parent[j] >= 0) lev[parent[j]] = std::max(lev[parent[j]], lev[j] + 1);
+		nlev = std::max(nlev, lev[j] + 1);
+	}
+	std::vector<int> lcount(nlev + 1, 0);
+	for (int j = 0; j < M; j++) lcount[lev[j] + 1]++;
+	int tail_level = nlev;
+	while (tail_level > 0 && lcount[tail_level] <= 2) tail_level--;
+	for (int l = 0; l < nlev; l++) lcount[l + 1] += lcount[l];
+	std::vector<int> order(M), lfill(nlev, 0);
+	for (int j = 0; j < M; j++) order[lcount[lev[j]] + lfill[lev[j]]++] = j; // ascending j inside a level
+	ch.M = M; ch.nnzL = nnzL; ch.nlevels = tail_level;
+	ch.level_ptr.assign(lcount.begin(), lcount.begin() + tail_level + 1);
+	ch.tail_begin = lcount[tail_level];
+	// tail columns must be walked in ascending index (= a topological order), not level order
+	std::sort(order.begin() + ch.tail_begin, order.end());
+	ch.colptr = sc.alloc<int>(M + 1); ch.rowidx = sc.alloc<int>(nnzL); ch.perm = sc.alloc<int>(M); ch.pinv = sc.alloc<int>(M);
+	ch.order = sc.alloc<int>(M); ch.L = sc.alloc<double>((size_t)nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)M * 36);
+	ch.d_err = sc.alloc<int>(1);
+	h2d(ctx, ch.colptr, colptr.data(), (M + 1) * sizeof(int)); h2d(ctx, ch.rowidx, rowidx.data(), (size_t)nnzL * sizeof(int));
+	h2d(ctx, ch.perm, perm.data(), M * sizeof(int)); h2d(ctx, ch.pinv, pinv.data(), M * sizeof(int));
+	h2d(ctx, ch.order, order.data(), M * sizeof(int));
+	dev_zero(ctx, ch.d_err, sizeof(int));
+	dev_zero(ctx, ch.L, (size_t)nnzL * 36 * sizeof(double));
+}
+
+static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch)
+{
+	hipStream_t s = ctx->stream;
+	if (sy.nnzb)
+		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, s, sy.nnzb, sy.upper_keys, sy.S, ch.pinv, ch.colptr, ch.rowidx,
+		                   fixed, ch.L);
+	for (int l = 0; l < ch.nlevels; l++)
+	{
+		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
+		if (n) hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+	}
+	if (ch.M - ch.tail_begin > 0)
+		hipLaunchKernelGGL(k_chol_factor_tail, dim3(1), dim3(256), 0, s, ch.M - ch.tail_begin, ch.order + ch.tail_begin, ch.colptr, ch.rowidx, ch.L,
+		                   ch.Dinv, ch.d_err);
+}
+
+// z = (L L^T)^-1 r in the original numbering, rz_dot[seg] += r . z
+static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, double* v, double* z, const unsigned char* fixed, const int* pose_seg,
+                       double* dot, int dot_stride)
+{
+	hipStream_t s = ctx->stream;
+	const size_t ns = (size_t)ch.M * 6;
+	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, ch.M, ch.perm, r, fixed, v);
+	for (int l = 0; l < ch.nlevels; l++)
+	{
+		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
+		if (n) hipLaunchKernelGGL(k_chol_fwd_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+	}
+	if (ch.M - ch.tail_begin > 0)
+		hipLaunchKernelGGL(k_chol_solve_tail, dim3(1), dim3(256), 0, s, ch.M - ch.tail_begin, ch.order + ch.tail_begin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+	for (int l = ch.nlevels - 1; l >= 0; l--)
+	{
+		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
+		if (n) hipLaunchKernelGGL(k_chol_bwd_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+	}
+	hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CG pieces
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_x_init(int M, const double* __restrict__ x0, const unsigned char* __restrict__ fixed, double* __restrict__ x)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)M * 6) return;
+	double v = x0 ? x0[i] : 0.0;
+	if (fixed && fixed[i]) v = 0.0;
+	x[i] = v;
+}
+
+// r = E - y ; rr += r.r ; ee += E.E   (fixed scalars are not part of the system)
+__global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* __restrict__ y, const int* __restrict__ pose_seg,
+                            const unsigned char* __restrict__ fixed, double* __restrict__ r, PcgSeg* seg)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool v = row < M;
+	double a[2] = { 0, 0 };
+	int sg = 0;
+	if (v)
+	{
+		sg = pose_seg[row];
+		for (int i = 0; i < 6; i++)
+		{
+			const size_t o = (size_t)row * 6 + i;
+			double e = E[o], d = e - y[o];
+			if (fixed && fixed[o]) { e = 0; d = 0; }
+			if (r) r[o] = d;
+			a[0] += d * d; a[1] += e * e;
+		}
+	}
+	wave_scatter_add<2>(&seg[sg].rr, a, v); // rr, ee are adjacent
+}
+
+// p = z, per system: thresholds, convergence state
+__global__ void k_pcg_start(int nseg, PcgSeg* seg, const unsigned char* __restrict__ active, double rel_tol, int* ndone)
+{
+	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	PcgSeg& g = seg[s];
+	g.thresh = rel_tol * rel_tol * g.ee;
+	g.pAp = 0; g.rz[1] = 0; g.its = 0;
+	g.active = active ? active[s] : 1;
+	g.done = (!g.active || !(g.rr > g.thresh)) ? 1 : 0;
+	g.rr = 0;
+	if (g.done) atomicAdd(ndone, 1);
+}
+__global__ void k_copy(size_t n, const double* __restrict__ a, double* __restrict__ b)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) b[i] = a[i];
+}
+
+// alpha = rz/pAp ; x += alpha p ; r -= alpha Ap ; rr += r.r
+__global__ void k_pcg_update1(int M, int cur, const double* __restrict__ Ap, const int* __restrict__ pose_seg, double* __restrict__ x,
+                              double* __restrict__ r, const double* __restrict__ p, PcgSeg* seg)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	bool v = row < M;
+	double rr = 0;
+	int sg = 0;
+	if (v)
+	{
+		sg = pose_seg[row];
+		const PcgSeg& g = seg[sg];
+		if (g.done) v = false;
+		else
+		{
+			const double alpha = g.rz[cur] / g.pAp;
+			for (int i = 0; i < 6; i++)
+			{
+				const size_t o = (size_t)row * 6 + i;
+				x[o] += alpha * p[o];
+				const double t = r[o] - alpha * Ap[o];
+				r[o] = t;
+				rr += t * t;
+			}
+		}
+	}
+	wave_scatter_add<1>(&seg[sg].rr, &rr, v);
+}
+
+// beta = rz[nxt]/rz[cur] ; p = z + beta p ; Ap = 0 ; per system: convergence test, reset accumulators
+__global__ void k_pcg_update2(int M, int cur, const double* __restrict__ z, const int* __restrict__ pose_seg, double* __restrict__ p,
+                              double* __restrict__ Ap, PcgSeg* seg, int* ndone)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= M) return;
+	const int sg = pose_seg[row];
+	PcgSeg& g = seg[sg];
+	const bool done = g.done;
+	const double rzn = g.rz[cur ^ 1], rzc = g.rz[cur];
+	for (int i = 0; i < 6; i++) Ap[(size_t)row * 6 + i] = 0.0;
+	if (!done)
+	{
+		const double beta = rzn / rzc;
+		for (int i = 0; i < 6; i++) { const size_t o = (size_t)row * 6 + i; p[o] = z[o] + beta * p[o]; }
+	}
+}
+// after update2 (separate launch: the flags it writes are read by every row of the system)
+__global__ void k_pcg_check(int nseg, int cur, PcgSeg* seg, int* ndone)
+{
+	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	PcgSeg& g = seg[s];
+	if (g.done) return;
+	const double rr = g.rr;
+	g.pAp = 0; g.rr = 0; g.rz[cur] = 0; // rz[cur] is the accumulator of the next iteration
+	g.its++;
+	if (!(rr > g.thresh) || !(rr == rr)) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
+}
+
+int solve_batch(lsfm_context* ctx, const SolveIO& io)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	const int M = io.M, nseg = io.nseg;
+	hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+	float ms = 0;
+	LSFM_CHECK_HIP(hipEventCreate(&ea)); LSFM_CHECK_HIP(hipEventCreate(&eb)); LSFM_CHECK_HIP(hipEventCreate(&ec));
+	LSFM_CHECK_HIP(hipEventRecord(ea, s));
+	SchurSystem sy;
+	build_schur(ctx, io, sy);
+	LSFM_CHECK_HIP(hipEventRecord(eb, s));
+	LSFM_CHECK_HIP(hipEventSynchronize(eb));
+	LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
+	if (ctx->stats) ctx->stats->t_schur_ms += ms;
+	LSFM_CHECK_HIP(hipEventRecord(ea, s));
+
+	// ---- preconditioner ----
+	CholDev ch;
+	chol_analyse(ctx, sy, io.d_pose_origin, ch);
+	chol_factor(ctx, sy, io.d_fixed, ch);
+	int* d_misc = sc.alloc<int>(4); // [1] ndone
+	dev_zero(ctx, d_misc, 4 * sizeof(int));
+
+	// ---- CG ----
+	std::vector<PcgSeg> hseg(nseg);
+	{
+		int row = 0;
+		for (int g = 0; g < nseg; g++) { memset(&hseg[g], 0, sizeof(PcgSeg)); hseg[g].row0 = row; row += io.seg_rows[g]; }
+	}
+	PcgSeg* seg = sc.alloc<PcgSeg>(nseg);
+	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg);
+	double* x = io.x_pose;
+	const size_t nscal = (size_t)M * 6;
+	double* r = sc.alloc<double>(nscal); double* z = sc.alloc<double>(nscal); double* p = sc.alloc<double>(nscal);
+	double* Ap = sc.alloc<double>(nscal); double* v = sc.alloc<double>(nscal);
+	const int nbr = (M + 127) / 128, nbs = (nseg + 127) / 128;
+	const unsigned nbe = (unsigned)((nscal + 255) / 256);
+	hipLaunchKernelGGL(k_x_init, dim3(nbe), dim3(256), 0, s, M, io.x0, io.d_fixed, x);
+	dev_zero(ctx, Ap, nscal * sizeof(double));
+	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
+	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg);
+	chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[0], SEG_STRIDE);
+	hipLaunchKernelGGL(k_copy, dim3(nbe), dim3(256), 0, s, nscal, z, p);
+	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
+	dev_zero(ctx, Ap, nscal * sizeof(double));
+	int cerr = d2h_int(ctx, ch.d_err);
+	if (cerr) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
+
+	const int maxit = 50;
+	int its = 0, ndone = d2h_int(ctx, d_misc + 1);
+	while (ndone < nseg && its < maxit)
+	{
+		const int cur = its & 1;
+		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
+		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, Ap, io.d_pose_seg, x, r, p, seg);
+		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
+		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
+		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, cur, seg, d_misc + 1);
+		its++;
+		ndone = d2h_int(ctx, d_misc + 1);
+	}
+	// ---- true residual, statistics; SpMV launches timed with HIP events on this stream ----
+	const int nsample = 5;
+	float sp_ms = 0;
+	for (int k = 0; k < nsample; k++)
+	{
+		dev_zero(ctx, Ap, nscal * sizeof(double));
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
+		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+		LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+		float t = 0;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+		sp_ms += t;
+	}
+	std::vector<PcgSeg> hs2(nseg);
+	d2h(ctx, hs2.data(), seg, sizeof(PcgSeg) * nseg);
+	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg); // zeroed accumulators
+	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg);
+	d2h(ctx, hseg.data(), seg, sizeof(PcgSeg) * nseg);
+	int notconv = 0;
+	double maxrel = 0;
+	for (int g = 0; g < nseg; g++)
+	{
+		if (!hs2[g].active) continue;
+		const double rel = hseg[g].ee > 0 ? sqrt(hseg[g].rr / hseg[g].ee) : 0.0;
+		maxrel = std::max(maxrel, rel);
+		if (hs2[g].done != 1 && !(rel < 1e-9)) notconv++;
+	}
+	LSFM_CHECK_HIP(hipEventRecord(eb, s));
+	launch_backsub(ctx, io, sy, x);
+	LSFM_CHECK_HIP(hipGetLastError());
+	LSFM_CHECK_HIP(hipEventRecord(ec, s));
+	LSFM_CHECK_HIP(hipEventSynchronize(ec));
+	if (ctx->stats)
+	{
+		lsfm_stats* st = ctx->stats;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); st->t_pcg_ms += ms;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, eb, ec)); st->t_backsub_ms += ms;
+		st->pcg_iterations += its;
+		st->spmv_launches += nsample;
+		st->spmv_ms += sp_ms;
+		st->spmv_bytes += nsample * spmv_bytes(sy);
+		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
+		st->max_rel_residual = std::max(st->max_rel_residual, maxrel);
+	}
+	(void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec);
+	return notconv;
+}
+
+} // namespace lsfm

@@ -16,6 +16,7 @@
 
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
+#include "lsfm_solve.hpp"
 
 namespace lsfm {
 
@@ -298,213 +299,6 @@ k_spmv(int nchunks, const int* __restrict__ chunk_row, const int* __restrict__ c
 	}
 }
 
-// ---- block-Jacobi preconditioner: inverse of the diagonal blocks (6x6 SPD, Cholesky) -------------------------
-__global__ void k_diag_inverse(int M, const int* __restrict__ rowptr, const int* __restrict__ colidx, const double* __restrict__ S,
-                               const unsigned char* __restrict__ fixed, double* __restrict__ Minv, int* __restrict__ bad)
-{
-	int p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= M) return;
-	// the diagonal block is the first entry of the row in the upper pattern
-	double A[36], L[36], Li[36];
-	ld<36>(A, S + (size_t)rowptr[p] * 36);
-	if (colidx[rowptr[p]] != p) { atomicExch(bad, 1 + p); return; }
-	for (int i = 0; i < 6; i++)
-	{
-		const bool fx = fixed && fixed[(size_t)p * 6 + i];
-		for (int j = 0; j < 6; j++)
-		{
-			const bool fj = fixed && fixed[(size_t)p * 6 + j];
-			if (fx || fj) A[i * 6 + j] = (i == j) ? 1.0 : 0.0;
-		}
-	}
-	zero<36>(L);
-	bool ok = true;
-	for (int j = 0; j < 6; j++)
-	{
-		double d = A[j * 6 + j];
-		for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
-		if (!(d > 0)) { ok = false; d = 1.0; }
-		L[j * 6 + j] = sqrt(d);
-		for (int i = j + 1; i < 6; i++)
-		{
-			double s = A[i * 6 + j];
-			for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-			L[i * 6 + j] = s / L[j * 6 + j];
-		}
-	}
-	if (!ok) atomicExch(bad, -(1 + p));
-	zero<36>(Li); // L^-1 (lower)
-	for (int j = 0; j < 6; j++)
-	{
-		Li[j * 6 + j] = 1.0 / L[j * 6 + j];
-		for (int i = j + 1; i < 6; i++)
-		{
-			double s = 0;
-			for (int k = j; k < i; k++) s -= L[i * 6 + k] * Li[k * 6 + j];
-			Li[i * 6 + j] = s / L[i * 6 + i];
-		}
-	}
-	double Ai[36]; // A^-1 = L^-T L^-1
-	for (int i = 0; i < 6; i++)
-		for (int j = 0; j < 6; j++)
-		{
-			double s = 0;
-			for (int k = (i > j ? i : j); k < 6; k++) s += Li[k * 6 + i] * Li[k * 6 + j];
-			Ai[i * 6 + j] = s;
-		}
-	for (int i = 0; i < 6; i++)
-		for (int j = 0; j < 6; j++)
-			if (fixed && (fixed[(size_t)p * 6 + i] || fixed[(size_t)p * 6 + j])) Ai[i * 6 + j] = 0.0;
-	st<36>(Minv + (size_t)p * 36, Ai);
-}
-
-// ---- PCG pieces (K10b/K10c) ---------------------------------------------------------------------------------
-struct PcgSeg {
-	double rz[2];
-	double pAp;
-	double rz0, ez, thresh;
-	int done, its, row0, active;
-};
-static_assert(sizeof(PcgSeg) % sizeof(double) == 0, "PcgSeg is strided in doubles by the SpMV's fused dot product");
-
-// r = E - y, z = Minv r, p = z, rz[0] += r.z, ez += E.Minv E ; x = x0 (fixed scalars forced to 0)
-__global__ void k_pcg_init(int M, const double* __restrict__ E, const double* __restrict__ y, const double* __restrict__ Minv,
-                           const int* __restrict__ pose_seg, const unsigned char* __restrict__ fixed, double* __restrict__ r, double* __restrict__ z,
-                           double* __restrict__ p, PcgSeg* seg)
-{
-	int row = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool v = row < M;
-	double rz = 0, ez = 0;
-	int sg = 0;
-	if (v)
-	{
-		sg = pose_seg[row];
-		double rr[6], ee[6], mi[36], zz[6], ze[6];
-		for (int i = 0; i < 6; i++)
-		{
-			ee[i] = E[(size_t)row * 6 + i];
-			rr[i] = ee[i] - y[(size_t)row * 6 + i];
-			if (fixed && fixed[(size_t)row * 6 + i]) { rr[i] = 0; ee[i] = 0; }
-		}
-		ld<36>(mi, Minv + (size_t)row * 36);
-		mm<6, 6, 1, false>(mi, rr, zz);
-		mm<6, 6, 1, false>(mi, ee, ze);
-		for (int i = 0; i < 6; i++)
-		{
-			r[(size_t)row * 6 + i] = rr[i]; z[(size_t)row * 6 + i] = zz[i]; p[(size_t)row * 6 + i] = zz[i];
-			rz += rr[i] * zz[i]; ez += ee[i] * ze[i];
-		}
-	}
-	wave_scatter_add<1>(&seg[sg].rz[0], &rz, v);
-	wave_scatter_add<1>(&seg[sg].ez, &ez, v);
-}
-
-__global__ void k_pcg_init2(int nseg, PcgSeg* seg, const unsigned char* __restrict__ active, double rel_tol, int* ndone)
-{
-	int s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= nseg) return;
-	PcgSeg& g = seg[s];
-	g.rz0 = g.rz[0];
-	const double floor_ = 1e-30 * g.ez; // (1e-15 relative to the right-hand side)^2
-	g.thresh = fmax(rel_tol * rel_tol * g.rz0, floor_);
-	g.pAp = 0; g.rz[1] = 0; g.its = 0;
-	g.active = active ? active[s] : 1;
-	g.done = (!g.active || !(g.rz0 > g.thresh)) ? 1 : 0;
-	if (g.done) atomicAdd(ndone, 1);
-}
-
-// alpha = rz/pAp ; x += alpha p ; r -= alpha Ap ; z = Minv r ; rz[nxt] += r.z
-__global__ void k_pcg_update1(int M, int cur, const double* __restrict__ Ap, const double* __restrict__ Minv, const int* __restrict__ pose_seg,
-                              double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, const double* __restrict__ p, PcgSeg* seg)
-{
-	int row = blockIdx.x * blockDim.x + threadIdx.x;
-	bool v = row < M;
-	double rz = 0;
-	int sg = 0;
-	if (v)
-	{
-		sg = pose_seg[row];
-		const PcgSeg& g = seg[sg];
-		if (g.done) v = false;
-		else
-		{
-			const double alpha = g.rz[cur] / g.pAp;
-			double rr[6], mi[36], zz[6];
-			for (int i = 0; i < 6; i++)
-			{
-				const size_t o = (size_t)row * 6 + i;
-				x[o] += alpha * p[o];
-				rr[i] = r[o] - alpha * Ap[o];
-				r[o] = rr[i];
-			}
-			ld<36>(mi, Minv + (size_t)row * 36);
-			mm<6, 6, 1, false>(mi, rr, zz);
-			for (int i = 0; i < 6; i++) { z[(size_t)row * 6 + i] = zz[i]; rz += rr[i] * zz[i]; }
-		}
-	}
-	wave_scatter_add<1>(&seg[sg].rz[cur ^ 1], &rz, v);
-}
-
-// beta = rz[nxt]/rz[cur] ; p = z + beta p ; Ap = 0 ; per system: convergence test, reset accumulators
-__global__ void k_pcg_update2(int M, int cur, const double* __restrict__ z, const int* __restrict__ pose_seg, double* __restrict__ p,
-                              double* __restrict__ Ap, PcgSeg* seg, int* ndone)
-{
-	int row = blockIdx.x * blockDim.x + threadIdx.x;
-	if (row >= M) return;
-	const int sg = pose_seg[row];
-	PcgSeg& g = seg[sg];
-	const bool done = g.done;
-	const double rzn = g.rz[cur ^ 1], rzc = g.rz[cur];
-	for (int i = 0; i < 6; i++) Ap[(size_t)row * 6 + i] = 0.0;
-	if (!done)
-	{
-		const double beta = rzn / rzc;
-		for (int i = 0; i < 6; i++) { const size_t o = (size_t)row * 6 + i; p[o] = z[o] + beta * p[o]; }
-	}
-	if (row == g.row0 && !done)
-	{
-		g.pAp = 0;
-		g.its++;
-		// rz[cur] is zeroed by k_pcg_rotate before it becomes the accumulator again
-		if (!(rzn > g.thresh) || !(rzn == rzn)) { g.done = (rzn == rzn) ? 1 : 2; atomicAdd(ndone, 1); }
-	}
-}
-__global__ void k_pcg_rotate(int nseg, int cur, PcgSeg* seg)
-{
-	int s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s < nseg) seg[s].rz[cur] = 0.0;
-}
-
-// final: true residual per system ||E - S x||^2 and ||E||^2 ; copy x0 for carried maps
-__global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* __restrict__ y, const int* __restrict__ pose_seg,
-                            const unsigned char* __restrict__ fixed, double* __restrict__ acc)
-{
-	int row = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool v = row < M;
-	double a[2] = { 0, 0 };
-	int sg = 0;
-	if (v)
-	{
-		sg = pose_seg[row];
-		for (int i = 0; i < 6; i++)
-		{
-			if (fixed && fixed[(size_t)row * 6 + i]) continue;
-			double e = E[(size_t)row * 6 + i], d = e - y[(size_t)row * 6 + i];
-			a[0] += d * d; a[1] += e * e;
-		}
-	}
-	wave_scatter_add<2>(acc + (size_t)sg * 2, a, v);
-}
-
-__global__ void k_x_init(int M, const double* __restrict__ x0, const unsigned char* __restrict__ fixed, double* __restrict__ x)
-{
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= (size_t)M * 6) return;
-	double v = x0 ? x0[i] : 0.0;
-	if (fixed && fixed[i]) v = 0.0;
-	x[i] = v;
-}
-
 // K11: one lane per feature (Imp.cpp:2980-3020); features of carried maps keep their values
 __global__ void k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
                           const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,
@@ -535,17 +329,7 @@ __global__ void k_low_words(int n, const unsigned long long* __restrict__ keys, 
 	if (i < n) out[i] = (int)(keys[i] & 0xffffffffull);
 }
 
-struct SchurSystem {
-	int M = 0, nnzb = 0, nfull = 0, nchunks = 0;
-	int *rowptr = nullptr, *colidx = nullptr;      // upper block CSR (diagonal block first in every row)
-	double* S = nullptr;                           // [nnzb*36]
-	double* E = nullptr;                           // [M*6]
-	double* IV = nullptr;                          // [NF*9]
-	int *frow = nullptr, *fcol = nullptr, *fblk = nullptr; // both orientations, row sorted; fblk = (upper index << 1) | transposed
-	int *chunk_row = nullptr, *chunk_beg = nullptr;
-};
-
-static void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags)
+void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
@@ -573,7 +357,7 @@ static void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned 
 	hipLaunchKernelGGL(k_chunk_fill, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, cptr, sy.chunk_row, sy.chunk_beg);
 }
 
-static void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
@@ -619,12 +403,13 @@ static void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
 	if (NF) hipLaunchKernelGGL(k_schur_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
+	sy.upper_keys = list;
 	build_spmv_index(ctx, sy, list, d_flags);
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 
-static inline void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,
-                               const double* dotw, const int* pose_seg, double* dot, int dot_stride = 1)
+void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,
+                 const double* dotw, const int* pose_seg, double* dot, int dot_stride)
 {
 	const int threads = sy.nchunks * 8;
 	if (threads)
@@ -633,147 +418,13 @@ static inline void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const d
 }
 
 // algorithmic bytes of one SpMV on the upper-block storage: blocks + column indices + row pointers + x and y
-static double spmv_bytes(const SchurSystem& sy) { return (double)sy.nnzb * (288 + 4) + 4.0 * (sy.M + 1) + 2.0 * 48 * sy.M; }
+double spmv_bytes(const SchurSystem& sy) { return (double)sy.nnzb * (288 + 4) + 4.0 * (sy.M + 1) + 2.0 * 48 * sy.M; }
 
-int solve_batch(lsfm_context* ctx, const SolveIO& io)
+void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x)
 {
-	hipStream_t s = ctx->stream;
-	Arena& sc = ctx->scratch;
-	const int M = io.M, nseg = io.nseg;
-	hipEvent_t ea = nullptr, eb = nullptr;
-	float ms = 0;
-	LSFM_CHECK_HIP(hipEventCreate(&ea)); LSFM_CHECK_HIP(hipEventCreate(&eb));
-	LSFM_CHECK_HIP(hipEventRecord(ea, s));
-	SchurSystem sy;
-	build_schur(ctx, io, sy);
-	double* Minv = sc.alloc<double>((size_t)M * 36);
-	int* d_misc = sc.alloc<int>(4); // [0] bad diagonal, [1] ndone
-	dev_zero(ctx, d_misc, 4 * sizeof(int));
-	if (M) hipLaunchKernelGGL(k_diag_inverse, dim3((M + 127) / 128), dim3(128), 0, s, M, sy.rowptr, sy.colidx, sy.S, io.d_fixed, Minv, d_misc);
-	LSFM_CHECK_HIP(hipEventRecord(eb, s));
-	LSFM_CHECK_HIP(hipEventSynchronize(eb));
-	LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
-	if (ctx->stats) ctx->stats->t_schur_ms += ms;
-	LSFM_CHECK_HIP(hipEventRecord(ea, s));
-
-	// ---- PCG ----
-	std::vector<PcgSeg> hseg(nseg);
-	{
-		int row = 0;
-		for (int g = 0; g < nseg; g++) { memset(&hseg[g], 0, sizeof(PcgSeg)); hseg[g].row0 = row; row += io.seg_rows[g]; }
-	}
-	PcgSeg* seg = sc.alloc<PcgSeg>(nseg);
-	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg);
-	double* x = io.x_pose;
-	double* r = sc.alloc<double>((size_t)M * 6);
-	double* z = sc.alloc<double>((size_t)M * 6);
-	double* p = sc.alloc<double>((size_t)M * 6);
-	double* Ap = sc.alloc<double>((size_t)M * 6);
-	double* racc = sc.alloc<double>((size_t)nseg * 2);
-	const int nbr = (M + 127) / 128;
-	const size_t nscal = (size_t)M * 6;
-	hipLaunchKernelGGL(k_x_init, dim3((unsigned)((nscal + 255) / 256)), dim3(256), 0, s, M, io.x0, io.d_fixed, x);
-	dev_zero(ctx, Ap, nscal * sizeof(double));
-	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr);
-	hipLaunchKernelGGL(k_pcg_init, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, Minv, io.d_pose_seg, io.d_fixed, r, z, p, seg);
-	hipLaunchKernelGGL(k_pcg_init2, dim3((nseg + 127) / 128), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
-	dev_zero(ctx, Ap, nscal * sizeof(double));
-	int bad = d2h_int(ctx, d_misc);
-	if (bad > 0) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system: block row " + std::to_string(bad - 1) + " has no diagonal block");
-
-	int maxrows = 1;
-	for (int g = 0; g < nseg; g++) maxrows = std::max(maxrows, io.seg_rows[g]);
-	const long maxit = (long)ctx->pcg.max_it_factor * 6 * maxrows + 200;
-	const int per_graph = maxrows <= 8 ? 8 : (maxrows <= 64 ? 32 : 64); // iterations per graph replay (even)
-	auto enqueue_iteration = [&](int cur) {
-		// SpMV also zeroes the rz accumulator of this iteration (it reads no scalars)
-		hipLaunchKernelGGL(k_pcg_rotate, dim3((nseg + 127) / 128), dim3(128), 0, s, nseg, cur ^ 1, seg);
-		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, (int)(sizeof(PcgSeg) / sizeof(double)));
-		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, Ap, Minv, io.d_pose_seg, x, r, z, p, seg);
-		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
-	};
-	hipGraph_t graph = nullptr;
-	hipGraphExec_t gexec = nullptr;
-	bool use_graph = true;
-	if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess)
-	{
-		for (int it = 0; it < per_graph; it++) enqueue_iteration(it & 1);
-		if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
-	}
-	else
-		use_graph = false;
-	(void)hipGetLastError();
-	long its = 0;
-	int ndone = d2h_int(ctx, d_misc + 1);
-	hipEvent_t es0 = ctx->ev0, es1 = ctx->ev1;
-	while (ndone < nseg && its < maxit)
-	{
-		// one SpMV per replay is bracketed by events on this stream: live sample of the kernel's duration
-		if (ctx->stats)
-		{
-			double* scratch_y = r; // not: timing sample must not disturb the iteration -> use a separate vector
-			(void)scratch_y;
-		}
-		if (use_graph) LSFM_CHECK_HIP(hipGraphLaunch(gexec, s));
-		else for (int it = 0; it < per_graph; it++) enqueue_iteration(it & 1);
-		its += per_graph;
-		ndone = d2h_int(ctx, d_misc + 1);
-	}
-	if (gexec) (void)hipGraphExecDestroy(gexec);
-	if (graph) (void)hipGraphDestroy(graph);
-	// ---- true residual, statistics ----
-	dev_zero(ctx, Ap, nscal * sizeof(double));
-	dev_zero(ctx, racc, (size_t)nseg * 2 * sizeof(double));
-	// timed SpMV launches (same kernel, same matrix, same stream as inside the loop)
-	const int nsample = 5;
-	float sp_ms = 0;
-	for (int k = 0; k < nsample; k++)
-	{
-		dev_zero(ctx, Ap, nscal * sizeof(double));
-		LSFM_CHECK_HIP(hipEventRecord(es0, s));
-		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr);
-		LSFM_CHECK_HIP(hipEventRecord(es1, s));
-		LSFM_CHECK_HIP(hipEventSynchronize(es1));
-		float t = 0;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&t, es0, es1));
-		sp_ms += t;
-	}
-	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, racc);
-	std::vector<double> hr((size_t)nseg * 2);
-	d2h(ctx, hr.data(), racc, hr.size() * sizeof(double));
-	d2h(ctx, hseg.data(), seg, sizeof(PcgSeg) * nseg);
-	int notconv = 0;
-	double maxrel = 0;
-	for (int g = 0; g < nseg; g++)
-	{
-		if (!hseg[g].active) continue;
-		if (hseg[g].done != 1) notconv++;
-		if (hr[2 * g + 1] > 0) maxrel = std::max(maxrel, sqrt(hr[2 * g] / hr[2 * g + 1]));
-	}
-	// ---- features ----
-	LSFM_CHECK_HIP(hipEventRecord(eb, s));
 	if (io.NF)
-		hipLaunchKernelGGL(k_backsub, dim3((io.NF + 255) / 256), dim3(256), 0, s, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x, io.d_feat_seg,
-		                   io.d_seg_active, io.x_feat);
-	LSFM_CHECK_HIP(hipGetLastError());
-	hipEvent_t ec = nullptr;
-	LSFM_CHECK_HIP(hipEventCreate(&ec));
-	LSFM_CHECK_HIP(hipEventRecord(ec, s));
-	LSFM_CHECK_HIP(hipEventSynchronize(ec));
-	if (ctx->stats)
-	{
-		lsfm_stats* st = ctx->stats;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); st->t_pcg_ms += ms;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, eb, ec)); st->t_backsub_ms += ms;
-		st->pcg_iterations += its;
-		st->spmv_launches += nsample;
-		st->spmv_ms += sp_ms;
-		st->spmv_bytes += nsample * spmv_bytes(sy);
-		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
-		st->max_rel_residual = std::max(st->max_rel_residual, maxrel);
-	}
-	(void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec);
-	return notconv;
+		hipLaunchKernelGGL(k_backsub, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x,
+		                   io.d_feat_seg, io.d_seg_active, io.x_feat);
 }
 
 // y = S x for an externally supplied symmetric block matrix (upper block CSR): measurement entry of the C ABI
@@ -803,7 +454,7 @@ int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx
 	{
 		dev_zero(ctx, dy, (size_t)m * 6 * sizeof(double));
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
-		launch_spmv(ctx, sy, dx, dy, nullptr, nullptr, nullptr, nullptr);
+		launch_spmv(ctx, sy, dx, dy, nullptr, nullptr, nullptr, nullptr, 1);
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
 		LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
 		float t = 0;

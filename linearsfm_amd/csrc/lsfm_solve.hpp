@@ -1,0 +1,25 @@
+// Shared between lsfm_solve.hip (Schur assembly, SpMV, back-substitution) and lsfm_pcg.hip (preconditioned CG).
+#pragma once
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+struct SchurSystem {
+	int M = 0, nnzb = 0, nfull = 0, nchunks = 0;
+	int *rowptr = nullptr, *colidx = nullptr;      // upper block CSR (diagonal block first in every row)
+	const unsigned long long* upper_keys = nullptr; // [nnzb] sorted (row << 32 | col) of the upper pattern
+	double* S = nullptr;                           // [nnzb*36]
+	double* E = nullptr;                           // [M*6]
+	double* IV = nullptr;                          // [NF*9]
+	int *frow = nullptr, *fcol = nullptr, *fblk = nullptr; // both orientations, row sorted; fblk = (upper index << 1) | transposed
+	int *chunk_row = nullptr, *chunk_beg = nullptr;
+};
+
+void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
+void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags);
+void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed, const double* dotw,
+                 const int* pose_seg, double* dot, int dot_stride);
+double spmv_bytes(const SchurSystem& sy);
+void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);
+
+} // namespace lsfm

@@ -168,26 +168,46 @@ static int cmp_degidx(const void* a, const void* b)
 	return x->idx < y->idx ? -1 : (x->idx > y->idx);
 }
 
+static int bitlen(unsigned x) { int l = 0; while (x) { l++; x >>= 1; } return l; }
+
+/* Three candidate orderings are compared by symbolic fill and the best is returned:
+ *  natural, ascending degree, and a nested dissection along the join tree: block index p is the position of the
+ *  pose in the joint state = (Stereo) the index of the local map that brought it, so the binary join tree is the
+ *  bit structure of p.  An edge (p,q) crosses the cut of tree level bitlen(p^q); the endpoint of higher degree
+ *  (the hub pose of that sub-map) is put into that level's separator (a vertex cover of the crossing edges);
+ *  blocks are eliminated by ascending separator level. */
 void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm)
 {
-	degidx* d = xm(nb * sizeof *d);
-	int *pinv = xm(nb * sizeof(int)), *Cp, *Ci, *parent = xm(nb * sizeof(int)), *cc = xm(nb * sizeof(int));
+	degidx* d = xm((nb + 1) * sizeof *d);
+	int *pinv = xm((nb + 1) * sizeof(int)), *Cp, *Ci, *parent = xm((nb + 1) * sizeof(int)), *cc = xm((nb + 1) * sizeof(int));
+	int *deg = calloc(nb + 1, sizeof(int)), *best = xm((nb + 1) * sizeof(int));
 	double* Cx;
-	int j, p;
-	long fill_nat, fill_deg;
-	for (j = 0; j < nb; j++) { d[j].deg = 0; d[j].idx = j; }
+	int j, p, cand;
+	long fill, best_fill = -1;
 	for (j = 0; j < nb; j++)
 		for (p = Ap[j]; p < Ap[j + 1]; p++)
-			if (Ai[p] != j) { d[j].deg++; d[Ai[p]].deg++; }
-	qsort(d, nb, sizeof *d, cmp_degidx);
-	for (j = 0; j < nb; j++) { perm[j] = d[j].idx; pinv[d[j].idx] = j; }
-	symperm(nb, Ap, Ai, NULL, NULL, &Cp, &Ci, &Cx);
-	fill_nat = symbolic_lnz(nb, Cp, Ci, parent, cc);
-	free(Cp); free(Ci);
-	symperm(nb, Ap, Ai, NULL, pinv, &Cp, &Ci, &Cx);
-	fill_deg = symbolic_lnz(nb, Cp, Ci, parent, cc);
-	free(Cp); free(Ci);
-	if (fill_nat <= fill_deg)
-		for (j = 0; j < nb; j++) perm[j] = j;
-	free(d); free(pinv); free(parent); free(cc);
+			if (Ai[p] != j) { deg[j]++; deg[Ai[p]]++; }
+	for (cand = 0; cand < 3; cand++)
+	{
+		for (j = 0; j < nb; j++) { d[j].deg = 0; d[j].idx = j; }
+		if (cand == 1) for (j = 0; j < nb; j++) d[j].deg = deg[j];
+		if (cand == 2)
+			for (j = 0; j < nb; j++)
+				for (p = Ap[j]; p < Ap[j + 1]; p++)
+				{
+					int i = Ai[p], l, v;
+					if (i == j) continue;
+					l = bitlen((unsigned)(i ^ j));
+					v = (deg[i] > deg[j] || (deg[i] == deg[j] && i > j)) ? i : j;
+					if (l > d[v].deg) d[v].deg = l;
+				}
+		qsort(d, nb, sizeof *d, cmp_degidx);
+		for (j = 0; j < nb; j++) { perm[j] = d[j].idx; pinv[d[j].idx] = j; }
+		symperm(nb, Ap, Ai, NULL, pinv, &Cp, &Ci, &Cx);
+		fill = symbolic_lnz(nb, Cp, Ci, parent, cc);
+		free(Cp); free(Ci);
+		if (best_fill < 0 || fill < best_fill) { best_fill = fill; memcpy(best, perm, nb * sizeof(int)); }
+	}
+	memcpy(perm, best, nb * sizeof(int));
+	free(d); free(pinv); free(parent); free(cc); free(deg); free(best);
 }

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--new-per-frame", type=int, default=130)
     ap.add_argument("--vis", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=384, help="local maps given to the CPU baseline (0 = skip)")
-    ap.add_argument("--tol", type=float, default=1e-10)
+    ap.add_argument("--tol", type=float, default=1e-15)
     args = ap.parse_args()
 
     import torch

@@ -63,7 +63,7 @@ struct DevBatch {
 	double* V = nullptr;    // [NF*9]
 };
 
-struct PcgOptions { double rel_tol = 1e-10; int max_it_factor = 4; };
+struct PcgOptions { double rel_tol = 1e-15; int max_it_factor = 4; };
 
 } // namespace lsfm
 

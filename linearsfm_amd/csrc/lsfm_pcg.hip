@@ -26,7 +26,7 @@ namespace lsfm {
 struct PcgSeg {
 	double rz[2];
 	double pAp;
-	double rr, ee, thresh;
+	double rr, ee, thresh, rr_prev;
 	int done, its, row0, active;
 };
 static_assert(sizeof(PcgSeg) % sizeof(double) == 0, "PcgSeg is strided in doubles by the fused dot products");
@@ -441,10 +441,10 @@ __global__ void k_x_init(int M, const double* __restrict__ x0, const unsigned ch
 
 // r = E - y ; rr += r.r ; ee += E.E   (fixed scalars are not part of the system)
 __global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* __restrict__ y, const int* __restrict__ pose_seg,
-                            const unsigned char* __restrict__ fixed, double* __restrict__ r, PcgSeg* seg)
+                            const unsigned char* __restrict__ fixed, double* __restrict__ r, PcgSeg* seg, int with_ee)
 {
 	int row = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool v = row < M;
+	bool v = row < M;
 	double a[2] = { 0, 0 };
 	int sg = 0;
 	if (v)
@@ -458,7 +458,9 @@ __global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* _
 			if (r) r[o] = d;
 			a[0] += d * d; a[1] += e * e;
 		}
+		if (seg[sg].done) v = false; // converged systems are frozen
 	}
+	if (!with_ee) a[1] = 0.0;
 	wave_scatter_add<2>(&seg[sg].rr, a, v); // rr, ee are adjacent
 }
 
@@ -472,6 +474,7 @@ __global__ void k_pcg_start(int nseg, PcgSeg* seg, const unsigned char* __restri
 	g.pAp = 0; g.rz[1] = 0; g.its = 0;
 	g.active = active ? active[s] : 1;
 	g.done = (!g.active || !(g.rr > g.thresh)) ? 1 : 0;
+	g.rr_prev = g.rr;
 	g.rr = 0;
 	if (g.done) atomicAdd(ndone, 1);
 }
@@ -481,33 +484,19 @@ __global__ void k_copy(size_t n, const double* __restrict__ a, double* __restric
 	if (i < n) b[i] = a[i];
 }
 
-// alpha = rz/pAp ; x += alpha p ; r -= alpha Ap ; rr += r.r
-__global__ void k_pcg_update1(int M, int cur, const double* __restrict__ Ap, const int* __restrict__ pose_seg, double* __restrict__ x,
-                              double* __restrict__ r, const double* __restrict__ p, PcgSeg* seg)
+// alpha = rz/pAp ; x += alpha p ; y = 0.  The residual is then RECOMPUTED as E - S x (residual replacement in every
+// iteration): with the exact factor as preconditioner CG acts as iterative refinement, and the recursively updated
+// residual would hide the attainable accuracy (the camera systems reach condition numbers ~1e9).
+__global__ void k_pcg_update1(int M, int cur, const int* __restrict__ pose_seg, double* __restrict__ x, const double* __restrict__ p,
+                              double* __restrict__ y, const PcgSeg* __restrict__ seg)
 {
 	int row = blockIdx.x * blockDim.x + threadIdx.x;
-	bool v = row < M;
-	double rr = 0;
-	int sg = 0;
-	if (v)
-	{
-		sg = pose_seg[row];
-		const PcgSeg& g = seg[sg];
-		if (g.done) v = false;
-		else
-		{
-			const double alpha = g.rz[cur] / g.pAp;
-			for (int i = 0; i < 6; i++)
-			{
-				const size_t o = (size_t)row * 6 + i;
-				x[o] += alpha * p[o];
-				const double t = r[o] - alpha * Ap[o];
-				r[o] = t;
-				rr += t * t;
-			}
-		}
-	}
-	wave_scatter_add<1>(&seg[sg].rr, &rr, v);
+	if (row >= M) return;
+	const PcgSeg& g = seg[pose_seg[row]];
+	for (int i = 0; i < 6; i++) y[(size_t)row * 6 + i] = 0.0;
+	if (g.done) return;
+	const double alpha = g.rz[cur] / g.pAp;
+	for (int i = 0; i < 6; i++) { const size_t o = (size_t)row * 6 + i; x[o] += alpha * p[o]; }
 }
 
 // beta = rz[nxt]/rz[cur] ; p = z + beta p ; Ap = 0 ; per system: convergence test, reset accumulators
@@ -537,7 +526,9 @@ __global__ void k_pcg_check(int nseg, int cur, PcgSeg* seg, int* ndone)
 	const double rr = g.rr;
 	g.pAp = 0; g.rr = 0; g.rz[cur] = 0; // rz[cur] is the accumulator of the next iteration
 	g.its++;
-	if (!(rr > g.thresh) || !(rr == rr)) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
+	// converged, or the true residual stopped shrinking (attainable accuracy reached)
+	if (!(rr > g.thresh) || !(rr < 0.25 * g.rr_prev) || !(rr == rr)) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
+	g.rr_prev = rr;
 }
 
 int solve_batch(lsfm_context* ctx, const SolveIO& io)
@@ -581,7 +572,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipLaunchKernelGGL(k_x_init, dim3(nbe), dim3(256), 0, s, M, io.x0, io.d_fixed, x);
 	dev_zero(ctx, Ap, nscal * sizeof(double));
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
-	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg);
+	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 1);
 	chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[0], SEG_STRIDE);
 	hipLaunchKernelGGL(k_copy, dim3(nbe), dim3(256), 0, s, nscal, z, p);
 	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
@@ -595,7 +586,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	{
 		const int cur = its & 1;
 		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
-		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, Ap, io.d_pose_seg, x, r, p, seg);
+		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, io.d_pose_seg, x, p, Ap, seg);
+		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
+		hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 0);
 		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
 		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
 		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, cur, seg, d_misc + 1);
@@ -619,7 +612,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	std::vector<PcgSeg> hs2(nseg);
 	d2h(ctx, hs2.data(), seg, sizeof(PcgSeg) * nseg);
 	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg); // zeroed accumulators
-	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg);
+	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg, 1);
 	d2h(ctx, hseg.data(), seg, sizeof(PcgSeg) * nseg);
 	int notconv = 0;
 	double maxrel = 0;

@@ -207,6 +207,9 @@ void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm)
 		fill = symbolic_lnz(nb, Cp, Ci, parent, cc);
 		free(Cp); free(Ci);
 		if (best_fill < 0 || fill < best_fill) { best_fill = fill; memcpy(best, perm, nb * sizeof(int)); }
+		/* test hook: ORC_ORDER=0|1|2 forces one candidate (used to show how far two valid fp64 solves of the same
+		 * system differ on ill-conditioned joins) */
+		if (getenv("ORC_ORDER") && atoi(getenv("ORC_ORDER")) == cand) { memcpy(best, perm, nb * sizeof(int)); break; }
 	}
 	memcpy(perm, best, nb * sizeof(int));
 	free(d); free(pinv); free(parent); free(cc); free(deg); free(best);

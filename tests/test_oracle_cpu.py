@@ -1,0 +1,140 @@
+"""CPU-only tests: the oracle against the REAL reference's outputs stored in tests/golden/ (transform + join assembly at
+every tree level, made by tests/golden/make_golden.py from oracle/_ref/ref_dump), algebraic self-checks of the oracle's
+solve (the one stage the reference cannot pin here: CHOLMOD is absent), the synthetic generator, file formats."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import assert_maps_close, get_map, load_golden, ref_map, rel_err
+from linearsfm_amd import synth
+from refdump import dense_info
+
+GOLD = ["stereo_n5.npz", "stereo_n8.npz", "mono_n5.npz", "mono_n8.npz"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_oracle_transform_and_assembly_vs_reference(oracle, name):
+    z = load_golden(name)
+    mono = str(z["type"]) == "Monocular"
+    for j in range(int(z["njoins"])):
+        A, B = get_map(z, f"join{j}.A"), get_map(z, f"join{j}.B")
+        E = oracle.transform(A, mono, B["Ref"], B["ScaP"], B["Fix"])
+        exp = ref_map(z, f"join{j}.end")
+        exp["FRef"] = A["FRef"]
+        assert_maps_close(E, exp, 1e-12, f"{name} join{j} transform")
+        J, eP, eF, sa, _, _ = oracle.join_assemble(E, B, mono)
+        for k in ("Ui", "Uj", "photo", "feature"):
+            assert np.array_equal(J[k], z[f"join{j}.solve.{k}"]), (j, k)
+        assert np.array_equal(J["stno"], z[f"join{j}.joint.stno"])
+        assert np.array_equal(J["FBlock"], z[f"join{j}.joint.FBlock"])
+        for k, x in (("U", J["U"]), ("W", J["W"]), ("V", J["V"]), ("ea", eP), ("eb", eF)):
+            assert rel_err(x, z[f"join{j}.solve.{k}"]) < 1e-12, (j, k)
+        if mono:
+            ref_sa = [int(z[f"join{j}.solve.{k}"][0]) for k in ("Ref", "ScaP", "Fix", "Sign", "FixBlk")]
+            assert sa == ref_sa
+        # the oracle's own solution of this system is what the fixture carries to the next level
+        st, rc, _ = oracle.solve(J, eP, eF, mono, sa)
+        assert rc == 0
+        assert rel_err(st, z[f"join{j}.sol"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_transform_is_congruence(oracle, name):
+    """I' = J^T I J is symmetric positive semi-definite with the same inertia; checked densely (independent of the
+    block bookkeeping): x^T I x of the old state perturbation equals x'^T I' x' to first order is implied by
+    symmetry + unchanged rank."""
+    z = load_golden(name)
+    mono = str(z["type"]) == "Monocular"
+    A, B = get_map(z, "join0.A"), get_map(z, "join0.B")
+    E = oracle.transform(A, mono, B["Ref"], B["ScaP"], B["Fix"])
+    I0, I1 = dense_info(A), dense_info(E)
+    assert np.allclose(I1, I1.T, rtol=0, atol=1e-9 * np.abs(I1).max())
+    w1 = np.linalg.eigvalsh(I1)
+    assert w1.min() > -1e-9 * w1.max()
+    if not mono:
+        assert np.linalg.matrix_rank(I0, tol=1e-9 * np.abs(I0).max()) == np.linalg.matrix_rank(I1, tol=1e-9 * np.abs(I1).max())
+
+
+def test_solve_satisfies_normal_equations(oracle):
+    """The joint estimate solves (I1 + I2) x = I1 x1 + I2 x2 -- checked on the dense full system, which
+    does not go through the Schur complement or the sparse Cholesky at all."""
+    z = load_golden("stereo_n8.npz")
+    j = int(z["njoins"]) - 1
+    J = dict(m=int(z[f"join{j}.solve.m"][0]), n=int(z[f"join{j}.solve.n"][0]), U=z[f"join{j}.solve.U"],
+             W=z[f"join{j}.solve.W"], V=z[f"join{j}.solve.V"], Ui=z[f"join{j}.solve.Ui"], Uj=z[f"join{j}.solve.Uj"],
+             photo=z[f"join{j}.solve.photo"], feature=z[f"join{j}.solve.feature"])
+    ea, eb = z[f"join{j}.solve.ea"], z[f"join{j}.solve.eb"]
+    st, rc, stats = oracle.solve(J, ea, eb, False)
+    assert rc == 0
+    I = dense_info(J)
+    b = np.concatenate([ea, eb])
+    assert np.linalg.norm(I @ st - b) / np.linalg.norm(b) < 1e-10
+    xd = np.linalg.solve(I, b)
+    assert np.max(np.abs(st - xd) / np.maximum(1, np.abs(xd))) < 1e-8
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_tree_reproduces_ground_truth_geometry(oracle, mono):
+    """End-to-end sanity of generator + oracle: the joined trajectory follows the synthetic camera path."""
+    N = 12
+    maps = synth.make_mono_set(N, 12, 4, seed=3) if mono else synth.make_stereo_set(N, 8, 4, seed=3)
+    out, timing, rc = oracle.divide_conquer([oracle.localmap_to_dict(m) for m in maps], mono)
+    assert rc == 0
+    stno, st = out["stno"], out["stVal"]
+    ids = -stno[stno <= 0][::6]
+    pos = st[: 6 * out["m"]].reshape(-1, 6)[:, :3]
+    o = np.argsort(ids)
+    steps = np.linalg.norm(np.diff(pos[o], axis=0), axis=1)
+    if mono:
+        steps = steps / steps[0]
+        assert np.all(np.abs(steps - 1.0) < 0.2)
+    else:
+        assert np.all(np.abs(steps - 0.5) < 0.05)
+    assert out["Ref"] == out["FRef"] == maps[0].Ref
+
+
+def test_match_hash_equals_linear_find(oracle):
+    maps = synth.make_stereo_set(9, 6, 5, seed=9)
+    d = [oracle.localmap_to_dict(m) for m in maps]
+    a, _, _ = oracle.divide_conquer(d, False, match_hash=False)
+    b, _, _ = oracle.divide_conquer(d, False, match_hash=True)
+    assert np.array_equal(a["stno"], b["stno"]) and np.array_equal(a["stVal"], b["stVal"])
+
+
+def test_localmap_text_roundtrip(oracle, tmp_path):
+    """Generator -> reference text format -> oracle reader / product reader give identical arrays."""
+    from linearsfm_amd import api
+    for mono, maps in ((False, synth.make_stereo_set(2, 4, 4, seed=1)), (True, synth.make_mono_set(2, 5, 4, seed=1))):
+        p = str(tmp_path / f"localmap_{int(mono)}.txt")
+        synth.write_localmap(p, maps[0])
+        g = oracle.map_to_dict(oracle.read_map(p, mono))
+        back = synth.read_localmap(p, mono)
+        h = api.read_localmap(p, mono)
+        for k in ("stno", "Ui", "Uj", "photo", "feature", "FBlock"):
+            assert np.array_equal(g[k], getattr(maps[0], k)) and np.array_equal(getattr(back, k), getattr(maps[0], k))
+            assert np.array_equal(h[k], getattr(maps[0], k))
+        for k in ("stVal", "U", "W", "V"):
+            assert np.array_equal(np.asarray(g[k]).ravel(), np.asarray(getattr(maps[0], k)).ravel())
+            assert np.array_equal(np.asarray(h[k]).ravel(), np.asarray(getattr(maps[0], k)).ravel())
+        assert g["Ref"] == maps[0].Ref == h["Ref"]
+        if mono:
+            assert (g["ScaP"], g["Fix"], g["Sign"]) == (maps[0].ScaP, maps[0].Fix, maps[0].Sign) == (h["ScaP"], h["Fix"], h["Sign"])
+
+
+def test_oracle_cli_and_output_formats(oracle, tmp_path):
+    """The oracle CLI takes the reference's flags and writes the reference's '%lf' files sorted by id."""
+    maps = synth.make_stereo_set(4, 4, 4, seed=2)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(os.path.dirname(oracle.__file__), "lsfm_oracle")
+    p, f, s = tmp_path / "Pose.txt", tmp_path / "Feature.txt", tmp_path / "State.txt"
+    out = subprocess.run([exe, "-path", str(d), "-num", "4", "-type", "Stereo", "-p", str(p), "-f", str(f), "-st", str(s)],
+                         capture_output=True, text=True, check=True).stdout
+    assert "Join Level 0 Local Map 1" in out and "Generate Level 2 Local Map 1" in out and "Total Used Time:" in out
+    poses = [l.split() for l in open(p)]
+    assert [int(r[0]) for r in poses] == sorted(int(r[0]) for r in poses) and all(len(r) == 7 for r in poses)
+    assert all(len(l.split()) == 4 for l in open(f))
+    assert all(len(l.split()) == 2 for l in open(s))
+    assert len(poses[0][1].split(".")[1]) == 6  # %lf

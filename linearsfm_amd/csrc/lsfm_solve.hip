@@ -164,62 +164,109 @@ __global__ void k_schur_u(int NU, const double* __restrict__ U, const int* __res
 	else { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) atomic_add_f64(s + c * 6 + r, u[r * 6 + c]); }
 }
 
-__global__ void __launch_bounds__(256)
+// K9, one lane per feature.  A tile of SCHUR_TILE consecutive features (one work-group) touches few distinct blocks
+// of S (its ~10 hub poses squared plus the handful of poses that observe the tile), while every feature contributes
+// k_f(k_f+1)/2 of them: all contributions are first summed in an LDS table keyed by the block's slot (ds_add_f64) and
+// each touched block leaves the work-group once, as 36 contiguous atomics.  (Scattering 8-byte atomics straight to HBM
+// ran at ~0.08 TB/s, MI355X_MICROARCH "Global float atomics": 64 lanes in 64 different rows.)
+#define SCHUR_TILE 128
+#define SCHUR_CAP 256 /* LDS block accumulators per work-group: 256 * 288 B = 72 KiB -> 2 work-groups per CU */
+#define SCHUR_ECAP 64 /* LDS accumulators for E (per pose) */
+
+__device__ __forceinline__ int lds_slot(int* keys, int cap, int key)
+{
+	unsigned h = ((unsigned)key * 2654435761u) & (unsigned)(cap - 1);
+	for (int probe = 0; probe < cap; probe++)
+	{
+		const int cur = keys[h];
+		if (cur == key) return (int)h;
+		if (cur == -1)
+		{
+			const int old = atomicCAS(&keys[h], -1, key);
+			if (old == -1 || old == key) return (int)h;
+		}
+		h = (h + 1) & (unsigned)(cap - 1);
+	}
+	return -1;
+}
+__device__ __forceinline__ void lds_add_f64(double* p, double v)
+{
+	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(SCHUR_TILE)
 k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
           const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
           double* __restrict__ S, double* __restrict__ E)
 {
-	int f = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool inb = f < NF;
-	int j0 = 0, len = 0;
-	double iv[9], ebf[3];
-	if (inb)
+	__shared__ int skey[SCHUR_CAP];
+	__shared__ int ekey[SCHUR_ECAP];
+	__shared__ double sval[SCHUR_CAP * 36];
+	__shared__ double evalv[SCHUR_ECAP * 6];
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SCHUR_CAP; i += SCHUR_TILE) skey[i] = -1;
+	for (int i = tid; i < SCHUR_ECAP; i += SCHUR_TILE) ekey[i] = -1;
+	for (int i = tid; i < SCHUR_CAP * 36; i += SCHUR_TILE) sval[i] = 0.0;
+	for (int i = tid; i < SCHUR_ECAP * 6; i += SCHUR_TILE) evalv[i] = 0.0;
+	__syncthreads();
+	const int f = blockIdx.x * SCHUR_TILE + tid;
+	if (f < NF)
 	{
-		j0 = fptr[f]; len = fptr[f + 1] - j0;
+		const int j0 = fptr[f], len = fptr[f + 1] - j0;
+		double iv[9];
 		ld<9>(iv, IV + (size_t)f * 9);
-		ebf[0] = eb[(size_t)f * 3]; ebf[1] = eb[(size_t)f * 3 + 1]; ebf[2] = eb[(size_t)f * 3 + 2];
-	}
-	int maxlen = len;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
-	for (int a = 0; a < maxlen; a++)
-	{
-		const bool va = inb && a < len;
-		double WV[18];
-		int pa = 0;
-		if (va)
+		const double eb0 = eb[(size_t)f * 3], eb1 = eb[(size_t)f * 3 + 1], eb2 = eb[(size_t)f * 3 + 2];
+		for (int a = 0; a < len; a++)
 		{
-			double Wa[18];
-			pa = photo[j0 + a];
+			double WV[18], Wa[18];
+			const int pa = photo[j0 + a];
 			ld<18>(Wa, W + (size_t)(j0 + a) * 18);
 			mm<6, 3, 3, false>(Wa, iv, WV); // W V^-1 (V^-1 symmetric), Imp.cpp:2260-2273
-		}
-		{
-			// E_p -= W V^-1 eb, Imp.cpp:2321-2328
-			double e[6];
+			{
+				// E_p -= W V^-1 eb, Imp.cpp:2321-2328
+				const int es = lds_slot(ekey, SCHUR_ECAP, pa);
 #pragma unroll
-			for (int r = 0; r < 6; r++) e[r] = va ? -(WV[3 * r] * ebf[0] + WV[3 * r + 1] * ebf[1] + WV[3 * r + 2] * ebf[2]) : 0.0;
-			wave_scatter_add<6>(E + (size_t)pa * 6, e, va);
-		}
-		for (int b = a; b < maxlen; b++)
-		{
-			const bool v = inb && b < len;
-			double X[36];
-			int slot = 0;
-			if (v)
+				for (int r = 0; r < 6; r++)
+				{
+					const double e = -(WV[3 * r] * eb0 + WV[3 * r + 1] * eb1 + WV[3 * r + 2] * eb2);
+					if (es >= 0) lds_add_f64(&evalv[es * 6 + r], e); else atomic_add_f64(E + (size_t)pa * 6 + r, e);
+				}
+			}
+			for (int b = a; b < len; b++)
 			{
 				double Wb[18], T[36];
 				const int pb = photo[j0 + b];
 				ld<18>(Wb, W + (size_t)(j0 + b) * 18);
-				mmt<6, 3, 6, false>(WV, Wb, T); // W_a V^-1 W_b^T = contribution to S(pa,pb)
-				slot = hash_find(tab, val, mask, pair_key(pa, pb));
-				if (a == b) { for (int q = 0; q < 36; q++) X[q] = -T[q]; }
-				else if (pa < pb) { for (int q = 0; q < 36; q++) X[q] = -T[q]; }
-				else if (pa > pb) { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) X[c * 6 + r] = -T[r * 6 + c]; }
-				else { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) X[r * 6 + c] = -(T[r * 6 + c] + T[c * 6 + r]); }
+				mmt<6, 3, 6, false>(WV, Wb, T); // W_a V^-1 W_b^T = contribution to S(pa,pb), Imp.cpp:2283-2318
+				const int slot = hash_find(tab, val, mask, pair_key(pa, pb));
+				const int ls = lds_slot(skey, SCHUR_CAP, slot);
+				double* dl = ls >= 0 ? &sval[ls * 36] : nullptr;
+				double* dg = S + (size_t)slot * 36;
+				// stored orientation: rows = the smaller pose index; a block of one pose with itself is stored full
+				const bool same = (pa == pb), tr = pa > pb, twice = same && a != b;
+#pragma unroll
+				for (int r = 0; r < 6; r++)
+#pragma unroll
+					for (int c = 0; c < 6; c++)
+					{
+						double x = -T[r * 6 + c];
+						if (twice) x -= T[c * 6 + r];
+						const int o = tr ? c * 6 + r : r * 6 + c;
+						if (dl) lds_add_f64(dl + o, x); else atomic_add_f64(dg + o, x);
+					}
 			}
-			wave_scatter_add<36>(S + (size_t)slot * 36, X, v);
 		}
+	}
+	__syncthreads();
+	for (int i = tid; i < SCHUR_CAP * 36; i += SCHUR_TILE)
+	{
+		const int k = skey[i / 36];
+		if (k >= 0) atomic_add_f64(S + (size_t)k * 36 + i % 36, sval[i]);
+	}
+	for (int i = tid; i < SCHUR_ECAP * 6; i += SCHUR_TILE)
+	{
+		const int k = ekey[i / 6];
+		if (k >= 0) atomic_add_f64(E + (size_t)k * 6 + i % 6, evalv[i]);
 	}
 }
 
@@ -402,7 +449,7 @@ void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	dev_zero(ctx, sy.S, (size_t)cnt * 36 * sizeof(double));
 	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
-	if (NF) hipLaunchKernelGGL(k_schur_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
+	if (NF) hipLaunchKernelGGL(k_schur_w, dim3((NF + SCHUR_TILE - 1) / SCHUR_TILE), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
 	sy.upper_keys = list;
 	build_spmv_index(ctx, sy, list, d_flags);
 	LSFM_CHECK_HIP(hipGetLastError());

@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+# HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 guide
+# prescribes + WRITE_SIZE; separate --pmc runs), averaged over the launches of one tree run.  None = not collected.
+TRAFFIC = {"schur": None, "trf": None}
 
 
 def cpu_baseline(maps, sample_maps):
@@ -101,9 +104,19 @@ def main():
         # dominant kernel of the solve: the block-sparse SpMV of the CG (k_spmv).  Duration sampled live with HIP events
         # on the library's stream inside every join (5 launches per level on that level's matrix); algorithmic bytes per
         # launch = nnzb*(288+4) + 4*(m+1) + 96*m on the upper-block storage.
-        sp_ms = acc["spmv_ms"] / max(1, acc["spmv_launches"])
-        sp_bytes = acc["spmv_bytes"] / max(1, acc["spmv_launches"])
-        achieved = sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms > 0 else 0.0
+        # Per-kernel live measurements (HIP events on the library's stream around the launches, accumulated over the timed
+        # steps).  The roofline object describes whichever of the instrumented kernels took the most device time.
+        kern = {}
+        for key, name in (("schur", "k_schur_w (K9: Schur assembly S -= W V^-1 W^T, E -= W V^-1 eb)"),
+                          ("trf", "k_tr_features (K3/K4: information transform I' = J^T I J of the W/V blocks)"),
+                          ("spmv", "k_spmv (K10a: 6x6-block symmetric SpMV of the CG)")):
+            n = max(1, acc[f"{key}_launches"])
+            kern[key] = dict(name=name, total_ms=acc[f"{key}_ms"] / args.steps, launches_per_step=acc[f"{key}_launches"] / args.steps,
+                             avg_ms=acc[f"{key}_ms"] / n, avg_bytes=acc[f"{key}_bytes"] / n)
+            kern[key]["gbs"] = kern[key]["avg_bytes"] / (kern[key]["avg_ms"] * 1e-3) / 1e9 if kern[key]["avg_ms"] > 0 else 0.0
+        # the SpMV inside the CG loop is not bracketed (only 5 timed extra launches per level are): scale by its real count
+        dom = max(("schur", "trf"), key=lambda k: kern[k]["total_ms"])
+        sp_ms, sp_bytes, achieved = kern[dom]["avg_ms"], kern[dom]["avg_bytes"], kern[dom]["gbs"]
         line = {
             "metric": "hierarchical linear map-joining solve wall-clock, NC3500-like stereo (all transforms + joins)",
             "value": ms_per_step / world,
@@ -126,11 +139,16 @@ def main():
             "pcg_iterations_per_step": acc["pcg_iterations"] / args.steps,
             "max_rel_residual": stats["max_rel_residual"],
             "not_converged": stats["not_converged"],
-            "roofline": {"bound": "hbm", "kernel": "k_spmv (6x6-block symmetric SpMV of the CG)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kern[dom]["name"], "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get(dom),
                          "avg_launch_ms": sp_ms, "algorithmic_bytes_per_launch": sp_bytes,
-                         "note": "average over the per-level samples; the matrices of this workload (<= ~20 MB) are "
-                                 "cache resident, see DESIGN.md"},
+                         "launches_per_step": kern[dom]["launches_per_step"],
+                         "note": "one launch per tree level (12 levels + final re-anchoring); average over all of them, small "
+                                 "low-level launches included; algorithmic bytes = every input and output moved once "
+                                 "(DESIGN.md); traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/), null if "
+                                 "not collected for this kernel"},
+            "kernels": {k: {"avg_launch_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"], "ms_per_step": v["total_ms"],
+                            "launches_per_step": v["launches_per_step"]} for k, v in kern.items()},
         }
         if args.cpu_sample > 0:
             S = min(args.cpu_sample, args.maps)

@@ -64,6 +64,11 @@ typedef struct lsfm_stats {
 	double max_rel_residual;/* max over systems of ||E - S x|| / ||E|| at exit */
 	int levels, joins, transforms;
 	int not_converged;      /* number of systems that hit the iteration cap */
+	/* the two HBM-streaming kernels, each bracketed by HIP events on the context's stream (one launch per tree level):
+	 * K9 k_schur_w (Schur assembly) and K3/K4 k_tr_features (information transform).  bytes = algorithmic bytes of
+	 * those launches */
+	long schur_launches, trf_launches;
+	double schur_ms, schur_bytes, trf_ms, trf_bytes;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */

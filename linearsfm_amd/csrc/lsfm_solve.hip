@@ -449,7 +449,23 @@ void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	dev_zero(ctx, sy.S, (size_t)cnt * 36 * sizeof(double));
 	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
-	if (NF) hipLaunchKernelGGL(k_schur_w, dim3((NF + SCHUR_TILE - 1) / SCHUR_TILE), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
+	if (NF)
+	{
+		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
+		hipLaunchKernelGGL(k_schur_w, dim3((NF + SCHUR_TILE - 1) / SCHUR_TILE), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
+		if (ctx->stats)
+		{
+			float t = 0;
+			LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+			LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+			LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+			ctx->stats->schur_launches++;
+			ctx->stats->schur_ms += t;
+			// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
+			ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)NF * (72 + 24 + 4) + (double)cnt * 288 + (double)M * 48;
+		}
+	}
 	sy.upper_keys = list;
 	build_spmv_index(ctx, sy, list, d_flags);
 	LSFM_CHECK_HIP(hipGetLastError());

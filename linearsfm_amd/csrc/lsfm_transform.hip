@@ -592,8 +592,23 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 	hipStream_t s = ctx->stream;
 	const int M = in.M;
 	if (in.NF)
+	{
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
 		hipLaunchKernelGGL(k_tr_features<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.feat, in.fptr, in.V,
 		                   in.W, in.photo, KW, Dp, Cp, out.feat, out.fptr, out.V, out.W, out.photo, out.feature, Gpose, PP);
+		if (ctx->stats)
+		{
+			float t = 0;
+			LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+			LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+			LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+			ctx->stats->trf_launches++;
+			ctx->stats->trf_ms += t;
+			// in: W block + photo per entry, V + value + run pointer per feature; out: W' block + photo' + feature' per entry,
+			// V' + value + run pointer per feature
+			ctx->stats->trf_bytes += (double)in.NW * (144 + 4) + (double)out.NW * (144 + 8) + 2.0 * in.NF * (72 + 24 + 4);
+		}
+	}
 	if (in.NU)
 		hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
 		                   Dp, Cp, out.U, out.Ui, out.Uj, Gpose);

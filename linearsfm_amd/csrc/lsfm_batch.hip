@@ -43,7 +43,7 @@ void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, boo
 	}
 	o.M = o.pose_off[N]; o.NF = o.feat_off[N]; o.NU = o.u_off[N]; o.NW = o.w_off[N];
 	std::vector<double> pose((size_t)o.M * 6), feat((size_t)o.NF * 3);
-	std::vector<int> pid(o.M), fid(o.NF), Ui(o.NU), Uj(o.NU), photo(o.NW), feature(o.NW), fptr(o.NF + 1);
+	std::vector<int> pid(o.M), porg(o.M), fid(o.NF), Ui(o.NU), Uj(o.NU), photo(o.NW), feature(o.NW), fptr(o.NF + 1);
 	for (int k = 0; k < N; k++)
 	{
 		const lsfm_map& g = maps[k];
@@ -52,6 +52,7 @@ void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, boo
 		{
 			if (g.stno[6 * i] > 0) LSFM_FAIL(LSFM_ERR_ARG, "state label of a pose must be <= 0");
 			pid[po + i] = -g.stno[6 * i];
+			porg[po + i] = k;
 			memcpy(&pose[(size_t)(po + i) * 6], g.stVal + 6 * i, 6 * sizeof(double));
 		}
 		for (int i = 0; i < g.n; i++)
@@ -83,12 +84,13 @@ void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, boo
 		}
 	}
 	fptr[o.NF] = o.NW;
-	o.pose = ar.alloc<double>((size_t)o.M * 6); o.pose_id = ar.alloc<int>(o.M);
+	o.pose = ar.alloc<double>((size_t)o.M * 6); o.pose_id = ar.alloc<int>(o.M); o.pose_origin = ar.alloc<int>(o.M);
 	o.feat = ar.alloc<double>((size_t)o.NF * 3); o.feat_id = ar.alloc<int>(o.NF);
 	o.U = ar.alloc<double>((size_t)o.NU * 36); o.Ui = ar.alloc<int>(o.NU); o.Uj = ar.alloc<int>(o.NU);
 	o.W = ar.alloc<double>((size_t)o.NW * 18); o.photo = ar.alloc<int>(o.NW); o.feature = ar.alloc<int>(o.NW);
 	o.fptr = ar.alloc<int>(o.NF + 1); o.V = ar.alloc<double>((size_t)o.NF * 9);
 	h2d(ctx, o.pose, pose.data(), pose.size() * sizeof(double)); h2d(ctx, o.pose_id, pid.data(), pid.size() * sizeof(int));
+	h2d(ctx, o.pose_origin, porg.data(), porg.size() * sizeof(int));
 	h2d(ctx, o.feat, feat.data(), feat.size() * sizeof(double)); h2d(ctx, o.feat_id, fid.data(), fid.size() * sizeof(int));
 	h2d(ctx, o.Ui, Ui.data(), Ui.size() * sizeof(int)); h2d(ctx, o.Uj, Uj.data(), Uj.size() * sizeof(int));
 	h2d(ctx, o.photo, photo.data(), photo.size() * sizeof(int)); h2d(ctx, o.feature, feature.data(), feature.size() * sizeof(int));

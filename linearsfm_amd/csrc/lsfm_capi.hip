@@ -89,8 +89,8 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	Arena& mine = ctx->arena[t->slot];
 	mine.reset(); // X is dead from here on
 	DevBatch Y;
-	if (t->mono) LSFM_FAIL(LSFM_ERR_ARG, "Monocular joins are not implemented on the device yet");
-	join_batch_stereo(ctx, mine, Xt, Y, nullptr, nullptr);
+	if (t->mono) join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
+	else join_batch_stereo(ctx, mine, Xt, Y, nullptr, nullptr);
 	double t2 = now_ms();
 	t->level = Y;
 	if (st)
@@ -108,7 +108,7 @@ template <class T> void rebase(T*& p, ptrdiff_t delta)
 DevBatch rebased(const DevBatch& b, ptrdiff_t d)
 {
 	DevBatch o = b;
-	rebase(o.d_pose_off, d); rebase(o.d_feat_off, d); rebase(o.pose, d); rebase(o.pose_id, d); rebase(o.pose_map, d);
+	rebase(o.d_pose_off, d); rebase(o.d_feat_off, d); rebase(o.pose, d); rebase(o.pose_id, d); rebase(o.pose_map, d); rebase(o.pose_origin, d);
 	rebase(o.feat, d); rebase(o.feat_id, d); rebase(o.feat_map, d); rebase(o.U, d); rebase(o.Ui, d); rebase(o.Uj, d);
 	rebase(o.W, d); rebase(o.photo, d); rebase(o.feature, d); rebase(o.fptr, d); rebase(o.V, d);
 	return o;
@@ -262,16 +262,30 @@ int lsfm_join_stereo(lsfm_context* ctx, const lsfm_map* End, const lsfm_map* Cur
 	});
 }
 
-int lsfm_join_mono(lsfm_context* ctx, const lsfm_map*, const lsfm_map*, lsfm_map*, double*, double*)
+int lsfm_join_mono(lsfm_context* ctx, const lsfm_map* End, const lsfm_map* Cur, lsfm_map* joint, double* eP_out, double* eF_out)
 {
-	if (ctx) ctx->last_error = "lsfm_join_mono: not implemented on the device yet";
-	return LSFM_ERR_ARG;
+	if (!End || !Cur || !joint) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		lsfm_map two[2] = { *End, *Cur };
+		ctx->ensure_arenas(estimate_arena(two, 2, 1));
+		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
+		DevBatch X, Y;
+		batch_upload(ctx, ctx->arena[0], two, 2, true, X);
+		lsfm_stats st;
+		memset(&st, 0, sizeof st);
+		ctx->stats = &st;
+		try { join_batch_mono(ctx, ctx->arena[1], X, Y, eP_out, eF_out); }
+		catch (...) { ctx->stats = nullptr; throw; }
+		ctx->stats = nullptr;
+		batch_download_map(ctx, Y, 0, true, joint);
+		return st.not_converged ? LSFM_NOT_CONVERGED : LSFM_OK;
+	});
 }
 
-// raw-pointer solver with the reference's argument list (Imp.h:209)
-int lsfm_solve_stereo(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U, const double* W,
-                      const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU,
-                      int nW, const double* x0)
+// raw-pointer solver with the reference's argument list (Imp.h:209 / 223); fixed_blk / fixed_scalar < 0: Stereo
+static int solve_raw(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                     const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU,
+                     int nW, const double* x0, int fixed_blk, int fixed_scalar)
 {
 	if (!stVal || m <= 0 || n < 0 || nU < 0 || nW < 0) return LSFM_ERR_ARG;
 	return guarded(ctx, [&]() {
@@ -308,6 +322,15 @@ int lsfm_solve_stereo(lsfm_context* ctx, double* stVal, const double* eb, const 
 		io.U = dU; io.Ui = dUi; io.Uj = dUj; io.W = dW; io.photo = dph; io.fptr = dfp; io.V = dV;
 		io.ea = dea; io.eb = deb; io.x0 = dx0; io.x_pose = dxp; io.x_feat = dxf;
 		io.seg_rows.assign(1, m);
+		if (fixed_blk >= 0 || fixed_scalar >= 0)
+		{
+			std::vector<unsigned char> fx((size_t)m * 6, 0);
+			if (fixed_blk >= 0 && fixed_blk < m) for (int i = 0; i < 6; i++) fx[(size_t)fixed_blk * 6 + i] = 1;
+			if (fixed_scalar >= 0 && fixed_scalar < 6 * m) fx[fixed_scalar] = 1;
+			unsigned char* dfx = ar.alloc<unsigned char>((size_t)m * 6);
+			h2d(ctx, dfx, fx.data(), fx.size());
+			io.d_fixed = dfx;
+		}
 		int rc = solve_batch(ctx, io);
 		d2h(ctx, stVal, dxp, (size_t)m * 6 * sizeof(double));
 		d2h(ctx, stVal + 6 * m, dxf, (size_t)n * 3 * sizeof(double));
@@ -315,11 +338,24 @@ int lsfm_solve_stereo(lsfm_context* ctx, double* stVal, const double* eb, const 
 	});
 }
 
-int lsfm_solve_mono(lsfm_context* ctx, double*, const double*, const double*, const double*, const double*, const double*, const int*,
-                    const int*, const int*, const int*, int, int, int, int, int, int, int, int, int, const double*)
+int lsfm_solve_stereo(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                      const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU,
+                      int nW, const double* x0)
 {
-	if (ctx) ctx->last_error = "lsfm_solve_mono: not implemented on the device yet";
-	return LSFM_ERR_ARG;
+	return solve_raw(ctx, stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, x0, -1, -1);
+}
+
+// Imp.cpp:6756-7041: the 6 scalars of block `Ref` (= scalars ScaP..ScaP+5, the call site passes ScaP = 6*Ref) and scalar
+// `Fix` are removed from the system, the solution is 0 there, and finally stVal[Fix] = Sign (Imp.cpp:7026)
+int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const double* ea, const double* U, const double* W,
+                    const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU,
+                    int nW, int Ref, int ScaP, int Fix, int Sign, int FixBlk, const double* x0)
+{
+	(void)FixBlk;
+	if (ScaP != 6 * Ref || Ref < 0 || Ref >= m || Fix < 0 || Fix >= 6 * m) return LSFM_ERR_ARG;
+	int rc = solve_raw(ctx, stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, x0, Ref, Fix);
+	if (rc >= 0) stVal[Fix] = Sign;
+	return rc;
 }
 
 int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y,

@@ -52,6 +52,7 @@ struct DevBatch {
 	double* pose = nullptr; // [M*6]
 	int* pose_id = nullptr; // [M]  = -stno
 	int* pose_map = nullptr; // [M]
+	int* pose_origin = nullptr; // [M] index of the local map that brought the pose (drives the elimination order)
 	// features
 	double* feat = nullptr; // [NF*3]
 	int* feat_id = nullptr; // [NF]
@@ -110,6 +111,7 @@ struct JoinWork; // device work arrays shared between assembly and solve
 // Produces `out` (ceil(B/2) maps) with the solved state.  eP_out / eF_out (host, optional) receive the right-hand
 // sides of group 0 when B <= 2 (stage-level C ABI).
 void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out);
+void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out);
 
 struct SolveIO {
 	// system of `nseg` independent camera systems laid out back to back (block rows = poses of the batch)

@@ -10,14 +10,9 @@
 // feature (O(n1*n2), Imp.cpp:2581-2599); here one radix sort of (pair, label, side) keys does it for the level.
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
+#include "lsfm_join.hpp"
 
 namespace lsfm {
-
-struct JGroup {
-	int F0E, nE, F0C, nC; // feature ranges of End / Cur in the input batch (nC = 0: carried map)
-	int FY0;              // first joint feature
-	int rC0;              // rank offset of Cur's unmatched features
-};
 
 __global__ void k_join_keys(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, unsigned long long* __restrict__ keys,
                             int* __restrict__ vals)
@@ -55,7 +50,7 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
                                 const double* __restrict__ V, const int* __restrict__ fptr, const int* __restrict__ match,
                                 const int* __restrict__ R, const JGroup* __restrict__ grp, int* __restrict__ newf, int* __restrict__ lenE,
                                 int* __restrict__ lenC, double* __restrict__ Vy, double* __restrict__ eF, int* __restrict__ fid_y,
-                                double* __restrict__ feat_y)
+                                double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC)
 {
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
@@ -69,6 +64,7 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
 	newf[f] = nf;
 	int len = fptr[f + 1] - fptr[f];
 	if (!cur) lenE[nf] = len; else lenC[nf] = len;
+	if (srcE) { if (!cur) srcE[nf] = f; else srcC[nf] = f; }
 	const double* v = V + (size_t)f * 9;
 	const double* x = feat + (size_t)f * 3;
 	for (int i = 0; i < 9; i++) atomic_add_f64(Vy + (size_t)nf * 9 + i, v[i]);
@@ -245,6 +241,8 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	// ---- joint arrays (K6) ----
 	out.pose = ar.alloc<double>((size_t)in.M * 6);
 	out.pose_id = ar.alloc<int>(in.M);
+	out.pose_origin = ar.alloc<int>(in.M);
+	if (in.M) LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_origin, in.pose_origin, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
 	out.feat = ar.alloc<double>((size_t)NFY * 3);
 	out.feat_id = ar.alloc<int>(NFY);
 	out.U = ar.alloc<double>((size_t)in.NU * 36); out.Ui = ar.alloc<int>(in.NU); out.Uj = ar.alloc<int>(in.NU);
@@ -271,7 +269,7 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	dev_zero(ctx, eP, (size_t)in.M * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
 	if (in.NF)
 		hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,
-		                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat);
+		                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, (int*)nullptr, (int*)nullptr);
 	hipLaunchKernelGGL(k_add_lens, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY, lenE, lenC, lens);
 	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
 	if (in.NW)
@@ -293,7 +291,7 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	io.M = in.M; io.NF = NFY; io.NU = in.NU; io.NW = in.NW; io.nseg = G;
 	io.d_pose_seg = out.pose_map; io.d_feat_seg = out.feat_map; io.d_seg_active = d_act;
 	io.U = out.U; io.Ui = out.Ui; io.Uj = out.Uj; io.W = out.W; io.photo = out.photo; io.fptr = out.fptr; io.V = out.V;
-	io.ea = eP; io.eb = eF; io.x0 = in.pose; io.d_fixed = nullptr;
+	io.ea = eP; io.eb = eF; io.x0 = in.pose; io.d_fixed = nullptr; io.d_pose_origin = out.pose_origin;
 	io.x_pose = out.pose; io.x_feat = out.feat;
 	io.seg_rows = seg_rows;
 	int rc = solve_batch(ctx, io);

@@ -1,0 +1,25 @@
+// Shared by the Stereo and the Mono join (lsfm_join.hip, lsfm_join_mono.hip).
+#pragma once
+#include "lsfm_internal.hpp"
+
+namespace lsfm {
+
+struct JGroup {
+	int F0E, nE, F0C, nC; // feature ranges of End / Cur in the input batch (nC = 0: carried map)
+	int FY0;              // first joint feature
+	int rC0;              // rank offset of Cur's unmatched features
+};
+
+__global__ void k_join_keys(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, unsigned long long* __restrict__ keys,
+                            int* __restrict__ vals);
+__global__ void k_join_match(int NF, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int* __restrict__ match,
+                             int* __restrict__ unmatched);
+__global__ void k_gather_at(const int* __restrict__ src, const int* __restrict__ idx, int n, int* __restrict__ out);
+__global__ void k_join_features(int NF, const int* __restrict__ feat_map, const int* __restrict__ feat_id, const double* __restrict__ feat,
+                                const double* __restrict__ V, const int* __restrict__ fptr, const int* __restrict__ match,
+                                const int* __restrict__ R, const JGroup* __restrict__ grp, int* __restrict__ newf, int* __restrict__ lenE,
+                                int* __restrict__ lenC, double* __restrict__ Vy, double* __restrict__ eF, int* __restrict__ fid_y,
+                                double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC);
+__global__ void k_add_lens(int n, const int* __restrict__ a, const int* __restrict__ b, int* __restrict__ out);
+
+} // namespace lsfm

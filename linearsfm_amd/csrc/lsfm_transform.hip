@@ -659,6 +659,8 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	if (in.NF) LSFM_CHECK_HIP(hipMemcpyAsync(out.feat_id, in.feat_id, (size_t)in.NF * sizeof(int), hipMemcpyDeviceToDevice, s));
 	out.pose = ar.alloc<double>((size_t)in.M * 6);
 	out.pose_id = ar.alloc<int>(in.M);
+	out.pose_origin = ar.alloc<int>(in.M);
+	if (in.M) LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_origin, in.pose_origin, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
 	out.feat = ar.alloc<double>((size_t)in.NF * 3);
 	out.V = ar.alloc<double>((size_t)in.NF * 9);
 	out.fptr = ar.alloc<int>(in.NF + 1);

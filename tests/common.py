@@ -92,3 +92,21 @@ def feat_param_err(stA, stB, stno):
     mask = stno > 0
     a, b = np.asarray(stA)[mask], np.asarray(stB)[mask]
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def oracle_noise_floor(oracle, dicts, mono, ref_stval, stno):
+    """How far two valid fp64 evaluations of the reference path differ on this input: the oracle re-run with its
+    Cholesky forced to a different (equally valid) elimination order (ORC_ORDER, oracle/lsfm_chol.c).  On long chains
+    the camera systems are so ill-conditioned that this floor, not the implementation, limits any parity number."""
+    import os
+    old = os.environ.get("ORC_ORDER")
+    os.environ["ORC_ORDER"] = "1"
+    try:
+        alt, _, rc = oracle.divide_conquer(dicts, mono)
+    finally:
+        if old is None:
+            os.environ.pop("ORC_ORDER")
+        else:
+            os.environ["ORC_ORDER"] = old
+    assert rc == 0
+    return max(pose_param_err(alt["stVal"], ref_stval, stno), feat_param_err(alt["stVal"], ref_stval, stno))

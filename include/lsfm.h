@@ -50,6 +50,10 @@ typedef struct lsfm_map {
 	int *photo, *feature;
 	double* V;
 	int* FBlock;
+	/* optional extension (NULL = absent): per pose, the index of the LOCAL MAP that brought it into the tree.  Only
+	 * used to order the Cholesky preconditioner along the join tree; filled on outputs, honoured on inputs, so that a
+	 * map produced by one lsfm_tree_run can seed another (multi-GPU subtree sharding). */
+	int* pose_origin;
 } lsfm_map;
 
 typedef struct lsfm_stats {
@@ -129,6 +133,10 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
 typedef struct lsfm_tree lsfm_tree;
 int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_tree** out);
 int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* tree, lsfm_stats* stats);
+/* on = 1 (default): the final map is re-expressed in its first frame (Imp.cpp:2039-2063).  on = 0: it is left in the
+ * frame of its last join -- what the reference's loop holds for an intermediate tree node; used when the tree is a
+ * SUBTREE whose root is joined further by another call (multi-GPU sharding). */
+int lsfm_tree_set_final_reanchor(lsfm_tree* tree, int on);
 int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* tree);
 /* convenience: upload + run + download */

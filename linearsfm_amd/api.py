@@ -25,7 +25,7 @@ class LsfmMap(C.Structure):
                 ("stno", C.POINTER(C.c_int)), ("stVal", C.POINTER(C.c_double)),
                 ("U", C.POINTER(C.c_double)), ("Ui", C.POINTER(C.c_int)), ("Uj", C.POINTER(C.c_int)),
                 ("W", C.POINTER(C.c_double)), ("photo", C.POINTER(C.c_int)), ("feature", C.POINTER(C.c_int)),
-                ("V", C.POINTER(C.c_double)), ("FBlock", C.POINTER(C.c_int))]
+                ("V", C.POINTER(C.c_double)), ("FBlock", C.POINTER(C.c_int)), ("pose_origin", C.POINTER(C.c_int))]
 
 
 class LsfmStats(C.Structure):
@@ -73,6 +73,7 @@ def lib():
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
         L.lsfm_tree_upload.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(vp)]
         L.lsfm_tree_run.argtypes = [vp, vp, P(LsfmStats)]
+        L.lsfm_tree_set_final_reanchor.argtypes = [vp, C.c_int]
         L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
         L.lsfm_tree_free.argtypes = [vp, vp]
         L.lsfm_tree_free.restype = None
@@ -87,7 +88,8 @@ def lib():
 
 EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_last_error", "lsfm_stream",
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
-           "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_download",
+           "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
+           "lsfm_tree_download",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench"]
 
@@ -118,6 +120,9 @@ class HostMap:
         c.U = _ptr(self.U, C.c_double); c.Ui = _ptr(self.Ui, C.c_int); c.Uj = _ptr(self.Uj, C.c_int)
         c.W = _ptr(self.W, C.c_double); c.photo = _ptr(self.photo, C.c_int); c.feature = _ptr(self.feature, C.c_int)
         c.V = _ptr(self.V, C.c_double); c.FBlock = _ptr(self.FBlock, C.c_int)
+        if g.get("pose_origin") is not None:
+            self.pose_origin = _c(g["pose_origin"], np.int32)
+            c.pose_origin = _ptr(self.pose_origin, C.c_int)
         self.c = c
 
 
@@ -136,6 +141,8 @@ def map_to_dict(g: LsfmMap, release=True):
              W=_arr(g.W, 18 * g.nW, np.float64).reshape(-1, 18), photo=_arr(g.photo, g.nW, np.int32),
              feature=_arr(g.feature, g.nW, np.int32), V=_arr(g.V, 9 * g.n, np.float64).reshape(-1, 9),
              FBlock=_arr(g.FBlock, g.n, np.int32))
+    if g.pose_origin:
+        d["pose_origin"] = _arr(g.pose_origin, g.m, np.int32)
     if release:
         lib().lsfm_map_release(C.byref(g))
     return d
@@ -236,8 +243,10 @@ class Context:
     def tree_free(self, tree):
         lib().lsfm_tree_free(self._h, tree)
 
-    def divide_conquer(self, maps, mono):
+    def divide_conquer(self, maps, mono, final_reanchor=True):
         t = self.tree_upload(maps, mono)
+        if not final_reanchor:
+            lib().lsfm_tree_set_final_reanchor(t, 0)
         try:
             stats, rc = self.tree_run(t)
             out = self.tree_download(t)

@@ -52,7 +52,7 @@ void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, boo
 		{
 			if (g.stno[6 * i] > 0) LSFM_FAIL(LSFM_ERR_ARG, "state label of a pose must be <= 0");
 			pid[po + i] = -g.stno[6 * i];
-			porg[po + i] = k;
+			porg[po + i] = g.pose_origin ? g.pose_origin[i] : k;
 			memcpy(&pose[(size_t)(po + i) * 6], g.stVal + 6 * i, 6 * sizeof(double));
 		}
 		for (int i = 0; i < g.n; i++)
@@ -123,6 +123,9 @@ void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, 
 	g->U = host_alloc<double>((size_t)nU * 36); g->Ui = host_alloc<int>(nU); g->Uj = host_alloc<int>(nU);
 	g->W = host_alloc<double>((size_t)nW * 18); g->photo = host_alloc<int>(nW); g->feature = host_alloc<int>(nW);
 	g->V = host_alloc<double>((size_t)n * 9); g->FBlock = host_alloc<int>(n);
+	g->pose_origin = host_alloc<int>(m);
+	if (b.pose_origin) d2h(ctx, g->pose_origin, b.pose_origin + po, m * sizeof(int));
+	else for (int i = 0; i < m; i++) g->pose_origin[i] = k;
 	std::vector<int> pid(m), fid(n), fptr(n + 1);
 	d2h(ctx, pid.data(), b.pose_id + po, m * sizeof(int));
 	d2h(ctx, fid.data(), b.feat_id + fo, n * sizeof(int));
@@ -147,6 +150,6 @@ extern "C" void lsfm_map_release(lsfm_map* g)
 {
 	if (!g) return;
 	free(g->stno); free(g->stVal); free(g->U); free(g->Ui); free(g->Uj); free(g->W); free(g->photo); free(g->feature);
-	free(g->V); free(g->FBlock);
+	free(g->V); free(g->FBlock); free(g->pose_origin);
 	memset(g, 0, sizeof *g);
 }

@@ -15,6 +15,7 @@ struct lsfm_tree {
 	DevBatch level;    // current level (lives in ctx->arena[slot])
 	int slot = 0;
 	bool done = false;
+	bool final_reanchor = true;
 };
 
 namespace {
@@ -168,7 +169,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 			while (t->level.B > 1) run_level(ctx, t, st);
 			// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
 			DevBatch& X = t->level;
-			if (X.B == 1 && X.Ref[0] > X.FRef[0])
+			if (t->final_reanchor && X.B == 1 && X.Ref[0] > X.FRef[0])
 			{
 				std::vector<int> tref(1, X.FRef[0]), tscap(1, X.FScaP[0]), tfix(1, X.FFix[0]);
 				Arena& other = ctx->arena[t->slot ^ 1];
@@ -199,6 +200,13 @@ int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)
 		batch_download_map(ctx, t->level, 0, t->mono, out);
 		return LSFM_OK;
 	});
+}
+
+int lsfm_tree_set_final_reanchor(lsfm_tree* t, int on)
+{
+	if (!t) return LSFM_ERR_ARG;
+	t->final_reanchor = on != 0;
+	return LSFM_OK;
 }
 
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* t)

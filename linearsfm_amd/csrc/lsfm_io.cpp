@@ -50,6 +50,7 @@ int lsfm_read_localmap(const char* path, int mono, lsfm_map* g)
 	for (int i = 0; i < g->nW && ok; i++) ok &= fscanf(f, "%d", &g->photo[i]) == 1;
 	for (int i = 0; i < g->nW && ok; i++) ok &= fscanf(f, "%d", &g->feature[i]) == 1;
 	g->V = xalloc<double>((size_t)g->n * 9); g->FBlock = xalloc<int>(g->n);
+	g->pose_origin = NULL;
 	for (long i = 0; i < 9L * g->n && ok; i++) ok &= fscanf(f, "%lf", &g->V[i]) == 1;
 	for (int i = 0; i < g->n && ok; i++) ok &= fscanf(f, "%d", &g->FBlock[i]) == 1;
 	fclose(f);

@@ -15,8 +15,9 @@
 
 #define ORC_PI 3.1415926 /* Imp.h:57 -- the truncated literal is part of the reference's behaviour */
 
-static int g_match_hash = 0;
+static int g_match_hash = 0, g_final_reanchor = 1;
 void orc_set_match_hash(int on) { g_match_hash = on; }
+void orc_set_final_reanchor(int on) { g_final_reanchor = on; }
 
 static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
 static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
@@ -1644,7 +1645,7 @@ int orc_divide_conquer(orc_map* LM, int nLocalMapCount, int mono, orc_map* out, 
 		L++;
 		if (nLocalMapCount == 1) { G = LM[0]; memset(&LM[0], 0, sizeof G); }
 	}
-	if (G.Ref > G.FRef)
+	if (g_final_reanchor && G.Ref > G.FRef)
 	{
 		orc_map Tmp;
 		transform_any(&G, mono, G.FRef, G.FScaP, G.FFix, &Tmp);

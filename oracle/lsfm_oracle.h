@@ -95,6 +95,9 @@ int orc_chol_solve(int n, const int* Ap, const int* Ai, const double* Ax, const 
 void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm);
 
 void orc_set_match_hash(int on);
+/* on = 0: orc_divide_conquer leaves the final map in the frame of its last join (a subtree root, Imp.cpp:2032),
+ * instead of taking it back to its first frame (Imp.cpp:2039-2063) */
+void orc_set_final_reanchor(int on);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ def lib():
         L.orc_join_mono.argtypes = [P(OrcMap), P(OrcMap), P(OrcMap)]
         L.orc_divide_conquer.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), C.c_int, dp]
         L.orc_set_match_hash.argtypes = [C.c_int]
+        L.orc_set_final_reanchor.argtypes = [C.c_int]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _LIB = L
@@ -213,10 +214,11 @@ def schur(j, eP, eF, accumulate_u):
     return out
 
 
-def divide_conquer(dicts, mono, verbose=False, match_hash=True):
+def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True):
     """Full hierarchical join of a list of map dicts; returns (final map dict, timing[4], rc)."""
     L = lib()
     L.orc_set_match_hash(int(match_hash))
+    L.orc_set_final_reanchor(int(final_reanchor))
     N = len(dicts)
     arr = (OrcMap * N)()
     for k, d in enumerate(dicts):

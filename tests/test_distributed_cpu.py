@@ -1,0 +1,71 @@
+"""world_size-2 (and 3) gloo tests of the multi-GPU scheduling (linearsfm_amd/distributed.py) on CPU.  The compute back
+end here is the oracle (tests only); on the GPU box the same scheduler drives the HIP library."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from linearsfm_amd import synth
+from linearsfm_amd.distributed import shard_bounds, sharded_divide_conquer
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_run_tree(maps, mono, final_reanchor):
+    from oracle import pyoracle as po
+    dicts = [po.localmap_to_dict(m) if not isinstance(m, dict) else m for m in maps]
+    out, _, rc = po.divide_conquer(dicts, mono, final_reanchor=final_reanchor)
+    assert rc == 0
+    return out
+
+
+def _make(n_maps, mono):
+    return synth.make_mono_set(n_maps, 6, 4, seed=21) if mono else synth.make_stereo_set(n_maps, 5, 4, seed=21)
+
+
+def _worker(rank, world, port, n_maps, mono, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = sharded_divide_conquer(_make(n_maps, mono), mono, _oracle_run_tree)
+    if rank == 0:
+        q.put({k: out[k] for k in ("stno", "stVal", "Ui", "Uj", "photo", "feature", "Ref", "FRef")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_maps,mono", [(2, 8, False), (2, 7, False), (3, 11, False), (2, 6, True)])
+def test_subtree_sharding_equals_serial_tree(oracle, world, n_maps, mono):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_maps, mono, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = _oracle_run_tree(_make(n_maps, mono), mono, True)
+    # identical tree shape => identical arithmetic: bitwise equal to the single-process order
+    for k in ("stno", "Ui", "Uj", "photo", "feature"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert got["Ref"] == exp["Ref"] and got["FRef"] == exp["FRef"]
+    assert np.array_equal(got["stVal"], exp["stVal"])
+
+
+def test_shard_bounds_are_subtrees():
+    for n, w in ((3499, 8), (16, 4), (5, 2), (7, 3), (1, 2)):
+        size, b = shard_bounds(n, w)
+        assert size & (size - 1) == 0 and size * w >= n
+        assert b[0][0] == 0 and max(h for _, h in b) == n
+        assert all(lo % size == 0 or lo == n for lo, _ in b)

@@ -195,3 +195,29 @@ def test_tree_mono_vs_oracle(ctx, oracle, N, npf, vis, seed):
     tol = max(1e-6, 10 * oracle_noise_floor(oracle, dicts, True, exp["stVal"], exp["stno"])) if N >= 64 else 1e-6
     assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < tol
     assert feat_param_err(got["stVal"], exp["stVal"], exp["stno"]) < tol
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_subtree_sharding_on_device_equals_single_tree(ctx, mono):
+    """The multi-GPU schedule (linearsfm_amd/distributed.py) with the HIP back end, the 2 'ranks' run one after the
+    other on this one GPU: blocks of 2^k local maps are subtrees, roots are joined by a second tree run."""
+    from linearsfm_amd.distributed import shard_bounds
+    N = 12
+    maps = synth.make_mono_set(N, 8, 4, seed=31) if mono else synth.make_stereo_set(N, 6, 5, seed=31)
+    dicts = [m.__dict__ for m in maps]
+    single, _, rc = ctx.divide_conquer(dicts, mono)
+    assert rc == 0
+    _, bounds = shard_bounds(N, 2)
+    roots = []
+    for r, (lo, hi) in enumerate(bounds):
+        root, _, rc = ctx.divide_conquer(dicts[lo:hi], mono, final_reanchor=(r % 2 == 1))
+        assert rc == 0 and "pose_origin" in root
+        root["pose_origin"] = root["pose_origin"] + lo  # local map index inside the whole tree
+        roots.append(root)
+    merged, _, rc = ctx.divide_conquer(roots, mono)
+    assert rc == 0
+    assert np.array_equal(merged["stno"], single["stno"])
+    for k in ("Ui", "Uj", "photo", "feature"):
+        assert np.array_equal(merged[k], single[k]), k
+    assert pose_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-8
+    assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-8

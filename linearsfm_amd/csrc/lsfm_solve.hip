@@ -197,8 +197,9 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v)
 __global__ void __launch_bounds__(SCHUR_TILE)
 k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
           const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-          double* __restrict__ S, double* __restrict__ E)
+          double* __restrict__ S, double* __restrict__ E, const unsigned char* __restrict__ only)
 {
+	if (only && !only[blockIdx.x]) return; // fallback pass: only the tiles the panel kernel could not take
 	__shared__ int skey[SCHUR_CAP];
 	__shared__ int ekey[SCHUR_ECAP];
 	__shared__ double sval[SCHUR_CAP * 36];
@@ -453,7 +454,13 @@ void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
-		hipLaunchKernelGGL(k_schur_w, dim3((NF + SCHUR_TILE - 1) / SCHUR_TILE), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E);
+		const int ntiles = (NF + SCHUR_TILE - 1) / SCHUR_TILE;
+		unsigned char* fb = sc.alloc<unsigned char>(ntiles);
+		dev_zero(ctx, fb, ntiles);
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s)); // re-record after the memset
+		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
+		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
+		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
 		if (ctx->stats)
 		{
 			float t = 0;

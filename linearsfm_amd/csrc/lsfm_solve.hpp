@@ -20,6 +20,8 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed, const double* dotw,
                  const int* pose_seg, double* dot, int dot_stride);
 double spmv_bytes(const SchurSystem& sy);
+void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
+                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback);
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);
 
 } // namespace lsfm

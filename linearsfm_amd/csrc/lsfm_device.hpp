@@ -226,4 +226,69 @@ __device__ __forceinline__ void wave_scatter_add(double* dst, const double* vals
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// work-group level scatter-add through a small LDS table (keys[cap] = -1 when empty, vals[cap*N])
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_slot(int* keys, int cap, int key)
+{
+	unsigned h = ((unsigned)key * 2654435761u) & (unsigned)(cap - 1);
+	for (int probe = 0; probe < cap; probe++)
+	{
+		const int cur = keys[h];
+		if (cur == key) return (int)h;
+		if (cur == -1)
+		{
+			const int old = atomicCAS(&keys[h], -1, key);
+			if (old == -1 || old == key) return (int)h;
+		}
+		h = (h + 1) & (unsigned)(cap - 1);
+	}
+	return -1;
+}
+__device__ __forceinline__ void lds_add_f64(double* p, double v)
+{
+	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Adds x[0..N) to the accumulator of `key` for every valid lane: in the work-group's LDS table when the key fits,
+// straight to gdst (global, atomics) otherwise.  Lanes of a wave that all carry the same key are summed across the wave
+// first.  Must be called by all 64 lanes.  The table is flushed once per work-group by tile_flush().
+template <int N>
+__device__ __forceinline__ void tile_scatter_add(int* keys, double* vals, int cap, int key, double* gdst, const double* x, bool valid)
+{
+	const unsigned long long mask = __ballot(valid);
+	if (mask == 0ull) return;
+	const int leader = __ffsll((long long)mask) - 1;
+	const int first = __shfl(key, leader, LSFM_WAVE);
+	const bool uniform = __ballot(valid && key != first) == 0ull;
+	if (uniform && __popcll(mask) > 1)
+	{
+		const int lane = threadIdx.x & (LSFM_WAVE - 1);
+		int sl = -1;
+		if (lane == leader) sl = lds_slot(keys, cap, key);
+#pragma unroll
+		for (int i = 0; i < N; i++)
+		{
+			const double s = wave_sum(valid ? x[i] : 0.0);
+			if (lane == leader) { if (sl >= 0) lds_add_f64(vals + sl * N + i, s); else atomic_add_f64(gdst + i, s); }
+		}
+	}
+	else if (valid)
+	{
+		const int sl = lds_slot(keys, cap, key);
+#pragma unroll
+		for (int i = 0; i < N; i++) { if (sl >= 0) lds_add_f64(vals + sl * N + i, x[i]); else atomic_add_f64(gdst + i, x[i]); }
+	}
+}
+// after a __syncthreads(): every touched accumulator leaves the work-group once, N contiguous adds at gbase + key*N
+template <int N>
+__device__ __forceinline__ void tile_flush(const int* keys, const double* vals, int cap, double* gbase)
+{
+	for (int i = threadIdx.x; i < cap * N; i += blockDim.x)
+	{
+		const int k = keys[i / N];
+		if (k >= 0) atomic_add_f64(gbase + (size_t)k * N + i % N, vals[i]);
+	}
+}
+
 } // namespace lsfm

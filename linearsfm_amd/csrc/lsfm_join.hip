@@ -108,6 +108,12 @@ k_join_rhs_w(int NFY, const int* __restrict__ fptr_y, const double* __restrict__
              const int* __restrict__ srcf, const double* __restrict__ pose, const double* __restrict__ feat, double* __restrict__ eP,
              double* __restrict__ eF)
 {
+	constexpr int ECAP = 128;
+	__shared__ int ekeys[ECAP];
+	__shared__ double evals[ECAP * 6];
+	for (int i = threadIdx.x; i < ECAP; i += blockDim.x) ekeys[i] = -1;
+	for (int i = threadIdx.x; i < ECAP * 6; i += blockDim.x) evals[i] = 0.0;
+	__syncthreads();
 	int nf = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool inb = nf < NFY;
 	int j0 = 0, len = 0;
@@ -136,9 +142,11 @@ k_join_rhs_w(int NFY, const int* __restrict__ fptr_y, const double* __restrict__
 #pragma unroll
 				for (int r = 0; r < 6; r++) ef[c] = fma(W[3 * r + c], xp[r], ef[c]);
 		}
-		wave_scatter_add<6>(eP + (size_t)(v ? k : 0) * 6, y, v);
+		tile_scatter_add<6>(ekeys, evals, ECAP, k, eP + (size_t)(v ? k : 0) * 6, y, v);
 	}
 	if (inb) { eF[(size_t)nf * 3] += ef[0]; eF[(size_t)nf * 3 + 1] += ef[1]; eF[(size_t)nf * 3 + 2] += ef[2]; }
+	__syncthreads();
+	tile_flush<6>(ekeys, evals, ECAP, eP);
 }
 
 // eP += U x, eP += U^T x for off-diagonal blocks, Imp.cpp:2666-2688

@@ -157,7 +157,7 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 	}
 }
 
-__global__ void __launch_bounds__(64) k_chol_factor_level(const int* __restrict__ cols, const int* __restrict__ colptr,
+__global__ void __launch_bounds__(256) k_chol_factor_level(const int* __restrict__ cols, const int* __restrict__ colptr,
                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
 {
 	chol_factor_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, err);
@@ -398,7 +398,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	for (int l = 0; l < ch.nlevels; l++)
 	{
 		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
-		if (n) hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		if (n) hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(256), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
 	}
 	if (ch.M - ch.tail_begin > 0)
 		hipLaunchKernelGGL(k_chol_factor_tail, dim3(1), dim3(256), 0, s, ch.M - ch.tail_begin, ch.order + ch.tail_begin, ch.colptr, ch.rowidx, ch.L,

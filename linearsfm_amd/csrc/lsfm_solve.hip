@@ -173,27 +173,6 @@ __global__ void k_schur_u(int NU, const double* __restrict__ U, const int* __res
 #define SCHUR_CAP 256 /* LDS block accumulators per work-group: 256 * 288 B = 72 KiB -> 2 work-groups per CU */
 #define SCHUR_ECAP 64 /* LDS accumulators for E (per pose) */
 
-__device__ __forceinline__ int lds_slot(int* keys, int cap, int key)
-{
-	unsigned h = ((unsigned)key * 2654435761u) & (unsigned)(cap - 1);
-	for (int probe = 0; probe < cap; probe++)
-	{
-		const int cur = keys[h];
-		if (cur == key) return (int)h;
-		if (cur == -1)
-		{
-			const int old = atomicCAS(&keys[h], -1, key);
-			if (old == -1 || old == key) return (int)h;
-		}
-		h = (h + 1) & (unsigned)(cap - 1);
-	}
-	return -1;
-}
-__device__ __forceinline__ void lds_add_f64(double* p, double v)
-{
-	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 __global__ void __launch_bounds__(SCHUR_TILE)
 k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
           const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,

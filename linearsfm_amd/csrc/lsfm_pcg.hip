@@ -14,7 +14,9 @@
 //     one work-group per block column; the narrow top of the tree runs inside a single launch.
 // With the exact factor CG is iterative refinement: 2-3 iterations to 1e-12.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 
 #include "lsfm_device.hpp"
@@ -550,8 +552,14 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 
 	// ---- preconditioner ----
 	CholDev ch;
+	const bool dbg = getenv("LSFM_DEBUG") != nullptr;
+	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tw0 = wall();
 	chol_analyse(ctx, sy, io.d_pose_origin, ch);
+	double tw1 = wall();
 	chol_factor(ctx, sy, io.d_fixed, ch);
+	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
+	double tw2 = wall();
 	int* d_misc = sc.alloc<int>(4); // [1] ndone
 	dev_zero(ctx, d_misc, 4 * sizeof(int));
 
@@ -594,6 +602,12 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, cur, seg, d_misc + 1);
 		its++;
 		ndone = d2h_int(ctx, d_misc + 1);
+	}
+	if (dbg)
+	{
+		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d | analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
+		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, tw1 - tw0, tw2 - tw1, its, wall() - tw2);
 	}
 	// ---- true residual, statistics; SpMV launches timed with HIP events on this stream ----
 	const int nsample = 5;

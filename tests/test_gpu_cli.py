@@ -1,0 +1,50 @@
+"""The drop-in process boundary: linearsfm_amd/LinearSFM (HIP library behind the reference's command line and file
+formats, LinearSFMImp.cpp:7989-8105) against the oracle's CLI on the same localmap_k.txt files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from linearsfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _table(path):
+    return np.array([[float(x) for x in line.split()] for line in open(path)])
+
+
+@pytest.mark.parametrize("typ", ["Stereo", "Monocular"])
+def test_cli_matches_oracle_cli(oracle, tmp_path, typ):
+    mono = typ == "Monocular"
+    maps = synth.make_mono_set(6, 8, 4, seed=41) if mono else synth.make_stereo_set(6, 6, 4, seed=41)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    ora = os.path.join(ROOT, "oracle", "lsfm_oracle")
+    assert os.path.exists(exe), "build() must have produced the CLI"
+    outs = {}
+    for tag, binary in (("hip", exe), ("oracle", ora)):
+        p, f, s = (str(tmp_path / f"{tag}_{n}.txt") for n in ("Pose", "Feature", "State"))
+        r = subprocess.run([binary, "-path", str(d), "-num", "6", "-type", typ, "-p", p, "-f", f, "-st", s],
+                           capture_output=True, text=True, check=True)
+        outs[tag] = (r.stdout, _table(p), _table(f), _table(s))
+    so, sh = outs["oracle"][0], outs["hip"][0]
+    # same progress lines (LinearSFMImp.cpp:1952, 1995, 2072)
+    strip = lambda t: [l for l in t.splitlines() if l and not l.startswith("Total Used Time")]
+    assert strip(so) == strip(sh)
+    assert "Total Used Time:" in sh
+    for a, b in zip(outs["hip"][1:], outs["oracle"][1:]):
+        assert a.shape == b.shape
+        assert np.array_equal(a[:, 0], b[:, 0])            # ids, sorted
+        assert np.max(np.abs(a[:, 1:] - b[:, 1:])) <= 2e-6  # "%lf": 6 decimals
+
+
+def test_cli_errors_like_the_reference(tmp_path):
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    r = subprocess.run([exe, "-num", "3", "-type", "Stereo"], capture_output=True, text=True)
+    assert r.returncode == 0 and "LinerSFM Error: Please Input Right File Path:" in r.stdout   # Imp.cpp:8075-8076
+    r = subprocess.run([exe, "-help"], capture_output=True, text=True)
+    assert "Linear SFM Solution General Options" in r.stdout

@@ -45,6 +45,7 @@ struct CholDev {
 	int* pinv = nullptr;    // [M] old -> new
 	int* order = nullptr;   // [M] columns sorted by elimination-tree level
 	std::vector<int> level_ptr; // host: order[level_ptr[l] .. level_ptr[l+1]) = columns of level l (before the tail)
+	std::vector<int> level_maxpairs; // host: largest n(n+1)/2 over the columns of the level (grid of the update launch)
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
 	int* d_err = nullptr;
@@ -83,8 +84,10 @@ __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ 
 
 // one work-group factors one block column: L_jj = chol(A_jj); L_ij = A_ij L_jj^-T; A_ik -= L_ij L_kj^T for the blocks
 // below (right-looking; targets in other columns are updated atomically because the columns of one level run together)
+__device__ void chol_column_update(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride);
+
 __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                   double* __restrict__ Dinv, int* err)
+                                   double* __restrict__ Dinv, int* err, bool do_update)
 {
 	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
 	const int tid = threadIdx.x, nt = blockDim.x;
@@ -139,9 +142,15 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 		for (int k = 0; k < 6; k++) blk[k] = o[k];
 	}
 	__syncthreads();
-	// trailing updates: pairs a >= b of the blocks below the diagonal
+	if (do_update) chol_column_update(j, colptr, rowidx, L, tid, nt);
+}
+
+// trailing updates of column j: pairs a >= b of its blocks below the diagonal, pair index pr = first, first+stride, ...
+__device__ void chol_column_update(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
+{
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
 	const int npairs = n * (n + 1) / 2;
-	for (int pr = tid; pr < npairs; pr += nt)
+	for (int pr = first; pr < npairs; pr += stride)
 	{
 		// decode pr -> (a,b), a >= b, row-major over the lower triangle
 		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
@@ -159,10 +168,17 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 	}
 }
 
-__global__ void __launch_bounds__(256) k_chol_factor_level(const int* __restrict__ cols, const int* __restrict__ colptr,
-                                                           const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+// level step 1: diagonal factor + scaling of every column of the level (one small work-group per column)
+__global__ void __launch_bounds__(64) k_chol_factor_level(const int* __restrict__ cols, const int* __restrict__ colptr,
+                                                          const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
 {
-	chol_factor_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, err);
+	chol_factor_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, err, false);
+}
+// level step 2: trailing updates, blockIdx.y splits the pairs of one column over several work-groups
+__global__ void __launch_bounds__(256) k_chol_update_level(const int* __restrict__ cols, const int* __restrict__ colptr,
+                                                           const int* __restrict__ rowidx, double* __restrict__ L)
+{
+	chol_column_update(cols[blockIdx.x], colptr, rowidx, L, blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
 }
 // the narrow top of the elimination tree: one work-group walks the remaining columns in index order
 __global__ void __launch_bounds__(256) k_chol_factor_tail(int ncols, const int* __restrict__ cols, const int* __restrict__ colptr,
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(256) k_chol_factor_tail(int ncols, const int* 
 {
 	for (int k = 0; k < ncols; k++)
 	{
-		chol_factor_column(cols[k], colptr, rowidx, L, Dinv, err);
+		chol_factor_column(cols[k], colptr, rowidx, L, Dinv, err, true);
 		__threadfence();
 		__syncthreads();
 	}
@@ -378,6 +394,13 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const int* d_
 	for (int j = 0; j < M; j++) order[lcount[lev[j]] + lfill[lev[j]]++] = j; // ascending j inside a level
 	ch.M = M; ch.nnzL = nnzL; ch.nlevels = tail_level;
 	ch.level_ptr.assign(lcount.begin(), lcount.begin() + tail_level + 1);
+	ch.level_maxpairs.assign(tail_level, 0);
+	for (int j = 0; j < M; j++)
+		if (lev[j] < tail_level)
+		{
+			const int nb = ccount[j] - 1;
+			ch.level_maxpairs[lev[j]] = std::max(ch.level_maxpairs[lev[j]], nb * (nb + 1) / 2);
+		}
 	ch.tail_begin = lcount[tail_level];
 	// tail columns must be walked in ascending index (= a topological order), not level order
 	std::sort(order.begin() + ch.tail_begin, order.end());
@@ -400,7 +423,10 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	for (int l = 0; l < ch.nlevels; l++)
 	{
 		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
-		if (n) hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(256), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		if (!n) continue;
+		hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		const int mp = ch.level_maxpairs[l];
+		if (mp > 0) hipLaunchKernelGGL(k_chol_update_level, dim3(n, (mp + 255) / 256), dim3(256), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L);
 	}
 	if (ch.M - ch.tail_begin > 0)
 		hipLaunchKernelGGL(k_chol_factor_tail, dim3(1), dim3(256), 0, s, ch.M - ch.tail_begin, ch.order + ch.tail_begin, ch.colptr, ch.rowidx, ch.L,

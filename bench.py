@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 # HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 guide
 # prescribes + WRITE_SIZE; separate --pmc runs), averaged over the launches of one tree run.  None = not collected.
-TRAFFIC = {"schur": None, "trf": None}
+# Source: profiles/r01_pmc_traffic_summary.json (from r01_pmc_{FETCH,WRITE}_SIZE_counter_collection.csv, 3499-map run).
+TRAFFIC = {"schur": 9.148e8, "trf": 2.012e9}
 
 
 def cpu_baseline(maps, sample_maps):
@@ -101,20 +102,16 @@ def main():
     ctx.tree_free(tree)
 
     if rank == 0:
-        # dominant kernel of the solve: the block-sparse SpMV of the CG (k_spmv).  Duration sampled live with HIP events
-        # on the library's stream inside every join (5 launches per level on that level's matrix); algorithmic bytes per
-        # launch = nnzb*(288+4) + 4*(m+1) + 96*m on the upper-block storage.
         # Per-kernel live measurements (HIP events on the library's stream around the launches, accumulated over the timed
         # steps).  The roofline object describes whichever of the instrumented kernels took the most device time.
         kern = {}
-        for key, name in (("schur", "k_schur_w (K9: Schur assembly S -= W V^-1 W^T, E -= W V^-1 eb)"),
+        for key, name in (("schur", "k_schur_panel + k_schur_w fallback tiles (K9: Schur assembly S -= W V^-1 W^T, E -= W V^-1 eb)"),
                           ("trf", "k_tr_features (K3/K4: information transform I' = J^T I J of the W/V blocks)"),
                           ("spmv", "k_spmv (K10a: 6x6-block symmetric SpMV of the CG)")):
             n = max(1, acc[f"{key}_launches"])
             kern[key] = dict(name=name, total_ms=acc[f"{key}_ms"] / args.steps, launches_per_step=acc[f"{key}_launches"] / args.steps,
                              avg_ms=acc[f"{key}_ms"] / n, avg_bytes=acc[f"{key}_bytes"] / n)
             kern[key]["gbs"] = kern[key]["avg_bytes"] / (kern[key]["avg_ms"] * 1e-3) / 1e9 if kern[key]["avg_ms"] > 0 else 0.0
-        # the SpMV inside the CG loop is not bracketed (only 5 timed extra launches per level are): scale by its real count
         dom = max(("schur", "trf"), key=lambda k: kern[k]["total_ms"])
         sp_ms, sp_bytes, achieved = kern[dom]["avg_ms"], kern[dom]["avg_bytes"], kern[dom]["gbs"]
         line = {

@@ -1,23 +1,32 @@
-// K9, panel formulation: S(p,q) -= sum_f W_pf V_f^-1 W_qf^T and E_p -= sum_f W_pf V_f^-1 eb_f  (Imp.cpp:2244-2332).
+// K9, panel formulation on the matrix cores: S(p,q) -= sum_f W_pf V_f^-1 W_qf^T and E_p -= sum_f W_pf V_f^-1 eb_f
+// (Imp.cpp:2244-2332).
 //
-// A tile of PN_TILE consecutive features is observed by a small set of poses (its ~12 hub poses plus the few frames
-// that see it): at most PN_SMAX "slots".  Instead of one lane per FEATURE adding each of its k_f(k_f+1)/2 products
-// somewhere (atomics: to HBM 0.08 TB/s, to LDS 64-way same-address conflicts on the hub pairs), one lane owns one
-// POSE PAIR of the tile and walks the tile's features, reading the W blocks from an LDS panel A[f][slot] (staged
-// PN_PASS features at a time, absent blocks skipped through a presence mask).  Every pair block is accumulated in
-// registers and leaves the work-group once, as 36 contiguous adds.  Tiles with more than PN_SMAX poses (sub-map
-// boundaries at the top of the tree can exceed it) are flagged and handled by the per-feature kernel k_schur_w.
+// A tile of PM_TILE consecutive features is observed by a small set of poses (its ~12 hub poses plus the few frames
+// that see it): at most PM_SMAX "slots".  With V_f^-1 = L_f L_f^T the tile's contribution is a dense symmetric rank-k
+// update  P P^T,  P = [ W_sf L_f ]  (rows = 6 * slot + r, columns = 3 * feature + c, absent blocks zero), i.e. a real
+// contraction over the 3 * PM_TILE feature columns: the panel is staged PM_PASS features at a time in LDS and the
+// 16x16 tiles of the upper block triangle of P P^T are accumulated with v_mfma_f64_16x16x4_f64, the tiles dealt round
+// robin to the four waves of the work-group.  No lane idles on an absent pose pair, the LDS traffic is two doubles per
+// lane per 1024 multiply-adds, and every touched block of S leaves the work-group once.  The right-hand side part is
+// the panel times y = L^T eb, one panel row per lane.
+// Tiles with more than PM_SMAX poses (sub-map boundaries at the top of the tree can exceed it) or with a V^-1 that has
+// no Cholesky factor are flagged and handled by the per-feature kernel k_schur_w.
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
 #include "lsfm_solve.hpp"
 
 namespace lsfm {
 
-#define PN_TILE 128
-#define PN_PASS 16
-#define PN_SMAX 31
-#define PN_HASH 64
-#define PN_THREADS 256
+#define PM_TILE 128
+#define PM_PASS 16
+#define PM_K (3 * PM_PASS)
+#define PM_KS (PM_K + 1) /* odd row stride: the 16 rows x 2 k of a half-wave fall into distinct LDS banks */
+#define PM_SMAX 32
+#define PM_ROWS (6 * PM_SMAX)
+#define PM_HASH 64
+#define PM_THREADS 256
+
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned long long pn_mix64(unsigned long long x)
 {
@@ -39,188 +48,234 @@ __device__ __forceinline__ int pn_hash_find(const unsigned long long* __restrict
 	return -1;
 }
 
-// acc (6x6, rows = slot i, cols = slot j) += (A_i V^-1) A_j^T, row by row to keep few registers live
-__device__ __forceinline__ void pn_accumulate(double* acc, const double* __restrict__ Ai, const double* __restrict__ Aj, const double* __restrict__ iv)
+struct PmShared {
+	int hkey[PM_HASH];
+	int hslot[PM_HASH];
+	int pose_of[PM_SMAX];
+	int nslots, bad;
+	int fp[PM_PASS + 1];
+	double Ls[PM_PASS * 6]; // l00 l10 l11 l20 l21 l22 of V^-1 = L L^T
+	double ys[PM_K];        // L^T eb
+	double P[PM_ROWS * PM_KS];
+};
+
+// T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + 4 t; slots past the last
+// tile recompute tile (0,0) and are dropped)
+template <int T>
+__device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, const int* __restrict__ fptr, const int* __restrict__ photo,
+                                        const double* __restrict__ W, const double* __restrict__ IV, const double* __restrict__ eb,
+                                        const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+                                        double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
 {
-	double aj[18], v[9];
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
+	const int rows = 6 * ns, NT = (rows + 15) >> 4, ntile = NT * (NT + 1) / 2;
+	int ti[T], tj[T], offA[T], offB[T]; // wave-uniform
+	const int lbase = (lane & 15) * PM_KS + (lane >> 4);
+	v4d acc[T];
 #pragma unroll
-	for (int q = 0; q < 18; q++) aj[q] = Aj[q];
-#pragma unroll
-	for (int q = 0; q < 9; q++) v[q] = iv[q];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
+	for (int t = 0; t < T; t++)
 	{
-		const double a0 = Ai[3 * r], a1 = Ai[3 * r + 1], a2 = Ai[3 * r + 2];
-		const double t0 = a0 * v[0] + a1 * v[3] + a2 * v[6];
-		const double t1 = a0 * v[1] + a1 * v[4] + a2 * v[7];
-		const double t2 = a0 * v[2] + a1 * v[5] + a2 * v[8];
-#pragma unroll
-		for (int c = 0; c < 6; c++) acc[r * 6 + c] += t0 * aj[3 * c] + t1 * aj[3 * c + 1] + t2 * aj[3 * c + 2];
+		const int q = wave + 4 * t;
+		int i = 0, j = 0;
+		if (q < ntile)
+		{
+			// q = j (j + 1) / 2 + i, i <= j
+			j = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+			while (j * (j + 1) / 2 > q) j--;
+			while ((j + 1) * (j + 2) / 2 <= q) j++;
+			i = q - j * (j + 1) / 2;
+		}
+		ti[t] = q < ntile ? i : -1;
+		tj[t] = j;
+		offA[t] = 16 * i * PM_KS;
+		offB[t] = 16 * j * PM_KS;
+		acc[t] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
 	}
+	double eacc = 0.0;
+	for (int p0 = f0; p0 < f1; p0 += PM_PASS)
+	{
+		const int nf = min(PM_PASS, f1 - p0);
+		__syncthreads(); // the previous pass is fully consumed
+		for (int q = tid; q < NT * 16 * PM_KS; q += PM_THREADS) sh.P[q] = 0.0;
+		if (tid <= nf) sh.fp[tid] = fptr[p0 + tid];
+		if (tid < PM_PASS)
+		{
+			double l[6] = { 0, 0, 0, 0, 0, 0 }, y[3] = { 0, 0, 0 };
+			if (tid < nf)
+			{
+				const double* a = IV + (size_t)(p0 + tid) * 9;
+				const double* e = eb + (size_t)(p0 + tid) * 3;
+				const double d0 = a[0];
+				l[0] = sqrt(d0);
+				l[1] = a[3] / l[0];
+				l[3] = a[6] / l[0];
+				const double d1 = a[4] - l[1] * l[1];
+				l[2] = sqrt(d1);
+				l[4] = (a[7] - l[3] * l[1]) / l[2];
+				const double d2 = a[8] - l[3] * l[3] - l[4] * l[4];
+				l[5] = sqrt(d2);
+				if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) sh.bad = 1;
+				y[0] = l[0] * e[0] + l[1] * e[1] + l[3] * e[2];
+				y[1] = l[2] * e[1] + l[4] * e[2];
+				y[2] = l[5] * e[2];
+			}
+			for (int q = 0; q < 6; q++) sh.Ls[tid * 6 + q] = l[q];
+			for (int q = 0; q < 3; q++) sh.ys[tid * 3 + q] = y[q];
+		}
+		__syncthreads();
+		// stage P = W L: one lane per row of a W block (6 consecutive lanes read one block's 144 bytes); two blocks of
+		// one (pose, feature) add up, as in the reference's pair loop
+		const int qb = sh.fp[0], nrow = (sh.fp[nf] - qb) * 6;
+		for (int w = tid; w < nrow; w += PM_THREADS)
+		{
+			const int e = w / 6, r = w - 6 * e, j = qb + e;
+			int fl = 0;
+			while (fl + 1 < nf && sh.fp[fl + 1] <= j) fl++;
+			const int key = photo[j];
+			unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+			while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+			const int sl = sh.hslot[h];
+			const double* wr = W + (size_t)j * 18 + 3 * r;
+			const double w0 = wr[0], w1 = wr[1], w2 = wr[2];
+			const double* l = &sh.Ls[fl * 6];
+			double* d = &sh.P[(6 * sl + r) * PM_KS + 3 * fl];
+			__hip_atomic_fetch_add(d + 0, w0 * l[0] + w1 * l[1] + w2 * l[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_add(d + 1, w1 * l[2] + w2 * l[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_add(d + 2, w2 * l[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		__syncthreads();
+		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328
+		if (tid < rows)
+		{
+			const double* pr = &sh.P[tid * PM_KS];
+			double s = 0.0;
+			for (int k = 0; k < 3 * nf; k++) s = fma(pr[k], sh.ys[k], s);
+			eacc -= s;
+		}
+		// P P^T, four feature columns per MFMA: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15]
+		const int nks = (3 * nf + 3) >> 2;
+		for (int ks = 0; ks < nks; ks++)
+		{
+#pragma unroll
+			for (int t = 0; t < T; t++)
+			{
+				const double a = sh.P[offA[t] + lbase + 4 * ks], b = sh.P[offB[t] + lbase + 4 * ks];
+				acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+			}
+		}
+	}
+	__syncthreads();
+	if (sh.bad)
+	{
+		if (tid == 0) fallback[blockIdx.x] = 1;
+		return;
+	}
+	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair, in the (now free) panel ----
+	int* pslot = reinterpret_cast<int*>(sh.P);
+	for (int q = tid; q < ns * ns; q += PM_THREADS)
+	{
+		const int si = q / ns, sj = q - si * ns;
+		pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int t = 0; t < T; t++)
+	{
+		if (ti[t] < 0) continue;
+		const int C = 16 * tj[t] + (lane & 15);
+		if (C >= rows) continue;
+		const int sj = C / 6, c = C - 6 * sj;
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+		{
+			// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+			const int R = 16 * ti[t] + (lane >> 4) + 4 * e;
+			const double v = acc[t][e];
+			if (R >= rows || !(v != 0.0)) continue; // exact zero: this pose pair shares no feature of the tile
+			const int si = R / 6, r = R - 6 * si;
+			if (si > sj) continue; // diagonal tile: the mirrored element covers it
+			const int slot = pslot[si * ns + sj];
+			if (slot < 0) continue;
+			double* d = S + (size_t)slot * 36;
+			if (si == sj)
+			{
+				// a pose with itself is stored full; across a tile boundary only this half was computed
+				atomic_add_f64(d + r * 6 + c, -v);
+				if (ti[t] != tj[t]) atomic_add_f64(d + c * 6 + r, -v);
+			}
+			else
+			{
+				// stored orientation: rows = smaller pose index
+				const bool up = sh.pose_of[si] <= sh.pose_of[sj];
+				atomic_add_f64(d + (up ? r * 6 + c : c * 6 + r), -v);
+			}
+		}
+	}
+	if (tid < rows && eacc != 0.0) atomic_add_f64(E + (size_t)sh.pose_of[tid / 6] * 6 + tid % 6, eacc);
 }
 
-__global__ void __launch_bounds__(PN_THREADS)
+__global__ void __launch_bounds__(PM_THREADS, 2)
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
               const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
               double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
 {
-	__shared__ int hkey[PN_HASH];
-	__shared__ int hslot[PN_HASH];
-	__shared__ int pose_of[PN_SMAX + 1];
-	__shared__ int nslots;
-	__shared__ unsigned pres[PN_PASS];
-	__shared__ double ivs[PN_PASS * 9];
-	__shared__ double ebs[PN_PASS * 3];
-	__shared__ double A[PN_PASS * PN_SMAX * 18];
+	__shared__ PmShared sh;
 	const int tid = threadIdx.x;
-	const int f0 = blockIdx.x * PN_TILE, f1 = min(f0 + PN_TILE, NF);
+	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
 	const int jb = fptr[f0], je = fptr[f1];
-	if (tid < PN_HASH) { hkey[tid] = -1; hslot[tid] = -1; }
-	if (tid == 0) nslots = 0;
+	if (tid < PM_HASH) { sh.hkey[tid] = -1; sh.hslot[tid] = -1; }
+	if (tid == 0) { sh.nslots = 0; sh.bad = 0; }
 	__syncthreads();
 	// ---- the tile's poses -> slots ----
-	for (int j = jb + tid; j < je; j += PN_THREADS)
+	for (int j = jb + tid; j < je; j += PM_THREADS)
 	{
 		const int key = photo[j];
-		unsigned h = ((unsigned)key * 2654435761u) & (PN_HASH - 1);
-		for (int probe = 0; probe < PN_HASH; probe++)
+		unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+		for (int probe = 0; probe < PM_HASH; probe++)
 		{
-			const int cur = hkey[h];
+			const int cur = sh.hkey[h];
 			if (cur == key) break;
 			if (cur == -1)
 			{
-				const int old = atomicCAS(&hkey[h], -1, key);
+				const int old = atomicCAS(&sh.hkey[h], -1, key);
 				if (old == -1 || old == key) break;
 			}
-			h = (h + 1) & (PN_HASH - 1);
+			h = (h + 1) & (PM_HASH - 1);
 		}
 	}
 	__syncthreads();
-	if (tid < PN_HASH && hkey[tid] != -1)
+	if (tid < PM_HASH && sh.hkey[tid] != -1)
 	{
-		const int id = atomicAdd(&nslots, 1);
-		hslot[tid] = id;
-		if (id < PN_SMAX) pose_of[id] = hkey[tid];
+		const int id = atomicAdd(&sh.nslots, 1);
+		sh.hslot[tid] = id;
+		if (id < PM_SMAX) sh.pose_of[id] = sh.hkey[tid];
 	}
 	__syncthreads();
-	const int ns = nslots;
-	if (ns > PN_SMAX)
+	const int ns = sh.nslots;
+	if (ns > PM_SMAX)
 	{
-		// more than PN_HASH distinct poses also ends here: the table is then full, nslots = PN_HASH > PN_SMAX
+		// more than PM_HASH distinct poses also ends here: the table is then full, nslots = PM_HASH > PM_SMAX
 		if (tid == 0) fallback[blockIdx.x] = 1;
 		return;
 	}
-	// ---- pair tasks: lane t owns pairs t and t + PN_THREADS of the ns(ns+1)/2 slot pairs ----
-	const int ntask = ns * (ns + 1) / 2;
-	int ti[2], tj[2];
-	bool used[2] = { false, false };
-	double acc0[36], acc1[36], eacc[6];
-	zero<36>(acc0); zero<36>(acc1); zero<6>(eacc);
-#pragma unroll
-	for (int u = 0; u < 2; u++)
-	{
-		const int pr = tid + u * PN_THREADS;
-		int a = 0, b = 0;
-		if (pr < ntask)
-		{
-			a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
-			while (a * (a + 1) / 2 > pr) a--;
-			while ((a + 1) * (a + 2) / 2 <= pr) a++;
-			b = pr - a * (a + 1) / 2;
-		}
-		ti[u] = (pr < ntask) ? b : -1; // b <= a: slot pair (b, a)
-		tj[u] = a;
-	}
-	bool eused = false;
-	for (int p0 = f0; p0 < f1; p0 += PN_PASS)
-	{
-		const int p1 = min(p0 + PN_PASS, f1);
-		__syncthreads(); // the previous pass is fully consumed
-		for (int q = tid; q < PN_PASS * PN_SMAX * 18; q += PN_THREADS) A[q] = 0.0;
-		if (tid < PN_PASS) pres[tid] = 0u;
-		if (tid < (p1 - p0) * 9) ivs[tid] = IV[(size_t)p0 * 9 + tid];
-		if (tid < (p1 - p0) * 3) ebs[tid] = eb[(size_t)p0 * 3 + tid];
-		__syncthreads();
-		// stage the W blocks of the pass; two blocks of one (pose, feature) add up, as in the reference's pair loop
-		const int qb = fptr[p0], qe = fptr[p1];
-		for (int j = qb + tid; j < qe; j += PN_THREADS)
-		{
-			// feature of entry j: the run that contains it (<= PN_PASS runs)
-			int fl = 0;
-			while (fl + 1 < p1 - p0 && fptr[p0 + fl + 1] <= j) fl++;
-			const int key = photo[j];
-			unsigned h = ((unsigned)key * 2654435761u) & (PN_HASH - 1);
-			while (hkey[h] != key) h = (h + 1) & (PN_HASH - 1);
-			const int sl = hslot[h];
-			double* d = &A[(fl * PN_SMAX + sl) * 18];
-			const double* w = W + (size_t)j * 18;
-			const unsigned old = atomicOr(&pres[fl], 1u << sl);
-			if (old & (1u << sl))
-			{
-				for (int q = 0; q < 18; q++) __hip_atomic_fetch_add(d + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-			else
-			{
-				// first block of this (feature, pose): the cell was zeroed; a duplicate arriving concurrently adds atomically
-				for (int q = 0; q < 18; q++) __hip_atomic_fetch_add(d + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-		}
-		__syncthreads();
-		// ---- consume ----
-		for (int fl = 0; fl < p1 - p0; fl++)
-		{
-			const unsigned m = pres[fl];
-			const double* iv = &ivs[fl * 9];
-			if (ti[0] >= 0 && ((m >> ti[0]) & 1u) && ((m >> tj[0]) & 1u))
-			{
-				pn_accumulate(acc0, &A[(fl * PN_SMAX + ti[0]) * 18], &A[(fl * PN_SMAX + tj[0]) * 18], iv);
-				used[0] = true;
-			}
-			if (ti[1] >= 0 && ((m >> ti[1]) & 1u) && ((m >> tj[1]) & 1u))
-			{
-				pn_accumulate(acc1, &A[(fl * PN_SMAX + ti[1]) * 18], &A[(fl * PN_SMAX + tj[1]) * 18], iv);
-				used[1] = true;
-			}
-			if (tid < ns && ((m >> tid) & 1u))
-			{
-				// E_p -= W V^-1 eb, Imp.cpp:2321-2328
-				const double* a = &A[(fl * PN_SMAX + tid) * 18];
-				const double e0 = ebs[fl * 3], e1 = ebs[fl * 3 + 1], e2 = ebs[fl * 3 + 2];
-				const double y0 = iv[0] * e0 + iv[1] * e1 + iv[2] * e2, y1 = iv[3] * e0 + iv[4] * e1 + iv[5] * e2,
-				             y2 = iv[6] * e0 + iv[7] * e1 + iv[8] * e2;
-#pragma unroll
-				for (int r = 0; r < 6; r++) eacc[r] -= a[3 * r] * y0 + a[3 * r + 1] * y1 + a[3 * r + 2] * y2;
-				eused = true;
-			}
-		}
-	}
-	// ---- every touched block leaves the work-group once ----
-#pragma unroll
-	for (int u = 0; u < 2; u++)
-	{
-		if (!used[u]) continue;
-		const double* acc = u ? acc1 : acc0;
-		const int pa = pose_of[ti[u]], pb = pose_of[tj[u]];
-		const int slot = pn_hash_find(tab, val, mask, pa, pb);
-		double* d = S + (size_t)slot * 36;
-		// acc = sum (A_i V^-1) A_j^T is the contribution to S(pa, pb); stored orientation: rows = smaller pose index
-		if (pa <= pb) { for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -acc[q]); }
-		else { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) atomic_add_f64(d + c * 6 + r, -acc[r * 6 + c]); }
-	}
-	if (eused)
-	{
-		const int p = pose_of[tid];
-		for (int r = 0; r < 6; r++) atomic_add_f64(E + (size_t)p * 6 + r, eacc[r]);
-	}
+	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + 3) >> 2; // tiles per wave, uniform
+#define PM_GO(T) pm_body<T>(sh, ns, f0, f1, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
+	if (tpw <= 1) PM_GO(1);
+	else if (tpw <= 3) PM_GO(3);
+	else if (tpw <= 6) PM_GO(6);
+	else if (tpw <= 9) PM_GO(9);
+	else if (tpw <= 14) PM_GO(14);
+	else PM_GO(20);
+#undef PM_GO
 }
 
-int schur_panel_tile() { return PN_TILE; }
+int schur_panel_tile() { return PM_TILE; }
 
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback)
 {
 	if (NF)
-		hipLaunchKernelGGL(k_schur_panel, dim3((NF + PN_TILE - 1) / PN_TILE), dim3(PN_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val,
+		hipLaunchKernelGGL(k_schur_panel, dim3((NF + PM_TILE - 1) / PM_TILE), dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val,
 		                   mask, S, E, fallback);
 }
 

@@ -46,6 +46,13 @@ struct CholDev {
 	int* order = nullptr;   // [M] columns sorted by elimination-tree level
 	std::vector<int> level_ptr; // host: order[level_ptr[l] .. level_ptr[l+1]) = columns of level l (before the tail)
 	std::vector<int> level_maxpairs; // host: largest n(n+1)/2 over the columns of the level (grid of the update launch)
+	// tasks: connected pieces of the elimination tree that one work-group walks serially (small sub-trees, chains)
+	int* task_cols = nullptr;          // [M] columns grouped by task, ascending inside a task
+	int* task_ptr = nullptr;           // [ntasks+1] tasks ordered by task level
+	std::vector<int> tlevel_ptr;       // host: tasks of task level l = [tlevel_ptr[l], tlevel_ptr[l+1])
+	std::vector<int> tlevel_maxsize;   // host: most columns in a task of the level (LDS of the solve launches)
+	int* col_task = nullptr;           // [M] task (position in task_ptr) of a column
+	int* col_lpos = nullptr;           // [M] position of a column inside its task
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
 	int* d_err = nullptr;
@@ -270,6 +277,115 @@ __global__ void __launch_bounds__(256) k_chol_solve_tail(int ncols, const int* _
 	for (int k = ncols - 1; k >= 0; k--) { chol_bwd_column(cols[k], colptr, rowidx, L, Dinv, v); __threadfence(); __syncthreads(); }
 }
 
+// one work-group per task: its columns in ascending order (children before parents) / descending for the back solve
+__global__ void __launch_bounds__(256) k_chol_factor_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
+                                                            double* __restrict__ Dinv, int* err)
+{
+	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1];
+	for (int k = b; k < e; k++)
+	{
+		chol_factor_column(task_cols[k], colptr, rowidx, L, Dinv, err, true);
+		if (k + 1 < e) { __threadfence(); __syncthreads(); }
+	}
+}
+// Triangular solves by task.  The entries of v that belong to the task's own columns live in LDS while the work-group
+// walks the task: a column step inside a task then costs LDS latency instead of a global atomic + fence round trip
+// (measured 2.7 us per step, the critical path of the whole solve).  Rows outside the task (ancestors) are updated /
+// read in global memory; nobody inside the task reads them.
+__global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                                         const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
+                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
+                                                         const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	extern __shared__ double lv[];
+	__shared__ double sy[6];
+	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	for (int q = tid; q < (e - b) * 6; q += nt) lv[q] = v[(size_t)task_cols[b + q / 6] * 6 + q % 6];
+	__syncthreads();
+	for (int k = b; k < e; k++)
+	{
+		const int j = task_cols[k];
+		const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+		if (tid < 6)
+		{
+			const double* Li = Dinv + (size_t)j * 36;
+			double s = 0;
+			for (int q = 0; q <= tid; q++) s = fma(Li[tid * 6 + q], lv[(k - b) * 6 + q], s);
+			sy[tid] = s;
+		}
+		__syncthreads();
+		if (tid < 6) lv[(k - b) * 6 + tid] = sy[tid];
+		for (int w = tid; w < n * 6; w += nt)
+		{
+			const int en = c0 + 1 + w / 6, r = w % 6;
+			const double* blk = L + (size_t)en * 36 + r * 6;
+			double s = 0;
+			for (int q = 0; q < 6; q++) s = fma(blk[q], sy[q], s);
+			const int i = rowidx[en];
+			if (col_task[i] == me) lds_add_f64(&lv[col_lpos[i] * 6 + r], -s);
+			else atomic_add_f64(v + (size_t)i * 6 + r, -s);
+		}
+		__syncthreads();
+	}
+	for (int q = tid; q < (e - b) * 6; q += nt) v[(size_t)task_cols[b + q / 6] * 6 + q % 6] = lv[q];
+}
+__global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                                         const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
+                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
+                                                         const double* __restrict__ Dinv, double* __restrict__ v)
+{
+	extern __shared__ double lv[];
+	__shared__ double red[256];
+	__shared__ double ss[6];
+	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	const int c = tid % 6, g = tid / 6, ng = nt / 6;
+	for (int q = tid; q < (e - b) * 6; q += nt) lv[q] = v[(size_t)task_cols[b + q / 6] * 6 + q % 6];
+	__syncthreads();
+	for (int k = e - 1; k >= b; k--)
+	{
+		const int j = task_cols[k];
+		const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+		double s = 0;
+		if (g < ng)
+			for (int en = g; en < n; en += ng)
+			{
+				const double* blk = L + (size_t)(c0 + 1 + en) * 36;
+				const int i = rowidx[c0 + 1 + en];
+				if (col_task[i] == me)
+				{
+					const double* xi = &lv[col_lpos[i] * 6];
+					for (int r = 0; r < 6; r++) s = fma(blk[r * 6 + c], xi[r], s);
+				}
+				else
+				{
+					const double* xi = v + (size_t)i * 6;
+					for (int r = 0; r < 6; r++) s = fma(blk[r * 6 + c], xi[r], s);
+				}
+			}
+		red[tid] = (g < ng) ? s : 0.0;
+		__syncthreads();
+		if (tid < 6)
+		{
+			double t = lv[(k - b) * 6 + tid];
+			for (int q = 0; q < ng; q++) t -= red[q * 6 + tid];
+			ss[tid] = t;
+		}
+		__syncthreads();
+		if (tid < 6)
+		{
+			const double* Li = Dinv + (size_t)j * 36;
+			double t = 0;
+			for (int q = tid; q < 6; q++) t = fma(Li[q * 6 + tid], ss[q], t);
+			lv[(k - b) * 6 + tid] = t;
+		}
+		__syncthreads();
+	}
+	for (int q = tid; q < (e - b) * 6; q += nt) v[(size_t)task_cols[b + q / 6] * 6 + q % 6] = lv[q];
+}
+
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
                           double* __restrict__ v)
 {
@@ -404,6 +520,66 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const int* d_
 	ch.tail_begin = lcount[tail_level];
 	// tail columns must be walked in ascending index (= a topological order), not level order
 	std::sort(order.begin() + ch.tail_begin, order.end());
+	// ---- tasks.  Sub-trees of at most task_x columns are walked by one work-group each (task level 0); above them
+	// every chain of the tree (a separator of the dissection: each column the only large child of the next) is one
+	// task, levelled by the chains below it.  Launches per triangular solve: ~ depth of the dissection, not the
+	// height of the elimination tree. ----
+	{
+		static const int task_x = getenv("LSFM_TASK_X") ? atoi(getenv("LSFM_TASK_X")) : 32;
+		std::vector<int> size(M, 1), ntc(M, 0), topchild(M, -1), task(M, -1), tlev;
+		for (int j = 0; j < M; j++) if (parent[j] >= 0) size[parent[j]] += size[j];
+		for (int j = 0; j < M; j++)
+			if (size[j] > task_x && parent[j] >= 0) { ntc[parent[j]]++; topchild[parent[j]] = j; }
+		int ntasks = 0;
+		// large columns, ascending: children first
+		for (int j = 0; j < M; j++)
+		{
+			if (size[j] <= task_x) continue;
+			if (ntc[j] == 1) { task[j] = task[topchild[j]]; continue; }
+			task[j] = ntasks++;
+			tlev.push_back(1);
+		}
+		// level of a chain = 1 + highest chain below it (ascending order sees the children first)
+		for (int j = 0; j < M; j++)
+		{
+			if (size[j] <= task_x) continue;
+			const int pj = parent[j];
+			if (pj >= 0 && task[pj] != task[j]) tlev[task[pj]] = std::max(tlev[task[pj]], tlev[task[j]] + 1);
+		}
+		// small sub-trees, descending: parents first
+		for (int j = M - 1; j >= 0; j--)
+		{
+			if (size[j] > task_x) continue;
+			const int pj = parent[j];
+			if (pj >= 0 && size[pj] <= task_x) task[j] = task[pj];
+			else { task[j] = ntasks++; tlev.push_back(0); }
+		}
+		int ntl = 0;
+		for (int t = 0; t < ntasks; t++) ntl = std::max(ntl, tlev[t] + 1);
+		// order tasks by level, columns by (task order, ascending index)
+		std::vector<int> tl_count(ntl + 1, 0), tpos(ntasks), tsize(ntasks, 0);
+		for (int t = 0; t < ntasks; t++) tl_count[tlev[t] + 1]++;
+		for (int l = 0; l < ntl; l++) tl_count[l + 1] += tl_count[l];
+		{
+			std::vector<int> f(ntl, 0);
+			for (int t = 0; t < ntasks; t++) tpos[t] = tl_count[tlev[t]] + f[tlev[t]]++;
+		}
+		for (int j = 0; j < M; j++) tsize[tpos[task[j]]]++;
+		std::vector<int> tptr(ntasks + 1, 0), tcols(M), tf(ntasks, 0);
+		for (int t = 0; t < ntasks; t++) tptr[t + 1] = tptr[t] + tsize[t];
+		for (int j = 0; j < M; j++) { const int t = tpos[task[j]]; tcols[tptr[t] + tf[t]++] = j; }
+		ch.tlevel_ptr = tl_count;
+		ch.tlevel_maxsize.assign(ntl, 0);
+		std::vector<int> ctask(M), clpos(M);
+		for (int t = 0; t < ntasks; t++)
+			for (int k = tptr[t]; k < tptr[t + 1]; k++) { ctask[tcols[k]] = t; clpos[tcols[k]] = k - tptr[t]; }
+		for (int l = 0; l < ntl; l++)
+			for (int t = tl_count[l]; t < tl_count[l + 1]; t++) ch.tlevel_maxsize[l] = std::max(ch.tlevel_maxsize[l], tsize[t]);
+		ch.col_task = sc.alloc<int>(M); ch.col_lpos = sc.alloc<int>(M);
+		h2d(ctx, ch.col_task, ctask.data(), M * sizeof(int)); h2d(ctx, ch.col_lpos, clpos.data(), M * sizeof(int));
+		ch.task_cols = sc.alloc<int>(M); ch.task_ptr = sc.alloc<int>(ntasks + 1);
+		h2d(ctx, ch.task_cols, tcols.data(), M * sizeof(int)); h2d(ctx, ch.task_ptr, tptr.data(), (ntasks + 1) * sizeof(int));
+	}
 	ch.colptr = sc.alloc<int>(M + 1); ch.rowidx = sc.alloc<int>(nnzL); ch.perm = sc.alloc<int>(M); ch.pinv = sc.alloc<int>(M);
 	ch.order = sc.alloc<int>(M); ch.L = sc.alloc<double>((size_t)nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)M * 36);
 	ch.d_err = sc.alloc<int>(1);
@@ -420,6 +596,16 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	if (sy.nnzb)
 		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, s, sy.nnzb, sy.upper_keys, sy.S, ch.pinv, ch.colptr, ch.rowidx,
 		                   fixed, ch.L);
+	static const bool task_factor = !getenv("LSFM_LEVEL_FACTOR");
+	if (task_factor)
+	{
+		for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
+		{
+			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
+			if (n) hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		}
+		return;
+	}
 	for (int l = 0; l < ch.nlevels; l++)
 	{
 		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
@@ -440,6 +626,25 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 	hipStream_t s = ctx->stream;
 	const size_t ns = (size_t)ch.M * 6;
 	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, ch.M, ch.perm, r, fixed, v);
+	static const bool task_solve = !getenv("LSFM_LEVEL_SOLVE");
+	int task_max = 0;
+	for (int m : ch.tlevel_maxsize) task_max = std::max(task_max, m);
+	if (task_solve && task_max * 48 <= 48 * 1024) // the task's slice of v must fit LDS; else one launch per tree level
+	{
+		const int ntl = (int)ch.tlevel_ptr.size() - 1;
+		for (int l = 0; l < ntl; l++)
+		{
+			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
+			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * 48, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+		}
+		for (int l = ntl - 1; l >= 0; l--)
+		{
+			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
+			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * 48, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+		}
+		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
+		return;
+	}
 	for (int l = 0; l < ch.nlevels; l++)
 	{
 		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
@@ -544,19 +749,27 @@ __global__ void k_pcg_update2(int M, int cur, const double* __restrict__ z, cons
 		for (int i = 0; i < 6; i++) { const size_t o = (size_t)row * 6 + i; p[o] = z[o] + beta * p[o]; }
 	}
 }
-// after update2 (separate launch: the flags it writes are read by every row of the system)
-__global__ void k_pcg_check(int nseg, int cur, PcgSeg* seg, int* ndone)
+// after the residual is known and before the preconditioner is applied to it: convergence test per system
+__global__ void k_pcg_check(int nseg, PcgSeg* seg, int* ndone)
 {
 	int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= nseg) return;
 	PcgSeg& g = seg[s];
 	if (g.done) return;
 	const double rr = g.rr;
-	g.pAp = 0; g.rr = 0; g.rz[cur] = 0; // rz[cur] is the accumulator of the next iteration
 	g.its++;
 	// converged, or the true residual stopped shrinking (attainable accuracy reached)
 	if (!(rr > g.thresh) || !(rr < 0.25 * g.rr_prev) || !(rr == rr)) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
 	g.rr_prev = rr;
+}
+// after update2 (separate launch: update2 reads the scalars of its system from every row): reset the accumulators
+__global__ void k_pcg_reset(int nseg, int cur, PcgSeg* seg)
+{
+	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	PcgSeg& g = seg[s];
+	if (g.done) return;
+	g.pAp = 0; g.rr = 0; g.rz[cur] = 0; // rz[cur] is the accumulator of the next iteration
 }
 
 int solve_batch(lsfm_context* ctx, const SolveIO& io)
@@ -623,17 +836,20 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, io.d_pose_seg, x, p, Ap, seg);
 		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
 		hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 0);
-		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
-		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
-		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, cur, seg, d_misc + 1);
+		// the test comes before the preconditioner: the apply for a residual that already passed would be wasted
+		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, seg, d_misc + 1);
 		its++;
 		ndone = d2h_int(ctx, d_misc + 1);
+		if (ndone >= nseg) break;
+		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
+		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
+		hipLaunchKernelGGL(k_pcg_reset, dim3(nbs), dim3(128), 0, s, nseg, cur, seg);
 	}
 	if (dbg)
 	{
 		LSFM_CHECK_HIP(hipStreamSynchronize(s));
-		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d | analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
-		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, tw1 - tw0, tw2 - tw1, its, wall() - tw2);
+		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d task levels=%d | analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
+		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, (int)ch.tlevel_ptr.size() - 1, tw1 - tw0, tw2 - tw1, its, wall() - tw2);
 	}
 	// ---- true residual, statistics; SpMV launches timed with HIP events on this stream ----
 	const int nsample = 5;

@@ -53,6 +53,9 @@ struct CholDev {
 	std::vector<int> tlevel_maxsize;   // host: most columns in a task of the level (LDS of the solve launches)
 	int* col_task = nullptr;           // [M] task (position in task_ptr) of a column
 	int* col_lpos = nullptr;           // [M] position of a column inside its task
+	int* col_nin = nullptr;            // [M] leading rows of a column (below the diagonal) that belong to its own task
+	std::vector<int> tlevel_col0;      // host: task_cols[tlevel_col0[l] .. tlevel_col0[l+1]) = columns of the level's tasks
+	std::vector<int> tlevel_outer;     // host: largest number of deferred update pairs of a column of the level
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
 	int* d_err = nullptr;
@@ -152,7 +155,23 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 	if (do_update) chol_column_update(j, colptr, rowidx, L, tid, nt);
 }
 
-// trailing updates of column j: pairs a >= b of its blocks below the diagonal, pair index pr = first, first+stride, ...
+// one trailing update of column j: blocks a >= b below the diagonal give L_a L_b^T, subtracted from block (ra, rb)
+__device__ __forceinline__ void chol_pair_update(int c0, int a, int b, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L)
+{
+	const int ra = rowidx[c0 + 1 + a], rb = rowidx[c0 + 1 + b];
+	double La[36], Lb[36], T[36];
+	ld<36>(La, L + (size_t)(c0 + 1 + a) * 36);
+	ld<36>(Lb, L + (size_t)(c0 + 1 + b) * 36);
+	mmt<6, 6, 6, false>(La, Lb, T);
+	// the rows of column j from rb on are a subset of column rb's rows; when the two lists coincide (columns of one
+	// separator: nested patterns) the target is at the same offset, else binary search
+	const int cb = colptr[rb], nb = colptr[rb + 1] - cb;
+	int pos = cb + (a - b);
+	if (!(a - b < nb && rowidx[pos] == ra)) pos = find_row(rowidx, cb, cb + nb, ra);
+	double* d = L + (size_t)pos * 36;
+	for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -T[q]);
+}
+// trailing updates of column j: all pairs a >= b, pair index pr = first, first+stride, ...
 __device__ void chol_column_update(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
 {
 	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
@@ -163,15 +182,30 @@ __device__ void chol_column_update(int j, const int* __restrict__ colptr, const 
 		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
 		while (a * (a + 1) / 2 > pr) a--;
 		while ((a + 1) * (a + 2) / 2 <= pr) a++;
-		const int b = pr - a * (a + 1) / 2;
-		const int ra = rowidx[c0 + 1 + a], rb = rowidx[c0 + 1 + b];
-		double La[36], Lb[36], T[36];
-		ld<36>(La, L + (size_t)(c0 + 1 + a) * 36);
-		ld<36>(Lb, L + (size_t)(c0 + 1 + b) * 36);
-		mmt<6, 6, 6, false>(La, Lb, T); // L_a L_b^T = update of block (ra, rb)
-		const int pos = find_row(rowidx, colptr[rb], colptr[rb + 1], ra);
-		double* d = L + (size_t)pos * 36;
-		for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -T[q]);
+		chol_pair_update(c0, a, pr - a * (a + 1) / 2, colptr, rowidx, L);
+	}
+}
+// the pairs whose target column rb is one of the first m rows (the rows inside the task): needed before the task's next column
+__device__ void chol_column_update_inner(int j, int m, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
+{
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+	for (int idx = first; idx < m * n; idx += stride)
+	{
+		const int b = idx / n, a = idx - b * n;
+		if (a >= b) chol_pair_update(c0, a, b, colptr, rowidx, L);
+	}
+}
+// the pairs with b >= m: targets in columns outside the task, nobody inside the task waits for them
+__device__ void chol_column_update_outer(int j, int m, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
+{
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1 - m;
+	const int npairs = n * (n + 1) / 2;
+	for (int pr = first; pr < npairs; pr += stride)
+	{
+		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+		while (a * (a + 1) / 2 > pr) a--;
+		while ((a + 1) * (a + 2) / 2 <= pr) a++;
+		chol_pair_update(c0, a + m, pr - a * (a + 1) / 2 + m, colptr, rowidx, L);
 	}
 }
 
@@ -279,15 +313,28 @@ __global__ void __launch_bounds__(256) k_chol_solve_tail(int ncols, const int* _
 
 // one work-group per task: its columns in ascending order (children before parents) / descending for the back solve
 __global__ void __launch_bounds__(256) k_chol_factor_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
-                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                                            double* __restrict__ Dinv, int* err)
+                                                            const int* __restrict__ col_nin, const int* __restrict__ colptr,
+                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
 {
 	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1];
 	for (int k = b; k < e; k++)
 	{
-		chol_factor_column(task_cols[k], colptr, rowidx, L, Dinv, err, true);
-		if (k + 1 < e) { __threadfence(); __syncthreads(); }
+		const int j = task_cols[k];
+		chol_factor_column(j, colptr, rowidx, L, Dinv, err, false);
+		if (k + 1 < e)
+		{
+			chol_column_update_inner(j, col_nin[j], colptr, rowidx, L, threadIdx.x, blockDim.x);
+			__threadfence();
+			__syncthreads();
+		}
 	}
+}
+// the deferred updates of the level's tasks, into the columns above them: one column per blockIdx.x, pairs split over blockIdx.y
+__global__ void __launch_bounds__(256) k_chol_update_outer(const int* __restrict__ cols, const int* __restrict__ col_nin, const int* __restrict__ colptr,
+                                                            const int* __restrict__ rowidx, double* __restrict__ L)
+{
+	const int j = cols[blockIdx.x];
+	chol_column_update_outer(j, col_nin[j], colptr, rowidx, L, blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
 }
 // Triangular solves by task.  The entries of v that belong to the task's own columns live in LDS while the work-group
 // walks the task: a column step inside a task then costs LDS latency instead of a global atomic + fence round trip
@@ -575,6 +622,20 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const int* d_
 			for (int k = tptr[t]; k < tptr[t + 1]; k++) { ctask[tcols[k]] = t; clpos[tcols[k]] = k - tptr[t]; }
 		for (int l = 0; l < ntl; l++)
 			for (int t = tl_count[l]; t < tl_count[l + 1]; t++) ch.tlevel_maxsize[l] = std::max(ch.tlevel_maxsize[l], tsize[t]);
+		ch.tlevel_col0.assign(ntl + 1, 0);
+		for (int l = 0; l <= ntl; l++) ch.tlevel_col0[l] = tptr[tl_count[l]];
+		std::vector<int> nin(M, 0);
+		ch.tlevel_outer.assign(ntl, 0);
+		for (int j = 0; j < M; j++)
+		{
+			int m = 0;
+			while (colptr[j] + 1 + m < colptr[j + 1] && task[rowidx[colptr[j] + 1 + m]] == task[j]) m++;
+			nin[j] = m;
+			const int no = ccount[j] - 1 - m, l = tlev[task[j]];
+			ch.tlevel_outer[l] = std::max(ch.tlevel_outer[l], no * (no + 1) / 2);
+		}
+		ch.col_nin = sc.alloc<int>(M);
+		h2d(ctx, ch.col_nin, nin.data(), M * sizeof(int));
 		ch.col_task = sc.alloc<int>(M); ch.col_lpos = sc.alloc<int>(M);
 		h2d(ctx, ch.col_task, ctask.data(), M * sizeof(int)); h2d(ctx, ch.col_lpos, clpos.data(), M * sizeof(int));
 		ch.task_cols = sc.alloc<int>(M); ch.task_ptr = sc.alloc<int>(ntasks + 1);
@@ -602,7 +663,10 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+			if (!n) continue;
+			hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+			const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
+			if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, (mp + 255) / 256), dim3(256), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 		}
 		return;
 	}

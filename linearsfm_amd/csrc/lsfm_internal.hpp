@@ -78,7 +78,7 @@ struct lsfm_context {
 	lsfm::PcgOptions pcg;
 	std::string last_error;
 	int* h_pinned = nullptr; // small pinned staging buffer for counters
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run
 	void ensure_arenas(size_t bytes_each);
 };

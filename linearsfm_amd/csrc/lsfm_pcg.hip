@@ -470,15 +470,28 @@ __global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double
 // ---------------------------------------------------------------------------------------------------------------
 static int bitlen(unsigned x) { int l = 0; while (x) { l++; x >>= 1; } return l; }
 
-static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const int* d_origin, CholDev& ch)
+struct CholHostIn {
+	std::vector<unsigned long long> keys; // sorted upper pattern of S
+	std::vector<int> origin;              // local map that brought each pose
+};
+// the two small device -> host copies of the analysis (a synchronisation), separate from the host work so that the
+// caller can enqueue the numeric Schur assembly in between and let it run under the symbolic factorisation
+static void chol_fetch(lsfm_context* ctx, const SchurSystem& sy, const int* d_origin, CholHostIn& in)
+{
+	const int M = sy.M, nnzb = sy.nnzb;
+	in.keys.resize(nnzb);
+	in.origin.resize(M);
+	if (d_origin) LSFM_CHECK_HIP(hipMemcpyAsync(in.origin.data(), d_origin, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	else std::iota(in.origin.begin(), in.origin.end(), 0);
+	d2h(ctx, in.keys.data(), sy.upper_keys, (size_t)nnzb * sizeof(unsigned long long));
+}
+
+static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHostIn& in, CholDev& ch)
 {
 	const int M = sy.M, nnzb = sy.nnzb;
 	Arena& sc = ctx->scratch;
-	std::vector<unsigned long long> keys(nnzb);
-	d2h(ctx, keys.data(), sy.upper_keys, (size_t)nnzb * sizeof(unsigned long long));
-	std::vector<int> origin(M);
-	if (d_origin) d2h(ctx, origin.data(), d_origin, (size_t)M * sizeof(int));
-	else std::iota(origin.begin(), origin.end(), 0);
+	const std::vector<unsigned long long>& keys = in.keys;
+	const std::vector<int>& origin = in.origin;
 	std::vector<int> deg(M, 0), sep(M, 0);
 	for (int e = 0; e < nnzb; e++)
 	{
@@ -841,25 +854,25 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
 	const int M = io.M, nseg = io.nseg;
-	hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+	hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr, ed = nullptr;
 	float ms = 0;
-	LSFM_CHECK_HIP(hipEventCreate(&ea)); LSFM_CHECK_HIP(hipEventCreate(&eb)); LSFM_CHECK_HIP(hipEventCreate(&ec));
+	LSFM_CHECK_HIP(hipEventCreate(&ea)); LSFM_CHECK_HIP(hipEventCreate(&eb)); LSFM_CHECK_HIP(hipEventCreate(&ec)); LSFM_CHECK_HIP(hipEventCreate(&ed));
 	LSFM_CHECK_HIP(hipEventRecord(ea, s));
 	SchurSystem sy;
-	build_schur(ctx, io, sy);
-	LSFM_CHECK_HIP(hipEventRecord(eb, s));
-	LSFM_CHECK_HIP(hipEventSynchronize(eb));
-	LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
-	if (ctx->stats) ctx->stats->t_schur_ms += ms;
-	LSFM_CHECK_HIP(hipEventRecord(ea, s));
-
-	// ---- preconditioner ----
 	CholDev ch;
+	CholHostIn hin;
 	const bool dbg = getenv("LSFM_DEBUG") != nullptr;
 	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	// pattern -> (copy it to the host) -> numeric assembly K9 enqueued -> symbolic factorisation on the host while K9
+	// runs -> numeric factorisation
+	build_schur_pattern(ctx, io, sy);
+	chol_fetch(ctx, sy, io.d_pose_origin, hin);
+	build_schur_values(ctx, io, sy);
+	LSFM_CHECK_HIP(hipEventRecord(eb, s));
 	double tw0 = wall();
-	chol_analyse(ctx, sy, io.d_pose_origin, ch);
+	chol_analyse(ctx, sy, hin, ch);
 	double tw1 = wall();
+	schur_values_stats(ctx, io, sy);
 	chol_factor(ctx, sy, io.d_fixed, ch);
 	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
 	double tw2 = wall();
@@ -943,16 +956,17 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		maxrel = std::max(maxrel, rel);
 		if (hs2[g].done != 1 && !(rel < 1e-9)) notconv++;
 	}
-	LSFM_CHECK_HIP(hipEventRecord(eb, s));
+	LSFM_CHECK_HIP(hipEventRecord(ec, s));
 	launch_backsub(ctx, io, sy, x);
 	LSFM_CHECK_HIP(hipGetLastError());
-	LSFM_CHECK_HIP(hipEventRecord(ec, s));
-	LSFM_CHECK_HIP(hipEventSynchronize(ec));
+	LSFM_CHECK_HIP(hipEventRecord(ed, s));
+	LSFM_CHECK_HIP(hipEventSynchronize(ed));
 	if (ctx->stats)
 	{
 		lsfm_stats* st = ctx->stats;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); st->t_pcg_ms += ms;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, eb, ec)); st->t_backsub_ms += ms;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); st->t_schur_ms += ms;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, eb, ec)); st->t_pcg_ms += ms;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ec, ed)); st->t_backsub_ms += ms;
 		st->pcg_iterations += its;
 		st->spmv_launches += nsample;
 		st->spmv_ms += sp_ms;
@@ -960,7 +974,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
 		st->max_rel_residual = std::max(st->max_rel_residual, maxrel);
 	}
-	(void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec);
+	(void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec); (void)hipEventDestroy(ed);
 	return notconv;
 }
 

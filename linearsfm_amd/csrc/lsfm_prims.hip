@@ -117,6 +117,8 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev0));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev1));
+		LSFM_CHECK_HIP(hipEventCreate(&c->ev2));
+		LSFM_CHECK_HIP(hipEventCreate(&c->ev3));
 		if (arena_bytes) c->ensure_arenas(arena_bytes);
 	}
 	catch (const lsfm::Error& e)
@@ -139,6 +141,8 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->h_pinned) (void)hipHostFree(c->h_pinned);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->ev2) (void)hipEventDestroy(c->ev2);
+	if (c->ev3) (void)hipEventDestroy(c->ev3);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }

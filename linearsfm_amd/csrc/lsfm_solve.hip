@@ -384,7 +384,8 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 	hipLaunchKernelGGL(k_chunk_fill, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, cptr, sy.chunk_row, sy.chunk_beg);
 }
 
-void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+// Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only
+void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
@@ -424,6 +425,22 @@ void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	sy.colidx = sc.alloc<int>(cnt + 1);
 	if (cnt) hipLaunchKernelGGL(k_pat_assign, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, list, tab, hval, mask, sy.colidx);
 	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, cnt, list, 32, sy.rowptr);
+	sy.tab = tab; sy.hval = hval; sy.mask = mask;
+	sy.upper_keys = list;
+	build_spmv_index(ctx, sy, list, d_flags);
+	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+// Values of S and E: enqueued without a host synchronisation (the caller overlaps host work with K9); the K9 launch is
+// bracketed by the events ev2/ev3 of the context, read back by schur_values_stats() after the caller's next sync
+void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	const int M = io.M, NF = io.NF, cnt = sy.nnzb;
+	const unsigned long long* tab = sy.tab;
+	const int* hval = sy.hval;
+	const unsigned long long mask = sy.mask;
 	sy.S = sc.alloc<double>((size_t)cnt * 36);
 	sy.E = sc.alloc<double>((size_t)M * 6);
 	dev_zero(ctx, sy.S, (size_t)cnt * 36 * sizeof(double));
@@ -432,29 +449,28 @@ void build_schur(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
 		const int ntiles = (NF + SCHUR_TILE - 1) / SCHUR_TILE;
 		unsigned char* fb = sc.alloc<unsigned char>(ntiles);
 		dev_zero(ctx, fb, ntiles);
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s)); // re-record after the memset
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev2, s));
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
 		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
-		if (ctx->stats)
-		{
-			float t = 0;
-			LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
-			LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
-			LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
-			ctx->stats->schur_launches++;
-			ctx->stats->schur_ms += t;
-			// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
-			ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)NF * (72 + 24 + 4) + (double)cnt * 288 + (double)M * 48;
-		}
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev3, s));
 	}
-	sy.upper_keys = list;
-	build_spmv_index(ctx, sy, list, d_flags);
 	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+void schur_values_stats(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy)
+{
+	if (!ctx->stats || !io.NF) return;
+	float t = 0;
+	LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev3));
+	LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev2, ctx->ev3));
+	ctx->stats->schur_launches++;
+	ctx->stats->schur_ms += t;
+	// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
+	ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)io.NF * (72 + 24 + 4) + (double)sy.nnzb * 288 + (double)io.M * 48;
 }
 
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,

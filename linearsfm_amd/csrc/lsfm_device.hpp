@@ -211,13 +211,18 @@ __device__ __forceinline__ void wave_scatter_add(double* dst, const double* vals
 	bool uniform = __ballot(valid && mine != first) == 0ull;
 	if (uniform && __popcll(mask) > 1)
 	{
-		int lane = threadIdx.x & (LSFM_WAVE - 1);
+		// lane i keeps sum i: the N sums leave as ONE wave instruction over N contiguous doubles (one lane issuing N
+		// single-lane atomics serialises on the same 64-byte lines: measured 1.3 ms for 7k waves on one 288-byte row)
+		static_assert(N <= LSFM_WAVE, "one lane per value");
+		const int lane = threadIdx.x & (LSFM_WAVE - 1);
+		double keep = 0.0;
 #pragma unroll
 		for (int i = 0; i < N; i++)
 		{
-			double s = wave_sum(valid ? vals[i] : 0.0);
-			if (lane == leader) atomic_add_f64(dst + i, s);
+			const double s = wave_sum(valid ? vals[i] : 0.0);
+			if (lane == i) keep = s;
 		}
+		if (lane < N) atomic_add_f64(reinterpret_cast<double*>((size_t)first) + lane, keep);
 	}
 	else if (valid)
 	{

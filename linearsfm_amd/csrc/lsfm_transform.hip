@@ -7,8 +7,8 @@
 //                                                   Mono: C_2 = "J3" (column of the old scale pose h_2)
 // so  I' = D^T I D  +  [D^T G_s] e_{h_s}^T + e_{h_s} [D^T G_s]^T  +  e_{h_s} (C_s^T G_t) e_{h_t}^T ,  G_s = I C_s .
 // The reference accumulates the same sums block by block ("Algorithm Line 3/4/5/6").  Here:
-//   k_tr_features  one lane per feature: V' = D_f^T V D_f, W' = D_k^T W D_f, the feature rows of G, the pose rows of
-//                  G (scatter-add, pre-reduced over the wave when the lanes hit the same pose), C_f^T G_f
+//   k_tr_feat_pre / k_tr_entries / k_tr_feat_post   V' = D_f^T V D_f, W' = D_k^T W D_f, the feature rows of G, the
+//                  pose rows of G (LDS table per work-group), C_f^T G_f  -- one lane per W block for the bulk
 //   k_tr_ublocks   one lane per U block: U' = D_a^T U D_b and the U part of the pose rows of G
 //   k_tr_poseslots one lane per pose: the new (k,h_s) blocks D_k^T G_s,k and C_k^T G_k
 //   k_tr_diag      adds sum_a C_a^T G_a to the (h,h) blocks
@@ -290,151 +290,285 @@ __global__ void k_tr_gather_counts(const int* __restrict__ KU, const int* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// the feature kernel (K3/K4 of SURVEY 2a): Imp.cpp:1300-1915 / 5017-6501
+// the feature stage (K3/K4 of SURVEY 2a): Imp.cpp:1300-1915 / 5017-6501, in three launches
+//   k_tr_feat_pre   one lane per feature : x', D_f, C_s,f, V' = D_f^T V D_f, new run pointer
+//   k_tr_entries    one lane per W block : W' = D_k^T W D_f at its new place, the block's share of the feature rows
+//                   of G (W^T C_s,k, summed per feature through LDS) and of the pose rows of G (W C_s,f, LDS table)
+//   k_tr_feat_post  one lane per feature : G_s,f complete, the new block(s) to the hub pose(s), C_s^T G_t
+// The W blocks -- 90 % of the bytes -- are read and written by consecutive lanes (one 144-byte block per lane,
+// contiguous over the wave); a lane per feature walking its run strided the wave's accesses by the run length and
+// needed 340 registers (one wave per SIMD).
 // ---------------------------------------------------------------------------------------------------------
+#define TRE_TILE 256 /* features per work-group: the LDS pose table is flushed once per tile */
+#define TRE_ROUND 256 /* W blocks per round = threads */
+
 template <int NH>
 __global__ void __launch_bounds__(256)
-k_tr_features(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const double* __restrict__ feat,
-              const int* __restrict__ fptr, const double* __restrict__ Vold, const double* __restrict__ Wold, const int* __restrict__ photo,
-              const int* __restrict__ KW, const double* __restrict__ Dp, const double* __restrict__ Cp,
-              double* __restrict__ nfeat, int* __restrict__ nfptr, double* __restrict__ Vn, double* __restrict__ Wn_, int* __restrict__ nphoto,
-              int* __restrict__ nfeature, double* __restrict__ Gpose, double* __restrict__ PP)
+k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const double* __restrict__ feat, const int* __restrict__ fptr,
+              const double* __restrict__ Vold, const int* __restrict__ KW, double* __restrict__ nfeat, int* __restrict__ nfptr,
+              double* __restrict__ Vn, double* __restrict__ FD)
 {
-	// pose rows of G: accumulated per work-group in LDS, flushed once (scattered 8-byte atomics to HBM run at 0.08 TB/s)
-	constexpr int GCAP = 64;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	const TMap* t = &tm[feat_map[f]];
+	const int j0 = fptr[f];
+	const double* x = feat + (size_t)f * 3;
+	if (!(t->active > 0 && t->nh == NH))
+	{
+		// pass-through map: plain copy at the new offsets
+		nfeat[3 * (size_t)f] = x[0]; nfeat[3 * (size_t)f + 1] = x[1]; nfeat[3 * (size_t)f + 2] = x[2];
+		for (int i = 0; i < 9; i++) Vn[(size_t)f * 9 + i] = Vold[(size_t)f * 9 + i];
+		nfptr[f] = t->W0n + (j0 - t->W0);
+		return;
+	}
+	nfptr[f] = t->W0n + NH * (f - t->F0) + (KW[j0] - t->kW0);
+	double Df[9], Cf[NH][18], xn[3];
+	// new feature value, Imp.cpp:449-451 / 3300-3302
+	double d[3] = { x[0] - t->t1[0], x[1] - t->t1[1], x[2] - t->t1[2] };
+	mv3(t->R1, d, xn);
+	if (NH == 2) { xn[0] = xn[0] / t->scale1; xn[1] = xn[1] / t->scale1; xn[2] = xn[2] / t->scale1; }
+	nfeat[3 * (size_t)f] = xn[0]; nfeat[3 * (size_t)f + 1] = xn[1]; nfeat[3 * (size_t)f + 2] = xn[2];
+	// D_f, C_f: Imp.cpp:638-680 / 3587-3684
+	if (NH == 1)
+	{
+		double dd[3] = { xn[0] - t->t[0], xn[1] - t->t[1], xn[2] - t->t[2] }, tmp1[3], tmp2[3], tmp3[3];
+		mv3(t->dRA, dd, tmp1); mv3(t->dRB, dd, tmp2); mv3(t->dRG, dd, tmp3);
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+		{
+			Df[3 * r] = t->R[3 * r]; Df[3 * r + 1] = t->R[3 * r + 1]; Df[3 * r + 2] = t->R[3 * r + 2];
+			Cf[0][6 * r] = -t->R[3 * r]; Cf[0][6 * r + 1] = -t->R[3 * r + 1]; Cf[0][6 * r + 2] = -t->R[3 * r + 2];
+			Cf[0][6 * r + 3] = tmp1[r]; Cf[0][6 * r + 4] = tmp2[r]; Cf[0][6 * r + 5] = tmp3[r];
+		}
+	}
+	else
+	{
+		double adt[9], atmp[9], adtt[9];
+		mono_trans_jac(*t, xn, Df, adt, atmp, adtt);
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+		{
+#pragma unroll
+			for (int c = 0; c < 3; c++) { Cf[0][6 * r + c] = adt[3 * r + c]; Cf[NH - 1][6 * r + c] = adtt[3 * r + c]; Cf[NH - 1][6 * r + 3 + c] = 0.0; }
+			Cf[0][6 * r + 3] = atmp[3 * r]; Cf[0][6 * r + 4] = atmp[3 * r + 1]; Cf[0][6 * r + 5] = atmp[3 * r + 2];
+		}
+		if (t->c2fix) for (int r = 0; r < 3; r++) Cf[0][6 * r + t->newFix] = 0.0;
+		if (t->c3zero) zero<18>(Cf[NH - 1]);
+	}
+	// V' = D_f^T V D_f
+	double V[9], T[9], Vnew[9];
+	ld<9>(V, Vold + (size_t)f * 9);
+	mtm<3, 3, 3, false>(Df, V, T);
+	mm<3, 3, 3, false>(T, Df, Vnew);
+	st<9>(Vn + (size_t)f * 9, Vnew);
+	double* fd = FD + (size_t)f * (9 + 18 * NH);
+	st<9>(fd, Df);
+#pragma unroll
+	for (int s = 0; s < NH; s++) st<18>(fd + 9 + 18 * s, Cf[s]);
+}
+
+template <int NH>
+__global__ void __launch_bounds__(TRE_ROUND, 2)
+k_tr_entries(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const int* __restrict__ fptr,
+             const double* __restrict__ Wold, const int* __restrict__ photo, const int* __restrict__ KW, const double* __restrict__ Dp,
+             const double* __restrict__ Cp, const double* __restrict__ FD, double* __restrict__ Wn_, int* __restrict__ nphoto,
+             int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ)
+{
+	constexpr int GCAP = NH == 1 ? 64 : 32, TW = 18 * NH; // LDS: 18 KB pose table + 36 KB block rows -> two work-groups per CU
 	__shared__ int gkeys[GCAP];
 	__shared__ double gvals[NH * GCAP * 36];
-	for (int i = threadIdx.x; i < GCAP; i += blockDim.x) gkeys[i] = -1;
-	for (int i = threadIdx.x; i < NH * GCAP * 36; i += blockDim.x) gvals[i] = 0.0;
+	__shared__ double sT[TRE_ROUND * 18];
+	__shared__ int sFp[TRE_TILE + 1];
+	const int tid = threadIdx.x;
+	const int f0 = blockIdx.x * TRE_TILE, f1 = min(f0 + TRE_TILE, NF), nft = f1 - f0;
+	for (int i = tid; i < GCAP; i += TRE_ROUND) gkeys[i] = -1;
+	for (int i = tid; i < NH * GCAP * 36; i += TRE_ROUND) gvals[i] = 0.0;
+	for (int i = tid; i <= nft; i += TRE_ROUND) sFp[i] = fptr[f0 + i];
 	__syncthreads();
+	int la = 0; // first feature (tile-local) of the round
+	while (la < nft)
+	{
+		// a round = whole features from la on with at most TRE_ROUND blocks; a longer feature is walked in chunks
+		const int e0 = sFp[la];
+		int lb = la + 1;
+		{
+			int lo = la + 1, hi = nft; // largest lb with sFp[lb] - e0 <= TRE_ROUND (at least la + 1)
+			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] - e0 <= TRE_ROUND) lo = mid; else hi = mid - 1; }
+			lb = lo;
+		}
+		const int e1 = sFp[lb];
+		for (int ce0 = e0; ce0 < e1 || ce0 == e0; ce0 += TRE_ROUND)
+		{
+			const int ce1 = min(ce0 + TRE_ROUND, e1);
+			const int j = ce0 + tid;
+			const bool have = j < ce1;
+			bool act = false;
+			int f = 0, k = 0, sl = -1;
+			double W[18];
+			const double* fd = nullptr;
+			if (have)
+			{
+				int lo = la, hi = lb - 1; // feature of block j: last fl with sFp[fl] <= j
+				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] <= j) lo = mid; else hi = mid - 1; }
+				f = f0 + lo;
+				const TMap* t = &tm[feat_map[f]];
+				k = photo[j];
+				ld<18>(W, Wold + (size_t)j * 18);
+				act = t->active > 0 && t->nh == NH;
+				if (!act)
+				{
+					const int pos = t->W0n + (j - t->W0);
+					st<18>(Wn_ + (size_t)pos * 18, W);
+					nphoto[pos] = k; nfeature[pos] = f;
+				}
+				else
+				{
+					fd = FD + (size_t)f * (9 + TW);
+					const bool hub = (k == t->hub[0]) || (NH == 2 && k == t->hub[1]);
+					if (!hub)
+					{
+						// W' = D_k^T W D_f at its new place: after the feature's hub block(s), old order kept
+						double Dk[36], T1[18], Df[9], Wn[18];
+						ld<36>(Dk, Dp + (size_t)k * 36);
+						mtm<6, 6, 3, false>(Dk, W, T1);
+						ld<9>(Df, fd);
+						mm<6, 3, 3, false>(T1, Df, Wn);
+						const int pos = t->W0n + NH * (f - t->F0 + 1) + (KW[j] - t->kW0);
+						st<18>(Wn_ + (size_t)pos * 18, Wn);
+						nphoto[pos] = k; nfeature[pos] = f;
+					}
+					else
+					{
+						// an old block to a hub pose: the epilogue folds it into the new hub block; remember where it is
+						// (-1 none, >= 0 the block, -2 several -- duplicates add up -- and the epilogue walks the run)
+						int* h = hubJ + (size_t)f * NH + ((k == t->hub[0]) ? 0 : NH - 1);
+						if (atomicCAS(h, -1, j) != -1) atomicExch(h, -2);
+					}
+					sl = lds_slot(gkeys, GCAP, k);
+				}
+			}
+#pragma unroll
+			for (int s = 0; s < NH; s++)
+			{
+				if (act)
+				{
+					double Ck[36], T[18], Cf[18];
+					ld<36>(Ck, Cp + (size_t)s * M * 36 + (size_t)k * 36);
+					zero<18>(T);
+					mtm<6, 3, 6, true>(W, Ck, T); // share of G_s,f: W^T C_s,k   [3x6]
+					st<18>(&sT[tid * 18], T);
+					ld<18>(Cf, fd + 9 + 18 * s);
+					// pose row of G_s: W C_s,f   [6x6], one row at a time
+					double* gl = sl >= 0 ? &gvals[(s * GCAP + sl) * 36] : nullptr;
+					double* gg = Gpose + (size_t)s * M * 36 + (size_t)k * 36;
+#pragma unroll
+					for (int r = 0; r < 6; r++)
+#pragma unroll
+						for (int c = 0; c < 6; c++)
+						{
+							const double v = W[3 * r] * Cf[c] + W[3 * r + 1] * Cf[6 + c] + W[3 * r + 2] * Cf[12 + c];
+							if (gl) lds_add_f64(gl + r * 6 + c, v); else atomic_add_f64(gg + r * 6 + c, v);
+						}
+				}
+				__syncthreads();
+				// per feature sums of the W^T C_s,k rows of this chunk (the rows of inactive maps are never read)
+				for (int idx = tid; idx < (lb - la) * 18; idx += TRE_ROUND)
+				{
+					const int fl = la + idx / 18, q = idx % 18;
+					const int r0 = max(sFp[fl], ce0) - ce0, r1 = min(sFp[fl + 1], ce1) - ce0;
+					const TMap* t = &tm[feat_map[f0 + fl]];
+					if (!(t->active > 0 && t->nh == NH)) continue;
+					double sum = 0.0;
+					for (int r = r0; r < r1; r++) sum += sT[r * 18 + q];
+					double* g = Gsum + (size_t)(f0 + fl) * TW + 18 * s + q;
+					if (sFp[fl] >= ce0) *g = sum; else if (r1 > r0) *g += sum; // first chunk of the feature stores
+				}
+				__syncthreads();
+			}
+			if (ce1 >= e1) break;
+		}
+		la = lb;
+	}
+#pragma unroll
+	for (int s = 0; s < NH; s++) tile_flush<36>(gkeys, gvals + s * GCAP * 36, GCAP, Gpose + (size_t)s * M * 36);
+}
+
+template <int NH>
+__global__ void __launch_bounds__(256)
+k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const int* __restrict__ fptr,
+               const double* __restrict__ Vold, const double* __restrict__ Wold, const int* __restrict__ photo, const double* __restrict__ Dp,
+               const double* __restrict__ FD, const double* __restrict__ Gsum, const int* __restrict__ hubJ, const int* __restrict__ nfptr,
+               double* __restrict__ Wn_,
+               int* __restrict__ nphoto, int* __restrict__ nfeature, double* __restrict__ PP)
+{
+	constexpr int TW = 18 * NH;
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool inb = f < NF;
 	const TMap* t = inb ? &tm[feat_map[f]] : nullptr;
 	const bool act = inb && t->active > 0 && t->nh == NH;
-	int j0 = 0, len = 0, base = 0;
-	double Df[9], Cf[NH][18], G[NH][18], hubW[NH][18], xn[3];
-	int hub0 = -1, hub1 = -1;
-	if (inb)
+	double Df[9], Cf[NH][18], G[NH][18];
+	if (act)
 	{
-		j0 = fptr[f]; len = fptr[f + 1] - j0;
-		const double* x = feat + (size_t)f * 3;
-		if (!act)
-		{
-			// pass-through map: plain copy at the new offsets
-			base = t->W0n + (j0 - t->W0);
-			nfeat[3 * (size_t)f] = x[0]; nfeat[3 * (size_t)f + 1] = x[1]; nfeat[3 * (size_t)f + 2] = x[2];
-			for (int i = 0; i < 9; i++) Vn[(size_t)f * 9 + i] = Vold[(size_t)f * 9 + i];
-			nfptr[f] = base;
-			for (int j = 0; j < len; j++)
-			{
-				for (int i = 0; i < 18; i++) Wn_[(size_t)(base + j) * 18 + i] = Wold[(size_t)(j0 + j) * 18 + i];
-				nphoto[base + j] = photo[j0 + j];
-				nfeature[base + j] = f;
-			}
-		}
-		else
-		{
-			hub0 = t->hub[0]; hub1 = NH == 2 ? t->hub[1] : -1;
-			base = t->W0n + NH * (f - t->F0) + (KW[j0] - t->kW0);
-			nfptr[f] = base;
-			// new feature value, Imp.cpp:449-451 / 3300-3302
-			double d[3] = { x[0] - t->t1[0], x[1] - t->t1[1], x[2] - t->t1[2] };
-			mv3(t->R1, d, xn);
-			if (NH == 2) { xn[0] = xn[0] / t->scale1; xn[1] = xn[1] / t->scale1; xn[2] = xn[2] / t->scale1; }
-			nfeat[3 * (size_t)f] = xn[0]; nfeat[3 * (size_t)f + 1] = xn[1]; nfeat[3 * (size_t)f + 2] = xn[2];
-			// D_f, C_f: Imp.cpp:638-680 / 3587-3684
-			if (NH == 1)
-			{
-				double dd[3] = { xn[0] - t->t[0], xn[1] - t->t[1], xn[2] - t->t[2] }, tmp1[3], tmp2[3], tmp3[3];
-				mv3(t->dRA, dd, tmp1); mv3(t->dRB, dd, tmp2); mv3(t->dRG, dd, tmp3);
-#pragma unroll
-				for (int r = 0; r < 3; r++)
-				{
-					Df[3 * r] = t->R[3 * r]; Df[3 * r + 1] = t->R[3 * r + 1]; Df[3 * r + 2] = t->R[3 * r + 2];
-					Cf[0][6 * r] = -t->R[3 * r]; Cf[0][6 * r + 1] = -t->R[3 * r + 1]; Cf[0][6 * r + 2] = -t->R[3 * r + 2];
-					Cf[0][6 * r + 3] = tmp1[r]; Cf[0][6 * r + 4] = tmp2[r]; Cf[0][6 * r + 5] = tmp3[r];
-				}
-			}
-			else
-			{
-				double adt[9], atmp[9], adtt[9];
-				mono_trans_jac(*t, xn, Df, adt, atmp, adtt);
-#pragma unroll
-				for (int r = 0; r < 3; r++)
-				{
-#pragma unroll
-					for (int c = 0; c < 3; c++) { Cf[0][6 * r + c] = adt[3 * r + c]; Cf[NH - 1][6 * r + c] = adtt[3 * r + c]; Cf[NH - 1][6 * r + 3 + c] = 0.0; }
-					Cf[0][6 * r + 3] = atmp[3 * r]; Cf[0][6 * r + 4] = atmp[3 * r + 1]; Cf[0][6 * r + 5] = atmp[3 * r + 2];
-				}
-				if (t->c2fix) for (int r = 0; r < 3; r++) Cf[0][6 * r + t->newFix] = 0.0;
-				if (t->c3zero) zero<18>(Cf[NH - 1]);
-			}
-			// V' = D_f^T V D_f ; G_s = V C_s (feature row of I C_s)
-			double V[9], T[9];
-			ld<9>(V, Vold + (size_t)f * 9);
-			mtm<3, 3, 3, false>(Df, V, T);
-			double Vnew[9];
-			mm<3, 3, 3, false>(T, Df, Vnew);
-			st<9>(Vn + (size_t)f * 9, Vnew);
-#pragma unroll
-			for (int s = 0; s < NH; s++) { mm<3, 3, 6, false>(V, Cf[s], G[s]); zero<18>(hubW[s]); }
-		}
-	}
-	// run loop: all lanes of the wave iterate together (wave_scatter_add is a wave collective)
-	int maxlen = act ? len : 0;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
-	int kept = 0;
-	for (int it = 0; it < maxlen; it++)
-	{
-		const bool v = act && it < len;
-		double W[18];
-		int k = 0;
-		if (v)
-		{
-			const int j = j0 + it;
-			k = photo[j];
-			ld<18>(W, Wold + (size_t)j * 18);
-			double Dk[36], T[18], Wn[18];
-			ld<36>(Dk, Dp + (size_t)k * 36);
-			mtm<6, 6, 3, false>(Dk, W, T);      // D_k^T W        [6x3]
-			mm<6, 3, 3, false>(T, Df, Wn);      // ... D_f        [6x3]
-			if (k == hub0) { for (int i = 0; i < 18; i++) hubW[0][i] += Wn[i]; }
-			else if (NH == 2 && k == hub1) { for (int i = 0; i < 18; i++) hubW[NH - 1][i] += Wn[i]; }
-			else
-			{
-				const int pos = base + NH + kept;
-				st<18>(Wn_ + (size_t)pos * 18, Wn);
-				nphoto[pos] = k; nfeature[pos] = f;
-				kept++;
-			}
-		}
+		const double* fd = FD + (size_t)f * (9 + TW);
+		ld<9>(Df, fd);
+		double V[9];
+		ld<9>(V, Vold + (size_t)f * 9);
+		const int base = nfptr[f];
+		const int hubs[2] = { t->hub[0], NH == 2 ? t->hub[1] : -1 };
+		double hubW[NH][18];
 #pragma unroll
 		for (int s = 0; s < NH; s++)
 		{
-			double Gp[36];
-			if (v)
-			{
-				double Ck[36];
-				ld<36>(Ck, Cp + (size_t)s * M * 36 + (size_t)k * 36);
-				mtm<6, 3, 6, true>(W, Ck, G[s]);    // G_s,f += W^T C_s,k     [3x6]
-				mm<6, 3, 6, false>(W, Cf[s], Gp);   // pose row: W C_s,f      [6x6]
-			}
-			tile_scatter_add<36>(gkeys, gvals + s * GCAP * 36, GCAP, k, Gpose + (size_t)s * M * 36 + (size_t)(v ? k : 0) * 36, Gp, v);
+			ld<18>(Cf[s], fd + 9 + 18 * s);
+			double Gs[18];
+			ld<18>(Gs, Gsum + (size_t)f * TW + 18 * s);
+			mm<3, 3, 6, false>(V, Cf[s], G[s]); // G_s,f = V C_s,f + sum_k W_kf^T C_s,k
+			for (int i = 0; i < 18; i++) G[s][i] += Gs[i];
+			zero<18>(hubW[s]);
 		}
-	}
-	// leading hub block(s) of the feature: W'(h_s, f) = hubW_s + G_s^T D_f ; C_s^T G_t for the (h,h) blocks
+		// old blocks of the feature to the hub pose(s): their D_k^T W D_f joins the new hub block.  The entry kernel
+		// left the block's index; only duplicates make the lane walk its run
+		bool walk = false;
 #pragma unroll
-	for (int s = 0; s < NH; s++)
-	{
-		if (act)
+		for (int s = 0; s < NH; s++)
+		{
+			const int j = hubJ[(size_t)f * NH + s];
+			if (j == -2) walk = true;
+			if (j < 0) continue;
+			double W[18], Dk[36], T1[18], Wn[18];
+			ld<18>(W, Wold + (size_t)j * 18);
+			ld<36>(Dk, Dp + (size_t)hubs[s] * 36);
+			mtm<6, 6, 3, false>(Dk, W, T1);
+			mm<6, 3, 3, false>(T1, Df, Wn);
+			for (int i = 0; i < 18; i++) hubW[s][i] += Wn[i];
+		}
+		if (walk)
+			for (int j = fptr[f]; j < fptr[f + 1]; j++)
+			{
+				const int k = photo[j];
+				const int s = (k == hubs[0]) ? 0 : ((NH == 2 && k == hubs[1]) ? 1 : -1);
+				if (s < 0 || hubJ[(size_t)f * NH + (s == 0 ? 0 : NH - 1)] != -2) continue;
+				double W[18], Dk[36], T1[18], Wn[18];
+				ld<18>(W, Wold + (size_t)j * 18);
+				ld<36>(Dk, Dp + (size_t)k * 36);
+				mtm<6, 6, 3, false>(Dk, W, T1);
+				mm<6, 3, 3, false>(T1, Df, Wn);
+				for (int i = 0; i < 18; i++) hubW[s == 0 ? 0 : NH - 1][i] += Wn[i];
+			}
+		// leading hub block(s) of the feature: W'(h_s, f) = hubW_s + G_s^T D_f
+#pragma unroll
+		for (int s = 0; s < NH; s++)
 		{
 			double Wh[18];
 			ld<18>(Wh, hubW[s]);
 			mtm<3, 6, 3, true>(G[s], Df, Wh);
 			st<18>(Wn_ + (size_t)(base + s) * 18, Wh);
-			nphoto[base + s] = s == 0 ? hub0 : hub1; nfeature[base + s] = f;
+			nphoto[base + s] = hubs[s]; nfeature[base + s] = f;
 		}
+	}
+	// C_s^T G_t for the (h,h) blocks, summed per map
+#pragma unroll
+	for (int s = 0; s < NH; s++)
 #pragma unroll
 		for (int s2 = s; s2 < NH; s2++)
 		{
@@ -444,13 +578,8 @@ k_tr_features(int NF, int M, const TMap* __restrict__ tm, const int* __restrict_
 			const int mp = act ? feat_map[f] : 0;
 			wave_scatter_add<36>(PP + ((size_t)mp * 3 + idx) * 36, P, act);
 		}
-	}
-	__syncthreads();
-#pragma unroll
-	for (int s = 0; s < NH; s++) tile_flush<36>(gkeys, gvals + s * GCAP * 36, GCAP, Gpose + (size_t)s * M * 36);
 }
 
-// one lane per U block: Imp.cpp:725-1266 / 3767-4984
 template <int NH>
 __global__ void k_tr_ublocks(int NU, int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Uold,
                              const int* __restrict__ Ui, const int* __restrict__ Uj, const int* __restrict__ KU, const double* __restrict__ Dp,
@@ -521,18 +650,22 @@ __global__ void k_tr_poseslots(int M, const TMap* __restrict__ tm, const int* __
                                const double* __restrict__ Cp, const double* __restrict__ Gpose, double* __restrict__ Un, int* __restrict__ nUi,
                                int* __restrict__ nUj, double* __restrict__ PP)
 {
-	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= M) return;
+	const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = k0 < M;
+	const int k = inb ? k0 : 0;
 	const int mp = pose_map[k];
 	const TMap& t = tm[mp];
-	if (t.active <= 0 || t.nh != NH) return;
+	const bool act = inb && t.active > 0 && t.nh == NH; // no early return: the per-map sums below are wave collectives
 	double D[36];
 	ld<36>(D, Dp + (size_t)k * 36);
 	const int h0 = t.hub[0], h1 = NH == 2 ? t.hub[1] : -1;
 	const int slot1 = t.U0n + (k - t.P0), slot2 = t.U0n + t.m + (k - t.P0);
 	// labels, Imp.cpp:711-723 / 3739-3765 (the second set compares against posID as well -- reference quirk)
-	if (k <= h0) { nUi[slot1] = k; nUj[slot1] = h0; } else { nUi[slot1] = h0; nUj[slot1] = k; }
-	if (NH == 2) { if (k <= h0) { nUi[slot2] = k; nUj[slot2] = h1; } else { nUi[slot2] = h1; nUj[slot2] = k; } }
+	if (act)
+	{
+		if (k <= h0) { nUi[slot1] = k; nUj[slot1] = h0; } else { nUi[slot1] = h0; nUj[slot1] = k; }
+		if (NH == 2) { if (k <= h0) { nUi[slot2] = k; nUj[slot2] = h1; } else { nUi[slot2] = h1; nUj[slot2] = k; } }
+	}
 #pragma unroll
 	for (int s = 0; s < NH; s++)
 	{
@@ -540,7 +673,8 @@ __global__ void k_tr_poseslots(int M, const TMap* __restrict__ tm, const int* __
 		ld<36>(G, Gpose + (size_t)s * M * 36 + (size_t)k * 36);
 		mtm<6, 6, 6, false>(D, G, X); // contribution to I'(k, h_s)
 		const int hs = s == 0 ? h0 : h1;
-		if (NH == 2 && s == 1 && k == h0)
+		if (!act) {}
+		else if (NH == 2 && s == 1 && k == h0)
 		{
 			// pair (h_1,h_2): everything goes to the first-set slot of h_2 (the reference splits it over two slots with
 			// the same coordinates; only their sum is defined)
@@ -569,7 +703,7 @@ __global__ void k_tr_poseslots(int M, const TMap* __restrict__ tm, const int* __
 			ld<36>(C, Cp + (size_t)s0 * M * 36 + (size_t)k * 36);
 			mtm<6, 6, 6, false>(C, G, P);
 			const int idx = (s0 == 0 ? s : 2);
-			for (int q = 0; q < 36; q++) atomic_add_f64(PP + ((size_t)mp * 3 + idx) * 36 + q, P[q]);
+			wave_scatter_add<36>(PP + ((size_t)mp * 3 + idx) * 36, P, act);
 		}
 	}
 }
@@ -603,9 +737,18 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 	const int M = in.M;
 	if (in.NF)
 	{
+		// per feature: D_f and C_s,f (written by the prologue, read per W block), sums of W^T C_s,k (entries -> epilogue)
+		double* FD = ctx->scratch.alloc<double>((size_t)in.NF * (9 + 18 * NH));
+		double* Gsum = ctx->scratch.alloc<double>((size_t)in.NF * 18 * NH);
+		int* hubJ = ctx->scratch.alloc<int>((size_t)in.NF * NH);
+		LSFM_CHECK_HIP(hipMemsetAsync(hubJ, 0xff, (size_t)in.NF * NH * sizeof(int), s));
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
-		hipLaunchKernelGGL(k_tr_features<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.feat, in.fptr, in.V,
-		                   in.W, in.photo, KW, Dp, Cp, out.feat, out.fptr, out.V, out.W, out.photo, out.feature, Gpose, PP);
+		hipLaunchKernelGGL(k_tr_feat_pre<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, d_tm, in.feat_map, in.feat, in.fptr, in.V, KW, out.feat,
+		                   out.fptr, out.V, FD);
+		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.W,
+		                   in.photo, KW, Dp, Cp, FD, out.W, out.photo, out.feature, Gsum, Gpose, hubJ);
+		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,
+		                   Dp, FD, Gsum, hubJ, out.fptr, out.W, out.photo, out.feature, PP);
 		if (ctx->stats)
 		{
 			float t = 0;

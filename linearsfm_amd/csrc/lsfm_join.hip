@@ -50,14 +50,18 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
                                 const double* __restrict__ V, const int* __restrict__ fptr, const int* __restrict__ match,
                                 const int* __restrict__ R, const JGroup* __restrict__ grp, int* __restrict__ newf, int* __restrict__ lenE,
                                 int* __restrict__ lenC, double* __restrict__ Vy, double* __restrict__ eF, int* __restrict__ fid_y,
-                                double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC)
+                                double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC, int side)
 {
+	// two launches: side 0 = features of the first map of every pair (plain stores into the zeroed joint arrays), then
+	// side 1 = features of the second map, which add to their match (each joint feature has one writer per launch:
+	// no atomics -- 12 scattered 8-byte atomics per feature cost 0.3 ms per level)
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
 	int mp = feat_map[f];
 	const JGroup& g = grp[mp >> 1];
 	int nf;
 	const bool cur = mp & 1;
+	if ((int)cur != side) return;
 	if (!cur) nf = g.FY0 + (f - g.F0E);
 	else if (match[f] >= 0) nf = g.FY0 + (match[f] - g.F0E);
 	else nf = g.FY0 + g.nE + (R[f] - g.rC0);
@@ -67,9 +71,9 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
 	if (srcE) { if (!cur) srcE[nf] = f; else srcC[nf] = f; }
 	const double* v = V + (size_t)f * 9;
 	const double* x = feat + (size_t)f * 3;
-	for (int i = 0; i < 9; i++) atomic_add_f64(Vy + (size_t)nf * 9 + i, v[i]);
+	for (int i = 0; i < 9; i++) Vy[(size_t)nf * 9 + i] += v[i];
 	// eF += V x  with each map's own estimate (Imp.cpp:2752-2757, 2802-2807, 2874-2879)
-	for (int r = 0; r < 3; r++) atomic_add_f64(eF + (size_t)nf * 3 + r, v[3 * r] * x[0] + v[3 * r + 1] * x[1] + v[3 * r + 2] * x[2]);
+	for (int r = 0; r < 3; r++) eF[(size_t)nf * 3 + r] += v[3 * r] * x[0] + v[3 * r + 1] * x[1] + v[3 * r + 2] * x[2];
 	if (!cur || match[f] < 0)
 	{
 		fid_y[nf] = feat_id[f];
@@ -276,8 +280,9 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
 	dev_zero(ctx, eP, (size_t)in.M * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
 	if (in.NF)
-		hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,
-		                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, (int*)nullptr, (int*)nullptr);
+		for (int side = 0; side < 2; side++)
+			hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,
+			                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, (int*)nullptr, (int*)nullptr, side);
 	hipLaunchKernelGGL(k_add_lens, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY, lenE, lenC, lens);
 	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
 	if (in.NW)

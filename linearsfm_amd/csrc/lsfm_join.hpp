@@ -19,7 +19,7 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
                                 const double* __restrict__ V, const int* __restrict__ fptr, const int* __restrict__ match,
                                 const int* __restrict__ R, const JGroup* __restrict__ grp, int* __restrict__ newf, int* __restrict__ lenE,
                                 int* __restrict__ lenC, double* __restrict__ Vy, double* __restrict__ eF, int* __restrict__ fid_y,
-                                double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC);
+                                double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC, int side);
 __global__ void k_add_lens(int n, const int* __restrict__ a, const int* __restrict__ b, int* __restrict__ out);
 
 } // namespace lsfm

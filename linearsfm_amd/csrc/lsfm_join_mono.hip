@@ -386,8 +386,9 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	hipLaunchKernelGGL(k_fill_int, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY + 1, srcE, -1);
 	hipLaunchKernelGGL(k_fill_int, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY + 1, srcC, -1);
 	if (in.NF)
-		hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, RF, d_grp,
-		                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, srcE, srcC);
+		for (int side = 0; side < 2; side++)
+			hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, RF, d_grp,
+			                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, srcE, srcC, side);
 	hipLaunchKernelGGL(k_mono_w_count, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY, srcE, srcC, in.fptr, in.photo, out.feat_map, d_mg, lens);
 	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
 	{

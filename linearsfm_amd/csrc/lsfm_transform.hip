@@ -581,62 +581,87 @@ k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict
 }
 
 template <int NH>
-__global__ void k_tr_ublocks(int NU, int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Uold,
-                             const int* __restrict__ Ui, const int* __restrict__ Uj, const int* __restrict__ KU, const double* __restrict__ Dp,
-                             const double* __restrict__ Cp, double* __restrict__ Un, int* __restrict__ nUi, int* __restrict__ nUj,
-                             double* __restrict__ Gpose)
+__global__ void __launch_bounds__(128, 1)
+k_tr_ublocks(int NU, int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Uold,
+             const int* __restrict__ Ui, const int* __restrict__ Uj, const int* __restrict__ KU, const double* __restrict__ Dp,
+             const double* __restrict__ Cp, double* __restrict__ Un, int* __restrict__ nUi, int* __restrict__ nUj,
+             double* __restrict__ Gpose)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= NU) return;
+	// pose rows of G: summed per work-group in an LDS table first (the hub rows collect a block from every pose: 108
+	// scattered 8-byte atomics per lane ran at the 0.08 TB/s of 64-rows-per-instruction atomics)
+	constexpr int GCAP = 64;
+	__shared__ int gkeys[GCAP];
+	__shared__ double gvals[NH * GCAP * 36];
+	for (int q = threadIdx.x; q < GCAP; q += blockDim.x) gkeys[q] = -1;
+	for (int q = threadIdx.x; q < NH * GCAP * 36; q += blockDim.x) gvals[q] = 0.0;
+	__syncthreads();
+	const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = i0 < NU;
+	const int i = inb ? i0 : 0;
 	const int a = Ui[i], b = Uj[i];
 	const TMap& t = tm[pose_map[a]];
+	const bool act = inb && t.active > 0 && t.nh == NH;
 	double U[36];
 	ld<36>(U, Uold + (size_t)i * 36);
-	if (t.active <= 0)
+	if (inb && t.active <= 0)
 	{
 		const int pos = t.U0n + (i - t.U0);
 		st<36>(Un + (size_t)pos * 36, U);
 		nUi[pos] = a; nUj[pos] = b;
-		return;
 	}
-	if (t.nh != NH) return;
-	double Da[36], Db[36], T1[36], T[36];
-	ld<36>(Da, Dp + (size_t)a * 36); ld<36>(Db, Dp + (size_t)b * 36);
-	mtm<6, 6, 6, false>(Da, U, T1);
-	mm<6, 6, 6, false>(T1, Db, T);            // D_a^T U D_b, block (a,b) with a<=b
-	int slot = -1;                            // Imp.cpp:1079-1094 / 4249-4271
-	if (a == t.hub[0]) slot = t.U0n + (b - t.P0);
-	else if (b == t.hub[0]) slot = t.U0n + (a - t.P0);
-	else if (NH == 2 && a == t.hub[1]) slot = t.U0n + t.m + (b - t.P0);
-	else if (NH == 2 && b == t.hub[1]) slot = t.U0n + t.m + (a - t.P0);
-	if (slot >= 0)
+	if (act)
 	{
-		for (int q = 0; q < 36; q++) atomic_add_f64(Un + (size_t)slot * 36 + q, T[q]);
+		double T1[36], T[36];
+		{
+			double Da[36];
+			ld<36>(Da, Dp + (size_t)a * 36);
+			mtm<6, 6, 6, false>(Da, U, T1);
+		}
+		{
+			double Db[36];
+			ld<36>(Db, Dp + (size_t)b * 36);
+			mm<6, 6, 6, false>(T1, Db, T);        // D_a^T U D_b, block (a,b) with a<=b
+		}
+		int slot = -1;                            // Imp.cpp:1079-1094 / 4249-4271
+		if (a == t.hub[0]) slot = t.U0n + (b - t.P0);
+		else if (b == t.hub[0]) slot = t.U0n + (a - t.P0);
+		else if (NH == 2 && a == t.hub[1]) slot = t.U0n + t.m + (b - t.P0);
+		else if (NH == 2 && b == t.hub[1]) slot = t.U0n + t.m + (a - t.P0);
+		if (slot >= 0)
+		{
+			for (int q = 0; q < 36; q++) atomic_add_f64(Un + (size_t)slot * 36 + q, T[q]);
+		}
+		else
+		{
+			const int pos = t.U0n + NH * t.m + (KU[i] - t.kU0);
+			st<36>(Un + (size_t)pos * 36, T);
+			nUi[pos] = a; nUj[pos] = b;
+		}
 	}
-	else
-	{
-		const int pos = t.U0n + NH * t.m + (KU[i] - t.kU0);
-		st<36>(Un + (size_t)pos * 36, T);
-		nUi[pos] = a; nUj[pos] = b;
-	}
-	// pose rows of G_s = I C_s : G_a += U C_b ; a != b: G_b += U^T C_a
+	// pose rows of G_s = I C_s : G_a += U C_b ; a != b: G_b += U^T C_a   (wave collectives: every lane takes part)
 #pragma unroll
 	for (int s = 0; s < NH; s++)
 	{
 		double C[36], Y[36];
-		ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)b * 36);
-		mm<6, 6, 6, false>(U, C, Y);
-		for (int q = 0; q < 36; q++) atomic_add_f64(Gpose + (size_t)s * M * 36 + (size_t)a * 36 + q, Y[q]);
-		if (a != b)
+		if (act)
+		{
+			ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)b * 36);
+			mm<6, 6, 6, false>(U, C, Y);
+		}
+		tile_scatter_add<36>(gkeys, gvals + s * GCAP * 36, GCAP, a, Gpose + (size_t)s * M * 36 + (size_t)a * 36, Y, act);
+		const bool off = act && a != b;
+		if (off)
 		{
 			ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)a * 36);
 			mtm<6, 6, 6, false>(U, C, Y);
-			for (int q = 0; q < 36; q++) atomic_add_f64(Gpose + (size_t)s * M * 36 + (size_t)b * 36 + q, Y[q]);
 		}
+		tile_scatter_add<36>(gkeys, gvals + s * GCAP * 36, GCAP, b, Gpose + (size_t)s * M * 36 + (size_t)b * 36, Y, off);
 	}
+	__syncthreads();
+#pragma unroll
+	for (int s = 0; s < NH; s++) tile_flush<36>(gkeys, gvals + s * GCAP * 36, GCAP, Gpose + (size_t)s * M * 36);
 }
 
-// adds X (a contribution to I'(r,c), r != c allowed in any order) to the stored upper-orientation block
 __device__ __forceinline__ void add_oriented(double* dst, const double* X, int r, int c)
 {
 	if (r < c) { for (int q = 0; q < 36; q++) dst[q] += X[q]; }

@@ -102,39 +102,47 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
 	const int tid = threadIdx.x, nt = blockDim.x;
 	__shared__ double sLi[36];
-	if (tid == 0)
+	if (tid < LSFM_WAVE)
 	{
-		double A[36], Lc[36], Li[36];
-		ld<36>(A, L + (size_t)c0 * 36);
-		zero<36>(Lc); zero<36>(Li);
+		// 6x6 Cholesky and its inverse by the first wave: lane 6 r + c holds element (r,c), pivots and columns travel
+		// by shuffles (one thread doing it alone took ~3 us of the ~5 us column step on the critical path)
+		const bool in = tid < 36;
+		const int r = in ? tid / 6 : 0, c = in ? tid % 6 : 0;
+		double a = in ? L[(size_t)c0 * 36 + tid] : 0.0;
 		bool ok = true;
-		for (int c = 0; c < 6; c++)
+#pragma unroll
+		for (int k = 0; k < 6; k++)
 		{
-			double d = A[c * 6 + c];
-			for (int k = 0; k < c; k++) d -= Lc[c * 6 + k] * Lc[c * 6 + k];
+			double d = __shfl(a, k * 6 + k, LSFM_WAVE);
 			if (!(d > 0)) { ok = false; d = 1.0; }
-			Lc[c * 6 + c] = sqrt(d);
-			for (int i = c + 1; i < 6; i++)
-			{
-				double s = A[i * 6 + c];
-				for (int k = 0; k < c; k++) s -= Lc[i * 6 + k] * Lc[c * 6 + k];
-				Lc[i * 6 + c] = s / Lc[c * 6 + c];
-			}
+			const double piv = sqrt(d);
+			if (in && c == k) a = (r == k) ? piv : (r > k ? a / piv : a);
+			const double lrk = __shfl(a, r * 6 + k, LSFM_WAVE), lck = __shfl(a, c * 6 + k, LSFM_WAVE);
+			if (in && r > k && c > k) a -= lrk * lck;
 		}
-		if (!ok) atomicExch(err, 1 + j);
-		for (int c = 0; c < 6; c++)
+		if (c > r) a = 0.0;
+		if (!ok && tid == 0) atomicExch(err, 1 + j);
+		if (in) L[(size_t)c0 * 36 + tid] = a;
+		// inverse, column `tid` per lane (lanes 0..5): L x = e_tid by forward substitution, L's entries broadcast
+		double x[6];
+#pragma unroll
+		for (int i = 0; i < 6; i++)
 		{
-			Li[c * 6 + c] = 1.0 / Lc[c * 6 + c];
-			for (int i = c + 1; i < 6; i++)
+			double sacc = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+			for (int k = 0; k < i; k++) sacc -= __shfl(a, i * 6 + k, LSFM_WAVE) * x[k];
+			x[i] = sacc / __shfl(a, i * 6 + i, LSFM_WAVE);
+		}
+		if (tid < 6)
+		{
+#pragma unroll
+			for (int i = 0; i < 6; i++)
 			{
-				double s = 0;
-				for (int k = c; k < i; k++) s -= Lc[i * 6 + k] * Li[k * 6 + c];
-				Li[i * 6 + c] = s / Lc[i * 6 + i];
+				const double v = i >= tid ? x[i] : 0.0;
+				sLi[i * 6 + tid] = v;
+				Dinv[(size_t)j * 36 + i * 6 + tid] = v;
 			}
 		}
-		st<36>(L + (size_t)c0 * 36, Lc);
-		st<36>(Dinv + (size_t)j * 36, Li);
-		for (int q = 0; q < 36; q++) sLi[q] = Li[q];
 	}
 	__syncthreads();
 	// L_ij = A_ij * Li^T : one thread per (block, row)
@@ -156,6 +164,7 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 }
 
 // one trailing update of column j: blocks a >= b below the diagonal give L_a L_b^T, subtracted from block (ra, rb)
+template <bool ATOMIC>
 __device__ __forceinline__ void chol_pair_update(int c0, int a, int b, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L)
 {
 	const int ra = rowidx[c0 + 1 + a], rb = rowidx[c0 + 1 + b];
@@ -169,7 +178,8 @@ __device__ __forceinline__ void chol_pair_update(int c0, int a, int b, const int
 	int pos = cb + (a - b);
 	if (!(a - b < nb && rowidx[pos] == ra)) pos = find_row(rowidx, cb, cb + nb, ra);
 	double* d = L + (size_t)pos * 36;
-	for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -T[q]);
+	if (ATOMIC) { for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -T[q]); }
+	else { for (int q = 0; q < 36; q++) d[q] -= T[q]; } // the caller owns the target column: one pair per target block
 }
 // trailing updates of column j: all pairs a >= b, pair index pr = first, first+stride, ...
 __device__ void chol_column_update(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
@@ -182,7 +192,7 @@ __device__ void chol_column_update(int j, const int* __restrict__ colptr, const 
 		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
 		while (a * (a + 1) / 2 > pr) a--;
 		while ((a + 1) * (a + 2) / 2 <= pr) a++;
-		chol_pair_update(c0, a, pr - a * (a + 1) / 2, colptr, rowidx, L);
+		chol_pair_update<true>(c0, a, pr - a * (a + 1) / 2, colptr, rowidx, L);
 	}
 }
 // the pairs whose target column rb is one of the first m rows (the rows inside the task): needed before the task's next column
@@ -192,20 +202,51 @@ __device__ void chol_column_update_inner(int j, int m, const int* __restrict__ c
 	for (int idx = first; idx < m * n; idx += stride)
 	{
 		const int b = idx / n, a = idx - b * n;
-		if (a >= b) chol_pair_update(c0, a, b, colptr, rowidx, L);
+		if (a >= b) chol_pair_update<false>(c0, a, b, colptr, rowidx, L); // in-task columns: only this work-group touches them now
 	}
 }
-// the pairs with b >= m: targets in columns outside the task, nobody inside the task waits for them
+// the pairs with b >= m: targets in columns outside the task, nobody inside the task waits for them.  Other columns
+// update the same blocks, so these are atomics -- made contiguous: every lane parks its 6x6 product in LDS and the
+// work-group adds block after block with consecutive lanes on consecutive doubles (one lane per block scatters 64
+// rows per wave instruction: ~0.1 TB/s)
+#define CHOL_OUT_THREADS 128
 __device__ void chol_column_update_outer(int j, int m, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
 {
+	__shared__ double sT[CHOL_OUT_THREADS * 37];
+	__shared__ int spos[CHOL_OUT_THREADS];
 	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1 - m;
 	const int npairs = n * (n + 1) / 2;
-	for (int pr = first; pr < npairs; pr += stride)
+	const int tid = threadIdx.x;
+	for (int base = first; base < npairs; base += stride)
 	{
-		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
-		while (a * (a + 1) / 2 > pr) a--;
-		while ((a + 1) * (a + 2) / 2 <= pr) a++;
-		chol_pair_update(c0, a + m, pr - a * (a + 1) / 2 + m, colptr, rowidx, L);
+		const int pr = base + tid;
+		int pos = -1;
+		if (pr < npairs)
+		{
+			int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+			while (a * (a + 1) / 2 > pr) a--;
+			while ((a + 1) * (a + 2) / 2 <= pr) a++;
+			const int b = pr - a * (a + 1) / 2 + m;
+			a += m;
+			const int ra = rowidx[c0 + 1 + a], rb = rowidx[c0 + 1 + b];
+			double La[36], Lb[36], T[36];
+			ld<36>(La, L + (size_t)(c0 + 1 + a) * 36);
+			ld<36>(Lb, L + (size_t)(c0 + 1 + b) * 36);
+			mmt<6, 6, 6, false>(La, Lb, T);
+			const int cb = colptr[rb], nb = colptr[rb + 1] - cb;
+			pos = cb + (a - b);
+			if (!(a - b < nb && rowidx[pos] == ra)) pos = find_row(rowidx, cb, cb + nb, ra);
+			for (int q = 0; q < 36; q++) sT[tid * 37 + q] = T[q];
+		}
+		spos[tid] = pos;
+		__syncthreads();
+		for (int idx = tid; idx < CHOL_OUT_THREADS * 36; idx += CHOL_OUT_THREADS)
+		{
+			const int p = idx / 36, q = idx - p * 36;
+			const int ps = spos[p];
+			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[p * 37 + q]);
+		}
+		__syncthreads();
 	}
 }
 
@@ -330,11 +371,12 @@ __global__ void __launch_bounds__(256) k_chol_factor_tasks(const int* __restrict
 	}
 }
 // the deferred updates of the level's tasks, into the columns above them: one column per blockIdx.x, pairs split over blockIdx.y
-__global__ void __launch_bounds__(256) k_chol_update_outer(const int* __restrict__ cols, const int* __restrict__ col_nin, const int* __restrict__ colptr,
-                                                            const int* __restrict__ rowidx, double* __restrict__ L)
+__global__ void __launch_bounds__(CHOL_OUT_THREADS) k_chol_update_outer(const int* __restrict__ cols, const int* __restrict__ col_nin,
+                                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                                         double* __restrict__ L)
 {
 	const int j = cols[blockIdx.x];
-	chol_column_update_outer(j, col_nin[j], colptr, rowidx, L, blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
+	chol_column_update_outer(j, col_nin[j], colptr, rowidx, L, blockIdx.y * CHOL_OUT_THREADS, gridDim.y * CHOL_OUT_THREADS);
 }
 // Triangular solves by task.  The entries of v that belong to the task's own columns live in LDS while the work-group
 // walks the task: a column step inside a task then costs LDS latency instead of a global atomic + fence round trip
@@ -679,7 +721,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			if (!n) continue;
 			hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
 			const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
-			if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, (mp + 255) / 256), dim3(256), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
+			if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 		}
 		return;
 	}

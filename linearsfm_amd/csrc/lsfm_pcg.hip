@@ -534,6 +534,10 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 	Arena& sc = ctx->scratch;
 	const std::vector<unsigned long long>& keys = in.keys;
 	const std::vector<int>& origin = in.origin;
+	// every index array of the analysis goes to the device in ONE copy (each copy is a host-device round trip)
+	std::vector<int> blob;
+	std::vector<std::pair<int**, size_t>> blob_dst;
+	auto pack = [&](int** dst, const std::vector<int>& v) { blob_dst.emplace_back(dst, blob.size()); blob.insert(blob.end(), v.begin(), v.end()); };
 	std::vector<int> deg(M, 0), sep(M, 0);
 	for (int e = 0; e < nnzb; e++)
 	{
@@ -689,19 +693,16 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 			const int no = ccount[j] - 1 - m, l = tlev[task[j]];
 			ch.tlevel_outer[l] = std::max(ch.tlevel_outer[l], no * (no + 1) / 2);
 		}
-		ch.col_nin = sc.alloc<int>(M);
-		h2d(ctx, ch.col_nin, nin.data(), M * sizeof(int));
-		ch.col_task = sc.alloc<int>(M); ch.col_lpos = sc.alloc<int>(M);
-		h2d(ctx, ch.col_task, ctask.data(), M * sizeof(int)); h2d(ctx, ch.col_lpos, clpos.data(), M * sizeof(int));
-		ch.task_cols = sc.alloc<int>(M); ch.task_ptr = sc.alloc<int>(ntasks + 1);
-		h2d(ctx, ch.task_cols, tcols.data(), M * sizeof(int)); h2d(ctx, ch.task_ptr, tptr.data(), (ntasks + 1) * sizeof(int));
+		pack(&ch.col_nin, nin); pack(&ch.col_task, ctask); pack(&ch.col_lpos, clpos); pack(&ch.task_cols, tcols); pack(&ch.task_ptr, tptr);
 	}
-	ch.colptr = sc.alloc<int>(M + 1); ch.rowidx = sc.alloc<int>(nnzL); ch.perm = sc.alloc<int>(M); ch.pinv = sc.alloc<int>(M);
-	ch.order = sc.alloc<int>(M); ch.L = sc.alloc<double>((size_t)nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)M * 36);
+	pack(&ch.colptr, colptr); pack(&ch.rowidx, rowidx); pack(&ch.perm, perm); pack(&ch.pinv, pinv); pack(&ch.order, order);
+	{
+		int* d_blob = sc.alloc<int>(blob.size());
+		h2d(ctx, d_blob, blob.data(), blob.size() * sizeof(int));
+		for (auto& pd : blob_dst) *pd.first = d_blob + pd.second;
+	}
+	ch.L = sc.alloc<double>((size_t)nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)M * 36);
 	ch.d_err = sc.alloc<int>(1);
-	h2d(ctx, ch.colptr, colptr.data(), (M + 1) * sizeof(int)); h2d(ctx, ch.rowidx, rowidx.data(), (size_t)nnzL * sizeof(int));
-	h2d(ctx, ch.perm, perm.data(), M * sizeof(int)); h2d(ctx, ch.pinv, pinv.data(), M * sizeof(int));
-	h2d(ctx, ch.order, order.data(), M * sizeof(int));
 	dev_zero(ctx, ch.d_err, sizeof(int));
 	dev_zero(ctx, ch.L, (size_t)nnzL * 36 * sizeof(double));
 }
@@ -927,8 +928,10 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		int row = 0;
 		for (int g = 0; g < nseg; g++) { memset(&hseg[g], 0, sizeof(PcgSeg)); hseg[g].row0 = row; row += io.seg_rows[g]; }
 	}
-	PcgSeg* seg = sc.alloc<PcgSeg>(nseg);
-	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg);
+	PcgSeg* seg = sc.alloc<PcgSeg>(2 * (size_t)nseg); // [nseg, 2 nseg): accumulators of the final residual check
+	hseg.resize(2 * (size_t)nseg);
+	std::copy(hseg.begin(), hseg.begin() + nseg, hseg.begin() + nseg);
+	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * 2 * nseg);
 	double* x = io.x_pose;
 	const size_t nscal = (size_t)M * 6;
 	double* r = sc.alloc<double>(nscal); double* z = sc.alloc<double>(nscal); double* p = sc.alloc<double>(nscal);
@@ -970,39 +973,33 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d task levels=%d | analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
 		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, (int)ch.tlevel_ptr.size() - 1, tw1 - tw0, tw2 - tw1, its, wall() - tw2);
 	}
-	// ---- true residual, statistics; SpMV launches timed with HIP events on this stream ----
-	const int nsample = 5;
+	// ---- true residual, statistics; one SpMV launch timed with HIP events on this stream.  Nothing here waits for
+	// the device before the back-substitution is enqueued: the per-system sums come back in one copy at the end ----
+	const int nsample = 1;
 	float sp_ms = 0;
-	for (int k = 0; k < nsample; k++)
-	{
-		dev_zero(ctx, Ap, nscal * sizeof(double));
-		LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
-		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
-		LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
-		LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
-		float t = 0;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
-		sp_ms += t;
-	}
-	std::vector<PcgSeg> hs2(nseg);
-	d2h(ctx, hs2.data(), seg, sizeof(PcgSeg) * nseg);
-	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * nseg); // zeroed accumulators
-	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg, 1);
-	d2h(ctx, hseg.data(), seg, sizeof(PcgSeg) * nseg);
+	PcgSeg* seg2 = seg + nseg; // zeroed accumulators of the final residual
+	dev_zero(ctx, Ap, nscal * sizeof(double));
+	LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
+	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
+	LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg2, 1);
+	LSFM_CHECK_HIP(hipEventRecord(ec, s));
+	launch_backsub(ctx, io, sy, x);
+	LSFM_CHECK_HIP(hipGetLastError());
+	LSFM_CHECK_HIP(hipEventRecord(ed, s));
+	std::vector<PcgSeg> hs2(2 * (size_t)nseg);
+	d2h(ctx, hs2.data(), seg, sizeof(PcgSeg) * 2 * nseg); // synchronises
+	LSFM_CHECK_HIP(hipEventElapsedTime(&sp_ms, ctx->ev0, ctx->ev1));
 	int notconv = 0;
 	double maxrel = 0;
 	for (int g = 0; g < nseg; g++)
 	{
 		if (!hs2[g].active) continue;
-		const double rel = hseg[g].ee > 0 ? sqrt(hseg[g].rr / hseg[g].ee) : 0.0;
+		const PcgSeg& fin = hs2[nseg + g];
+		const double rel = fin.ee > 0 ? sqrt(fin.rr / fin.ee) : 0.0;
 		maxrel = std::max(maxrel, rel);
 		if (hs2[g].done != 1 && !(rel < 1e-9)) notconv++;
 	}
-	LSFM_CHECK_HIP(hipEventRecord(ec, s));
-	launch_backsub(ctx, io, sy, x);
-	LSFM_CHECK_HIP(hipGetLastError());
-	LSFM_CHECK_HIP(hipEventRecord(ed, s));
-	LSFM_CHECK_HIP(hipEventSynchronize(ed));
 	if (ctx->stats)
 	{
 		lsfm_stats* st = ctx->stats;

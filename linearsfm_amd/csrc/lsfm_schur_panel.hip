@@ -25,6 +25,7 @@ namespace lsfm {
 #define PM_ROWS (6 * PM_SMAX)
 #define PM_HASH 64
 #define PM_THREADS 256
+#define PM_MAXE 4096 /* W blocks of the tile whose slot is kept in LDS (one byte each); later ones probe the hash again */
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -57,12 +58,13 @@ struct PmShared {
 	double Ls[PM_PASS * 6]; // l00 l10 l11 l20 l21 l22 of V^-1 = L L^T
 	double ys[PM_K];        // L^T eb
 	double P[PM_ROWS * PM_KS];
+	unsigned char eslot[PM_MAXE]; // slot of the tile's W blocks, filled once: the passes do not touch photo[] again
 };
 
 // T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + 4 t; slots past the last
 // tile recompute tile (0,0) and are dropped)
 template <int T>
-__device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, const int* __restrict__ fptr, const int* __restrict__ photo,
+__device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                         const double* __restrict__ W, const double* __restrict__ IV, const double* __restrict__ eb,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
@@ -92,6 +94,31 @@ __device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, co
 		acc[t] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
 	}
 	double eacc = 0.0;
+	// W rows of the next pass are fetched into registers before the MFMA loop of the current one: the staging after the
+	// barrier then works on LDS only (measured: staging with the global loads inside cost 4.5 of K9's 9.5 ms)
+	// Staging is by feature: 16 lanes per feature of the pass walk the rows of its blocks (3 doubles each, consecutive
+	// lanes on consecutive rows), so a lane knows its feature without searching the run pointers.
+	constexpr int PF = T <= 9 ? 8 : (T <= 14 ? 2 : 1); // rows per lane held in flight (register budget of the variant)
+	const int sfl = tid >> 4, sl16 = tid & 15;
+	double pw[PF][3];
+	auto prefetch = [&](int p0n) {
+		const int nfn = min(PM_PASS, f1 - p0n);
+		if (sfl < nfn)
+		{
+			const int qbn = fptr[p0n + sfl], nrown = (fptr[p0n + sfl + 1] - qbn) * 6;
+#pragma unroll
+			for (int i = 0; i < PF; i++)
+			{
+				const int w = sl16 + 16 * i;
+				if (w < nrown)
+				{
+					const double* wr = W + (size_t)qbn * 18 + (size_t)w * 3; // row r of block e: (qb + e) * 18 + 3 r
+					pw[i][0] = wr[0]; pw[i][1] = wr[1]; pw[i][2] = wr[2];
+				}
+			}
+		}
+	};
+	if (f0 < f1) prefetch(f0);
 	for (int p0 = f0; p0 < f1; p0 += PM_PASS)
 	{
 		const int nf = min(PM_PASS, f1 - p0);
@@ -123,27 +150,43 @@ __device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, co
 			for (int q = 0; q < 3; q++) sh.ys[tid * 3 + q] = y[q];
 		}
 		__syncthreads();
-		// stage P = W L: one lane per row of a W block (6 consecutive lanes read one block's 144 bytes); two blocks of
-		// one (pose, feature) add up, as in the reference's pair loop
-		const int qb = sh.fp[0], nrow = (sh.fp[nf] - qb) * 6;
-		for (int w = tid; w < nrow; w += PM_THREADS)
+		// stage P = W L
+		if (sfl < nf)
 		{
-			const int e = w / 6, r = w - 6 * e, j = qb + e;
-			int fl = 0;
-			while (fl + 1 < nf && sh.fp[fl + 1] <= j) fl++;
-			const int key = photo[j];
-			unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-			while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
-			const int sl = sh.hslot[h];
-			const double* wr = W + (size_t)j * 18 + 3 * r;
-			const double w0 = wr[0], w1 = wr[1], w2 = wr[2];
-			const double* l = &sh.Ls[fl * 6];
-			double* d = &sh.P[(6 * sl + r) * PM_KS + 3 * fl];
-			__hip_atomic_fetch_add(d + 0, w0 * l[0] + w1 * l[1] + w2 * l[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			__hip_atomic_fetch_add(d + 1, w1 * l[2] + w2 * l[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			__hip_atomic_fetch_add(d + 2, w2 * l[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const int qb = sh.fp[sfl], nrow = (sh.fp[sfl + 1] - qb) * 6;
+			const double* l = &sh.Ls[sfl * 6];
+			const double l0 = l[0], l1 = l[1], l2 = l[2], l3 = l[3], l4 = l[4], l5 = l[5];
+			auto stage = [&](int w, double w0, double w1, double w2) {
+				const int e = w / 6, r = w - 6 * e, j = qb + e;
+				int sl;
+				if (j - jb < PM_MAXE) sl = sh.eslot[j - jb];
+				else
+				{
+					const int key = photo[j];
+					unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+					while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+					sl = sh.hslot[h];
+				}
+				double* d = &sh.P[(6 * sl + r) * PM_KS + 3 * sfl];
+				// two blocks of one (pose, feature) add up, as in the reference's pair loop: atomics
+				__hip_atomic_fetch_add(d + 0, w0 * l0 + w1 * l1 + w2 * l3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_add(d + 1, w1 * l2 + w2 * l4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_add(d + 2, w2 * l5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			};
+#pragma unroll
+			for (int i = 0; i < PF; i++)
+			{
+				const int w = sl16 + 16 * i;
+				if (w < nrow) stage(w, pw[i][0], pw[i][1], pw[i][2]);
+			}
+			for (int w = sl16 + 16 * PF; w < nrow; w += 16)
+			{
+				const double* wr = W + (size_t)qb * 18 + (size_t)w * 3;
+				stage(w, wr[0], wr[1], wr[2]);
+			}
 		}
 		__syncthreads();
+		if (p0 + PM_PASS < f1) prefetch(p0 + PM_PASS);
 		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328
 		if (tid < rows)
 		{
@@ -258,8 +301,16 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		if (tid == 0) fallback[blockIdx.x] = 1;
 		return;
 	}
+	for (int j = jb + tid; j < je && j - jb < PM_MAXE; j += PM_THREADS)
+	{
+		const int key = photo[j];
+		unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+		while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+		sh.eslot[j - jb] = (unsigned char)sh.hslot[h];
+	}
+	// (visible to the passes through the barrier at the top of the first pass)
 	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + 3) >> 2; // tiles per wave, uniform
-#define PM_GO(T) pm_body<T>(sh, ns, f0, f1, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
+#define PM_GO(T) pm_body<T>(sh, ns, f0, f1, jb, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
 	if (tpw <= 1) PM_GO(1);
 	else if (tpw <= 3) PM_GO(3);
 	else if (tpw <= 6) PM_GO(6);

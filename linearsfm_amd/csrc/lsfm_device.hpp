@@ -296,4 +296,49 @@ __device__ __forceinline__ void tile_flush(const int* keys, const double* vals, 
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// entry-parallel walk over the runs of a tile of features (W blocks of a feature are contiguous: run pointers fptr)
+// ---------------------------------------------------------------------------------------------------------
+// One lane per W block, consecutive lanes on consecutive blocks (coalesced), in rounds of blockDim.x blocks made of
+// whole features (a longer run is cut into chunks).  entry(j, fl, out) computes TW values for block j of tile-local
+// feature fl; they are summed per feature through LDS and handed to feat(fl, q, sum, first) once per feature and
+// chunk (first = the chunk holds the feature's first block).  sFp: LDS, nft + 1 run pointers of the tile; sT: LDS,
+// blockDim.x * TW doubles.  All threads of the work-group must call it.
+template <int TW, class EntryFn, class FeatFn>
+__device__ __forceinline__ void tile_runs(int nft, const int* sFp, double* sT, EntryFn entry, FeatFn feat)
+{
+	const int tid = threadIdx.x, nt = blockDim.x;
+	int la = 0;
+	while (la < nft)
+	{
+		const int e0 = sFp[la];
+		int lo = la + 1, hi = nft; // largest lb with sFp[lb] - e0 <= nt (at least la + 1)
+		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] - e0 <= nt) lo = mid; else hi = mid - 1; }
+		const int lb = lo, e1 = sFp[lb];
+		for (int ce0 = e0;; ce0 += nt)
+		{
+			const int ce1 = min(ce0 + nt, e1);
+			const int j = ce0 + tid;
+			if (j < ce1)
+			{
+				int l2 = la, h2 = lb - 1; // feature of block j: last fl with sFp[fl] <= j
+				while (l2 < h2) { const int mid = (l2 + h2 + 1) >> 1; if (sFp[mid] <= j) l2 = mid; else h2 = mid - 1; }
+				entry(j, l2, &sT[tid * TW]);
+			}
+			__syncthreads();
+			for (int idx = tid; idx < (lb - la) * TW; idx += nt)
+			{
+				const int fl = la + idx / TW, q = idx % TW;
+				const int r0 = max(sFp[fl], ce0) - ce0, r1 = min(sFp[fl + 1], ce1) - ce0;
+				double sum = 0.0;
+				for (int r = r0; r < r1; r++) sum += sT[r * TW + q];
+				if (r1 > r0 || sFp[fl] >= ce0) feat(fl, q, sum, sFp[fl] >= ce0);
+			}
+			__syncthreads();
+			if (ce1 >= e1) break;
+		}
+		la = lb;
+	}
+}
+
 } // namespace lsfm

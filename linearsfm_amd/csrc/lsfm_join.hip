@@ -106,7 +106,9 @@ __global__ void k_join_wcopy(int NW, const double* __restrict__ W, const int* __
 }
 
 // right-hand side: eF += W^T x_pose, eP += W x_feat (each block with the estimates of the map it came from),
-// Imp.cpp:2770-2786, 2822-2838, 2891-2906.  One lane per joint feature.
+// Imp.cpp:2770-2786, 2822-2838, 2891-2906.  One lane per W block of the joint map (coalesced); the feature sums go
+// through LDS per run, the pose sums through an LDS table flushed once per work-group.
+#define RHS_TILE 512 /* joint features per work-group */
 __global__ void __launch_bounds__(256)
 k_join_rhs_w(int NFY, const int* __restrict__ fptr_y, const double* __restrict__ Wy, const int* __restrict__ photo_y,
              const int* __restrict__ srcf, const double* __restrict__ pose, const double* __restrict__ feat, double* __restrict__ eP,
@@ -115,42 +117,38 @@ k_join_rhs_w(int NFY, const int* __restrict__ fptr_y, const double* __restrict__
 	constexpr int ECAP = 128;
 	__shared__ int ekeys[ECAP];
 	__shared__ double evals[ECAP * 6];
+	__shared__ int sFp[RHS_TILE + 1];
+	__shared__ double sT[256 * 3];
+	const int f0 = blockIdx.x * RHS_TILE, nft = min(RHS_TILE, NFY - f0);
 	for (int i = threadIdx.x; i < ECAP; i += blockDim.x) ekeys[i] = -1;
 	for (int i = threadIdx.x; i < ECAP * 6; i += blockDim.x) evals[i] = 0.0;
+	for (int i = threadIdx.x; i <= nft; i += blockDim.x) sFp[i] = fptr_y[f0 + i];
 	__syncthreads();
-	int nf = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool inb = nf < NFY;
-	int j0 = 0, len = 0;
-	if (inb) { j0 = fptr_y[nf]; len = fptr_y[nf + 1] - j0; }
-	int maxlen = len;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
-	double ef[3] = { 0, 0, 0 };
-	for (int it = 0; it < maxlen; it++)
-	{
-		const bool v = inb && it < len;
-		double y[6];
-		int k = 0;
-		if (v)
-		{
-			int j = j0 + it;
-			k = photo_y[j];
-			double W[18];
+	tile_runs<3>(nft, sFp, sT,
+		[&](int j, int, double* out) {
+			const int k = photo_y[j];
+			double W[18], xp[6], xf[3];
 			ld<18>(W, Wy + (size_t)j * 18);
-			const double* xp = pose + (size_t)k * 6;
-			const double* xf = feat + (size_t)srcf[j] * 3;
+			ld<6>(xp, pose + (size_t)k * 6);
+			ld<3>(xf, feat + (size_t)srcf[j] * 3);
+			const int sl = lds_slot(ekeys, ECAP, k);
 #pragma unroll
-			for (int r = 0; r < 6; r++) y[r] = W[3 * r] * xf[0] + W[3 * r + 1] * xf[1] + W[3 * r + 2] * xf[2];
+			for (int r = 0; r < 6; r++)
+			{
+				const double y = W[3 * r] * xf[0] + W[3 * r + 1] * xf[1] + W[3 * r + 2] * xf[2];
+				if (sl >= 0) lds_add_f64(&evals[sl * 6 + r], y); else atomic_add_f64(eP + (size_t)k * 6 + r, y);
+			}
 #pragma unroll
 			for (int c = 0; c < 3; c++)
+			{
+				double sacc = 0.0;
 #pragma unroll
-				for (int r = 0; r < 6; r++) ef[c] = fma(W[3 * r + c], xp[r], ef[c]);
-		}
-		tile_scatter_add<6>(ekeys, evals, ECAP, k, eP + (size_t)(v ? k : 0) * 6, y, v);
-	}
-	if (inb) { eF[(size_t)nf * 3] += ef[0]; eF[(size_t)nf * 3 + 1] += ef[1]; eF[(size_t)nf * 3 + 2] += ef[2]; }
-	__syncthreads();
-	tile_flush<6>(ekeys, evals, ECAP, eP);
+				for (int r = 0; r < 6; r++) sacc = fma(W[3 * r + c], xp[r], sacc);
+				out[c] = sacc;
+			}
+		},
+		[&](int fl, int q, double sum, bool) { eF[(size_t)(f0 + fl) * 3 + q] += sum; });
+	tile_flush<6>(ekeys, evals, ECAP, eP); // tile_runs ends with a barrier
 }
 
 // eP += U x, eP += U^T x for off-diagonal blocks, Imp.cpp:2666-2688
@@ -290,7 +288,7 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 		                   newf, lenE, out.fptr, out.W, out.photo, out.feature, srcf);
 	// ---- right-hand sides ----
 	if (NFY)
-		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + 255) / 256), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);
+		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);
 	if (in.NU)
 		hipLaunchKernelGGL(k_join_rhs_u, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, in.U, in.Ui, in.Uj, in.pose, eP);
 	LSFM_CHECK_HIP(hipGetLastError());

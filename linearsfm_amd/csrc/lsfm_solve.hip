@@ -326,27 +326,46 @@ k_spmv(int nchunks, const int* __restrict__ chunk_row, const int* __restrict__ c
 	}
 }
 
-// K11: one lane per feature (Imp.cpp:2980-3020); features of carried maps keep their values
-__global__ void k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
-                          const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,
-                          const int* __restrict__ feat_seg, const unsigned char* __restrict__ active, double* __restrict__ xf)
+// K11 (Imp.cpp:2980-3020); features of carried maps keep their values
+#define BSUB_TILE 512 /* features per work-group */
+__global__ void __launch_bounds__(256)
+k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
+          const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,
+          const int* __restrict__ feat_seg, const unsigned char* __restrict__ active, double* __restrict__ xf)
 {
-	int f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= NF) return;
-	if (active && !active[feat_seg[f]]) return;
-	double eb2[3] = { 0, 0, 0 };
-	for (int j = fptr[f]; j < fptr[f + 1]; j++)
+	// one lane per W block (coalesced): W^T x_p, summed per feature through LDS; then x_f = V^-1 (eb - sum)
+	__shared__ int sFp[BSUB_TILE + 1];
+	__shared__ double sT[256 * 3];
+	__shared__ double sS[BSUB_TILE * 3];
+	const int f0 = blockIdx.x * BSUB_TILE, nft = min(BSUB_TILE, NF - f0);
+	for (int i = threadIdx.x; i <= nft; i += blockDim.x) sFp[i] = fptr[f0 + i];
+	for (int i = threadIdx.x; i < nft * 3; i += blockDim.x) sS[i] = 0.0;
+	__syncthreads();
+	tile_runs<3>(nft, sFp, sT,
+		[&](int j, int, double* out) {
+			double w[18];
+			ld<18>(w, W + (size_t)j * 18);
+			const double* a = xp + (size_t)photo[j] * 6;
+			double a6[6];
+			ld<6>(a6, a);
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+			{
+				double sacc = 0.0;
+#pragma unroll
+				for (int r = 0; r < 6; r++) sacc = fma(w[3 * r + c], a6[r], sacc);
+				out[c] = sacc;
+			}
+		},
+		[&](int fl, int q, double sum, bool) { sS[fl * 3 + q] += sum; });
+	for (int fl = threadIdx.x; fl < nft; fl += blockDim.x)
 	{
-		const double* w = W + (size_t)j * 18;
-		const double* a = xp + (size_t)photo[j] * 6;
-#pragma unroll
-		for (int c = 0; c < 3; c++)
-#pragma unroll
-			for (int r = 0; r < 6; r++) eb2[c] = fma(w[3 * r + c], a[r], eb2[c]);
+		const int f = f0 + fl;
+		if (active && !active[feat_seg[f]]) continue;
+		const double* iv = IV + (size_t)f * 9;
+		const double d[3] = { eb[(size_t)f * 3] - sS[fl * 3], eb[(size_t)f * 3 + 1] - sS[fl * 3 + 1], eb[(size_t)f * 3 + 2] - sS[fl * 3 + 2] };
+		for (int r = 0; r < 3; r++) xf[(size_t)f * 3 + r] = iv[3 * r] * d[0] + iv[3 * r + 1] * d[1] + iv[3 * r + 2] * d[2];
 	}
-	const double* iv = IV + (size_t)f * 9;
-	double d[3] = { eb[(size_t)f * 3] - eb2[0], eb[(size_t)f * 3 + 1] - eb2[1], eb[(size_t)f * 3 + 2] - eb2[2] };
-	for (int r = 0; r < 3; r++) xf[(size_t)f * 3 + r] = iv[3 * r] * d[0] + iv[3 * r + 1] * d[1] + iv[3 * r + 2] * d[2];
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -488,7 +507,7 @@ double spmv_bytes(const SchurSystem& sy) { return (double)sy.nnzb * (288 + 4) + 
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x)
 {
 	if (io.NF)
-		hipLaunchKernelGGL(k_backsub, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x,
+		hipLaunchKernelGGL(k_backsub, dim3((io.NF + BSUB_TILE - 1) / BSUB_TILE), dim3(256), 0, ctx->stream, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x,
 		                   io.d_feat_seg, io.d_seg_active, io.x_feat);
 }
 

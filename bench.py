@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 # HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 guide
 # prescribes + WRITE_SIZE; separate --pmc runs), averaged over the launches of one tree run.  None = not collected.
 # Source: profiles/r01_pmc_traffic_summary.json (from r01_pmc_{FETCH,WRITE}_SIZE_counter_collection.csv, 3499-map run).
-TRAFFIC = {"schur": 9.148e8, "trf": 2.012e9}
+TRAFFIC = {"schur": 7.559e8, "trf": 1.4107e9}
 
 
 def cpu_baseline(maps, sample_maps):
@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--maps", type=int, default=3499, help="local maps (3499 = NC3500-like)")
     ap.add_argument("--new-per-frame", type=int, default=130)
     ap.add_argument("--vis", type=int, default=5)
-    ap.add_argument("--cpu-sample", type=int, default=384, help="local maps given to the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="local maps given to the CPU baseline (0 = skip)")
     ap.add_argument("--tol", type=float, default=1e-15)
     args = ap.parse_args()
 
@@ -105,8 +105,8 @@ def main():
         # Per-kernel live measurements (HIP events on the library's stream around the launches, accumulated over the timed
         # steps).  The roofline object describes whichever of the instrumented kernels took the most device time.
         kern = {}
-        for key, name in (("schur", "k_schur_panel + k_schur_w fallback tiles (K9: Schur assembly S -= W V^-1 W^T, E -= W V^-1 eb)"),
-                          ("trf", "k_tr_features (K3/K4: information transform I' = J^T I J of the W/V blocks)"),
+        for key, name in (("schur", "k_schur_panel + k_schur_w fallback tiles (K9: Schur assembly S -= W V^-1 W^T, E -= W V^-1 eb; fp64 MFMA)"),
+                          ("trf", "k_tr_entries (K3/K4: information transform I' = J^T I J, one lane per W block)"),
                           ("spmv", "k_spmv (K10a: 6x6-block symmetric SpMV of the CG)")):
             n = max(1, acc[f"{key}_launches"])
             kern[key] = dict(name=name, total_ms=acc[f"{key}_ms"] / args.steps, launches_per_step=acc[f"{key}_launches"] / args.steps,
@@ -159,8 +159,10 @@ def main():
             g_out = c2.tree_download(tr)
             c2.tree_free(tr)
             c2.close()
+            from tools.full_parity import rel_poses
             mask = o_out["stno"] <= 0
             perr = float(np.max(np.abs(g_out["stVal"][mask] - o_out["stVal"][mask]) / np.maximum(1.0, np.abs(o_out["stVal"][mask]))))
+            rerr = float(np.max(np.abs(rel_poses(g_out["stVal"], o_out["stno"]) - rel_poses(o_out["stVal"], o_out["stno"]))))
             line["cpu_baseline"] = {"value": 1e3 * timing[0], "unit": "ms", "cores": 1, "kind": "port",
                                     "sample": f"first {S} of the {args.maps} local maps (same generator/seed), whole join tree, "
                                               f"oracle/lsfm_oracle.c single thread, sort-based feature matching; host has "
@@ -168,7 +170,11 @@ def main():
                                     "oracle_breakdown_ms": {"transform": 1e3 * timing[1], "join_assembly": 1e3 * timing[2],
                                                             "schur_cholesky_backsub": 1e3 * timing[3]},
                                     "gpu_same_sample_ms": st2["t_total_ms"],
-                                    "pose_param_max_rel_err_vs_oracle": perr}
+                                    "pose_param_max_rel_err_vs_oracle": perr,
+                                    "consecutive_frame_relative_pose_max_abs_err_vs_oracle": rerr,
+                                    "parity_note": "global pose parameters of a long open chain are conditioned ~1e12 at the top joins: "
+                                                   "two fp64 solves differ above 1e-6 there (DESIGN.md section 5); the relative poses "
+                                                   "between consecutive frames are the well-determined quantities"}
         print(json.dumps(line))
     ctx.close()
     if world > 1:

@@ -767,24 +767,25 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		double* Gsum = ctx->scratch.alloc<double>((size_t)in.NF * 18 * NH);
 		int* hubJ = ctx->scratch.alloc<int>((size_t)in.NF * NH);
 		LSFM_CHECK_HIP(hipMemsetAsync(hubJ, 0xff, (size_t)in.NF * NH * sizeof(int), s));
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
 		hipLaunchKernelGGL(k_tr_feat_pre<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, d_tm, in.feat_map, in.feat, in.fptr, in.V, KW, out.feat,
 		                   out.fptr, out.V, FD);
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s)); // the events bracket k_tr_entries alone
 		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.W,
 		                   in.photo, KW, Dp, Cp, FD, out.W, out.photo, out.feature, Gsum, Gpose, hubJ);
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
 		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,
 		                   Dp, FD, Gsum, hubJ, out.fptr, out.W, out.photo, out.feature, PP);
 		if (ctx->stats)
 		{
 			float t = 0;
-			LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
 			LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
 			LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
 			ctx->stats->trf_launches++;
 			ctx->stats->trf_ms += t;
-			// in: W block + photo per entry, V + value + run pointer per feature; out: W' block + photo' + feature' per entry,
-			// V' + value + run pointer per feature
-			ctx->stats->trf_bytes += (double)in.NW * (144 + 4) + (double)out.NW * (144 + 8) + 2.0 * in.NF * (72 + 24 + 4);
+			// k_tr_entries, every input and output once.  in: W block + photo + kept-rank per block, D_f/C_f + run pointer
+			// + map per feature; out: W' block + photo' + feature' per kept block, the W^T C sums per feature
+			ctx->stats->trf_bytes += (double)in.NW * (144 + 4 + 4) + (double)in.NF * ((9 + 18 * NH) * 8 + 8) +
+			                         (double)(out.NW - (double)NH * in.NF) * (144 + 8) + (double)in.NF * 18 * NH * 8;
 		}
 	}
 	if (in.NU)

@@ -89,10 +89,14 @@ def test_solver_entry_point_residual(ctx, oracle):
     assert np.linalg.norm(r) / np.linalg.norm(E) < 1e-9
 
 
-@pytest.mark.parametrize("N,npf,vis,seed", [(2, 6, 4, 1), (3, 5, 4, 2), (8, 4, 5, 3), (33, 6, 5, 4), (88, 20, 5, 5)])
+@pytest.mark.parametrize("N,npf,vis,seed", [(1, 6, 4, 7), (2, 6, 4, 1), (3, 5, 4, 2), (8, 4, 5, 3), (33, 6, 5, 4), (88, 20, 5, 5),
+                                            (40, 4, 40, 8), (280, 1, 270, 9)])
 def test_tree_stereo_vs_oracle(ctx, oracle, N, npf, vis, seed):
     """Whole hierarchical join (lmj_PF3D_Divide_ConquerStereo) on the device vs the oracle, same seeded inputs.
-    N=3, 33 exercise the unpaired carry (Imp.cpp:1940-1948) and the re-anchoring of odd outputs (Imp.cpp:1997)."""
+    N=1: nothing to join.  N=3, 33 exercise the unpaired carry (Imp.cpp:1940-1948) and the re-anchoring of odd outputs
+    (Imp.cpp:1997).  vis=40: features seen by more than 32 poses -> the Schur tiles exceed the panel kernel's slots and
+    take the per-feature kernel.  vis=270: runs of more than 256 W blocks per feature -> the chunked path of the
+    block-parallel kernels."""
     maps = synth.make_stereo_set(N, new_per_frame=npf, vis=vis, seed=seed)
     dicts = [oracle.localmap_to_dict(m) for m in maps]
     exp, _, rc = oracle.divide_conquer(dicts, False)
@@ -178,7 +182,8 @@ def test_mono_join_assembly_and_solve_vs_golden(ctx, oracle, name):
         assert np.max(np.abs(st - sol) / np.maximum(1, np.abs(sol))) < SOLVE_TOL
 
 
-@pytest.mark.parametrize("N,npf,vis,seed", [(2, 8, 4, 1), (3, 8, 4, 2), (5, 6, 4, 3), (8, 6, 5, 4), (33, 8, 4, 5), (88, 40, 4, 6)])
+@pytest.mark.parametrize("N,npf,vis,seed", [(2, 8, 4, 1), (3, 8, 4, 2), (5, 6, 4, 3), (8, 6, 5, 4), (33, 8, 4, 5), (88, 40, 4, 6),
+                                            (40, 6, 38, 9)])
 def test_tree_mono_vs_oracle(ctx, oracle, N, npf, vis, seed):
     """lmj_PF3D_Divide_ConquerMono on the device vs the oracle (88 maps = the RS90-like configuration's map count)."""
     maps = synth.make_mono_set(N, new_per_frame=npf, vis=vis, seed=seed)

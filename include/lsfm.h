@@ -144,6 +144,10 @@ int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono
 
 /* ---- file formats (Imp.cpp:3044-3132, 6660-6754, 2102-2117, 7876-7967) ---------------------------- */
 int lsfm_read_localmap(const char* path, int mono, lsfm_map* out); /* out: library-allocated */
+/* dir/localmap_<first>.txt ... localmap_<first+count-1>.txt (the loop around lmj_readInformation*, Imp.cpp:125 naming)
+ * on `threads` host threads (<= 0: one per core, at most 32); out[count] library-allocated, filled in order.  On a
+ * failure nothing is kept and *failed (optional) is the number of the first file that could not be read. */
+int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int threads, lsfm_map* out, int* failed);
 int lsfm_save_state(const char* path, const double* st, const int* stno, int n);
 int lsfm_save_poses(const char* pose_path, const char* feat_path, const int* stno, const double* st, int n);
 

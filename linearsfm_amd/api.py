@@ -79,6 +79,7 @@ def lib():
         L.lsfm_tree_free.restype = None
         L.lsfm_divide_conquer.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(LsfmMap), P(LsfmStats)]
         L.lsfm_read_localmap.argtypes = [C.c_char_p, C.c_int, P(LsfmMap)]
+        L.lsfm_read_localmaps.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P(LsfmMap), P(C.c_int)]
         L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
@@ -90,7 +91,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download",
-           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_save_state", "lsfm_save_poses",
+           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench"]
 
 
@@ -271,3 +272,13 @@ def read_localmap(path, mono):
     if rc:
         raise LsfmError(f"lsfm_read_localmap({path}) failed (rc={rc})")
     return map_to_dict(g)
+
+
+def read_localmaps(directory, count, mono, first=1, threads=0):
+    """localmap_<first>.txt ... of a directory, parsed on `threads` host threads (0: one per core)."""
+    arr = (LsfmMap * count)()
+    bad = C.c_int(0)
+    rc = lib().lsfm_read_localmaps(str(directory).encode(), int(first), int(count), int(mono), int(threads), arr, C.byref(bad))
+    if rc:
+        raise LsfmError(f"lsfm_read_localmaps({directory}) failed at localmap_{bad.value}.txt (rc={rc})")
+    return [map_to_dict(arr[k]) for k in range(count)]

@@ -62,11 +62,14 @@ int main(int argc, char** argv)
 	if (type < 0) { printf("LinerSFM Error: Please Set Data Type:\n"); return 0; }
 
 	std::vector<lsfm_map> maps(num);
-	for (int k = 0; k < num; k++)
 	{
-		char fn[4096];
-		snprintf(fn, sizeof fn, "%s/localmap_%d.txt", path.c_str(), k + 1); // Imp.cpp:125
-		if (lsfm_read_localmap(fn, type, &maps[k])) { fprintf(stderr, "LinearSFM: cannot read %s\n", fn); return 1; }
+		// localmap_1.txt ... localmap_<num>.txt (Imp.cpp:125), parsed on all host cores
+		int bad = 0;
+		if (lsfm_read_localmaps(path.c_str(), 1, num, type, 0, maps.data(), &bad))
+		{
+			fprintf(stderr, "LinearSFM: cannot read %s/localmap_%d.txt\n", path.c_str(), bad);
+			return 1;
+		}
 	}
 	lsfm_context* ctx = nullptr;
 	int rc = lsfm_context_create(gpu, 0, &ctx);

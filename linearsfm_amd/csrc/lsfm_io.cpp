@@ -12,49 +12,187 @@ namespace {
 template <class T> T* xalloc(size_t n) { return static_cast<T*>(malloc((n ? n : 1) * sizeof(T))); }
 }
 
+// Reader.  The reference reads a local map token by token with fscanf (Imp.cpp:3044-3132 / 6660-6754); a 3499-map set
+// is some GB of text and that loop is the largest wall-clock item outside the timed region.  Here a file is read in
+// one piece and tokenised in place (integers and the common decimals by hand, exactly rounded, the rest by strtod: the values are
+// bit-identical to "%lf"); lsfm_read_localmaps() spreads the files of a set over host threads.
+#include <atomic>
+#include <string>
+#include <thread>
+
+namespace {
+
+struct Tok {
+	const char* p;
+	const char* end;
+	bool ok = true;
+	void skip() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r' || *p == '\f' || *p == '\v')) p++; }
+	int geti()
+	{
+		skip();
+		if (p >= end) { ok = false; return 0; }
+		bool neg = false;
+		if (*p == '-' || *p == '+') { neg = *p == '-'; p++; }
+		if (p >= end || *p < '0' || *p > '9') { ok = false; return 0; }
+		long long v = 0;
+		while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; }
+		return (int)(neg ? -v : v);
+	}
+	// Decimal -> double.  Fast path (Clinger): a mantissa of at most 2^53 and a power of ten up to 10^22 are exact
+	// doubles, so one IEEE multiplication or division gives the correctly rounded value -- the same bits as "%lf".
+	// Everything else (more digits, large exponents, inf/nan, hexadecimal) goes to strtod on a bounded copy.
+	double slow(const char* start)
+	{
+		char tmp[512];
+		size_t n = std::min<size_t>(sizeof tmp - 1, (size_t)(end - start));
+		memcpy(tmp, start, n); tmp[n] = 0;
+		char* e = nullptr;
+		const double v = strtod(tmp, &e);
+		if (e == tmp) { ok = false; return 0; }
+		p = start + (e - tmp);
+		return v;
+	}
+	double getd()
+	{
+		static const double p10[23] = { 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+			                            1e17, 1e18, 1e19, 1e20, 1e21, 1e22 };
+		skip();
+		if (p >= end) { ok = false; return 0; }
+		const char* start = p;
+		const char* q = p;
+		bool neg = false;
+		if (*q == '-' || *q == '+') { neg = *q == '-'; q++; }
+		unsigned long long m = 0;
+		int nd = 0, e10 = 0;
+		bool any = false;
+		while (q < end && *q >= '0' && *q <= '9') { if (nd < 19) { m = m * 10 + (unsigned)(*q - '0'); if (m) nd++; } else e10++; q++; any = true; }
+		if (q < end && *q == '.')
+		{
+			q++;
+			while (q < end && *q >= '0' && *q <= '9') { if (nd < 19) { m = m * 10 + (unsigned)(*q - '0'); if (m) nd++; e10--; } q++; any = true; }
+		}
+		if (!any) return slow(start); // inf, nan, or not a number
+		bool inexact = nd >= 19; // digits were dropped: let strtod round
+		if (q < end && (*q == 'e' || *q == 'E'))
+		{
+			const char* r = q + 1;
+			bool eneg = false;
+			if (r < end && (*r == '-' || *r == '+')) { eneg = *r == '-'; r++; }
+			if (r < end && *r >= '0' && *r <= '9')
+			{
+				int ev = 0;
+				while (r < end && *r >= '0' && *r <= '9') { if (ev < 100000) ev = ev * 10 + (*r - '0'); r++; }
+				e10 += eneg ? -ev : ev;
+				q = r;
+			}
+		}
+		else if (q < end && (*q == 'x' || *q == 'X')) return slow(start); // hexadecimal float
+		if (inexact || m > (1ull << 53) || e10 > 22 || e10 < -22) return slow(start);
+		double v = (double)m;
+		if (e10 > 0) v *= p10[e10]; else if (e10 < 0) v /= p10[-e10];
+		p = q;
+		return neg ? -v : v;
+	}
+};
+
+int parse_localmap(const char* buf, size_t len, int mono, lsfm_map* g)
+{
+	Tok t{ buf, buf + len };
+	memset(g, 0, sizeof *g);
+	g->Ref = t.geti();
+	g->FRef = g->Ref;
+	g->Sign = 1;
+	if (mono)
+	{
+		g->ScaP = t.geti(); g->FScaP = g->ScaP;
+		g->Fix = t.geti(); g->FFix = g->Fix;
+		g->Sign = t.geti();
+	}
+	const int r = t.geti();
+	if (!t.ok || r < 0) return LSFM_ERR_IO;
+	g->stno = xalloc<int>(r); g->stVal = xalloc<double>(r);
+	for (int i = 0; i < r && t.ok; i++) { g->stno[i] = t.geti(); g->stVal[i] = t.getd(); }
+	g->m = t.geti(); g->n = t.geti(); g->nU = t.geti();
+	if (!t.ok || g->nU < 0 || g->m < 0 || g->n < 0 || 6L * g->m + 3L * g->n != r) { lsfm_map_release(g); return LSFM_ERR_IO; }
+	g->U = xalloc<double>((size_t)g->nU * 36); g->Ui = xalloc<int>(g->nU); g->Uj = xalloc<int>(g->nU);
+	for (long i = 0; i < 36L * g->nU && t.ok; i++) g->U[i] = t.getd();
+	for (int i = 0; i < g->nU && t.ok; i++) g->Ui[i] = t.geti();
+	for (int i = 0; i < g->nU && t.ok; i++) g->Uj[i] = t.geti();
+	g->nW = t.geti();
+	if (!t.ok || g->nW < 0) { lsfm_map_release(g); return LSFM_ERR_IO; }
+	g->W = xalloc<double>((size_t)g->nW * 18); g->photo = xalloc<int>(g->nW); g->feature = xalloc<int>(g->nW);
+	for (long i = 0; i < 18L * g->nW && t.ok; i++) g->W[i] = t.getd();
+	for (int i = 0; i < g->nW && t.ok; i++) g->photo[i] = t.geti();
+	for (int i = 0; i < g->nW && t.ok; i++) g->feature[i] = t.geti();
+	g->V = xalloc<double>((size_t)g->n * 9); g->FBlock = xalloc<int>(g->n);
+	g->pose_origin = NULL;
+	for (long i = 0; i < 9L * g->n && t.ok; i++) g->V[i] = t.getd();
+	for (int i = 0; i < g->n && t.ok; i++) g->FBlock[i] = t.geti();
+	if (!t.ok) { lsfm_map_release(g); return LSFM_ERR_IO; }
+	return LSFM_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 int lsfm_read_localmap(const char* path, int mono, lsfm_map* g)
 {
 	if (!path || !g) return LSFM_ERR_ARG;
-	FILE* f = fopen(path, "r");
+	FILE* f = fopen(path, "rb");
 	if (!f) return LSFM_ERR_IO;
-	memset(g, 0, sizeof *g);
-	bool ok = true;
-	int r = 0;
-	ok &= fscanf(f, "%d", &g->Ref) == 1;
-	g->FRef = g->Ref;
-	g->Sign = 1;
-	if (mono)
+	std::vector<char> buf;
+	if (fseek(f, 0, SEEK_END) == 0)
 	{
-		ok &= fscanf(f, "%d", &g->ScaP) == 1; g->FScaP = g->ScaP;
-		ok &= fscanf(f, "%d", &g->Fix) == 1; g->FFix = g->Fix;
-		ok &= fscanf(f, "%d", &g->Sign) == 1;
+		const long sz = ftell(f);
+		rewind(f);
+		if (sz > 0) { buf.resize((size_t)sz); buf.resize(fread(buf.data(), 1, (size_t)sz, f)); }
 	}
-	ok &= fscanf(f, "%d", &r) == 1;
-	if (!ok || r < 0) { fclose(f); return LSFM_ERR_IO; }
-	g->stno = xalloc<int>(r); g->stVal = xalloc<double>(r);
-	for (int i = 0; i < r && ok; i++) ok &= fscanf(f, "%d %lf", &g->stno[i], &g->stVal[i]) == 2;
-	ok &= fscanf(f, "%d", &g->m) == 1;
-	ok &= fscanf(f, "%d", &g->n) == 1;
-	ok &= fscanf(f, "%d", &g->nU) == 1;
-	if (!ok || g->nU < 0 || 6 * g->m + 3 * g->n != r) { fclose(f); lsfm_map_release(g); return LSFM_ERR_IO; }
-	g->U = xalloc<double>((size_t)g->nU * 36); g->Ui = xalloc<int>(g->nU); g->Uj = xalloc<int>(g->nU);
-	for (long i = 0; i < 36L * g->nU && ok; i++) ok &= fscanf(f, "%lf", &g->U[i]) == 1;
-	for (int i = 0; i < g->nU && ok; i++) ok &= fscanf(f, "%d", &g->Ui[i]) == 1;
-	for (int i = 0; i < g->nU && ok; i++) ok &= fscanf(f, "%d", &g->Uj[i]) == 1;
-	ok &= fscanf(f, "%d", &g->nW) == 1;
-	if (!ok || g->nW < 0) { fclose(f); lsfm_map_release(g); return LSFM_ERR_IO; }
-	g->W = xalloc<double>((size_t)g->nW * 18); g->photo = xalloc<int>(g->nW); g->feature = xalloc<int>(g->nW);
-	for (long i = 0; i < 18L * g->nW && ok; i++) ok &= fscanf(f, "%lf", &g->W[i]) == 1;
-	for (int i = 0; i < g->nW && ok; i++) ok &= fscanf(f, "%d", &g->photo[i]) == 1;
-	for (int i = 0; i < g->nW && ok; i++) ok &= fscanf(f, "%d", &g->feature[i]) == 1;
-	g->V = xalloc<double>((size_t)g->n * 9); g->FBlock = xalloc<int>(g->n);
-	g->pose_origin = NULL;
-	for (long i = 0; i < 9L * g->n && ok; i++) ok &= fscanf(f, "%lf", &g->V[i]) == 1;
-	for (int i = 0; i < g->n && ok; i++) ok &= fscanf(f, "%d", &g->FBlock[i]) == 1;
+	if (buf.empty())
+	{
+		// not seekable (pipe): read in pieces
+		char tmp[65536];
+		size_t n;
+		while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+	}
 	fclose(f);
-	if (!ok) { lsfm_map_release(g); return LSFM_ERR_IO; }
+	return parse_localmap(buf.data(), buf.size(), mono, g);
+}
+
+// localmap_<first>.txt .. localmap_<first+count-1>.txt of a directory (naming of the reference, Imp.cpp:125) on
+// `threads` host threads (<= 0: one per core, at most 32).  out[count] is filled in order; on failure everything read so
+// far is released, LSFM_ERR_IO is returned and *failed (optional) is the number of a file that could not be read.
+int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int threads, lsfm_map* out, int* failed)
+{
+	if (!dir || !out || count < 0) return LSFM_ERR_ARG;
+	if (failed) *failed = 0;
+	if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+	threads = std::max(1, std::min(threads, count));
+	std::atomic<int> next(0), bad(0);
+	for (int k = 0; k < count; k++) memset(&out[k], 0, sizeof(lsfm_map));
+	auto work = [&]() {
+		for (;;)
+		{
+			const int k = next.fetch_add(1);
+			if (k >= count) return;
+			const std::string fn = std::string(dir) + "/localmap_" + std::to_string(first + k) + ".txt";
+			if (lsfm_read_localmap(fn.c_str(), mono, &out[k]) != LSFM_OK)
+			{
+				int expect = 0;
+				bad.compare_exchange_strong(expect, first + k);
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < threads; t++) pool.emplace_back(work);
+	work();
+	for (auto& th : pool) th.join();
+	if (bad.load())
+	{
+		for (int k = 0; k < count; k++) lsfm_map_release(&out[k]);
+		if (failed) *failed = bad.load();
+		return LSFM_ERR_IO;
+	}
 	return LSFM_OK;
 }
 

@@ -138,3 +138,48 @@ def test_oracle_cli_and_output_formats(oracle, tmp_path):
     assert all(len(l.split()) == 4 for l in open(f))
     assert all(len(l.split()) == 2 for l in open(s))
     assert len(poses[0][1].split(".")[1]) == 6  # %lf
+
+
+def test_reader_number_forms_are_exact(tmp_path):
+    """The product reader tokenises by hand; every number form scanf("%lf") accepts must give the same bits as the C
+    library (= Python float): short decimals (fast path), 17-digit decimals, exponents, signs, inf/nan, leading zeros."""
+    from linearsfm_amd import api
+    toks = ["0.5", "-0.000000", "+1.5", "12345.678901", "123456789.123456", "0.1", "1e-3", "1E5", "-2.5e+10", "007.250",
+            "0.12345678901234567", "9007199254740993", "1234567890123456789012", "1e23", "4.9e-324", "1.7976931348623157e308",
+            "inf", "-inf", "3", "-7", ".5", "5.", "1e-400", "0x1.8p1"]
+    vals = [float.fromhex(t) if t.startswith("0x") else float(t) for t in toks]
+    r = 6 + 3 * ((len(toks) - 6 + 2) // 3)
+    vals_p = vals + [0.0] * (r - len(vals))
+    toks_p = toks + ["0"] * (r - len(toks))
+    n = (r - 6) // 3
+    p = tmp_path / "localmap_1.txt"
+    with open(p, "w") as f:
+        f.write("3\n%d\n" % r)
+        for i, t in enumerate(toks_p):
+            f.write("%d   %s\n" % (-4 if i < 6 else 1 + (i - 6) // 3, t))
+        f.write("1 %d 1\n" % n + " ".join(["1.25"] * 36) + "\n0\n0\n0\n\n\n" + " ".join(["2"] * (9 * n)) + "\n" + " ".join(["-1"] * n) + "\n")
+    g = api.read_localmap(str(p), False)
+    assert g["m"] == 1 and g["n"] == n and g["nU"] == 1 and g["nW"] == 0
+    got = np.asarray(g["stVal"])
+    exp = np.asarray(vals_p)
+    assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), [(t, a, b) for t, a, b in zip(toks_p, got, exp) if a != b]
+    assert np.all(np.asarray(g["U"]) == 1.25) and np.all(np.asarray(g["V"]) == 2.0)
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_parallel_set_reader_equals_reference_reader(oracle, tmp_path, mono):
+    """lsfm_read_localmaps (threads) == one lsfm_read_localmap per file == the fscanf port of Imp.cpp:3044-3132 / 6660-6754."""
+    from linearsfm_amd import api
+    maps = synth.make_mono_set(7, 6, 4, seed=3) if mono else synth.make_stereo_set(7, 6, 4, seed=3)
+    synth.write_set(str(tmp_path), maps)
+    par = api.read_localmaps(str(tmp_path), 7, mono, threads=3)
+    for k in range(7):
+        fn = str(tmp_path / f"localmap_{k + 1}.txt")
+        ref = oracle.map_to_dict(oracle.read_map(fn, mono))
+        one = api.read_localmap(fn, mono)
+        for key in ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V", "FBlock"):
+            a, b, c = (np.asarray(x[key]).ravel() for x in (ref, one, par[k]))
+            assert np.array_equal(a, b) and np.array_equal(b, c), (k, key)
+        assert ref["Ref"] == one["Ref"] == par[k]["Ref"]
+    with pytest.raises(api.LsfmError, match="localmap_8"):
+        api.read_localmaps(str(tmp_path), 9, mono, threads=2)

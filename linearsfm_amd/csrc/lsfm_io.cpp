@@ -161,7 +161,7 @@ int lsfm_read_localmap(const char* path, int mono, lsfm_map* g)
 
 // localmap_<first>.txt .. localmap_<first+count-1>.txt of a directory (naming of the reference, Imp.cpp:125) on
 // `threads` host threads (<= 0: one per core, at most 32).  out[count] is filled in order; on failure everything read so
-// far is released, LSFM_ERR_IO is returned and *failed (optional) is the number of a file that could not be read.
+// far is released, LSFM_ERR_IO is returned and *failed (optional) is the lowest number of a file that could not be read.
 int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int threads, lsfm_map* out, int* failed)
 {
 	if (!dir || !out || count < 0) return LSFM_ERR_ARG;
@@ -178,8 +178,9 @@ int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int thr
 			const std::string fn = std::string(dir) + "/localmap_" + std::to_string(first + k) + ".txt";
 			if (lsfm_read_localmap(fn.c_str(), mono, &out[k]) != LSFM_OK)
 			{
-				int expect = 0;
-				bad.compare_exchange_strong(expect, first + k);
+				// keep the lowest failing number, whatever the thread timing
+				int cur = bad.load();
+				while ((cur == 0 || first + k < cur) && !bad.compare_exchange_weak(cur, first + k)) {}
 			}
 		}
 	};

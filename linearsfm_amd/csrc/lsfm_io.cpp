@@ -168,7 +168,8 @@ int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int thr
 	if (failed) *failed = 0;
 	if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
 	threads = std::max(1, std::min(threads, count));
-	std::atomic<int> next(0), bad(0);
+	const int none = 0x7fffffff;
+	std::atomic<int> next(0), bad(none);
 	for (int k = 0; k < count; k++) memset(&out[k], 0, sizeof(lsfm_map));
 	auto work = [&]() {
 		for (;;)
@@ -180,7 +181,7 @@ int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int thr
 			{
 				// keep the lowest failing number, whatever the thread timing
 				int cur = bad.load();
-				while ((cur == 0 || first + k < cur) && !bad.compare_exchange_weak(cur, first + k)) {}
+				while (first + k < cur && !bad.compare_exchange_weak(cur, first + k)) {}
 			}
 		}
 	};
@@ -188,7 +189,7 @@ int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int thr
 	for (int t = 1; t < threads; t++) pool.emplace_back(work);
 	work();
 	for (auto& th : pool) th.join();
-	if (bad.load())
+	if (bad.load() != none)
 	{
 		for (int k = 0; k < count; k++) lsfm_map_release(&out[k]);
 		if (failed) *failed = bad.load();

@@ -148,6 +148,9 @@ int lsfm_read_localmap(const char* path, int mono, lsfm_map* out); /* out: libra
  * on `threads` host threads (<= 0: one per core, at most 32); out[count] library-allocated, filled in order.  On a
  * failure nothing is kept and *failed (optional) is the number of the first file that could not be read. */
 int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int threads, lsfm_map* out, int* failed);
+/* one map in the local-map text format at %.17g (write -> lsfm_read_localmap is the identity): stores a tree node with its
+ * information matrix, which the reference computes (DOC.pdf p.1) but never writes */
+int lsfm_write_localmap(const char* path, int mono, const lsfm_map* map);
 int lsfm_save_state(const char* path, const double* st, const int* stno, int n);
 int lsfm_save_poses(const char* pose_path, const char* feat_path, const int* stno, const double* st, int n);
 

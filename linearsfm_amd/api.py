@@ -79,6 +79,7 @@ def lib():
         L.lsfm_tree_free.restype = None
         L.lsfm_divide_conquer.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(LsfmMap), P(LsfmStats)]
         L.lsfm_read_localmap.argtypes = [C.c_char_p, C.c_int, P(LsfmMap)]
+        L.lsfm_write_localmap.argtypes = [C.c_char_p, C.c_int, P(LsfmMap)]
         L.lsfm_read_localmaps.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P(LsfmMap), P(C.c_int)]
         L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
@@ -91,7 +92,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download",
-           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_save_state", "lsfm_save_poses",
+           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench"]
 
 
@@ -272,6 +273,14 @@ def read_localmap(path, mono):
     if rc:
         raise LsfmError(f"lsfm_read_localmap({path}) failed (rc={rc})")
     return map_to_dict(g)
+
+
+def write_localmap(path, d, mono):
+    """A map dict (local map, joint map or final map with its information matrix) in the local-map text format."""
+    hm = HostMap(d)
+    rc = lib().lsfm_write_localmap(str(path).encode(), int(mono), C.byref(hm.c))
+    if rc:
+        raise LsfmError(f"lsfm_write_localmap({path}) failed (rc={rc})")
 
 
 def read_localmaps(directory, count, mono, first=1, threads=0):

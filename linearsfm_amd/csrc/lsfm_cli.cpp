@@ -2,7 +2,8 @@
 // program (main: linux/src/LinearSFM/LinearSFM.cpp:9-18, parser: LinearSFMImp.cpp:7989-8087, help: 8089-8105).
 //   LinearSFM -path <dir> -num <N> -type Monocular|Stereo [-p <poses>] [-f <features>] [-st <state>] [-help]
 // Extra flags that do not collide with the reference's: -gpu <ordinal>, -tol <pcg rel tol>, -full <file> (final state
-// at %.17g), -stats 1 (timing breakdown on stderr).
+// at %.17g), -info <file> (final map WITH its information matrix in the local-map format), -stats 1 (timing breakdown
+// on stderr).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +30,7 @@ static void print_help()
 
 int main(int argc, char** argv)
 {
-	std::string path, st, pose, fea, full;
+	std::string path, st, pose, fea, full, info;
 	int num = 0, type = -1, gpu = 0, want_stats = 0;
 	bool has_path = false, has_num = false;
 	double tol = 0;
@@ -55,6 +56,7 @@ int main(int argc, char** argv)
 		else if (name == "gpu") gpu = atoi(next());
 		else if (name == "tol") tol = atof(next());
 		else if (name == "full") full = next();
+		else if (name == "info") info = next();
 		else if (name == "stats") want_stats = atoi(next());
 	}
 	if (!has_path) { printf("LinerSFM Error: Please Input Right File Path:\n"); return 0; }
@@ -108,6 +110,7 @@ int main(int argc, char** argv)
 		FILE* f = fopen(full.c_str(), "w");
 		if (f) { for (int i = 0; i < r; i++) fprintf(f, "%d %.17g\n", out.stno[i], out.stVal[i]); fclose(f); }
 	}
+	if (!info.empty() && lsfm_write_localmap(info.c_str(), type, &out)) fprintf(stderr, "LinearSFM: cannot write %s\n", info.c_str());
 	lsfm_map_release(&out);
 	for (auto& g : maps) lsfm_map_release(&g);
 	lsfm_context_destroy(ctx);

@@ -198,6 +198,40 @@ int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int thr
 	return LSFM_OK;
 }
 
+// A map in the local-map text format the readers take (Imp.cpp:3044-3132 / 6660-6754), values at %.17g so that
+// writing and reading back is the identity.  The reference keeps the final map's information matrix (DOC.pdf p.1) but
+// never writes it; with this any tree node (lsfm_tree_download, lsfm_join_*) can be stored and joined further later.
+int lsfm_write_localmap(const char* path, int mono, const lsfm_map* g)
+{
+	if (!path || !g) return LSFM_ERR_ARG;
+	FILE* f = fopen(path, "w");
+	if (!f) return LSFM_ERR_IO;
+	std::vector<char> big(1 << 20);
+	setvbuf(f, big.data(), _IOFBF, big.size());
+	const int r = 6 * g->m + 3 * g->n;
+	fprintf(f, "%d\n", g->Ref);
+	if (mono) fprintf(f, "%d\n%d\n%d\n", g->ScaP, g->Fix, g->Sign);
+	fprintf(f, "%d\n", r);
+	for (int i = 0; i < r; i++) fprintf(f, "%d %.17g\n", g->stno[i], g->stVal[i]);
+	fprintf(f, "%d\n%d\n%d\n", g->m, g->n, g->nU);
+	auto dbl = [&](const double* v, long n) { for (long i = 0; i < n; i++) fprintf(f, i + 1 < n ? "%.17g " : "%.17g", v[i]); fputc('\n', f); };
+	auto itg = [&](const int* v, long n) { for (long i = 0; i < n; i++) fprintf(f, i + 1 < n ? "%d " : "%d", v[i]); fputc('\n', f); };
+	dbl(g->U, 36L * g->nU); itg(g->Ui, g->nU); itg(g->Uj, g->nU);
+	fprintf(f, "%d\n", g->nW);
+	dbl(g->W, 18L * g->nW); itg(g->photo, g->nW); itg(g->feature, g->nW);
+	dbl(g->V, 9L * g->n);
+	if (g->FBlock) itg(g->FBlock, g->n);
+	else
+	{
+		// first W block of every feature, -1 if none (Imp.h:75-121); W is sorted by feature
+		std::vector<int> fb(g->n, -1);
+		for (int j = g->nW - 1; j >= 0; j--) if (g->feature[j] >= 0 && g->feature[j] < g->n) fb[g->feature[j]] = j;
+		itg(fb.data(), g->n);
+	}
+	const bool ok = !ferror(f);
+	return (fclose(f) == 0 && ok) ? LSFM_OK : LSFM_ERR_IO;
+}
+
 // Imp.cpp:2102-2117
 int lsfm_save_state(const char* path, const double* st, const int* stno, int n)
 {

@@ -183,3 +183,23 @@ def test_parallel_set_reader_equals_reference_reader(oracle, tmp_path, mono):
         assert ref["Ref"] == one["Ref"] == par[k]["Ref"]
     with pytest.raises(api.LsfmError, match="localmap_8"):
         api.read_localmaps(str(tmp_path), 9, mono, threads=2)
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_localmap_writer_roundtrip(oracle, tmp_path, mono):
+    """lsfm_write_localmap -> lsfm_read_localmap is the identity (a joined map with its information matrix: the oracle's
+    tree output), and the file is readable by the fscanf port of the reference's reader too."""
+    from linearsfm_amd import api
+    maps = synth.make_mono_set(5, 6, 4, seed=4) if mono else synth.make_stereo_set(5, 6, 4, seed=4)
+    out, _, rc = oracle.divide_conquer([oracle.localmap_to_dict(m) for m in maps], mono)
+    assert rc == 0
+    p = str(tmp_path / "final_map.txt")
+    api.write_localmap(p, out, mono)
+    back = api.read_localmap(p, mono)
+    ref = oracle.map_to_dict(oracle.read_map(p, mono))
+    for key in ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V"):
+        a, b, c = (np.asarray(x[key]).ravel() for x in (out, back, ref))
+        assert np.array_equal(a, b) and np.array_equal(a, c), key
+    assert back["Ref"] == out["Ref"] and back["m"] == out["m"] and back["n"] == out["n"]
+    if mono:
+        assert (back["ScaP"], back["Fix"], back["Sign"]) == (out["ScaP"], out["Fix"], out["Sign"])

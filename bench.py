@@ -28,14 +28,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 TRAFFIC = {"schur": 7.559e8, "trf": 1.4107e9}
 
 
-def cpu_baseline(maps, sample_maps):
+def cpu_baseline(maps, sample_maps, mono):
     """Oracle (plain-C port of the reference path, single thread like the reference) on a bounded prefix of the same
     workload.  Checker/baseline only -- never part of the measured product path."""
     from oracle import pyoracle as po
     po.build()
     dicts = [po.localmap_to_dict(m) for m in maps[:sample_maps]]
     t0 = time.time()
-    out, timing, rc = po.divide_conquer(dicts, False, match_hash=True)
+    out, timing, rc = po.divide_conquer(dicts, mono, match_hash=True)
     wall = time.time() - t0
     return out, timing, rc, wall
 
@@ -45,9 +45,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--maps", type=int, default=3499, help="local maps (3499 = NC3500-like)")
-    ap.add_argument("--new-per-frame", type=int, default=130)
-    ap.add_argument("--vis", type=int, default=5)
+    ap.add_argument("--config", default="nc3500", choices=["nc3500", "rs468", "rs90", "synth16k"],
+                    help="synthetic stand-in of a BASELINE.json configuration (linearsfm_amd/synth.py CONFIGS); the headline "
+                         "metric is quoted on nc3500, the others are recorded in BASELINE.md")
+    ap.add_argument("--maps", type=int, default=0, help="local maps (0 = the configuration's own count)")
+    ap.add_argument("--new-per-frame", type=int, default=0)
+    ap.add_argument("--vis", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="local maps given to the CPU baseline (0 = skip)")
     ap.add_argument("--tol", type=float, default=1e-15)
     args = ap.parse_args()
@@ -68,11 +71,17 @@ def main():
 
     from linearsfm_amd import api, synth
 
-    # synthetic NC3500-like set; every rank its own seed (independent map sets)
-    maps = synth.make_stereo_set(args.maps, new_per_frame=args.new_per_frame, vis=args.vis, seed=1000 * rank)
+    typ, cN, cnpf, cvis = synth.CONFIGS[args.config]
+    mono = typ == "Monocular"
+    args.maps = args.maps or cN
+    args.new_per_frame = args.new_per_frame or cnpf
+    args.vis = args.vis or cvis
+    # synthetic stand-in set; every rank its own seed (independent map sets)
+    gen = synth.make_mono_set if mono else synth.make_stereo_set
+    maps = gen(args.maps, new_per_frame=args.new_per_frame, vis=args.vis, seed=1000 * rank)
     ctx = api.Context(local_rank)
     ctx.set_pcg(args.tol, 4)
-    tree = ctx.tree_upload(maps, False)   # PCIe copy, outside the timed region: inputs are resident from here on
+    tree = ctx.tree_upload(maps, mono)   # PCIe copy, outside the timed region: inputs are resident from here on
 
     def barrier():
         if world > 1:
@@ -115,7 +124,9 @@ def main():
         dom = max(("schur", "trf"), key=lambda k: kern[k]["total_ms"])
         sp_ms, sp_bytes, achieved = kern[dom]["avg_ms"], kern[dom]["avg_bytes"], kern[dom]["gbs"]
         line = {
-            "metric": "hierarchical linear map-joining solve wall-clock, NC3500-like stereo (all transforms + joins)",
+            "metric": "hierarchical linear map-joining solve wall-clock, %s (all transforms + joins)"
+                      % {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular", "rs90": "RS90-like monocular",
+                         "synth16k": "synthetic 16k monocular"}[args.config],
             "value": ms_per_step / world,
             "unit": "ms",
             "n_gpus": world,
@@ -127,7 +138,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"NC3500-like Stereo: {args.maps} local maps, {args.new_per_frame} new features/frame "
+            "config": {"workload": f"{args.config} stand-in ({typ}): {args.maps} local maps, {args.new_per_frame} new features/frame "
                                    f"visible in {args.vis} frames, {out['m']} poses / {out['n']} features in the final map",
                        "maps_per_gpu": args.maps, "pcg_rel_tol": args.tol,
                        "value_definition": "ms per join tree = ms_per_step / n_gpus (every GPU runs one tree per step)"},
@@ -149,11 +160,11 @@ def main():
         }
         if args.cpu_sample > 0:
             S = min(args.cpu_sample, args.maps)
-            o_out, timing, orc, wall = cpu_baseline(maps, S)
+            o_out, timing, orc, wall = cpu_baseline(maps, S, mono)
             # same prefix on the device, for a like-for-like ratio and a parity check of this very run
             c2 = api.Context(local_rank)
             c2.set_pcg(args.tol, 4)
-            tr = c2.tree_upload(maps[:S], False)
+            tr = c2.tree_upload(maps[:S], mono)
             c2.tree_run(tr)
             st2, _ = c2.tree_run(tr)
             g_out = c2.tree_download(tr)

@@ -4,7 +4,7 @@ that put the number in context on long open chains, where the camera system of t
 numbers ~1e12 and ANY two fp64 solves of the same system differ far above 1e-6 in the global (drift) directions:
   * oracle vs oracle with a different (equally valid) elimination order   -> the reference path's own noise floor
   * parity of the RELATIVE poses between consecutive frames               -> the well-determined local geometry
-usage: python tools/full_parity.py [maps=3499] [new_per_frame=130] [vis=5] [selfcheck=1]"""
+usage: python tools/full_parity.py [maps=3499] [new_per_frame=130] [vis=5] [selfcheck=1] [mono=0]"""
 import json
 import os
 import subprocess
@@ -41,24 +41,26 @@ def main():
     npf = int(sys.argv[2]) if len(sys.argv) > 2 else 130
     vis = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     selfcheck = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    mono = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
+    gen = synth.make_mono_set if mono else synth.make_stereo_set
     if os.environ.get("ORC_CHILD"):
-        maps = synth.make_stereo_set(N, new_per_frame=npf, vis=vis, seed=0)
-        out, _, _ = po.divide_conquer([po.localmap_to_dict(m) for m in maps], False, match_hash=True)
+        maps = gen(N, new_per_frame=npf, vis=vis, seed=0)
+        out, _, _ = po.divide_conquer([po.localmap_to_dict(m) for m in maps], mono, match_hash=True)
         np.save(os.environ["ORC_CHILD"], out["stVal"])
         return
     po.build()
-    maps = synth.make_stereo_set(N, new_per_frame=npf, vis=vis, seed=0)
+    maps = gen(N, new_per_frame=npf, vis=vis, seed=0)
     dicts = [po.localmap_to_dict(m) for m in maps]
     ctx = api.Context(0)
-    got, stats, rc = ctx.divide_conquer(dicts, False)
+    got, stats, rc = ctx.divide_conquer(dicts, mono)
     t0 = time.time()
-    exp, timing, orc = po.divide_conquer(dicts, False, match_hash=True)
+    exp, timing, orc = po.divide_conquer(dicts, mono, match_hash=True)
     mask = exp["stno"] <= 0
 
     def perr(a, b, m):
         return float(np.max(np.abs(a[m] - b[m]) / np.maximum(1.0, np.abs(b[m]))))
     rg, re = rel_poses(got["stVal"], exp["stno"]), rel_poses(exp["stVal"], exp["stno"])
-    res = dict(maps=N, new_per_frame=npf, vis=vis, m=int(exp["m"]), n=int(exp["n"]), nU=int(exp["nU"]), nW=int(exp["nW"]),
+    res = dict(maps=N, new_per_frame=npf, vis=vis, mono=mono, m=int(exp["m"]), n=int(exp["n"]), nU=int(exp["nU"]), nW=int(exp["nW"]),
                same_labels=bool(np.array_equal(got["stno"], exp["stno"])),
                same_structure=bool(np.array_equal(got["photo"], exp["photo"]) and np.array_equal(got["feature"], exp["feature"])
                                    and np.array_equal(got["Ui"], exp["Ui"]) and np.array_equal(got["Uj"], exp["Uj"])),
@@ -69,7 +71,7 @@ def main():
     if selfcheck:
         # the oracle against itself with the degree ordering instead of the nested-dissection one
         tmp = "/tmp/orc_selfcheck.npy"
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), str(N), str(npf), str(vis)],
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), str(N), str(npf), str(vis), str(selfcheck), str(int(mono))],
                               env=dict(os.environ, ORC_CHILD=tmp, ORC_ORDER="1"))
         alt = np.load(tmp)
         res["oracle_vs_oracle_reordered_pose_max_rel_err"] = perr(alt, exp["stVal"], mask)

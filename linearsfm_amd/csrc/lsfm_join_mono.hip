@@ -193,12 +193,20 @@ __global__ void k_mono_w_fill(int NFY, const int* __restrict__ srcE, const int* 
                               const double* __restrict__ feat, const int* __restrict__ fptr_y, double* __restrict__ Wy, int* __restrict__ photo_y,
                               int* __restrict__ feature_y, double* __restrict__ eP, double* __restrict__ eF)
 {
-	int nf = blockIdx.x * blockDim.x + threadIdx.x;
-	if (nf >= NFY) return;
-	const MGroup& g = grp[feat_map_y[nf]];
-	int pos = fptr_y[nf], flpos = -1;
+	// eP: summed per work-group in an LDS table keyed by pose and flushed once (every feature adds to its hub poses:
+	// global atomics on those few rows serialised -- 30 of the 55 ms of an RS468-like tree)
+	constexpr int ECAP = 128;
+	__shared__ int ekeys[ECAP];
+	__shared__ double evals[ECAP * 6];
+	for (int i = threadIdx.x; i < ECAP; i += blockDim.x) ekeys[i] = -1;
+	for (int i = threadIdx.x; i < ECAP * 6; i += blockDim.x) evals[i] = 0.0;
+	__syncthreads();
+	const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = nf < NFY;
+	const MGroup& g = grp[feat_map_y[inb ? nf : 0]];
+	int pos = inb ? fptr_y[nf] : 0, flpos = -1;
 	double ef[3] = { 0, 0, 0 };
-	for (int side = 0; side < 2; side++)
+	for (int side = 0; side < 2 && inb; side++)
 	{
 		const int f = side ? srcC[nf] : srcE[nf];
 		if (f < 0) continue;
@@ -222,12 +230,19 @@ __global__ void k_mono_w_fill(int NFY, const int* __restrict__ srcE, const int* 
 				pos++;
 			}
 			const double* xp = prior + (size_t)k * 6;
-			for (int r = 0; r < 6; r++) atomic_add_f64(eP + (size_t)kn * 6 + r, w[3 * r] * xf[0] + w[3 * r + 1] * xf[1] + w[3 * r + 2] * xf[2]);
+			const int es = lds_slot(ekeys, ECAP, kn);
+			for (int r = 0; r < 6; r++)
+			{
+				const double y = w[3 * r] * xf[0] + w[3 * r + 1] * xf[1] + w[3 * r + 2] * xf[2];
+				if (es >= 0) lds_add_f64(&evals[es * 6 + r], y); else atomic_add_f64(eP + (size_t)kn * 6 + r, y);
+			}
 			for (int c = 0; c < 3; c++)
 				for (int r = 0; r < 6; r++) ef[c] = fma(w[3 * r + c], xp[r], ef[c]);
 		}
 	}
-	eF[(size_t)nf * 3] += ef[0]; eF[(size_t)nf * 3 + 1] += ef[1]; eF[(size_t)nf * 3 + 2] += ef[2];
+	if (inb) { eF[(size_t)nf * 3] += ef[0]; eF[(size_t)nf * 3 + 1] += ef[1]; eF[(size_t)nf * 3 + 2] += ef[2]; }
+	__syncthreads();
+	tile_flush<6>(ekeys, evals, ECAP, eP);
 }
 
 __global__ void k_mono_fixed(int G, const MGroup* __restrict__ grp, const int* __restrict__ pnew, unsigned char* __restrict__ fixed)

@@ -78,6 +78,8 @@ struct lsfm_context {
 	lsfm::PcgOptions pcg;
 	std::string last_error;
 	int* h_pinned = nullptr; // small pinned staging buffer for counters
+	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
+	size_t stage_size = 0, stage_off = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run
 	void ensure_arenas(size_t bytes_each);

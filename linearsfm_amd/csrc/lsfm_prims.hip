@@ -70,8 +70,26 @@ void d2h_ints(lsfm_context* ctx, const int* dptr, int* h, size_t n)
 }
 void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes)
 {
-	if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-	// host buffers of callers are pageable and may go out of scope: make the copy complete before returning
+	if (!bytes) return;
+	// Callers pass pageable buffers that may go out of scope.  Small copies (index arrays, per-map parameters: a dozen
+	// per tree level) are staged through a pinned ring and only ENQUEUED -- stream order keeps them ahead of their
+	// consumers and the host does not stop for a round trip each time.  The ring is reused only after a
+	// synchronisation; larger copies wait for completion as before.
+	if (ctx->h_stage && bytes <= ctx->stage_size / 4)
+	{
+		const size_t need = (bytes + 63) & ~(size_t)63;
+		if (ctx->stage_off + need > ctx->stage_size)
+		{
+			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+			ctx->stage_off = 0;
+		}
+		char* slot = ctx->h_stage + ctx->stage_off;
+		memcpy(slot, h, bytes);
+		ctx->stage_off += need;
+		LSFM_CHECK_HIP(hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+		return;
+	}
+	LSFM_CHECK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
 	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 }
 void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes)
@@ -115,6 +133,8 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipSetDevice(device));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
+		c->stage_size = (size_t)16 << 20;
+		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev0));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev1));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev2));
@@ -139,6 +159,7 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->arena[0].destroy(); c->arena[1].destroy(); c->scratch.destroy();
 	if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+	if (c->h_stage) (void)hipHostFree(c->h_stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);

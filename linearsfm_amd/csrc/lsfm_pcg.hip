@@ -9,9 +9,11 @@
 //     map that brought it, so an edge (p,q) of S crosses the cut of tree level bitlen(origin_p ^ origin_q).  The
 //     endpoint of higher degree (the hub pose of that sub-map) goes into that level's separator; blocks are
 //     eliminated by ascending separator level.  Measured fill 1.5x nnz(S), elimination-tree height ~ 15 per level.
-//   * symbolic analysis (elimination tree, column patterns, level sets) on the host from the block pattern (a few
-//     hundred KB), numeric factorisation and triangular solves on the device, one launch per elimination-tree level,
-//     one work-group per block column; the narrow top of the tree runs inside a single launch.
+//   * symbolic analysis (elimination tree, column patterns, tasks) on the host from the block pattern (a few hundred
+//     KB), while the numeric Schur assembly runs on the device; numeric factorisation and triangular solves on the
+//     device.  The elimination tree is ~140 columns high at the top join but only ~8 TASK levels deep: a sub-tree of
+//     <= 32 columns, or a separator chain of the dissection, is one task, walked by one work-group; launches go by
+//     task level.
 // With the exact factor CG is iterative refinement: 2-3 iterations to 1e-12.
 #include <algorithm>
 #include <chrono>
@@ -94,10 +96,8 @@ __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ 
 
 // one work-group factors one block column: L_jj = chol(A_jj); L_ij = A_ij L_jj^-T; A_ik -= L_ij L_kj^T for the blocks
 // below (right-looking; targets in other columns are updated atomically because the columns of one level run together)
-__device__ void chol_column_update(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride);
-
 __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                   double* __restrict__ Dinv, int* err, bool do_update)
+                                   double* __restrict__ Dinv, int* err)
 {
 	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
 	const int tid = threadIdx.x, nt = blockDim.x;
@@ -160,7 +160,6 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 		for (int k = 0; k < 6; k++) blk[k] = o[k];
 	}
 	__syncthreads();
-	if (do_update) chol_column_update(j, colptr, rowidx, L, tid, nt);
 }
 
 // one trailing update of column j: blocks a >= b below the diagonal give L_a L_b^T, subtracted from block (ra, rb)
@@ -180,20 +179,6 @@ __device__ __forceinline__ void chol_pair_update(int c0, int a, int b, const int
 	double* d = L + (size_t)pos * 36;
 	if (ATOMIC) { for (int q = 0; q < 36; q++) atomic_add_f64(d + q, -T[q]); }
 	else { for (int q = 0; q < 36; q++) d[q] -= T[q]; } // the caller owns the target column: one pair per target block
-}
-// trailing updates of column j: all pairs a >= b, pair index pr = first, first+stride, ...
-__device__ void chol_column_update(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
-{
-	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
-	const int npairs = n * (n + 1) / 2;
-	for (int pr = first; pr < npairs; pr += stride)
-	{
-		// decode pr -> (a,b), a >= b, row-major over the lower triangle
-		int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
-		while (a * (a + 1) / 2 > pr) a--;
-		while ((a + 1) * (a + 2) / 2 <= pr) a++;
-		chol_pair_update<true>(c0, a, pr - a * (a + 1) / 2, colptr, rowidx, L);
-	}
 }
 // the pairs whose target column rb is one of the first m rows (the rows inside the task): needed before the task's next column
 __device__ void chol_column_update_inner(int j, int m, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
@@ -246,30 +231,6 @@ __device__ void chol_column_update_outer(int j, int m, const int* __restrict__ c
 			const int ps = spos[p];
 			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[p * 37 + q]);
 		}
-		__syncthreads();
-	}
-}
-
-// level step 1: diagonal factor + scaling of every column of the level (one small work-group per column)
-__global__ void __launch_bounds__(64) k_chol_factor_level(const int* __restrict__ cols, const int* __restrict__ colptr,
-                                                          const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
-{
-	chol_factor_column(cols[blockIdx.x], colptr, rowidx, L, Dinv, err, false);
-}
-// level step 2: trailing updates, blockIdx.y splits the pairs of one column over several work-groups
-__global__ void __launch_bounds__(256) k_chol_update_level(const int* __restrict__ cols, const int* __restrict__ colptr,
-                                                           const int* __restrict__ rowidx, double* __restrict__ L)
-{
-	chol_column_update(cols[blockIdx.x], colptr, rowidx, L, blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
-}
-// the narrow top of the elimination tree: one work-group walks the remaining columns in index order
-__global__ void __launch_bounds__(256) k_chol_factor_tail(int ncols, const int* __restrict__ cols, const int* __restrict__ colptr,
-                                                           const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
-{
-	for (int k = 0; k < ncols; k++)
-	{
-		chol_factor_column(cols[k], colptr, rowidx, L, Dinv, err, true);
-		__threadfence();
 		__syncthreads();
 	}
 }
@@ -361,7 +322,7 @@ __global__ void __launch_bounds__(256) k_chol_factor_tasks(const int* __restrict
 	for (int k = b; k < e; k++)
 	{
 		const int j = task_cols[k];
-		chol_factor_column(j, colptr, rowidx, L, Dinv, err, false);
+		chol_factor_column(j, colptr, rowidx, L, Dinv, err);
 		if (k + 1 < e)
 		{
 			chol_column_update_inner(j, col_nin[j], colptr, rowidx, L, threadIdx.x, blockDim.x);
@@ -713,30 +674,14 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	if (sy.nnzb)
 		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, s, sy.nnzb, sy.upper_keys, sy.S, ch.pinv, ch.colptr, ch.rowidx,
 		                   fixed, ch.L);
-	static const bool task_factor = !getenv("LSFM_LEVEL_FACTOR");
-	if (task_factor)
+	for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
 	{
-		for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
-		{
-			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (!n) continue;
-			hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
-			const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
-			if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
-		}
-		return;
-	}
-	for (int l = 0; l < ch.nlevels; l++)
-	{
-		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
+		const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
 		if (!n) continue;
-		hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
-		const int mp = ch.level_maxpairs[l];
-		if (mp > 0) hipLaunchKernelGGL(k_chol_update_level, dim3(n, (mp + 255) / 256), dim3(256), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L);
+		hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
+		if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 	}
-	if (ch.M - ch.tail_begin > 0)
-		hipLaunchKernelGGL(k_chol_factor_tail, dim3(1), dim3(256), 0, s, ch.M - ch.tail_begin, ch.order + ch.tail_begin, ch.colptr, ch.rowidx, ch.L,
-		                   ch.Dinv, ch.d_err);
 }
 
 // z = (L L^T)^-1 r in the original numbering, rz_dot[seg] += r . z

@@ -48,3 +48,29 @@ def test_cli_errors_like_the_reference(tmp_path):
     assert r.returncode == 0 and "LinerSFM Error: Please Input Right File Path:" in r.stdout   # Imp.cpp:8075-8076
     r = subprocess.run([exe, "-help"], capture_output=True, text=True)
     assert "Linear SFM Solution General Options" in r.stdout
+
+
+def test_cli_level_scheduled_solves_and_info_export(oracle, tmp_path):
+    """LSFM_LEVEL_SOLVE=1 forces the triangular solves that go by elimination-tree level (the path taken when a task's
+    slice of the vector does not fit LDS); -info stores the final map with its information matrix, re-readable."""
+    from linearsfm_amd import api
+    maps = synth.make_stereo_set(12, 6, 4, seed=43)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    full = {}
+    for tag, env in (("tasks", {}), ("levels", {"LSFM_LEVEL_SOLVE": "1"})):
+        s, info = str(tmp_path / f"{tag}_full.txt"), str(tmp_path / f"{tag}_info.txt")
+        subprocess.run([exe, "-path", str(d), "-num", "12", "-type", "Stereo", "-full", s, "-info", info],
+                       capture_output=True, text=True, check=True, env=dict(os.environ, **env))
+        full[tag] = (_table(s), api.read_localmap(info, False))
+    exp, _, rc = oracle.divide_conquer([oracle.localmap_to_dict(m) for m in maps], False)
+    assert rc == 0
+    for tag in full:
+        st, info = full[tag]
+        assert np.array_equal(st[:, 0], exp["stno"])
+        assert np.max(np.abs(st[:, 1] - exp["stVal"]) / np.maximum(1.0, np.abs(exp["stVal"]))) < 1e-6, tag
+        # the exported map is the final map: same state, same information blocks
+        assert np.array_equal(info["stno"], exp["stno"]) and np.array_equal(info["photo"], exp["photo"])
+        for k in ("U", "W", "V"):
+            assert np.max(np.abs(np.asarray(info[k]) - np.asarray(exp[k]))) / np.max(np.abs(np.asarray(exp[k]))) < 1e-6, (tag, k)

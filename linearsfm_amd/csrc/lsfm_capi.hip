@@ -12,7 +12,7 @@ struct lsfm_tree {
 	int N = 0;
 	Arena input_arena; // pristine copy of the N local maps, resident in HBM; lsfm_tree_run starts from a device copy of it
 	DevBatch input;
-	DevBatch level;    // current level (lives in ctx->arena[slot])
+	DevBatch level;    // current level (lives in ctx->arena[slot]; slot -1: the resident inputs)
 	int slot = 0;
 	bool done = false;
 	bool final_reanchor = true;
@@ -82,18 +82,22 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 		tref[e] = cref; tscap[e] = cscap; tfix[e] = cfix; ntr++;
 	}
 	double t0 = now_ms();
-	Arena& other = ctx->arena[t->slot ^ 1];
+	// three arenas in rotation: X (this level; slot -1 = the resident inputs, never written) stays alive until the join
+	// is done, because the W blocks of the maps the transform passes through are read from X, not copied (W_alias)
+	const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3, sm = t->slot < 0 ? 1 : (t->slot + 2) % 3;
+	Arena& other = ctx->arena[so];
 	other.reset();
 	DevBatch Xt;
-	transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt);
+	transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt, true);
 	double t1 = now_ms();
-	Arena& mine = ctx->arena[t->slot];
-	mine.reset(); // X is dead from here on
+	Arena& mine = ctx->arena[sm];
+	mine.reset();
 	DevBatch Y;
 	if (t->mono) join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
 	else join_batch_stereo(ctx, mine, Xt, Y, nullptr, nullptr);
 	double t2 = now_ms();
 	t->level = Y;
+	t->slot = sm;
 	if (st)
 	{
 		st->t_transform_ms += t1 - t0;
@@ -102,18 +106,6 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	}
 }
 
-template <class T> void rebase(T*& p, ptrdiff_t delta)
-{
-	if (p) p = reinterpret_cast<T*>(reinterpret_cast<char*>(p) + delta);
-}
-DevBatch rebased(const DevBatch& b, ptrdiff_t d)
-{
-	DevBatch o = b;
-	rebase(o.d_pose_off, d); rebase(o.d_feat_off, d); rebase(o.pose, d); rebase(o.pose_id, d); rebase(o.pose_map, d); rebase(o.pose_origin, d);
-	rebase(o.feat, d); rebase(o.feat_id, d); rebase(o.feat_map, d); rebase(o.U, d); rebase(o.Ui, d); rebase(o.Uj, d);
-	rebase(o.W, d); rebase(o.photo, d); rebase(o.feature, d); rebase(o.fptr, d); rebase(o.V, d);
-	return o;
-}
 size_t input_bytes(const lsfm_map* maps, int N)
 {
 	size_t nw = 0, nf = 0, nu = 0, m = 0;
@@ -159,20 +151,18 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		const double t0 = now_ms();
 		try
 		{
-			// start from a device-to-device copy of the resident inputs, so that a tree can be run repeatedly
-			t->slot = 0;
-			ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
-			if (t->input_arena.off > ctx->arena[0].cap) LSFM_FAIL(LSFM_ERR_OOM, "inputs do not fit the level arena");
-			LSFM_CHECK_HIP(hipMemcpyAsync(ctx->arena[0].base, t->input_arena.base, t->input_arena.off, hipMemcpyDeviceToDevice, ctx->stream));
-			ctx->arena[0].off = t->input_arena.off;
-			t->level = rebased(t->input, ctx->arena[0].base - t->input_arena.base);
+			// level 0 reads the resident inputs where they are (no level writes its input), so a tree can be run repeatedly
+			t->slot = -1;
+			ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
+			t->level = t->input;
 			while (t->level.B > 1) run_level(ctx, t, st);
 			// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
 			DevBatch& X = t->level;
 			if (t->final_reanchor && X.B == 1 && X.Ref[0] > X.FRef[0])
 			{
 				std::vector<int> tref(1, X.FRef[0]), tscap(1, X.FScaP[0]), tfix(1, X.FFix[0]);
-				Arena& other = ctx->arena[t->slot ^ 1];
+				const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3;
+				Arena& other = ctx->arena[so];
 				other.reset();
 				DevBatch Xt;
 				const double a = now_ms();
@@ -180,7 +170,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				st->t_transform_ms += now_ms() - a;
 				st->transforms++;
 				t->level = Xt;
-				t->slot ^= 1;
+				t->slot = so;
 			}
 			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 		}

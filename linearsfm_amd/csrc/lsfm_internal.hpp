@@ -62,6 +62,10 @@ struct DevBatch {
 	double* W = nullptr; int *photo = nullptr, *feature = nullptr;
 	int* fptr = nullptr;    // [NF+1] W run of each feature
 	double* V = nullptr;    // [NF*9]
+	// W blocks of maps a transform passed through unchanged are not copied when the batch only feeds a join: block j of
+	// such a map is W_alias[j + d_alias[map]] in the transform's INPUT (d_alias[map] == INT_MIN: materialised in W)
+	const double* W_alias = nullptr;
+	const int* d_alias = nullptr;
 };
 
 struct PcgOptions { double rel_tol = 1e-15; int max_it_factor = 4; };
@@ -71,7 +75,7 @@ struct PcgOptions { double rel_tol = 1e-15; int max_it_factor = 4; };
 struct lsfm_context {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	lsfm::Arena arena[2];   // ping-pong: level outputs / next level
+	lsfm::Arena arena[3];   // rotation: level input / transformed level / joined level
 	lsfm::Arena scratch;    // per-stage work space
 	int cur = 0;
 	size_t arena_bytes = 0;
@@ -105,7 +109,8 @@ void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b); // uploads po
 // target_ref[b] < 0 ... map b is passed through unchanged; otherwise the pose id the map is re-expressed in
 // (Mono: target_scap / target_fix as well).  out is allocated from `ar`.
 void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
-                     const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out);
+                     const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out,
+                     bool alias_passthrough = false);
 
 // ---- join + solve (lsfm_join.hip, lsfm_solve.hip): K5-K11 ---------------------------------------------------
 struct JoinWork; // device work arrays shared between assembly and solve

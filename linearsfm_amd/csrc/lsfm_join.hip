@@ -10,6 +10,7 @@
 // feature (O(n1*n2), Imp.cpp:2581-2599); here one radix sort of (pair, label, side) keys does it for the level.
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
+#include <climits>
 #include "lsfm_join.hpp"
 
 namespace lsfm {
@@ -91,13 +92,16 @@ __global__ void k_add_lens(int n, const int* __restrict__ a, const int* __restri
 __global__ void k_join_wcopy(int NW, const double* __restrict__ W, const int* __restrict__ photo, const int* __restrict__ feature,
                              const int* __restrict__ fptr, const int* __restrict__ feat_map, const int* __restrict__ newf,
                              const int* __restrict__ lenE, const int* __restrict__ fptr_y, double* __restrict__ Wy, int* __restrict__ photo_y,
-                             int* __restrict__ feature_y, int* __restrict__ srcf)
+                             int* __restrict__ feature_y, int* __restrict__ srcf, const double* __restrict__ W_alias,
+                             const int* __restrict__ alias)
 {
 	int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= NW) return;
 	int f = feature[j], nf = newf[f];
 	int dest = fptr_y[nf] + ((feat_map[f] & 1) ? lenE[nf] : 0) + (j - fptr[f]);
-	const double* w = W + (size_t)j * 18;
+	// blocks of a map the transform passed through are still in the transform's input
+	const int delta = alias ? alias[feat_map[f]] : INT_MIN;
+	const double* w = delta != INT_MIN ? W_alias + (size_t)(j + delta) * 18 : W + (size_t)j * 18;
 	double* o = Wy + (size_t)dest * 18;
 	for (int i = 0; i < 18; i++) o[i] = w[i];
 	photo_y[dest] = photo[j];
@@ -285,7 +289,7 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
 	if (in.NW)
 		hipLaunchKernelGGL(k_join_wcopy, dim3((in.NW + 255) / 256), dim3(256), 0, s, in.NW, in.W, in.photo, in.feature, in.fptr, in.feat_map,
-		                   newf, lenE, out.fptr, out.W, out.photo, out.feature, srcf);
+		                   newf, lenE, out.fptr, out.W, out.photo, out.feature, srcf, in.W_alias, in.d_alias);
 	// ---- right-hand sides ----
 	if (NFY)
 		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);

@@ -191,7 +191,8 @@ __global__ void k_mono_w_fill(int NFY, const int* __restrict__ srcE, const int* 
                               const int* __restrict__ photo, const double* __restrict__ W, const int* __restrict__ feat_map_y,
                               const MGroup* __restrict__ grp, const int* __restrict__ pnew, const double* __restrict__ prior,
                               const double* __restrict__ feat, const int* __restrict__ fptr_y, double* __restrict__ Wy, int* __restrict__ photo_y,
-                              int* __restrict__ feature_y, double* __restrict__ eP, double* __restrict__ eF)
+                              int* __restrict__ feature_y, double* __restrict__ eP, double* __restrict__ eF,
+                              const int* __restrict__ feat_map_src, const double* __restrict__ W_alias, const int* __restrict__ alias)
 {
 	// eP: summed per work-group in an LDS table keyed by pose and flushed once (every feature adds to its hub poses:
 	// global atomics on those few rows serialised -- 30 of the 55 ms of an RS468-like tree)
@@ -211,12 +212,15 @@ __global__ void k_mono_w_fill(int NFY, const int* __restrict__ srcE, const int* 
 		const int f = side ? srcC[nf] : srcE[nf];
 		if (f < 0) continue;
 		const double* xf = feat + (size_t)f * 3;
+		// blocks of a map the transform passed through are still in the transform's input
+		const int delta = alias ? alias[feat_map_src[f]] : INT_MIN;
+		const double* Wsrc = delta != INT_MIN ? W_alias + (ptrdiff_t)delta * 18 : W;
 		for (int j = fptr[f]; j < fptr[f + 1]; j++)
 		{
 			const int k = photo[j];
 			if (g.pair && (k == g.P1 || k == g.C1)) continue;
 			double w[18];
-			ld<18>(w, W + (size_t)j * 18);
+			ld<18>(w, Wsrc + (size_t)j * 18);
 			const int kn = pnew[k];
 			if (side == 1 && g.pair && k == g.C2 && flpos >= 0)
 			{
@@ -418,7 +422,7 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW);
 	if (NFY)
 		hipLaunchKernelGGL(k_mono_w_fill, dim3((NFY + 127) / 128), dim3(128), 0, s, NFY, srcE, srcC, in.fptr, in.photo, in.W, out.feat_map, d_mg,
-		                   pnew, prior, in.feat, out.fptr, out.W, out.photo, out.feature, eP, eF);
+		                   pnew, prior, in.feat, out.fptr, out.W, out.photo, out.feature, eP, eF, in.feat_map, in.W_alias, in.d_alias);
 	LSFM_CHECK_HIP(hipGetLastError());
 	if (eP_out) d2h(ctx, eP_out, eP, (size_t)MY * 6 * sizeof(double));
 	if (eF_out) d2h(ctx, eF_out, eF, (size_t)NFY * 3 * sizeof(double));

@@ -110,6 +110,7 @@ void lsfm_context::ensure_arenas(size_t bytes_each)
 	LSFM_CHECK_HIP(hipStreamSynchronize(stream));
 	arena[0].init(bytes_each);
 	arena[1].init(bytes_each);
+	arena[2].init(bytes_each);
 	scratch.init(bytes_each);
 	arena_bytes = bytes_each;
 }
@@ -157,7 +158,7 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	c->arena[0].destroy(); c->arena[1].destroy(); c->scratch.destroy();
+	c->arena[0].destroy(); c->arena[1].destroy(); c->arena[2].destroy(); c->scratch.destroy();
 	if (c->h_pinned) (void)hipHostFree(c->h_pinned);
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -15,6 +15,7 @@
 // Output slot layout is the reference's: per map first the m blocks (k,h_1) [Mono: then m blocks (k,h_2)], then the
 // untouched blocks in their old order; per feature first its block(s) to h_1 [h_2], then its old blocks.
 #include <algorithm>
+#include <climits>
 
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
@@ -306,7 +307,7 @@ template <int NH>
 __global__ void __launch_bounds__(256)
 k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const double* __restrict__ feat, const int* __restrict__ fptr,
               const double* __restrict__ Vold, const int* __restrict__ KW, double* __restrict__ nfeat, int* __restrict__ nfptr,
-              double* __restrict__ Vn, double* __restrict__ FD)
+              double* __restrict__ Vn, double* __restrict__ FD, int4* __restrict__ finfo)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
@@ -319,9 +320,12 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 		nfeat[3 * (size_t)f] = x[0]; nfeat[3 * (size_t)f + 1] = x[1]; nfeat[3 * (size_t)f + 2] = x[2];
 		for (int i = 0; i < 9; i++) Vn[(size_t)f * 9 + i] = Vold[(size_t)f * 9 + i];
 		nfptr[f] = t->W0n + (j0 - t->W0);
+		finfo[f] = make_int4(0, -1, -1, t->W0n - t->W0); // new place of block j: j + w
 		return;
 	}
 	nfptr[f] = t->W0n + NH * (f - t->F0) + (KW[j0] - t->kW0);
+	// per feature record for the block kernel: active, hub pose(s), new place of a kept block j = w + KW[j]
+	finfo[f] = make_int4(1, t->hub[0], NH == 2 ? t->hub[1] : -1, nfptr[f] + NH - KW[j0]);
 	double Df[9], Cf[NH][18], xn[3];
 	// new feature value, Imp.cpp:449-451 / 3300-3302
 	double d[3] = { x[0] - t->t1[0], x[1] - t->t1[1], x[2] - t->t1[2] };
@@ -369,10 +373,10 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 
 template <int NH>
 __global__ void __launch_bounds__(TRE_ROUND, 2)
-k_tr_entries(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const int* __restrict__ fptr,
+k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restrict__ fptr,
              const double* __restrict__ Wold, const int* __restrict__ photo, const int* __restrict__ KW, const double* __restrict__ Dp,
              const double* __restrict__ Cp, const double* __restrict__ FD, double* __restrict__ Wn_, int* __restrict__ nphoto,
-             int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ)
+             int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ, int alias_passthrough)
 {
 	constexpr int GCAP = NH == 1 ? 64 : 32, TW = 18 * NH; // LDS: 18 KB pose table + 36 KB block rows -> two work-groups per CU
 	__shared__ int gkeys[GCAP];
@@ -411,20 +415,25 @@ k_tr_entries(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__
 				int lo = la, hi = lb - 1; // feature of block j: last fl with sFp[fl] <= j
 				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] <= j) lo = mid; else hi = mid - 1; }
 				f = f0 + lo;
-				const TMap* t = &tm[feat_map[f]];
+				const int4 fi = finfo[f]; // x: active, y/z: hub poses, w: placement
 				k = photo[j];
-				ld<18>(W, Wold + (size_t)j * 18);
-				act = t->active > 0 && t->nh == NH;
+				act = fi.x != 0;
 				if (!act)
 				{
-					const int pos = t->W0n + (j - t->W0);
-					st<18>(Wn_ + (size_t)pos * 18, W);
+					// pass-through map: indices only when the consumer (a join) reads the block from the input (W_alias)
+					const int pos = j + fi.w;
+					if (!alias_passthrough)
+					{
+						ld<18>(W, Wold + (size_t)j * 18);
+						st<18>(Wn_ + (size_t)pos * 18, W);
+					}
 					nphoto[pos] = k; nfeature[pos] = f;
 				}
 				else
 				{
+					ld<18>(W, Wold + (size_t)j * 18);
 					fd = FD + (size_t)f * (9 + TW);
-					const bool hub = (k == t->hub[0]) || (NH == 2 && k == t->hub[1]);
+					const bool hub = (k == fi.y) || (NH == 2 && k == fi.z);
 					if (!hub)
 					{
 						// W' = D_k^T W D_f at its new place: after the feature's hub block(s), old order kept
@@ -433,7 +442,7 @@ k_tr_entries(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__
 						mtm<6, 6, 3, false>(Dk, W, T1);
 						ld<9>(Df, fd);
 						mm<6, 3, 3, false>(T1, Df, Wn);
-						const int pos = t->W0n + NH * (f - t->F0 + 1) + (KW[j] - t->kW0);
+						const int pos = fi.w + KW[j];
 						st<18>(Wn_ + (size_t)pos * 18, Wn);
 						nphoto[pos] = k; nfeature[pos] = f;
 					}
@@ -441,7 +450,7 @@ k_tr_entries(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__
 					{
 						// an old block to a hub pose: the epilogue folds it into the new hub block; remember where it is
 						// (-1 none, >= 0 the block, -2 several -- duplicates add up -- and the epilogue walks the run)
-						int* h = hubJ + (size_t)f * NH + ((k == t->hub[0]) ? 0 : NH - 1);
+						int* h = hubJ + (size_t)f * NH + ((k == fi.y) ? 0 : NH - 1);
 						if (atomicCAS(h, -1, j) != -1) atomicExch(h, -2);
 					}
 					sl = lds_slot(gkeys, GCAP, k);
@@ -476,8 +485,7 @@ k_tr_entries(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__
 				{
 					const int fl = la + idx / 18, q = idx % 18;
 					const int r0 = max(sFp[fl], ce0) - ce0, r1 = min(sFp[fl + 1], ce1) - ce0;
-					const TMap* t = &tm[feat_map[f0 + fl]];
-					if (!(t->active > 0 && t->nh == NH)) continue;
+					if (!finfo[f0 + fl].x) continue;
 					double sum = 0.0;
 					for (int r = r0; r < r1; r++) sum += sT[r * 18 + q];
 					double* g = Gsum + (size_t)(f0 + fl) * TW + 18 * s + q;
@@ -766,12 +774,13 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		double* FD = ctx->scratch.alloc<double>((size_t)in.NF * (9 + 18 * NH));
 		double* Gsum = ctx->scratch.alloc<double>((size_t)in.NF * 18 * NH);
 		int* hubJ = ctx->scratch.alloc<int>((size_t)in.NF * NH);
+		int4* finfo = ctx->scratch.alloc<int4>(in.NF);
 		LSFM_CHECK_HIP(hipMemsetAsync(hubJ, 0xff, (size_t)in.NF * NH * sizeof(int), s));
 		hipLaunchKernelGGL(k_tr_feat_pre<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, d_tm, in.feat_map, in.feat, in.fptr, in.V, KW, out.feat,
-		                   out.fptr, out.V, FD);
+		                   out.fptr, out.V, FD, finfo);
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s)); // the events bracket k_tr_entries alone
-		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.W,
-		                   in.photo, KW, Dp, Cp, FD, out.W, out.photo, out.feature, Gsum, Gpose, hubJ);
+		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, finfo, in.fptr, in.W,
+		                   in.photo, KW, Dp, Cp, FD, out.W, out.photo, out.feature, Gsum, Gpose, hubJ, out.W_alias ? 1 : 0);
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
 		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,
 		                   Dp, FD, Gsum, hubJ, out.fptr, out.W, out.photo, out.feature, PP);
@@ -800,7 +809,8 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 __global__ void k_set_last(int* p, int idx, int v) { p[idx] = v; }
 
 void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
-                     const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out)
+                     const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out,
+                     bool alias_passthrough)
 {
 	hipStream_t s = ctx->stream;
 	const int B = in.B, nh = mono ? 2 : 1;
@@ -901,6 +911,16 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		}
 	}
 	out.NU = out.u_off[B]; out.NW = out.w_off[B];
+	if (alias_passthrough && !in.W_alias)
+	{
+		// pass-through maps keep their W blocks in `in` (the caller keeps `in` alive until the join has consumed `out`)
+		std::vector<int> delta(B);
+		for (int b = 0; b < B; b++) delta[b] = tm[b].active ? INT_MIN : in.w_off[b] - out.w_off[b];
+		int* d_alias = ar.alloc<int>(B);
+		h2d(ctx, d_alias, delta.data(), B * sizeof(int));
+		out.d_alias = d_alias;
+		out.W_alias = in.W;
+	}
 	// second upload keeps what the device computed (hub indices, parameters): patch only the offset fields
 	{
 		std::vector<TMap> dev(B);

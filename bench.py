@@ -5,8 +5,8 @@ binary tree, the region the reference itself times: LinearSFMImp.cpp:1929 -> 206
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full join tree over one resident set of local maps.  Inputs are uploaded once and stay in HBM; every
-step starts from a device-to-device copy of them (inside the timed region).  N > 1: every rank runs the same-sized,
+A "step" = one full join tree over one resident set of local maps.  Inputs are uploaded once and stay in HBM; no level
+writes its input, so every step reads them in place.  N > 1: every rank runs the same-sized,
 independently seeded set on its own GPU (units = local maps; no data-path collective exists between independent
 map sets) -> "scaling": "weak".  Prints ONE JSON line on rank 0.
 """

@@ -414,7 +414,9 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	if (NF) hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.V, sy.IV);
 	int* d_flags = sc.alloc<int>(4); // [0] overflow, [1] count, [2] mirrored count
 	size_t cap = 1024;
-	while (cap < (size_t)4 * ((size_t)io.NU + 32 * (size_t)M + 64)) cap <<= 1;
+	// S has little more than U's pattern (the W-induced pairs are mostly hub links that U already holds): 4x head room over
+	// NU + 8 M entries; the loop below grows the table if a level needs more
+	while (cap < (size_t)4 * ((size_t)io.NU + 8 * (size_t)M + 64)) cap <<= 1;
 	unsigned long long *tab = nullptr, *list = nullptr;
 	int* hval = nullptr;
 	for (int attempt = 0;; attempt++)

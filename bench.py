@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--new-per-frame", type=int, default=0)
     ap.add_argument("--vis", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="local maps given to the CPU baseline (0 = skip)")
-    ap.add_argument("--tol", type=float, default=1e-15)
+    ap.add_argument("--tol", type=float, default=1e-12, help="relative residual at which the refinement of a system stops (library default)")
     args = ap.parse_args()
 
     import torch

@@ -80,8 +80,9 @@ typedef struct lsfm_stats {
  * demand from the inputs of the first call).  Fails with LSFM_ERR_NO_DEVICE when no GPU is usable. */
 int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out);
 void lsfm_context_destroy(lsfm_context* ctx);
-/* PCG controls: relative tolerance on the preconditioned residual (default 1e-10), iteration cap per system
- * = max_it_factor * (6m) + 200 (default factor 4). */
+/* Solver controls.  rel_tol: the refinement of a system stops when ||E - S x|| <= rel_tol * ||E|| (default 1e-12: the
+ * residual level of a direct fp64 solve, which is what the reference computes) or when the true residual stops
+ * shrinking; at most 50 refinement steps.  max_it_factor: kept for compatibility, unused. */
 int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor);
 const char* lsfm_last_error(lsfm_context* ctx);
 void* lsfm_stream(lsfm_context* ctx); /* hipStream_t the library launches on */

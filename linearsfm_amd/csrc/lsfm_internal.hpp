@@ -68,7 +68,7 @@ struct DevBatch {
 	const int* d_alias = nullptr;
 };
 
-struct PcgOptions { double rel_tol = 1e-15; int max_it_factor = 4; };
+struct PcgOptions { double rel_tol = 1e-12; int max_it_factor = 4; };
 
 } // namespace lsfm
 

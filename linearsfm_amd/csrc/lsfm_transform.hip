@@ -764,7 +764,7 @@ __global__ void k_tr_diag(int B, const TMap* __restrict__ tm, const double* __re
 
 template <int NH>
 static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, const TMap* d_tm, const int* KU, const int* KW,
-                         double* Dp, double* Cp, double* Gpose, double* PP)
+                         double* Dp, double* Cp, double* Gpose, double* PP, double nw_act_in, double nw_act_out, double nf_act)
 {
 	hipStream_t s = ctx->stream;
 	const int M = in.M;
@@ -791,10 +791,13 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 			LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
 			ctx->stats->trf_launches++;
 			ctx->stats->trf_ms += t;
-			// k_tr_entries, every input and output once.  in: W block + photo + kept-rank per block, D_f/C_f + run pointer
-			// + map per feature; out: W' block + photo' + feature' per kept block, the W^T C sums per feature
-			ctx->stats->trf_bytes += (double)in.NW * (144 + 4 + 4) + (double)in.NF * ((9 + 18 * NH) * 8 + 8) +
-			                         (double)(out.NW - (double)NH * in.NF) * (144 + 8) + (double)in.NF * 18 * NH * 8;
+			// k_tr_entries, every input and output once.  Blocks of transformed maps: W block + photo + kept-rank in, W' block
+			// + photo' + feature' out (the blocks to the hub poses are not written here); per feature of a transformed map
+			// D_f/C_f + record + run pointer in, the W^T C sums out.  Blocks of pass-through maps: photo in, photo' + feature'
+			// out, plus the W block itself both ways when it is copied (not aliased)
+			const double nw_pass = (double)in.NW - nw_act_in;
+			ctx->stats->trf_bytes += nw_act_in * (144 + 4 + 4) + nf_act * ((9 + 18 * NH) * 8 + 16 + 4) + (nw_act_out - NH * nf_act) * (144 + 8) +
+			                         nf_act * 18 * NH * 8 + nw_pass * (4 + 8 + (out.W_alias ? 0 : 288)) + (double)(in.NF - nf_act) * (16 + 4);
 		}
 	}
 	if (in.NU)
@@ -936,8 +939,15 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW);
 	dev_zero(ctx, out.U, (size_t)out.NU * 36 * sizeof(double)); // the (k,h) slots are accumulated into
 	hipLaunchKernelGGL(k_set_last, dim3(1), dim3(1), 0, s, out.fptr, in.NF, out.NW);
-	if (mono) launch_stage<2>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP);
-	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP);
+	double nw_act_in = 0, nw_act_out = 0, nf_act = 0;
+	for (int b = 0; b < B; b++)
+		if (tm[b].active)
+		{
+			nw_act_in += in.w_off[b + 1] - in.w_off[b]; nw_act_out += out.w_off[b + 1] - out.w_off[b];
+			nf_act += in.feat_off[b + 1] - in.feat_off[b];
+		}
+	if (mono) launch_stage<2>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act);
+	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act);
 	LSFM_CHECK_HIP(hipGetLastError());
 	(void)any;
 	// scratch is released by the caller's next stage only after these launches are ordered on the stream

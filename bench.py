@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="nc3500", choices=["nc3500", "rs468", "rs90", "synth16k"],
+    ap.add_argument("--config", default="nc3500", choices=["nc3500", "rs468", "rs90", "synth16k", "synth64k"],
                     help="synthetic stand-in of a BASELINE.json configuration (linearsfm_amd/synth.py CONFIGS); the headline "
                          "metric is quoted on nc3500, the others are recorded in BASELINE.md")
     ap.add_argument("--maps", type=int, default=0, help="local maps (0 = the configuration's own count)")
@@ -126,7 +126,7 @@ def main():
         line = {
             "metric": "hierarchical linear map-joining solve wall-clock, %s (all transforms + joins)"
                       % {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular", "rs90": "RS90-like monocular",
-                         "synth16k": "synthetic 16k monocular"}[args.config],
+                         "synth16k": "synthetic 16k monocular", "synth64k": "synthetic 64k stereo"}[args.config],
             "value": ms_per_step / world,
             "unit": "ms",
             "n_gpus": world,

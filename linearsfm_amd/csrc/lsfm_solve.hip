@@ -283,14 +283,14 @@ __global__ void k_chunk_fill(int M, const int* __restrict__ frow, const int* __r
 // 8 lanes per chunk of <= SPMV_CHUNK blocks of one block row, lane r<6 owns scalar row r.  Rows with a single chunk
 // store, longer rows (hub poses) add atomically into the pre-zeroed y.  dotw != null: dot[seg] += w . y (fused p.Ap).
 __global__ void __launch_bounds__(256)
-k_spmv(int nchunks, const int* __restrict__ chunk_row, const int* __restrict__ chunk_beg, const int* __restrict__ frow,
+k_spmv(const int* __restrict__ d_nchunks, const int* __restrict__ chunk_row, const int* __restrict__ chunk_beg, const int* __restrict__ frow,
        const int* __restrict__ fcol, const int* __restrict__ fblk, const double* __restrict__ S, const double* __restrict__ x,
        double* __restrict__ y, const unsigned char* __restrict__ fixed, const double* __restrict__ dotw, const int* __restrict__ pose_seg,
        double* __restrict__ dot, int dot_stride)
 {
 	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
 	const int c = gid >> 3, r = gid & 7;
-	const bool v = c < nchunks && r < 6;
+	const bool v = c < *d_nchunks && r < 6;
 	double sum = 0.0;
 	int row = 0;
 	bool single = true;
@@ -375,7 +375,7 @@ __global__ void k_low_words(int n, const unsigned long long* __restrict__ keys, 
 	if (i < n) out[i] = (int)(keys[i] & 0xffffffffull);
 }
 
-void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags)
+void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int nmir)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
@@ -384,8 +384,9 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 	int* fv = sc.alloc<int>(2 * (size_t)cnt + 1);
 	dev_zero(ctx, d_flags + 2, sizeof(int));
 	if (cnt) hipLaunchKernelGGL(k_full_keys, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, sorted_upper, fk, fv, d_flags + 2);
-	const int nmir = d2h_int(ctx, d_flags + 2);
-	sy.nfull = cnt + nmir;
+	// every block row holds its diagonal block (k_pat_insert_u inserts (p,p) for every pose), so exactly cnt - M blocks
+	// have a mirror image: no need to read the counter back
+	sy.nfull = cnt + (nmir >= 0 ? nmir : cnt - M); // external matrices pass their own off-diagonal count
 	dev_sort_pairs_u64(ctx, fk, fv, sy.nfull, 64);
 	sy.frow = sc.alloc<int>(M + 1);
 	sy.fcol = sc.alloc<int>(sy.nfull + 1);
@@ -397,7 +398,9 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 	int* cptr = sc.alloc<int>(M + 2);
 	hipLaunchKernelGGL(k_chunk_counts, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, ccnt);
 	dev_exclusive_scan(ctx, ccnt, cptr, M);
-	sy.nchunks = d2h_int(ctx, cptr + M);
+	// the number of chunks stays on the device; the launch is sized by its bound (every row adds at most one partial chunk)
+	sy.d_nchunks = cptr + M;
+	sy.nchunks = sy.nfull / SPMV_CHUNK + M;
 	sy.chunk_row = sc.alloc<int>(sy.nchunks + 1);
 	sy.chunk_beg = sc.alloc<int>(sy.nchunks + 1);
 	hipLaunchKernelGGL(k_chunk_fill, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, cptr, sy.chunk_row, sy.chunk_beg);
@@ -499,7 +502,7 @@ void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, doub
 {
 	const int threads = sy.nchunks * 8;
 	if (threads)
-		hipLaunchKernelGGL(k_spmv, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sy.nchunks, sy.chunk_row, sy.chunk_beg, sy.frow, sy.fcol,
+		hipLaunchKernelGGL(k_spmv, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sy.d_nchunks, sy.chunk_row, sy.chunk_beg, sy.frow, sy.fcol,
 		                   sy.fblk, sy.S, x, y, fixed, dotw, pose_seg, dot, dot_stride);
 }
 
@@ -534,7 +537,10 @@ int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx
 	h2d(ctx, dk, keys.data(), (size_t)nnzb * sizeof(unsigned long long));
 	h2d(ctx, sy.S, val, (size_t)nnzb * 36 * sizeof(double));
 	h2d(ctx, dx, x, (size_t)m * 6 * sizeof(double));
-	build_spmv_index(ctx, sy, dk, d_flags);
+	int nmir = 0;
+	for (int p = 0; p < m; p++)
+		for (int k = rowptr[p]; k < rowptr[p + 1]; k++) nmir += colidx[k] != p;
+	build_spmv_index(ctx, sy, dk, d_flags, nmir);
 	float total = 0;
 	for (int k = 0; k < reps + 2; k++)
 	{

@@ -13,6 +13,7 @@ struct SchurSystem {
 	double* IV = nullptr;                          // [NF*9]
 	int *frow = nullptr, *fcol = nullptr, *fblk = nullptr; // both orientations, row sorted; fblk = (upper index << 1) | transposed
 	int *chunk_row = nullptr, *chunk_beg = nullptr;
+	const int* d_nchunks = nullptr; // exact chunk count (device); nchunks is the bound the launch is sized by
 	const unsigned long long* tab = nullptr; // pose pair -> block of S (open addressing), values in hval
 	const int* hval = nullptr;
 	unsigned long long mask = 0;
@@ -21,7 +22,7 @@ struct SchurSystem {
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void schur_values_stats(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy);
-void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags);
+void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int nmir = -1);
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed, const double* dotw,
                  const int* pose_seg, double* dot, int dot_stride);
 double spmv_bytes(const SchurSystem& sy);

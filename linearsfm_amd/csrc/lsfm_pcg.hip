@@ -943,7 +943,8 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		const PcgSeg& fin = hs2[nseg + g];
 		const double rel = fin.ee > 0 ? sqrt(fin.rr / fin.ee) : 0.0;
 		maxrel = std::max(maxrel, rel);
-		if (hs2[g].done != 1 && !(rel < 1e-9)) notconv++;
+		// converged = stopped by the tolerance, or stopped by stagnation with a residual a direct solve would also leave
+		if (!(rel < 1e-8) || (hs2[g].done != 1 && !(rel < 1e-9))) notconv++;
 	}
 	if (ctx->stats)
 	{

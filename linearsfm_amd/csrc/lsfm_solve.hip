@@ -9,8 +9,8 @@
 //   K10 k_spmv / k_pcg_*  block-Jacobi preconditioned CG on the symmetric 6x6-block system, all independent systems
 //                         of the level iterate together with per-system scalars (replaces Imp.cpp:2334-2361)
 //   K11 k_backsub         features: x_f = V_f^-1 (eb_f - sum W_pf^T x_p)     (pba_solveFeatures, Imp.cpp:2980-3020)
-// S is kept as its upper block triangle (diagonal blocks full); the SpMV walks a row-sorted index of both
-// orientations that points into the same 288-byte blocks (no second copy of the values).
+// S is kept as its upper block triangle (diagonal blocks full); the SpMV reads every stored block once and adds its
+// mirrored part through an LDS window of y (k_spmv).
 #include <algorithm>
 #include <cmath>
 
@@ -21,7 +21,6 @@
 namespace lsfm {
 
 static const unsigned long long HEMPTY = ~0ull;
-#define SPMV_CHUNK 16
 
 __global__ void k_vinv(int NF, const double* __restrict__ V, double* __restrict__ IV)
 {
@@ -250,80 +249,153 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 	}
 }
 
-// ---- row-sorted index of both orientations -----------------------------------------------------------------
-__global__ void k_full_keys(int nnzb, const unsigned long long* __restrict__ sorted, unsigned long long* __restrict__ fkeys, int* __restrict__ fvals,
-                            int* __restrict__ count)
-{
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nnzb) return;
-	unsigned long long key = sorted[i];
-	unsigned p = (unsigned)(key >> 32), q = (unsigned)(key & 0xffffffffull);
-	fkeys[i] = key; fvals[i] = i << 1;
-	if (p != q)
-	{
-		int o = nnzb + atomicAdd(count, 1);
-		fkeys[o] = ((unsigned long long)q << 32) | p; fvals[o] = (i << 1) | 1;
-	}
-}
-__global__ void k_chunk_counts(int M, const int* __restrict__ frow, int* __restrict__ cnt)
-{
-	int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r < M) cnt[r] = (frow[r + 1] - frow[r] + SPMV_CHUNK - 1) / SPMV_CHUNK;
-	if (r == 0) cnt[M] = 0;
-}
-__global__ void k_chunk_fill(int M, const int* __restrict__ frow, const int* __restrict__ cptr, int* __restrict__ chunk_row, int* __restrict__ chunk_beg)
+// ---- K10a: y = S x on the upper-block storage, every stored block read ONCE --------------------------------
+// A work-group owns SPT consecutive block rows.  Lane group g (8 lanes, lane r < 6 = scalar row r) takes blocks (p,q) of
+// those rows: the row part B x_q goes to y_p and the mirrored part B^T x_p to y_q, both into an LDS window of y that
+// covers the tile's rows and the SPW rows after them (S is a pose chain: q - p is small), flushed once with
+// contiguous atomics.  Targets outside the window -- the columns of hub poses -- go through a small LDS table keyed
+// by row.  Rows longer than SP_LONG blocks (the hub poses: up to a block per pose) are not walked by their own tile;
+// instead every tile takes the hub blocks (h,q) whose COLUMN q it owns (their mirrored part lands in its window, their
+// row part in the table under h).  So nothing is read twice, no wave scatters 8-byte atomics over 64 rows, and the
+// index is just the upper block CSR plus the list of long rows.  (First version: a row-sorted index of both
+// orientations -- every block read twice, one more sort per level.)   y must be zero on entry.
+// dotw != null: dot[seg] += w . y (fused p.Ap).
+#define SPT 16   /* block rows per work-group */
+#define SPW 64   /* rows of the window after the tile */
+#define SP_LONG 256
+#define SP_FAR 64
+__global__ void k_spmv_long_rows(int M, const int* __restrict__ rowptr, int* __restrict__ nlong, int* __restrict__ longrows)
 {
 	int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= M) return;
-	int c0 = cptr[r], n = cptr[r + 1] - c0, b = frow[r];
-	for (int c = 0; c < n; c++) { chunk_row[c0 + c] = r; chunk_beg[c0 + c] = b + c * SPMV_CHUNK; }
+	if (r < M && rowptr[r + 1] - rowptr[r] > SP_LONG) longrows[atomicAdd(nlong, 1)] = r;
 }
-
-// ---- K10a: y = S x --------------------------------------------------------------------------------------
-// 8 lanes per chunk of <= SPMV_CHUNK blocks of one block row, lane r<6 owns scalar row r.  Rows with a single chunk
-// store, longer rows (hub poses) add atomically into the pre-zeroed y.  dotw != null: dot[seg] += w . y (fused p.Ap).
 __global__ void __launch_bounds__(256)
-k_spmv(const int* __restrict__ d_nchunks, const int* __restrict__ chunk_row, const int* __restrict__ chunk_beg, const int* __restrict__ frow,
-       const int* __restrict__ fcol, const int* __restrict__ fblk, const double* __restrict__ S, const double* __restrict__ x,
-       double* __restrict__ y, const unsigned char* __restrict__ fixed, const double* __restrict__ dotw, const int* __restrict__ pose_seg,
-       double* __restrict__ dot, int dot_stride)
+k_spmv(int M, const int* __restrict__ rowptr, const int* __restrict__ colidx, const int* __restrict__ nlong_p, const int* __restrict__ longrows,
+       const double* __restrict__ S, const double* __restrict__ x, double* __restrict__ y, const unsigned char* __restrict__ fixed,
+       const double* __restrict__ dotw, const int* __restrict__ pose_seg, double* __restrict__ dot, int dot_stride)
 {
-	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-	const int c = gid >> 3, r = gid & 7;
-	const bool v = c < *d_nchunks && r < 6;
-	double sum = 0.0;
-	int row = 0;
-	bool single = true;
-	if (v)
+	__shared__ int pre[SPT + 1];               // prefix of the short rows' lengths
+	__shared__ int rp[SPT + 1];
+	__shared__ double ywin[(SPT + SPW) * 6];
+	__shared__ int fkeys[SP_FAR];
+	__shared__ double fvals[SP_FAR * 6];
+	const int tid = threadIdx.x, g = tid >> 3, r = tid & 7, ng = blockDim.x >> 3;
+	const int r0 = blockIdx.x * SPT, r1 = min(r0 + SPT, M), nr = r1 - r0;
+	for (int i = tid; i < (SPT + SPW) * 6; i += blockDim.x) ywin[i] = 0.0;
+	for (int i = tid; i < SP_FAR; i += blockDim.x) fkeys[i] = -1;
+	for (int i = tid; i < SP_FAR * 6; i += blockDim.x) fvals[i] = 0.0;
+	for (int i = tid; i <= nr; i += blockDim.x) rp[i] = rowptr[r0 + i];
+	__syncthreads();
+	if (tid == 0)
 	{
-		row = chunk_row[c];
-		const int rb = frow[row], re = frow[row + 1];
-		const int b0 = chunk_beg[c], b1 = min(b0 + SPMV_CHUNK, re);
-		single = (re - rb) <= SPMV_CHUNK;
-		for (int k = b0; k < b1; k++)
+		int acc = 0;
+		for (int i = 0; i < nr; i++) { pre[i] = acc; const int len = rp[i + 1] - rp[i]; acc += len > SP_LONG ? 0 : len; }
+		pre[nr] = acc;
+	}
+	__syncthreads();
+	// target (row t, scalar r): window, table or global
+	auto add = [&](int t, double v) {
+		const int w = t - r0;
+		if (w >= 0 && w < SPT + SPW) { lds_add_f64(&ywin[w * 6 + r], v); return; }
+		const int sl = lds_slot(fkeys, SP_FAR, t);
+		if (sl >= 0) { lds_add_f64(&fvals[sl * 6 + r], v); return; }
+		// table full (a band wider than the window AND more far rows than slots): straight to memory, with its share of
+		// the fused dot product
+		if (fixed && fixed[(size_t)t * 6 + r]) return;
+		atomic_add_f64(y + (size_t)t * 6 + r, v);
+		if (dotw) atomic_add_f64(dot + (size_t)pose_seg[t] * dot_stride, dotw[(size_t)t * 6 + r] * v);
+	};
+	auto block = [&](int k, int p) {
+		const int q = colidx[k];
+		const double* blk = S + (size_t)k * 36;
+		const double* xq = x + (size_t)q * 6;
+		double sum = 0.0;
+#pragma unroll
+		for (int j = 0; j < 6; j++) sum = fma(blk[r * 6 + j], xq[j], sum);
+		add(p, sum);
+		if (q != p)
 		{
-			const int col = fcol[k], bt = fblk[k];
-			const double* blk = S + (size_t)(bt >> 1) * 36;
-			const double* xv = x + (size_t)col * 6;
-			if (bt & 1)
-			{
+			const double* xp = x + (size_t)p * 6;
+			double t = 0.0;
 #pragma unroll
-				for (int j = 0; j < 6; j++) sum = fma(blk[j * 6 + r], xv[j], sum);
-			}
+			for (int j = 0; j < 6; j++) t = fma(blk[j * 6 + r], xp[j], t);
+			add(q, t);
+		}
+	};
+	// (1) the short rows of the tile
+	const int nb = pre[nr];
+	if (r < 6)
+		for (int i = g; i < nb; i += ng)
+		{
+			int lo = 0, hi = nr - 1; // row of item i: last row with pre[row] <= i (rows of length 0 are skipped by the <=)
+			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= i) lo = mid; else hi = mid - 1; }
+			block(rp[lo] + (i - pre[lo]), r0 + lo);
+		}
+	// (2) the long rows: their blocks in the tile's columns.  One lane per long row finds where the tile's columns start
+	// in it (all searches run side by side), then the lane groups take the blocks
+	__shared__ int lstart[SP_FAR];
+	const int nlong = *nlong_p;
+	for (int l0 = 0; l0 < nlong; l0 += SP_FAR)
+	{
+		const int nl = min(SP_FAR, nlong - l0);
+		__syncthreads();
+		if (tid < nl)
+		{
+			const int h = longrows[l0 + tid];
+			int lo = rowptr[h], hi = rowptr[h + 1]; // first block of row h with column >= r0
+			// a hub row is (nearly) dense from its diagonal on: try the position a dense row would have first
+			const int guess = lo + max(r0 - h, 0);
+			if (guess < hi && colidx[guess] >= r0 && (guess == lo || colidx[guess - 1] < r0)) lo = guess;
 			else
+				while (lo < hi) { const int mid = (lo + hi) >> 1; if (colidx[mid] < r0) lo = mid + 1; else hi = mid; }
+			lstart[tid] = lo;
+		}
+		__syncthreads();
+		if (r < 6)
+			for (int li = 0; li < nl; li++)
 			{
-#pragma unroll
-				for (int j = 0; j < 6; j++) sum = fma(blk[r * 6 + j], xv[j], sum);
+				const int h = longrows[l0 + li], he = rowptr[h + 1];
+				for (int k = lstart[li] + g; k < he && colidx[k] < r1; k += ng) block(k, h);
+			}
+	}
+	__syncthreads();
+	// (3) flush: the window (contiguous), then the far rows
+	double w = 0.0;
+	int seg = 0;
+	bool any = false;
+	for (int i = tid; i < (SPT + SPW) * 6; i += blockDim.x)
+	{
+		const int t = r0 + i / 6;
+		const double v = ywin[i];
+		if (t < M && v != 0.0 && !(fixed && fixed[(size_t)t * 6 + i % 6]))
+		{
+			atomic_add_f64(y + (size_t)t * 6 + i % 6, v);
+			if (dotw)
+			{
+				const int sg = pose_seg[t];
+				if (any && sg != seg) { atomic_add_f64(dot + (size_t)seg * dot_stride, w); w = 0.0; }
+				seg = sg; any = true;
+				w = fma(dotw[(size_t)t * 6 + i % 6], v, w);
 			}
 		}
-		if (fixed && fixed[(size_t)row * 6 + r]) sum = 0.0;
-		if (single) y[(size_t)row * 6 + r] = sum; else atomic_add_f64(y + (size_t)row * 6 + r, sum);
 	}
-	if (dotw)
+	for (int i = tid; i < SP_FAR * 6; i += blockDim.x)
 	{
-		double w = v ? dotw[(size_t)row * 6 + r] * sum : 0.0;
-		wave_scatter_add<1>(dot + (size_t)(v ? pose_seg[row] : 0) * dot_stride, &w, v);
+		const int t = fkeys[i / 6];
+		const double v = fvals[i];
+		if (t >= 0 && v != 0.0 && !(fixed && fixed[(size_t)t * 6 + i % 6]))
+		{
+			atomic_add_f64(y + (size_t)t * 6 + i % 6, v);
+			if (dotw)
+			{
+				const int sg = pose_seg[t];
+				if (any && sg != seg) { atomic_add_f64(dot + (size_t)seg * dot_stride, w); w = 0.0; }
+				seg = sg; any = true;
+				w = fma(dotw[(size_t)t * 6 + i % 6], v, w);
+			}
+		}
 	}
+	if (dotw) wave_scatter_add<1>(dot + (size_t)seg * dot_stride, &w, any);
 }
 
 // K11 (Imp.cpp:2980-3020); features of carried maps keep their values
@@ -375,35 +447,28 @@ __global__ void k_low_words(int n, const unsigned long long* __restrict__ keys, 
 	if (i < n) out[i] = (int)(keys[i] & 0xffffffffull);
 }
 
-void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int nmir)
+void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
 	const int M = sy.M, cnt = sy.nnzb;
-	unsigned long long* fk = sc.alloc<unsigned long long>(2 * (size_t)cnt + 1);
-	int* fv = sc.alloc<int>(2 * (size_t)cnt + 1);
-	dev_zero(ctx, d_flags + 2, sizeof(int));
-	if (cnt) hipLaunchKernelGGL(k_full_keys, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, sorted_upper, fk, fv, d_flags + 2);
-	// every block row holds its diagonal block (k_pat_insert_u inserts (p,p) for every pose), so exactly cnt - M blocks
-	// have a mirror image: no need to read the counter back
-	sy.nfull = cnt + (nmir >= 0 ? nmir : cnt - M); // external matrices pass their own off-diagonal count
-	dev_sort_pairs_u64(ctx, fk, fv, sy.nfull, 64);
-	sy.frow = sc.alloc<int>(M + 1);
-	sy.fcol = sc.alloc<int>(sy.nfull + 1);
-	sy.fblk = fv;
-	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, sy.nfull, fk, 32, sy.frow);
-	if (sy.nfull) hipLaunchKernelGGL(k_low_words, dim3((sy.nfull + 255) / 256), dim3(256), 0, s, sy.nfull, fk, sy.fcol);
-	// chunks of <= SPMV_CHUNK blocks
-	int* ccnt = sc.alloc<int>(M + 1);
-	int* cptr = sc.alloc<int>(M + 2);
-	hipLaunchKernelGGL(k_chunk_counts, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, ccnt);
-	dev_exclusive_scan(ctx, ccnt, cptr, M);
-	// the number of chunks stays on the device; the launch is sized by its bound (every row adds at most one partial chunk)
-	sy.d_nchunks = cptr + M;
-	sy.nchunks = sy.nfull / SPMV_CHUNK + M;
-	sy.chunk_row = sc.alloc<int>(sy.nchunks + 1);
-	sy.chunk_beg = sc.alloc<int>(sy.nchunks + 1);
-	hipLaunchKernelGGL(k_chunk_fill, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.frow, cptr, sy.chunk_row, sy.chunk_beg);
+	(void)d_flags;
+	if (!sy.rowptr)
+	{
+		sy.rowptr = sc.alloc<int>(M + 1);
+		hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, cnt, sorted_upper, 32, sy.rowptr);
+	}
+	if (!sy.colidx)
+	{
+		sy.colidx = sc.alloc<int>(cnt + 1);
+		if (cnt) hipLaunchKernelGGL(k_low_words, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, sorted_upper, sy.colidx);
+	}
+	// the only extra index: the rows with more than SP_LONG blocks (hub poses)
+	int* nl = sc.alloc<int>(1);
+	sy.longrows = sc.alloc<int>(M + 1);
+	dev_zero(ctx, nl, sizeof(int));
+	if (M) hipLaunchKernelGGL(k_spmv_long_rows, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.rowptr, nl, sy.longrows);
+	sy.d_nlong = nl;
 }
 
 // Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only
@@ -500,10 +565,9 @@ void schur_values_stats(lsfm_context* ctx, const SolveIO& io, const SchurSystem&
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,
                  const double* dotw, const int* pose_seg, double* dot, int dot_stride)
 {
-	const int threads = sy.nchunks * 8;
-	if (threads)
-		hipLaunchKernelGGL(k_spmv, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sy.d_nchunks, sy.chunk_row, sy.chunk_beg, sy.frow, sy.fcol,
-		                   sy.fblk, sy.S, x, y, fixed, dotw, pose_seg, dot, dot_stride);
+	if (sy.M)
+		hipLaunchKernelGGL(k_spmv, dim3((sy.M + SPT - 1) / SPT), dim3(256), 0, ctx->stream, sy.M, sy.rowptr, sy.colidx, sy.d_nlong, sy.longrows, sy.S, x, y,
+		                   fixed, dotw, pose_seg, dot, dot_stride);
 }
 
 // algorithmic bytes of one SpMV on the upper-block storage: blocks + column indices + row pointers + x and y

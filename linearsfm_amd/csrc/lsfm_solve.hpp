@@ -5,15 +5,14 @@
 namespace lsfm {
 
 struct SchurSystem {
-	int M = 0, nnzb = 0, nfull = 0, nchunks = 0;
+	int M = 0, nnzb = 0;
 	int *rowptr = nullptr, *colidx = nullptr;      // upper block CSR (diagonal block first in every row)
 	const unsigned long long* upper_keys = nullptr; // [nnzb] sorted (row << 32 | col) of the upper pattern
 	double* S = nullptr;                           // [nnzb*36]
 	double* E = nullptr;                           // [M*6]
 	double* IV = nullptr;                          // [NF*9]
-	int *frow = nullptr, *fcol = nullptr, *fblk = nullptr; // both orientations, row sorted; fblk = (upper index << 1) | transposed
-	int *chunk_row = nullptr, *chunk_beg = nullptr;
-	const int* d_nchunks = nullptr; // exact chunk count (device); nchunks is the bound the launch is sized by
+	int* longrows = nullptr;        // rows with more than SP_LONG blocks (hub poses), *d_nlong of them
+	const int* d_nlong = nullptr;
 	const unsigned long long* tab = nullptr; // pose pair -> block of S (open addressing), values in hval
 	const int* hval = nullptr;
 	unsigned long long mask = 0;

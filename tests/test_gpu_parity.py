@@ -226,3 +226,31 @@ def test_subtree_sharding_on_device_equals_single_tree(ctx, mono):
         assert np.array_equal(merged[k], single[k]), k
     assert pose_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-8
     assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-8
+
+
+@pytest.mark.parametrize("m,band,hubs", [(700, 3, 2), (700, 80, 5), (300, 299, 0), (64, 1, 1), (1, 0, 0)])
+def test_spmv_long_rows_and_wide_bands(ctx, m, band, hubs):
+    """k_spmv paths: hub rows longer than a tile's budget (taken by the tiles that own their columns), bands wider than
+    the LDS window of y (far-row table / global adds), a dense matrix, tiny systems."""
+    rng = np.random.default_rng(m + band)
+    hub = set(int(h) for h in rng.choice(m, size=min(hubs, m), replace=False)) if hubs else set()
+    rowptr, colidx = [0], []
+    for p in range(m):
+        cols = set(range(p, min(m, p + band + 1))) | {h for h in hub if h >= p}
+        if p in hub:
+            cols |= set(range(p, m))
+        colidx += sorted(cols)
+        rowptr.append(len(colidx))
+    val = rng.normal(size=(len(colidx), 6, 6))
+    A = np.zeros((6 * m, 6 * m))
+    for p in range(m):
+        for k in range(rowptr[p], rowptr[p + 1]):
+            q = colidx[k]
+            if p == q:
+                val[k] = val[k] + val[k].T
+            A[6 * p:6 * p + 6, 6 * q:6 * q + 6] = val[k]
+            A[6 * q:6 * q + 6, 6 * p:6 * p + 6] = val[k].T
+    x = rng.normal(size=6 * m)
+    y, ms, by = ctx.spmv_bench(rowptr, colidx, val, x, reps=2)
+    ref = A @ x
+    assert np.max(np.abs(y - ref)) / np.max(np.abs(ref)) < 1e-12

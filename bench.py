@@ -163,7 +163,7 @@ def main():
             "kernels": {k: {"avg_launch_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"], "ms_per_step": v["total_ms"],
                             "launches_per_step": v["launches_per_step"]} for k, v in kern.items()},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU leg runs at N=1 only
             S = min(args.cpu_sample, args.maps)
             o_out, timing, orc, wall = cpu_baseline(maps, S, mono)
             # same prefix on the device, for a like-for-like ratio and a parity check of this very run

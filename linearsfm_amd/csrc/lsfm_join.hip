@@ -7,7 +7,7 @@
 // and the join reduces to renumbering features:  End's features keep their order, Cur's unmatched features are
 // appended (Imp.cpp:2630-2643), W runs of a shared feature are End's then Cur's (Imp.cpp:2761-2847), V is summed
 // (Imp.cpp:2796-2800).  The reference finds common features with std::find over all of Cur's labels per End
-// feature (O(n1*n2), Imp.cpp:2581-2599); here one radix sort of (pair, label, side) keys does it for the level.
+// feature (O(n1*n2), Imp.cpp:2581-2599); here one hash join per level.
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
 #include <climits>
@@ -15,29 +15,65 @@
 
 namespace lsfm {
 
-__global__ void k_join_keys(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, unsigned long long* __restrict__ keys,
-                            int* __restrict__ vals)
+// Common features of a pair (K5): a hash join.  The features of the first map of every pair go into an open-addressing
+// table keyed by (pair, label); the features of the second map probe it.  (The reference looks every End feature up in
+// Cur with std::find, O(n1 n2), Imp.cpp:2581-2599; the first version here sorted all (pair, label, side) keys of the
+// level, ~10 merge passes over up to 2.3 M keys.)  Labels are unique inside a map.
+__device__ __forceinline__ unsigned long long jh_mix(unsigned long long x)
+{
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+	return x;
+}
+__global__ void k_join_hash_insert(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, unsigned long long* tab,
+                                   int* __restrict__ tval, unsigned long long mask)
 {
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
-	int mp = feat_map[f];
-	keys[f] = ((unsigned long long)(mp >> 1) << 33) | ((unsigned long long)(unsigned)feat_id[f] << 1) | (unsigned long long)(mp & 1);
-	vals[f] = f;
+	const int mp = feat_map[f];
+	if (mp & 1) return;
+	const unsigned long long key = ((unsigned long long)(mp >> 1) << 32) | (unsigned)feat_id[f];
+	unsigned long long h = jh_mix(key) & mask;
+	for (;;)
+	{
+		const unsigned long long old = atomicCAS(&tab[h], ~0ull, key);
+		if (old == ~0ull || old == key) { tval[h] = f; return; }
+		h = (h + 1) & mask;
+	}
 }
-
-// after the sort equal (pair,label) keys are adjacent, End (side 0) first
-__global__ void k_join_match(int NF, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int* __restrict__ match,
-                             int* __restrict__ unmatched)
+__global__ void k_join_hash_probe(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, const unsigned long long* __restrict__ tab,
+                                  const int* __restrict__ tval, unsigned long long mask, int* __restrict__ match, int* __restrict__ unmatched)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= NF) return;
-	unsigned long long k = keys[i];
-	int f = vals[i];
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	const int mp = feat_map[f];
 	int mt = -1;
-	if ((k & 1ull) && i > 0 && keys[i - 1] == k - 1ull) mt = vals[i - 1];
+	if (mp & 1)
+	{
+		const unsigned long long key = ((unsigned long long)(mp >> 1) << 32) | (unsigned)feat_id[f];
+		unsigned long long h = jh_mix(key) & mask;
+		for (;;)
+		{
+			const unsigned long long cur = tab[h];
+			if (cur == key) { mt = tval[h]; break; }
+			if (cur == ~0ull) break;
+			h = (h + 1) & mask;
+		}
+	}
 	match[f] = mt;
-	unmatched[f] = ((k & 1ull) && mt < 0) ? 1 : 0;
-	if (i == 0) unmatched[NF] = 0;
+	unmatched[f] = ((mp & 1) && mt < 0) ? 1 : 0;
+	if (f == 0) unmatched[NF] = 0;
+}
+void join_match_features(lsfm_context* ctx, const DevBatch& in, int* match, int* unm)
+{
+	hipStream_t s = ctx->stream;
+	size_t cap = 1024;
+	while (cap < 2 * (size_t)in.NF) cap <<= 1;
+	unsigned long long* tab = ctx->scratch.alloc<unsigned long long>(cap);
+	int* tval = ctx->scratch.alloc<int>(cap);
+	LSFM_CHECK_HIP(hipMemsetAsync(tab, 0xff, cap * sizeof(unsigned long long), s));
+	const int nb = (in.NF + 255) / 256;
+	hipLaunchKernelGGL(k_join_hash_insert, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, tab, tval, (unsigned long long)(cap - 1));
+	hipLaunchKernelGGL(k_join_hash_probe, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, tab, tval, (unsigned long long)(cap - 1), match, unm);
 }
 
 __global__ void k_gather_at(const int* __restrict__ src, const int* __restrict__ idx, int n, int* __restrict__ out)
@@ -198,22 +234,12 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	(void)e0; (void)e1;
 
 	// ---- common features (K5) ----
-	unsigned long long* keys = ctx->scratch.alloc<unsigned long long>(in.NF + 1);
-	int* vals = ctx->scratch.alloc<int>(in.NF + 1);
 	int* match = ctx->scratch.alloc<int>(in.NF + 1);
 	int* unm = ctx->scratch.alloc<int>(in.NF + 2);
 	int* R = ctx->scratch.alloc<int>(in.NF + 2);
 	const int nb = (in.NF + 255) / 256;
-	if (in.NF)
-	{
-		hipLaunchKernelGGL(k_join_keys, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, keys, vals);
-		int gbits = 1;
-		while ((1 << gbits) < G + 1) gbits++;
-		dev_sort_pairs_u64(ctx, keys, vals, in.NF, 33 + gbits);
-		hipLaunchKernelGGL(k_join_match, dim3(nb), dim3(256), 0, s, in.NF, keys, vals, match, unm);
-	}
-	else
-		dev_zero(ctx, unm, 2 * sizeof(int));
+	if (in.NF) join_match_features(ctx, in, match, unm);
+	else dev_zero(ctx, unm, 2 * sizeof(int));
 	dev_exclusive_scan(ctx, unm, R, in.NF);
 	// unmatched counts per map -> joint feature offsets (host)
 	int* d_rb = ctx->scratch.alloc<int>(B + 1);

@@ -10,10 +10,9 @@ struct JGroup {
 	int rC0;              // rank offset of Cur's unmatched features
 };
 
-__global__ void k_join_keys(int NF, const int* __restrict__ feat_id, const int* __restrict__ feat_map, unsigned long long* __restrict__ keys,
-                            int* __restrict__ vals);
-__global__ void k_join_match(int NF, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int* __restrict__ match,
-                             int* __restrict__ unmatched);
+// match[f] = feature of the pair's first map with the same label (-1 none), unm[f] = 1 for unmatched features of the
+// second map (unm[NF] = 0)
+void join_match_features(lsfm_context* ctx, const DevBatch& in, int* match, int* unm);
 __global__ void k_gather_at(const int* __restrict__ src, const int* __restrict__ idx, int n, int* __restrict__ out);
 __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const int* __restrict__ feat_id, const double* __restrict__ feat,
                                 const double* __restrict__ V, const int* __restrict__ fptr, const int* __restrict__ match,

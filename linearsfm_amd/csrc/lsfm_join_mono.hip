@@ -310,22 +310,12 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	const int MY = M - 2 * npair;
 
 	// ---- common features (K5), same as Stereo ----
-	unsigned long long* keys = sc.alloc<unsigned long long>(in.NF + 1);
-	int* vals = sc.alloc<int>(in.NF + 1);
 	int* match = sc.alloc<int>(in.NF + 1);
 	int* unm = sc.alloc<int>(in.NF + 2);
 	int* RF = sc.alloc<int>(in.NF + 2);
 	const int nb = (in.NF + 255) / 256;
-	if (in.NF)
-	{
-		hipLaunchKernelGGL(k_join_keys, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, keys, vals);
-		int gbits = 1;
-		while ((1 << gbits) < G + 1) gbits++;
-		dev_sort_pairs_u64(ctx, keys, vals, in.NF, 33 + gbits);
-		hipLaunchKernelGGL(k_join_match, dim3(nb), dim3(256), 0, s, in.NF, keys, vals, match, unm);
-	}
-	else
-		dev_zero(ctx, unm, 2 * sizeof(int));
+	if (in.NF) join_match_features(ctx, in, match, unm);
+	else dev_zero(ctx, unm, 2 * sizeof(int));
 	dev_exclusive_scan(ctx, unm, RF, in.NF);
 	int* d_rb = sc.alloc<int>(B + 1);
 	hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, RF, in.d_feat_off, B + 1, d_rb);

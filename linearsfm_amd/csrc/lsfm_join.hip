@@ -125,23 +125,30 @@ __global__ void k_add_lens(int n, const int* __restrict__ a, const int* __restri
 	if (i == 0) out[n] = 0;
 }
 
+__global__ void k_join_wbase(int NF, const int* __restrict__ feat_map, const int* __restrict__ newf, const int* __restrict__ lenE,
+                             const int* __restrict__ fptr_y, int* __restrict__ wbase)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	const int nf = newf[f];
+	wbase[f] = fptr_y[nf] + ((feat_map[f] & 1) ? lenE[nf] : 0); // the second map's blocks follow the first map's
+}
 __global__ void k_join_wcopy(int NW, const double* __restrict__ W, const int* __restrict__ photo, const int* __restrict__ feature,
-                             const int* __restrict__ fptr, const int* __restrict__ feat_map, const int* __restrict__ newf,
-                             const int* __restrict__ lenE, const int* __restrict__ fptr_y, double* __restrict__ Wy, int* __restrict__ photo_y,
-                             int* __restrict__ feature_y, int* __restrict__ srcf, const double* __restrict__ W_alias,
-                             const int* __restrict__ alias)
+                             const int* __restrict__ fptr, const int* __restrict__ wbase, const int* __restrict__ newf,
+                             double* __restrict__ Wy, int* __restrict__ photo_y, int* __restrict__ feature_y, int* __restrict__ srcf,
+                             const double* __restrict__ W_alias, const int* __restrict__ alias, const int* __restrict__ feat_map)
 {
 	int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= NW) return;
-	int f = feature[j], nf = newf[f];
-	int dest = fptr_y[nf] + ((feat_map[f] & 1) ? lenE[nf] : 0) + (j - fptr[f]);
+	const int f = feature[j];
+	const int dest = wbase[f] + (j - fptr[f]);
 	// blocks of a map the transform passed through are still in the transform's input
 	const int delta = alias ? alias[feat_map[f]] : INT_MIN;
 	const double* w = delta != INT_MIN ? W_alias + (size_t)(j + delta) * 18 : W + (size_t)j * 18;
 	double* o = Wy + (size_t)dest * 18;
 	for (int i = 0; i < 18; i++) o[i] = w[i];
 	photo_y[dest] = photo[j];
-	feature_y[dest] = nf;
+	feature_y[dest] = newf[f];
 	srcf[dest] = f;
 }
 
@@ -225,13 +232,16 @@ __global__ void k_shift_segments(int n, const int* __restrict__ map_of, int* __r
 	if (i < n) seg[i] = map_of[i] >> 1;
 }
 
-void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out)
+// A Stereo join in two steps, so that a caller (the tree scheduler) can let the transform write its W blocks straight into
+// the joint map: join_stereo_prepare() needs the input maps without their W values (labels, estimates, V, run pointers)
+// and lays the joint map out; st.wbase[f] is where the run of input feature f starts in the joint W arrays.  Whoever
+// fills out.W / photo / feature / st.srcf from there (k_join_wcopy here, or the transform's block kernel) is followed by
+// join_stereo_finish(): right-hand sides and the solve.  Scratch taken in prepare is released by finish.
+void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, JoinState& st)
 {
 	hipStream_t s = ctx->stream;
 	const int B = in.B, G = (B + 1) / 2;
-	size_t smark = ctx->scratch.mark();
-	hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
-	(void)e0; (void)e1;
+	st.smark = ctx->scratch.mark();
 
 	// ---- common features (K5) ----
 	int* match = ctx->scratch.alloc<int>(in.NF + 1);
@@ -252,8 +262,9 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	out.pose_off.assign(G + 1, 0); out.feat_off.assign(G + 1, 0); out.u_off.assign(G + 1, 0); out.w_off.assign(G + 1, 0);
 	out.Ref.resize(G); out.FRef.resize(G); out.ScaP.assign(G, 0); out.Fix.assign(G, 0); out.Sign.assign(G, 1); out.FScaP.assign(G, 0); out.FFix.assign(G, 0);
 	std::vector<JGroup> grp(G);
-	std::vector<unsigned char> seg_active(G);
-	std::vector<int> seg_rows(G);
+	std::vector<unsigned char>& seg_active = st.seg_active;
+	std::vector<int>& seg_rows = st.seg_rows;
+	seg_active.assign(G, 0); seg_rows.assign(G, 0);
 	for (int g = 0; g < G; g++)
 	{
 		const int a = 2 * g, b = 2 * g + 1;
@@ -297,13 +308,13 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
 		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
 	}
-	int* newf = ctx->scratch.alloc<int>(in.NF + 1);
-	int* lenE = ctx->scratch.alloc<int>(NFY + 1);
+	int* newf = st.newf = ctx->scratch.alloc<int>(in.NF + 1);
+	int* lenE = st.lenE = ctx->scratch.alloc<int>(NFY + 1);
 	int* lenC = ctx->scratch.alloc<int>(NFY + 1);
 	int* lens = ctx->scratch.alloc<int>(NFY + 2);
-	int* srcf = ctx->scratch.alloc<int>(in.NW + 1);
-	double* eP = ctx->scratch.alloc<double>((size_t)in.M * 6);
-	double* eF = ctx->scratch.alloc<double>((size_t)NFY * 3);
+	st.srcf = ctx->scratch.alloc<int>(in.NW + 1);
+	double* eP = st.eP = ctx->scratch.alloc<double>((size_t)in.M * 6);
+	double* eF = st.eF = ctx->scratch.alloc<double>((size_t)NFY * 3);
 	dev_zero(ctx, lenE, (NFY + 1) * sizeof(int)); dev_zero(ctx, lenC, (NFY + 1) * sizeof(int));
 	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
 	dev_zero(ctx, eP, (size_t)in.M * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
@@ -313,9 +324,20 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 			                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, (int*)nullptr, (int*)nullptr, side);
 	hipLaunchKernelGGL(k_add_lens, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY, lenE, lenC, lens);
 	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
-	if (in.NW)
-		hipLaunchKernelGGL(k_join_wcopy, dim3((in.NW + 255) / 256), dim3(256), 0, s, in.NW, in.W, in.photo, in.feature, in.fptr, in.feat_map,
-		                   newf, lenE, out.fptr, out.W, out.photo, out.feature, srcf, in.W_alias, in.d_alias);
+	// where the run of every input feature starts in the joint map
+	st.wbase = ctx->scratch.alloc<int>(in.NF + 1);
+	if (in.NF) hipLaunchKernelGGL(k_join_wbase, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, newf, lenE, out.fptr, st.wbase);
+	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, JoinState& st, double* eP_out, double* eF_out)
+{
+	hipStream_t s = ctx->stream;
+	const int G = out.B, NFY = out.NF;
+	double *eP = st.eP, *eF = st.eF;
+	int* srcf = st.srcf;
+	const std::vector<unsigned char>& seg_active = st.seg_active;
+	const std::vector<int>& seg_rows = st.seg_rows;
 	// ---- right-hand sides ----
 	if (NFY)
 		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);
@@ -337,8 +359,18 @@ void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatc
 	io.seg_rows = seg_rows;
 	int rc = solve_batch(ctx, io);
 	LSFM_CHECK_HIP(hipStreamSynchronize(s));
-	ctx->scratch.release(smark);
+	ctx->scratch.release(st.smark);
 	if (rc > 0 && ctx->stats) ctx->stats->not_converged += rc;
+}
+
+void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out)
+{
+	JoinState st;
+	join_stereo_prepare(ctx, ar, in, out, st);
+	if (in.NW)
+		hipLaunchKernelGGL(k_join_wcopy, dim3((in.NW + 255) / 256), dim3(256), 0, ctx->stream, in.NW, in.W, in.photo, in.feature, in.fptr, st.wbase,
+		                   st.newf, out.W, out.photo, out.feature, st.srcf, in.W_alias, in.d_alias, in.feat_map);
+	join_stereo_finish(ctx, in, out, st, eP_out, eF_out);
 }
 
 } // namespace lsfm

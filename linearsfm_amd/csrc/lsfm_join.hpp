@@ -10,6 +10,17 @@ struct JGroup {
 	int rC0;              // rank offset of Cur's unmatched features
 };
 
+// state of a Stereo join between its two steps (lsfm_join.hip)
+struct JoinState {
+	size_t smark = 0;
+	int *newf = nullptr, *lenE = nullptr, *srcf = nullptr, *wbase = nullptr;
+	double *eP = nullptr, *eF = nullptr;
+	std::vector<unsigned char> seg_active;
+	std::vector<int> seg_rows;
+};
+void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, JoinState& st);
+void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, JoinState& st, double* eP_out, double* eF_out);
+
 // match[f] = feature of the pair's first map with the same label (-1 none), unm[f] = 1 for unmatched features of the
 // second map (unm[NF] = 0)
 void join_match_features(lsfm_context* ctx, const DevBatch& in, int* match, int* unm);

@@ -4,6 +4,7 @@
 #include <cmath>
 
 #include "lsfm_internal.hpp"
+#include "lsfm_join.hpp"
 
 using namespace lsfm;
 
@@ -81,20 +82,42 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 		// ... and End is expressed in Cur's frame (Imp.cpp:1964 / 6549)
 		tref[e] = cref; tscap[e] = cscap; tfix[e] = cfix; ntr++;
 	}
-	double t0 = now_ms();
+	const double t0 = now_ms();
 	// three arenas in rotation: X (this level; slot -1 = the resident inputs, never written) stays alive until the join
 	// is done, because the W blocks of the maps the transform passes through are read from X, not copied (W_alias)
 	const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3, sm = t->slot < 0 ? 1 : (t->slot + 2) % 3;
 	Arena& other = ctx->arena[so];
-	other.reset();
-	DevBatch Xt;
-	transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt, true);
-	double t1 = now_ms();
 	Arena& mine = ctx->arena[sm];
+	other.reset();
 	mine.reset();
-	DevBatch Y;
-	if (t->mono) join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
-	else join_batch_stereo(ctx, mine, Xt, Y, nullptr, nullptr);
+	DevBatch Xt, Y;
+	double t1;
+	if (t->mono)
+	{
+		transform_batch(ctx, other, X, tref, tscap, tfix, true, Xt, true);
+		t1 = now_ms();
+		join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
+	}
+	else
+	{
+		// Stereo: the joint map is laid out in the middle of the transform (labels, V' and run lengths are known before the
+		// W stage), and the transform's block kernel writes every W' block straight to its place in the joint map
+		JoinState js;
+		const size_t smark = ctx->scratch.mark();
+		double hook_ms = 0;
+		std::function<TrRedirect(DevBatch&)> hook = [&](DevBatch& mid) {
+			const double a = now_ms();
+			join_stereo_prepare(ctx, mine, mid, Y, js);
+			TrRedirect rd;
+			rd.wbase = js.wbase; rd.newf = js.newf; rd.W = Y.W; rd.photo = Y.photo; rd.feature = Y.feature; rd.srcf = js.srcf;
+			hook_ms = now_ms() - a;
+			return rd;
+		};
+		transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook);
+		t1 = now_ms() - hook_ms;
+		js.smark = smark; // everything of this level goes at once
+		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
+	}
 	double t2 = now_ms();
 	t->level = Y;
 	t->slot = sm;

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -108,9 +109,20 @@ void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b); // uploads po
 // ---- transform (lsfm_transform.hip): K1-K4 ------------------------------------------------------------------
 // target_ref[b] < 0 ... map b is passed through unchanged; otherwise the pose id the map is re-expressed in
 // (Mono: target_scap / target_fix as well).  out is allocated from `ar`.
+// Where the transform's W stage writes when its consumer has already laid out the next container (a join): the run of
+// input feature f starts at wbase[f] of W / photo / feature, blocks are labelled newf[f], srcf[] records the input feature.
+struct TrRedirect {
+	const int* wbase = nullptr;
+	const int* newf = nullptr;
+	double* W = nullptr;
+	int *photo = nullptr, *feature = nullptr, *srcf = nullptr;
+};
+// hook: called once everything of `out` except the information blocks exists (poses, feature values, V', run pointers,
+// offsets); its answer redirects the W blocks.  keep_scratch: the caller releases the scratch arena (allocations made in
+// the hook outlive the call).
 void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
                      const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out,
-                     bool alias_passthrough = false);
+                     bool alias_passthrough = false, const std::function<TrRedirect(DevBatch&)>* hook = nullptr);
 
 // ---- join + solve (lsfm_join.hip, lsfm_solve.hip): K5-K11 ---------------------------------------------------
 struct JoinWork; // device work arrays shared between assembly and solve

@@ -302,12 +302,6 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	out.V = ar.alloc<double>((size_t)NFY * 9);
 	batch_set_offsets(ctx, ar, out);
 	LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_id, in.pose_id, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
-	if (in.NU)
-	{
-		LSFM_CHECK_HIP(hipMemcpyAsync(out.U, in.U, (size_t)in.NU * 36 * sizeof(double), hipMemcpyDeviceToDevice, s));
-		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
-		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
-	}
 	int* newf = st.newf = ctx->scratch.alloc<int>(in.NF + 1);
 	int* lenE = st.lenE = ctx->scratch.alloc<int>(NFY + 1);
 	int* lenC = ctx->scratch.alloc<int>(NFY + 1);
@@ -338,6 +332,14 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	int* srcf = st.srcf;
 	const std::vector<unsigned char>& seg_active = st.seg_active;
 	const std::vector<int>& seg_rows = st.seg_rows;
+	// U is reused unchanged (global pose indices); copied here because the caller may still have been producing it
+	// (the transform's U stage) while the joint map was laid out
+	if (in.NU)
+	{
+		LSFM_CHECK_HIP(hipMemcpyAsync(out.U, in.U, (size_t)in.NU * 36 * sizeof(double), hipMemcpyDeviceToDevice, s));
+		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
+		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
+	}
 	// ---- right-hand sides ----
 	if (NFY)
 		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);

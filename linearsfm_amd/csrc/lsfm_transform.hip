@@ -320,12 +320,13 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 		nfeat[3 * (size_t)f] = x[0]; nfeat[3 * (size_t)f + 1] = x[1]; nfeat[3 * (size_t)f + 2] = x[2];
 		for (int i = 0; i < 9; i++) Vn[(size_t)f * 9 + i] = Vold[(size_t)f * 9 + i];
 		nfptr[f] = t->W0n + (j0 - t->W0);
-		finfo[f] = make_int4(0, -1, -1, t->W0n - t->W0); // new place of block j: j + w
+		finfo[f] = make_int4(0, -1, -1, -j0); // new place of block j: (start of the feature's new run) + w + j
 		return;
 	}
 	nfptr[f] = t->W0n + NH * (f - t->F0) + (KW[j0] - t->kW0);
-	// per feature record for the block kernel: active, hub pose(s), new place of a kept block j = w + KW[j]
-	finfo[f] = make_int4(1, t->hub[0], NH == 2 ? t->hub[1] : -1, nfptr[f] + NH - KW[j0]);
+	// per feature record for the block kernel: active, hub pose(s), new place of a kept block j = (start of the
+	// feature's new run) + w + KW[j]
+	finfo[f] = make_int4(1, t->hub[0], NH == 2 ? t->hub[1] : -1, NH - KW[j0]);
 	double Df[9], Cf[NH][18], xn[3];
 	// new feature value, Imp.cpp:449-451 / 3300-3302
 	double d[3] = { x[0] - t->t1[0], x[1] - t->t1[1], x[2] - t->t1[2] };
@@ -376,7 +377,8 @@ __global__ void __launch_bounds__(TRE_ROUND, 2)
 k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restrict__ fptr,
              const double* __restrict__ Wold, const int* __restrict__ photo, const int* __restrict__ KW, const double* __restrict__ Dp,
              const double* __restrict__ Cp, const double* __restrict__ FD, double* __restrict__ Wn_, int* __restrict__ nphoto,
-             int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ, int alias_passthrough)
+             int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ, int alias_passthrough,
+             const int* __restrict__ wbase, const int* __restrict__ newf, int* __restrict__ srcf)
 {
 	constexpr int GCAP = NH == 1 ? 64 : 32, TW = 18 * NH; // LDS: 18 KB pose table + 36 KB block rows -> two work-groups per CU
 	__shared__ int gkeys[GCAP];
@@ -421,13 +423,14 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 				if (!act)
 				{
 					// pass-through map: indices only when the consumer (a join) reads the block from the input (W_alias)
-					const int pos = j + fi.w;
+					const int pos = wbase[f] + fi.w + j;
 					if (!alias_passthrough)
 					{
 						ld<18>(W, Wold + (size_t)j * 18);
 						st<18>(Wn_ + (size_t)pos * 18, W);
 					}
-					nphoto[pos] = k; nfeature[pos] = f;
+					nphoto[pos] = k; nfeature[pos] = newf ? newf[f] : f;
+					if (srcf) srcf[pos] = f;
 				}
 				else
 				{
@@ -442,9 +445,10 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 						mtm<6, 6, 3, false>(Dk, W, T1);
 						ld<9>(Df, fd);
 						mm<6, 3, 3, false>(T1, Df, Wn);
-						const int pos = fi.w + KW[j];
+						const int pos = wbase[f] + fi.w + KW[j];
 						st<18>(Wn_ + (size_t)pos * 18, Wn);
-						nphoto[pos] = k; nfeature[pos] = f;
+						nphoto[pos] = k; nfeature[pos] = newf ? newf[f] : f;
+						if (srcf) srcf[pos] = f;
 					}
 					else
 					{
@@ -505,8 +509,8 @@ template <int NH>
 __global__ void __launch_bounds__(256)
 k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const int* __restrict__ fptr,
                const double* __restrict__ Vold, const double* __restrict__ Wold, const int* __restrict__ photo, const double* __restrict__ Dp,
-               const double* __restrict__ FD, const double* __restrict__ Gsum, const int* __restrict__ hubJ, const int* __restrict__ nfptr,
-               double* __restrict__ Wn_,
+               const double* __restrict__ FD, const double* __restrict__ Gsum, const int* __restrict__ hubJ, const int* __restrict__ wbase,
+               const int* __restrict__ newf, int* __restrict__ srcf, double* __restrict__ Wn_,
                int* __restrict__ nphoto, int* __restrict__ nfeature, double* __restrict__ PP)
 {
 	constexpr int TW = 18 * NH;
@@ -521,7 +525,7 @@ k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict
 		ld<9>(Df, fd);
 		double V[9];
 		ld<9>(V, Vold + (size_t)f * 9);
-		const int base = nfptr[f];
+		const int base = wbase[f];
 		const int hubs[2] = { t->hub[0], NH == 2 ? t->hub[1] : -1 };
 		double hubW[NH][18];
 #pragma unroll
@@ -571,7 +575,8 @@ k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict
 			ld<18>(Wh, hubW[s]);
 			mtm<3, 6, 3, true>(G[s], Df, Wh);
 			st<18>(Wn_ + (size_t)(base + s) * 18, Wh);
-			nphoto[base + s] = hubs[s]; nfeature[base + s] = f;
+			nphoto[base + s] = hubs[s]; nfeature[base + s] = newf ? newf[f] : f;
+			if (srcf) srcf[base + s] = f;
 		}
 	}
 	// C_s^T G_t for the (h,h) blocks, summed per map
@@ -764,10 +769,12 @@ __global__ void k_tr_diag(int B, const TMap* __restrict__ tm, const double* __re
 
 template <int NH>
 static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, const TMap* d_tm, const int* KU, const int* KW,
-                         double* Dp, double* Cp, double* Gpose, double* PP, double nw_act_in, double nw_act_out, double nf_act)
+                         double* Dp, double* Cp, double* Gpose, double* PP, double nw_act_in, double nw_act_out, double nf_act,
+                         const std::function<TrRedirect(DevBatch&)>* hook)
 {
 	hipStream_t s = ctx->stream;
 	const int M = in.M;
+	if (!in.NF && hook) (void)(*hook)(out); // nothing to redirect, but the consumer still lays out its container
 	if (in.NF)
 	{
 		// per feature: D_f and C_s,f (written by the prologue, read per W block), sums of W^T C_s,k (entries -> epilogue)
@@ -778,12 +785,16 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		LSFM_CHECK_HIP(hipMemsetAsync(hubJ, 0xff, (size_t)in.NF * NH * sizeof(int), s));
 		hipLaunchKernelGGL(k_tr_feat_pre<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, d_tm, in.feat_map, in.feat, in.fptr, in.V, KW, out.feat,
 		                   out.fptr, out.V, FD, finfo);
+		// the W blocks go to this container -- or straight into the next one when the consumer has laid it out already
+		TrRedirect rd;
+		if (hook) rd = (*hook)(out);
+		if (!rd.W) { rd = TrRedirect(); rd.wbase = out.fptr; rd.W = out.W; rd.photo = out.photo; rd.feature = out.feature; }
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s)); // the events bracket k_tr_entries alone
 		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, finfo, in.fptr, in.W,
-		                   in.photo, KW, Dp, Cp, FD, out.W, out.photo, out.feature, Gsum, Gpose, hubJ, out.W_alias ? 1 : 0);
+		                   in.photo, KW, Dp, Cp, FD, rd.W, rd.photo, rd.feature, Gsum, Gpose, hubJ, out.W_alias ? 1 : 0, rd.wbase, rd.newf, rd.srcf);
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
 		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,
-		                   Dp, FD, Gsum, hubJ, out.fptr, out.W, out.photo, out.feature, PP);
+		                   Dp, FD, Gsum, hubJ, rd.wbase, rd.newf, rd.srcf, rd.W, rd.photo, rd.feature, PP);
 		if (ctx->stats)
 		{
 			float t = 0;
@@ -813,7 +824,7 @@ __global__ void k_set_last(int* p, int idx, int v) { p[idx] = v; }
 
 void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
                      const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out,
-                     bool alias_passthrough)
+                     bool alias_passthrough, const std::function<TrRedirect(DevBatch&)>* hook)
 {
 	hipStream_t s = ctx->stream;
 	const int B = in.B, nh = mono ? 2 : 1;
@@ -914,7 +925,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		}
 	}
 	out.NU = out.u_off[B]; out.NW = out.w_off[B];
-	if (alias_passthrough && !in.W_alias)
+	if (alias_passthrough && !in.W_alias && !hook)
 	{
 		// pass-through maps keep their W blocks in `in` (the caller keeps `in` alive until the join has consumed `out`)
 		std::vector<int> delta(B);
@@ -936,7 +947,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		h2d(ctx, d_tm, dev.data(), sizeof(TMap) * B);
 	}
 	out.U = ar.alloc<double>((size_t)out.NU * 36); out.Ui = ar.alloc<int>(out.NU); out.Uj = ar.alloc<int>(out.NU);
-	out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW);
+	if (!hook) { out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW); }
 	dev_zero(ctx, out.U, (size_t)out.NU * 36 * sizeof(double)); // the (k,h) slots are accumulated into
 	hipLaunchKernelGGL(k_set_last, dim3(1), dim3(1), 0, s, out.fptr, in.NF, out.NW);
 	double nw_act_in = 0, nw_act_out = 0, nf_act = 0;
@@ -946,13 +957,13 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 			nw_act_in += in.w_off[b + 1] - in.w_off[b]; nw_act_out += out.w_off[b + 1] - out.w_off[b];
 			nf_act += in.feat_off[b + 1] - in.feat_off[b];
 		}
-	if (mono) launch_stage<2>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act);
-	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act);
+	if (mono) launch_stage<2>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act, hook);
+	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act, hook);
 	LSFM_CHECK_HIP(hipGetLastError());
 	(void)any;
 	// scratch is released by the caller's next stage only after these launches are ordered on the stream
 	LSFM_CHECK_HIP(hipStreamSynchronize(s));
-	ctx->scratch.release(smark);
+	if (!hook) ctx->scratch.release(smark); // with a hook its allocations outlive this call: the caller releases
 }
 
 } // namespace lsfm

@@ -373,14 +373,14 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 }
 
 template <int NH>
-__global__ void __launch_bounds__(TRE_ROUND, 2)
+__global__ void __launch_bounds__(TRE_ROUND, 3)
 k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restrict__ fptr,
              const double* __restrict__ Wold, const int* __restrict__ photo, const int* __restrict__ KW, const double* __restrict__ Dp,
              const double* __restrict__ Cp, const double* __restrict__ FD, double* __restrict__ Wn_, int* __restrict__ nphoto,
              int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ, int alias_passthrough,
              const int* __restrict__ wbase, const int* __restrict__ newf, int* __restrict__ srcf)
 {
-	constexpr int GCAP = NH == 1 ? 64 : 32, TW = 18 * NH; // LDS: 18 KB pose table + 36 KB block rows -> two work-groups per CU
+	constexpr int GCAP = 32, TW = 18 * NH; // LDS: 9 (18) KB pose table + 36 KB block rows -> three work-groups per CU
 	__shared__ int gkeys[GCAP];
 	__shared__ double gvals[NH * GCAP * 36];
 	__shared__ double sT[TRE_ROUND * 18];
@@ -392,6 +392,8 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 	for (int i = tid; i <= nft; i += TRE_ROUND) sFp[i] = fptr[f0 + i];
 	__syncthreads();
 	int la = 0; // first feature (tile-local) of the round
+	int pf_j = -1, pf_f = 0, pf_k = 0, pf_kw = 0, pf_wb = 0, pf_lab = 0;
+	int4 pf_fi = make_int4(0, 0, 0, 0);
 	while (la < nft)
 	{
 		// a round = whole features from la on with at most TRE_ROUND blocks; a longer feature is walked in chunks
@@ -414,22 +416,29 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 			const double* fd = nullptr;
 			if (have)
 			{
-				int lo = la, hi = lb - 1; // feature of block j: last fl with sFp[fl] <= j
-				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] <= j) lo = mid; else hi = mid - 1; }
-				f = f0 + lo;
-				const int4 fi = finfo[f]; // x: active, y/z: hub poses, w: placement
-				k = photo[j];
+				int4 fi; // x: active, y/z: hub poses, w: placement
+				int wb, lab, kw;
+				if (pf_j == j) { f = pf_f; fi = pf_fi; k = pf_k; wb = pf_wb; lab = pf_lab; kw = pf_kw; } // fetched during the last round
+				else
+				{
+					int lo = la, hi = lb - 1; // feature of block j: last fl with sFp[fl] <= j
+					while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] <= j) lo = mid; else hi = mid - 1; }
+					f = f0 + lo;
+					fi = finfo[f];
+					k = photo[j];
+					wb = wbase[f]; lab = newf ? newf[f] : f; kw = KW[j];
+				}
 				act = fi.x != 0;
 				if (!act)
 				{
 					// pass-through map: indices only when the consumer (a join) reads the block from the input (W_alias)
-					const int pos = wbase[f] + fi.w + j;
+					const int pos = wb + fi.w + j;
 					if (!alias_passthrough)
 					{
 						ld<18>(W, Wold + (size_t)j * 18);
 						st<18>(Wn_ + (size_t)pos * 18, W);
 					}
-					nphoto[pos] = k; nfeature[pos] = newf ? newf[f] : f;
+					nphoto[pos] = k; nfeature[pos] = lab;
 					if (srcf) srcf[pos] = f;
 				}
 				else
@@ -445,9 +454,9 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 						mtm<6, 6, 3, false>(Dk, W, T1);
 						ld<9>(Df, fd);
 						mm<6, 3, 3, false>(T1, Df, Wn);
-						const int pos = wbase[f] + fi.w + KW[j];
+						const int pos = wb + fi.w + kw;
 						st<18>(Wn_ + (size_t)pos * 18, Wn);
-						nphoto[pos] = k; nfeature[pos] = newf ? newf[f] : f;
+						nphoto[pos] = k; nfeature[pos] = lab;
 						if (srcf) srcf[pos] = f;
 					}
 					else
@@ -458,6 +467,19 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 						if (atomicCAS(h, -1, j) != -1) atomicExch(h, -2);
 					}
 					sl = lds_slot(gkeys, GCAP, k);
+				}
+			}
+			// the index data of this lane's block in the NEXT round (it starts where this one ends): the loads fly during the
+			// reductions below instead of heading the next round's dependent chain
+			{
+				const int jn = ce1 + tid;
+				pf_j = -1;
+				if (jn < sFp[nft])
+				{
+					int lo = 0, hi = nft - 1;
+					while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sFp[mid] <= jn) lo = mid; else hi = mid - 1; }
+					pf_j = jn; pf_f = f0 + lo;
+					pf_fi = finfo[pf_f]; pf_k = photo[jn]; pf_kw = KW[jn]; pf_wb = wbase[pf_f]; pf_lab = newf ? newf[pf_f] : pf_f;
 				}
 			}
 #pragma unroll

@@ -47,7 +47,6 @@ struct CholDev {
 	int* pinv = nullptr;    // [M] old -> new
 	int* order = nullptr;   // [M] columns sorted by elimination-tree level
 	std::vector<int> level_ptr; // host: order[level_ptr[l] .. level_ptr[l+1]) = columns of level l (before the tail)
-	std::vector<int> level_maxpairs; // host: largest n(n+1)/2 over the columns of the level (grid of the update launch)
 	// tasks: connected pieces of the elimination tree that one work-group walks serially (small sub-trees, chains)
 	int* task_cols = nullptr;          // [M] columns grouped by task, ascending inside a task
 	int* task_ptr = nullptr;           // [ntasks+1] tasks ordered by task level
@@ -577,13 +576,6 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 	for (int j = 0; j < M; j++) order[lcount[lev[j]] + lfill[lev[j]]++] = j; // ascending j inside a level
 	ch.M = M; ch.nnzL = nnzL; ch.nlevels = tail_level;
 	ch.level_ptr.assign(lcount.begin(), lcount.begin() + tail_level + 1);
-	ch.level_maxpairs.assign(tail_level, 0);
-	for (int j = 0; j < M; j++)
-		if (lev[j] < tail_level)
-		{
-			const int nb = ccount[j] - 1;
-			ch.level_maxpairs[lev[j]] = std::max(ch.level_maxpairs[lev[j]], nb * (nb + 1) / 2);
-		}
 	ch.tail_begin = lcount[tail_level];
 	// tail columns must be walked in ascending index (= a topological order), not level order
 	std::sort(order.begin() + ch.tail_begin, order.end());

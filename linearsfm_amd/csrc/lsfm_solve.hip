@@ -4,10 +4,10 @@
 //   K7  k_vinv            V^-1 per feature                                   (pba_inverseV, Imp.cpp:3022-3042)
 //   K8  k_pat_*           block pattern of S by hashing the pose pairs that share a feature + U's pattern
 //                         (replaces smask, Imp.cpp:2131-2205), sorted into block-CSR
-//   K9  k_schur_*         S(p,q) -= W_pf V_f^-1 W_qf^T, E_p -= W_pf V_f^-1 eb_f, one lane per feature, scatter-adds
-//                         pre-reduced over the wave (Imp.cpp:2244-2332)
-//   K10 k_spmv / k_pcg_*  block-Jacobi preconditioned CG on the symmetric 6x6-block system, all independent systems
-//                         of the level iterate together with per-system scalars (replaces Imp.cpp:2334-2361)
+//   K9  k_schur_*         S(p,q) -= W_pf V_f^-1 W_qf^T, E_p -= W_pf V_f^-1 eb_f (Imp.cpp:2244-2332): k_schur_panel
+//                         (lsfm_schur_panel.hip, fp64 MFMA on 128-feature tiles); k_schur_w here takes the tiles it flags
+//   K10 k_spmv / k_pcg_*  Cholesky-preconditioned CG (lsfm_pcg.hip) on the symmetric 6x6-block system, all independent
+//                         systems of the level together with per-system scalars (replaces Imp.cpp:2334-2361)
 //   K11 k_backsub         features: x_f = V_f^-1 (eb_f - sum W_pf^T x_p)     (pba_solveFeatures, Imp.cpp:2980-3020)
 // S is kept as its upper block triangle (diagonal blocks full); the SpMV reads every stored block once and adds its
 // mirrored part through an LDS window of y (k_spmv).

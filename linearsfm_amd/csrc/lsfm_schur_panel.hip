@@ -285,6 +285,7 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			}
 			h = (h + 1) & (PM_HASH - 1);
 		}
+		if (j - jb < PM_MAXE) sh.eslot[j - jb] = (unsigned char)h; // table position now, slot number once slots are dealt
 	}
 	__syncthreads();
 	if (tid < PM_HASH && sh.hkey[tid] != -1)
@@ -301,13 +302,7 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		if (tid == 0) fallback[blockIdx.x] = 1;
 		return;
 	}
-	for (int j = jb + tid; j < je && j - jb < PM_MAXE; j += PM_THREADS)
-	{
-		const int key = photo[j];
-		unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-		while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
-		sh.eslot[j - jb] = (unsigned char)sh.hslot[h];
-	}
+	for (int e = tid; e < je - jb && e < PM_MAXE; e += PM_THREADS) sh.eslot[e] = (unsigned char)sh.hslot[sh.eslot[e]];
 	// (visible to the passes through the barrier at the top of the first pass)
 	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + 3) >> 2; // tiles per wave, uniform
 #define PM_GO(T) pm_body<T>(sh, ns, f0, f1, jb, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)

@@ -373,7 +373,7 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 }
 
 template <int NH>
-__global__ void __launch_bounds__(TRE_ROUND, 3)
+__global__ void __launch_bounds__(TRE_ROUND, NH == 1 ? 3 : 2)
 k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restrict__ fptr,
              const double* __restrict__ Wold, const int* __restrict__ photo, const int* __restrict__ KW, const double* __restrict__ Dp,
              const double* __restrict__ Cp, const double* __restrict__ FD, double* __restrict__ Wn_, int* __restrict__ nphoto,

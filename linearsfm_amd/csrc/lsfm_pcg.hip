@@ -342,30 +342,51 @@ __global__ void __launch_bounds__(CHOL_OUT_THREADS) k_chol_update_outer(const in
 // walks the task: a column step inside a task then costs LDS latency instead of a global atomic + fence round trip
 // (measured 2.7 us per step, the critical path of the whole solve).  Rows outside the task (ancestors) are updated /
 // read in global memory; nobody inside the task reads them.
+// LDS per task column: its slice of v (6), the inverse pivot block (36) and three ints (column, first block, count):
+// everything a column step needs except the sub-diagonal blocks themselves is fetched side by side before the walk
+#define CHOL_TASK_LDS_PER_COL (6 * 8 + 36 * 8 + 3 * 4)
+__device__ __forceinline__ void chol_task_stage(int b, int e, const int* __restrict__ task_cols, const int* __restrict__ colptr,
+                                                const double* __restrict__ Dinv, const double* __restrict__ v, double* lv, double* sD, int* sj,
+                                                int* sc0, int* sn)
+{
+	const int tid = threadIdx.x, nt = blockDim.x, nc = e - b;
+	for (int q = tid; q < nc; q += nt)
+	{
+		const int j = task_cols[b + q];
+		sj[q] = j;
+		const int c0 = colptr[j];
+		sc0[q] = c0; sn[q] = colptr[j + 1] - c0 - 1;
+	}
+	for (int q = tid; q < nc * 6; q += nt) lv[q] = v[(size_t)task_cols[b + q / 6] * 6 + q % 6];
+	for (int q = tid; q < nc * 36; q += nt) sD[q] = Dinv[(size_t)task_cols[b + q / 36] * 36 + q % 36];
+	__syncthreads();
+}
 __global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                          const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
                                                          const double* __restrict__ Dinv, double* __restrict__ v)
 {
-	extern __shared__ double lv[];
+	extern __shared__ double lds[];
 	__shared__ double sy[6];
-	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x;
+	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x, nc = e - b;
 	const int tid = threadIdx.x, nt = blockDim.x;
-	for (int q = tid; q < (e - b) * 6; q += nt) lv[q] = v[(size_t)task_cols[b + q / 6] * 6 + q % 6];
-	__syncthreads();
-	for (int k = b; k < e; k++)
+	double* lv = lds;
+	double* sD = lds + 6 * nc;
+	int* sj = reinterpret_cast<int*>(sD + 36 * nc);
+	int *sc0 = sj + nc, *sn = sc0 + nc;
+	chol_task_stage(b, e, task_cols, colptr, Dinv, v, lv, sD, sj, sc0, sn);
+	for (int k = 0; k < nc; k++)
 	{
-		const int j = task_cols[k];
-		const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+		const int c0 = sc0[k], n = sn[k];
 		if (tid < 6)
 		{
-			const double* Li = Dinv + (size_t)j * 36;
+			const double* Li = sD + k * 36;
 			double s = 0;
-			for (int q = 0; q <= tid; q++) s = fma(Li[tid * 6 + q], lv[(k - b) * 6 + q], s);
+			for (int q = 0; q <= tid; q++) s = fma(Li[tid * 6 + q], lv[k * 6 + q], s);
 			sy[tid] = s;
 		}
 		__syncthreads();
-		if (tid < 6) lv[(k - b) * 6 + tid] = sy[tid];
+		if (tid < 6) lv[k * 6 + tid] = sy[tid];
 		for (int w = tid; w < n * 6; w += nt)
 		{
 			const int en = c0 + 1 + w / 6, r = w % 6;
@@ -378,25 +399,27 @@ __global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ 
 		}
 		__syncthreads();
 	}
-	for (int q = tid; q < (e - b) * 6; q += nt) v[(size_t)task_cols[b + q / 6] * 6 + q % 6] = lv[q];
+	for (int q = tid; q < nc * 6; q += nt) v[(size_t)sj[q / 6] * 6 + q % 6] = lv[q];
 }
 __global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                          const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
                                                          const double* __restrict__ Dinv, double* __restrict__ v)
 {
-	extern __shared__ double lv[];
+	extern __shared__ double lds[];
 	__shared__ double red[256];
 	__shared__ double ss[6];
-	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x;
+	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x, nc = e - b;
 	const int tid = threadIdx.x, nt = blockDim.x;
 	const int c = tid % 6, g = tid / 6, ng = nt / 6;
-	for (int q = tid; q < (e - b) * 6; q += nt) lv[q] = v[(size_t)task_cols[b + q / 6] * 6 + q % 6];
-	__syncthreads();
-	for (int k = e - 1; k >= b; k--)
+	double* lv = lds;
+	double* sD = lds + 6 * nc;
+	int* sj = reinterpret_cast<int*>(sD + 36 * nc);
+	int *sc0 = sj + nc, *sn = sc0 + nc;
+	chol_task_stage(b, e, task_cols, colptr, Dinv, v, lv, sD, sj, sc0, sn);
+	for (int k = nc - 1; k >= 0; k--)
 	{
-		const int j = task_cols[k];
-		const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+		const int c0 = sc0[k], n = sn[k];
 		double s = 0;
 		if (g < ng)
 			for (int en = g; en < n; en += ng)
@@ -418,21 +441,21 @@ __global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ 
 		__syncthreads();
 		if (tid < 6)
 		{
-			double t = lv[(k - b) * 6 + tid];
+			double t = lv[k * 6 + tid];
 			for (int q = 0; q < ng; q++) t -= red[q * 6 + tid];
 			ss[tid] = t;
 		}
 		__syncthreads();
 		if (tid < 6)
 		{
-			const double* Li = Dinv + (size_t)j * 36;
+			const double* Li = sD + k * 36;
 			double t = 0;
 			for (int q = tid; q < 6; q++) t = fma(Li[q * 6 + tid], ss[q], t);
-			lv[(k - b) * 6 + tid] = t;
+			lv[k * 6 + tid] = t;
 		}
 		__syncthreads();
 	}
-	for (int q = tid; q < (e - b) * 6; q += nt) v[(size_t)task_cols[b + q / 6] * 6 + q % 6] = lv[q];
+	for (int q = tid; q < nc * 6; q += nt) v[(size_t)sj[q / 6] * 6 + q % 6] = lv[q];
 }
 
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
@@ -686,18 +709,18 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 	static const bool task_solve = !getenv("LSFM_LEVEL_SOLVE");
 	int task_max = 0;
 	for (int m : ch.tlevel_maxsize) task_max = std::max(task_max, m);
-	if (task_solve && task_max * 48 <= 48 * 1024) // the task's slice of v must fit LDS; else one launch per tree level
+	if (task_solve && (size_t)task_max * CHOL_TASK_LDS_PER_COL <= 56 * 1024) // a task's per-column data must fit LDS; else one launch per tree level
 	{
 		const int ntl = (int)ch.tlevel_ptr.size() - 1;
 		for (int l = 0; l < ntl; l++)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * 48, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 		}
 		for (int l = ntl - 1; l >= 0; l--)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * 48, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 		}
 		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
 		return;

@@ -176,7 +176,8 @@ __device__ __forceinline__ void mono_trans_jac(const TMap& t, const double* xn, 
 
 // per pose: D (6x6) and C_s (6x6), Imp.cpp:485-635 / 3383-3584 and the gauge zeroing 3691-3710
 template <int NH>
-__global__ void k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map, int M, const TMap* __restrict__ tm,
+__global__ void __launch_bounds__(128, 1)
+k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map, int M, const TMap* __restrict__ tm,
                               double* __restrict__ Dp, double* __restrict__ Cp)
 {
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -706,7 +707,8 @@ __device__ __forceinline__ void add_oriented(double* dst, const double* X, int r
 
 // one lane per pose: new blocks (k,h_s) = D_k^T G_s,k (+ what k_tr_ublocks already put there) and C_k^T G_k
 template <int NH>
-__global__ void k_tr_poseslots(int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Dp,
+__global__ void __launch_bounds__(128, 1) // a lane holds several 6x6 blocks: let it have the registers (no spills)
+k_tr_poseslots(int M, const TMap* __restrict__ tm, const int* __restrict__ pose_map, const double* __restrict__ Dp,
                                const double* __restrict__ Cp, const double* __restrict__ Gpose, double* __restrict__ Un, int* __restrict__ nUi,
                                int* __restrict__ nUj, double* __restrict__ PP)
 {

@@ -56,6 +56,8 @@ struct CholDev {
 	int* col_lpos = nullptr;           // [M] position of a column inside its task
 	int* col_nin = nullptr;            // [M] leading rows of a column (below the diagonal) that belong to its own task
 	std::vector<int> tlevel_col0;      // host: task_cols[tlevel_col0[l] .. tlevel_col0[l+1]) = columns of the level's tasks
+	std::vector<int> tlevel_nsmall;    // host: the first tlevel_nsmall[l] tasks of level l fit LDS whole (small-task kernels)
+	std::vector<int> tlevel_small_lds; // host: dynamic LDS bytes of the level's small-task launches
 	std::vector<int> tlevel_outer;     // host: largest number of deferred update pairs of a column of the level
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
@@ -95,12 +97,11 @@ __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ 
 
 // one work-group factors one block column: L_jj = chol(A_jj); L_ij = A_ij L_jj^-T; A_ik -= L_ij L_kj^T for the blocks
 // below (right-looking; targets in other columns are updated atomically because the columns of one level run together)
-__device__ void chol_factor_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                   double* __restrict__ Dinv, int* err)
+// pivot block of column j (block c0 of Lb, memory or LDS): L_jj = chol(A_jj) in place, its inverse to Dinv and to sLi
+// (LDS, 36 doubles); ends with a barrier
+__device__ void chol_pivot(int j, int c0, double* L, double* __restrict__ Dinv, int* err, double* sLi)
 {
-	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
-	const int tid = threadIdx.x, nt = blockDim.x;
-	__shared__ double sLi[36];
+	const int tid = threadIdx.x;
 	if (tid < LSFM_WAVE)
 	{
 		// 6x6 Cholesky and its inverse by the first wave: lane 6 r + c holds element (r,c), pivots and columns travel
@@ -144,8 +145,11 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 		}
 	}
 	__syncthreads();
-	// L_ij = A_ij * Li^T : one thread per (block, row)
-	for (int w = tid; w < n * 6; w += nt)
+}
+// L_ij = A_ij * Li^T for the n blocks below the pivot block c0: one thread per (block, row)
+__device__ void chol_scale_column(int c0, int n, double* L, const double* sLi)
+{
+	for (int w = threadIdx.x; w < n * 6; w += blockDim.x)
 	{
 		double* blk = L + (size_t)(c0 + 1 + w / 6) * 36 + (w % 6) * 6;
 		double a[6], o[6];
@@ -158,6 +162,14 @@ __device__ void chol_factor_column(int j, const int* __restrict__ colptr, const 
 		}
 		for (int k = 0; k < 6; k++) blk[k] = o[k];
 	}
+}
+__device__ void chol_factor_column(int j, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
+                                   double* __restrict__ Dinv, int* err)
+{
+	__shared__ double sLi[36];
+	const int c0 = colptr[j], n = colptr[j + 1] - c0 - 1;
+	chol_pivot(j, c0, L, Dinv, err, sLi);
+	chol_scale_column(c0, n, L, sLi);
 	__syncthreads();
 }
 
@@ -458,6 +470,115 @@ __global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ 
 	for (int q = tid; q < nc * 6; q += nt) v[(size_t)sj[q / 6] * 6 + q % 6] = lv[q];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small tasks: everything the walk touches fits LDS.  The column steps of a task are a chain of dependent global
+// round trips (pivot block, scaled column, updated targets: ~6 per column, 10-14 us measured); when all blocks of the
+// task's columns (288 B each + row index) fit 60 KB they are fetched side by side once, the walk runs at LDS latency
+// and the result is written back once.  The host puts the small tasks first in every task level.
+// ---------------------------------------------------------------------------------------------------------------
+struct SmallTask {
+	int nc, nb;          // columns, blocks (pivot blocks included)
+	double* sB;          // [nb * 36] blocks, column after column
+	int* sR;             // [nb] row index of every block
+	int *sj, *sc0, *sn, *sm, *sbo; // per column: global column, first global block, blocks below the pivot, in-task rows, first LDS block
+};
+__device__ __forceinline__ size_t small_task_bytes(int nc, int nb) { return (size_t)nb * (288 + 4) + (size_t)(5 * nc + 1) * 4 + 8; }
+// lays the task out in LDS (base must be 8-byte aligned) and copies blocks and row indices in; ends with a barrier
+__device__ void small_task_stage(SmallTask& t, char* base, int b0, int nc, const int* __restrict__ task_cols, const int* __restrict__ col_nin,
+                                 const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L)
+{
+	const int tid = threadIdx.x, nt = blockDim.x;
+	__shared__ int s_nb;
+	t.nc = nc;
+	int* meta = reinterpret_cast<int*>(base);
+	t.sj = meta; t.sc0 = meta + nc; t.sn = meta + 2 * nc; t.sm = meta + 3 * nc; t.sbo = meta + 4 * nc; // sbo has nc + 1 entries
+	for (int q = tid; q < nc; q += nt)
+	{
+		const int j = task_cols[b0 + q];
+		t.sj[q] = j;
+		const int c0 = colptr[j];
+		t.sc0[q] = c0; t.sn[q] = colptr[j + 1] - c0 - 1; t.sm[q] = col_nin ? col_nin[j] : 0;
+	}
+	__syncthreads();
+	if (tid == 0)
+	{
+		int acc = 0;
+		for (int q = 0; q < nc; q++) { t.sbo[q] = acc; acc += 1 + t.sn[q]; }
+		t.sbo[nc] = acc;
+		s_nb = acc;
+	}
+	__syncthreads();
+	t.nb = s_nb;
+	size_t off = ((size_t)(5 * nc + 1) * 4 + 7) & ~(size_t)7;
+	t.sB = reinterpret_cast<double*>(base + off);
+	t.sR = reinterpret_cast<int*>(base + off + (size_t)t.nb * 288);
+	for (int e = tid; e < t.nb; e += nt)
+	{
+		int lo = 0, hi = nc - 1; // column of LDS block e
+		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.sbo[mid] <= e) lo = mid; else hi = mid - 1; }
+		t.sR[e] = rowidx[t.sc0[lo] + (e - t.sbo[lo])];
+	}
+	for (int i = tid; i < t.nb * 36; i += nt)
+	{
+		const int e = i / 36;
+		int lo = 0, hi = nc - 1;
+		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.sbo[mid] <= e) lo = mid; else hi = mid - 1; }
+		t.sB[i] = L[(size_t)(t.sc0[lo] + (e - t.sbo[lo])) * 36 + (i - e * 36)];
+	}
+	__syncthreads();
+}
+// LDS column of a global column index that belongs to the task (columns are ascending)
+__device__ __forceinline__ int small_task_col(const SmallTask& t, int col)
+{
+	int lo = 0, hi = t.nc - 1;
+	while (lo < hi) { const int mid = (lo + hi) >> 1; if (t.sj[mid] < col) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+__global__ void __launch_bounds__(256) k_chol_factor_small(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                                            const int* __restrict__ col_nin, const int* __restrict__ colptr,
+                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+{
+	extern __shared__ double lds_d[];
+	__shared__ double sLi[36];
+	const int b0 = task_ptr[blockIdx.x], nc = task_ptr[blockIdx.x + 1] - b0;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	SmallTask t;
+	small_task_stage(t, reinterpret_cast<char*>(lds_d), b0, nc, task_cols, col_nin, colptr, rowidx, L);
+	for (int k = 0; k < nc; k++)
+	{
+		const int cl = t.sbo[k], n = t.sn[k], m = t.sm[k];
+		chol_pivot(t.sj[k], cl, t.sB, Dinv, err, sLi); // pivot block in LDS; Dinv to memory; ends with a barrier
+		chol_scale_column(cl, n, t.sB, sLi);
+		__syncthreads();
+		// updates into the task's own columns (b < m), all in LDS; one pair per target block
+		for (int idx = tid; idx < m * n; idx += nt)
+		{
+			const int b = idx / n, a = idx - b * n;
+			if (a < b) continue;
+			double La[36], Lb[36], T[36];
+			ld<36>(La, t.sB + (size_t)(cl + 1 + a) * 36);
+			ld<36>(Lb, t.sB + (size_t)(cl + 1 + b) * 36);
+			mmt<6, 6, 6, false>(La, Lb, T);
+			const int ra = t.sR[cl + 1 + a], rb = t.sR[cl + 1 + b];
+			const int lq = small_task_col(t, rb);
+			const int cb = t.sbo[lq], nbk = 1 + t.sn[lq];
+			int pos = cb + (a - b);
+			if (!(a - b < nbk && t.sR[pos] == ra)) pos = find_row(t.sR, cb, cb + nbk, ra);
+			double* d = t.sB + (size_t)pos * 36;
+			for (int q = 0; q < 36; q++) d[q] -= T[q];
+		}
+		__syncthreads();
+	}
+	// the factor goes back to memory once (the deferred updates into ancestor columns read it there)
+	for (int i = tid; i < t.nb * 36; i += nt)
+	{
+		const int e = i / 36;
+		int lo = 0, hi = nc - 1;
+		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.sbo[mid] <= e) lo = mid; else hi = mid - 1; }
+		L[(size_t)(t.sc0[lo] + (e - t.sbo[lo])) * 36 + (i - e * 36)] = t.sB[i];
+	}
+}
+
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
                           double* __restrict__ v)
 {
@@ -602,13 +723,15 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 	ch.tail_begin = lcount[tail_level];
 	// tail columns must be walked in ascending index (= a topological order), not level order
 	std::sort(order.begin() + ch.tail_begin, order.end());
-	// ---- tasks.  Sub-trees of at most task_x columns are walked by one work-group each (task level 0); above them
+	// ---- tasks.  Sub-trees of at most task_x blocks are walked by one work-group each (task level 0); above them
 	// every chain of the tree (a separator of the dissection: each column the only large child of the next) is one
 	// task, levelled by the chains below it.  Launches per triangular solve: ~ depth of the dissection, not the
 	// height of the elimination tree. ----
 	{
-		static const int task_x = getenv("LSFM_TASK_X") ? atoi(getenv("LSFM_TASK_X")) : 32;
+		// "size" of a sub-tree = its blocks (pivot blocks included): a leaf task must fit LDS whole (small-task kernels)
+		static const int task_x = getenv("LSFM_TASK_X") ? atoi(getenv("LSFM_TASK_X")) : 90;
 		std::vector<int> size(M, 1), ntc(M, 0), topchild(M, -1), task(M, -1), tlev;
+		for (int j = 0; j < M; j++) size[j] = ccount[j];
 		for (int j = 0; j < M; j++) if (parent[j] >= 0) size[parent[j]] += size[j];
 		for (int j = 0; j < M; j++)
 			if (size[j] > task_x && parent[j] >= 0) { ntc[parent[j]]++; topchild[parent[j]] = j; }
@@ -642,9 +765,23 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 		std::vector<int> tl_count(ntl + 1, 0), tpos(ntasks), tsize(ntasks, 0);
 		for (int t = 0; t < ntasks; t++) tl_count[tlev[t] + 1]++;
 		for (int l = 0; l < ntl; l++) tl_count[l + 1] += tl_count[l];
+		// tasks whose blocks fit LDS whole go first in their level (they take the small-task kernels)
+		std::vector<long> tblocks(ntasks, 0), tcolsn(ntasks, 0);
+		for (int j = 0; j < M; j++) { tblocks[task[j]] += ccount[j]; tcolsn[task[j]]++; }
+		auto task_lds = [&](int t) { return tblocks[t] * (288 + 4) + (5 * tcolsn[t] + 1) * 4 + 16; };
+		const long small_cap = 60 * 1024;
+		ch.tlevel_nsmall.assign(ntl, 0);
+		ch.tlevel_small_lds.assign(ntl, 0);
 		{
 			std::vector<int> f(ntl, 0);
-			for (int t = 0; t < ntasks; t++) tpos[t] = tl_count[tlev[t]] + f[tlev[t]]++;
+			for (int pass = 0; pass < 2; pass++)
+				for (int t = 0; t < ntasks; t++)
+				{
+					const bool small = task_lds(t) <= small_cap;
+					if (small != (pass == 0)) continue;
+					tpos[t] = tl_count[tlev[t]] + f[tlev[t]]++;
+					if (small) { ch.tlevel_nsmall[tlev[t]]++; ch.tlevel_small_lds[tlev[t]] = std::max(ch.tlevel_small_lds[tlev[t]], (int)task_lds(t)); }
+				}
 		}
 		for (int j = 0; j < M; j++) tsize[tpos[task[j]]]++;
 		std::vector<int> tptr(ntasks + 1, 0), tcols(M), tf(ntasks, 0);
@@ -693,7 +830,14 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	{
 		const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
 		if (!n) continue;
-		hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		static const bool use_small = !getenv("LSFM_NO_SMALL_TASKS");
+		const int nsm = use_small ? ch.tlevel_nsmall[l] : 0;
+		if (nsm)
+			hipLaunchKernelGGL(k_chol_factor_small, dim3(nsm), dim3(l ? 256 : 128), (size_t)ch.tlevel_small_lds[l], s, ch.task_ptr + ch.tlevel_ptr[l],
+			                   ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		if (n - nsm)
+			hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n - nsm), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l] + nsm, ch.task_cols, ch.col_nin,
+			                   ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
 		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
 		if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 	}

@@ -325,11 +325,11 @@ __global__ void __launch_bounds__(256) k_chol_solve_tail(int ncols, const int* _
 }
 
 // one work-group per task: its columns in ascending order (children before parents) / descending for the back solve
-__global__ void __launch_bounds__(256) k_chol_factor_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
-                                                            const int* __restrict__ col_nin, const int* __restrict__ colptr,
-                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+__device__ void chol_factor_task_global(int task, const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                        const int* __restrict__ col_nin, const int* __restrict__ colptr,
+                                        const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
 {
-	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1];
+	const int b = task_ptr[task], e = task_ptr[task + 1];
 	for (int k = b; k < e; k++)
 	{
 		const int j = task_cols[k];
@@ -534,13 +534,13 @@ __device__ __forceinline__ int small_task_col(const SmallTask& t, int col)
 	while (lo < hi) { const int mid = (lo + hi) >> 1; if (t.sj[mid] < col) lo = mid + 1; else hi = mid; }
 	return lo;
 }
-__global__ void __launch_bounds__(256) k_chol_factor_small(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
-                                                            const int* __restrict__ col_nin, const int* __restrict__ colptr,
-                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+__device__ void chol_factor_task_lds(int task, const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                     const int* __restrict__ col_nin, const int* __restrict__ colptr,
+                                     const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
 {
 	extern __shared__ double lds_d[];
 	__shared__ double sLi[36];
-	const int b0 = task_ptr[blockIdx.x], nc = task_ptr[blockIdx.x + 1] - b0;
+	const int b0 = task_ptr[task], nc = task_ptr[task + 1] - b0;
 	const int tid = threadIdx.x, nt = blockDim.x;
 	SmallTask t;
 	small_task_stage(t, reinterpret_cast<char*>(lds_d), b0, nc, task_cols, col_nin, colptr, rowidx, L);
@@ -577,6 +577,16 @@ __global__ void __launch_bounds__(256) k_chol_factor_small(const int* __restrict
 		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.sbo[mid] <= e) lo = mid; else hi = mid - 1; }
 		L[(size_t)(t.sc0[lo] + (e - t.sbo[lo])) * 36 + (i - e * 36)] = t.sB[i];
 	}
+}
+
+// one task level of the factorisation in one launch: the first nsmall tasks of the level fit LDS whole, the others walk
+// their columns in memory; both kinds run side by side
+__global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
+                                                            const int* __restrict__ col_nin, const int* __restrict__ colptr,
+                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+{
+	if ((int)blockIdx.x < nsmall) chol_factor_task_lds(blockIdx.x, task_ptr, task_cols, col_nin, colptr, rowidx, L, Dinv, err);
+	else chol_factor_task_global(blockIdx.x, task_ptr, task_cols, col_nin, colptr, rowidx, L, Dinv, err);
 }
 
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
@@ -832,12 +842,8 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		if (!n) continue;
 		static const bool use_small = !getenv("LSFM_NO_SMALL_TASKS");
 		const int nsm = use_small ? ch.tlevel_nsmall[l] : 0;
-		if (nsm)
-			hipLaunchKernelGGL(k_chol_factor_small, dim3(nsm), dim3(l ? 256 : 128), (size_t)ch.tlevel_small_lds[l], s, ch.task_ptr + ch.tlevel_ptr[l],
-			                   ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
-		if (n - nsm)
-			hipLaunchKernelGGL(k_chol_factor_tasks, dim3(n - nsm), dim3(l ? 256 : 128), 0, s, ch.task_ptr + ch.tlevel_ptr[l] + nsm, ch.task_cols, ch.col_nin,
-			                   ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(l ? 256 : 128), nsm ? (size_t)ch.tlevel_small_lds[l] : 0, s, nsm, ch.task_ptr + ch.tlevel_ptr[l],
+		                   ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
 		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
 		if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 	}

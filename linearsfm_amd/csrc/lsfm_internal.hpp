@@ -41,6 +41,15 @@ struct Arena {
 	void release(size_t m) { off = m; }
 };
 
+// Zeroes everything allocated from an arena between construction and zero(): one memset for a run of accumulators
+// instead of one each (a level has ~25 of them)
+struct ZeroSpan {
+	Arena& ar;
+	size_t from;
+	explicit ZeroSpan(Arena& a) : ar(a), from((a.off + 255) & ~size_t(255)) {}
+	void zero(hipStream_t s) const;
+};
+
 // One tree level's maps, flat SoA on the device.  B maps; M poses, NF features, NU U blocks, NW W blocks in total.
 struct DevBatch {
 	int B = 0, M = 0, NF = 0, NU = 0, NW = 0;

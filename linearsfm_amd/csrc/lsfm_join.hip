@@ -303,15 +303,15 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	batch_set_offsets(ctx, ar, out);
 	LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_id, in.pose_id, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
 	int* newf = st.newf = ctx->scratch.alloc<int>(in.NF + 1);
-	int* lenE = st.lenE = ctx->scratch.alloc<int>(NFY + 1);
-	int* lenC = ctx->scratch.alloc<int>(NFY + 1);
 	int* lens = ctx->scratch.alloc<int>(NFY + 2);
 	st.srcf = ctx->scratch.alloc<int>(in.NW + 1);
+	ZeroSpan zs(ctx->scratch); // the accumulators of the level, zeroed by one memset
+	int* lenE = st.lenE = ctx->scratch.alloc<int>(NFY + 1);
+	int* lenC = ctx->scratch.alloc<int>(NFY + 1);
 	double* eP = st.eP = ctx->scratch.alloc<double>((size_t)in.M * 6);
 	double* eF = st.eF = ctx->scratch.alloc<double>((size_t)NFY * 3);
-	dev_zero(ctx, lenE, (NFY + 1) * sizeof(int)); dev_zero(ctx, lenC, (NFY + 1) * sizeof(int));
+	zs.zero(s);
 	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
-	dev_zero(ctx, eP, (size_t)in.M * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
 	if (in.NF)
 		for (int side = 0; side < 2; side++)
 			hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,

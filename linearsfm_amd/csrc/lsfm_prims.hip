@@ -18,6 +18,10 @@ void Arena::destroy()
 	if (base) (void)hipFree(base);
 	base = nullptr; cap = off = 0;
 }
+void ZeroSpan::zero(hipStream_t s) const
+{
+	if (ar.off > from) LSFM_CHECK_HIP(hipMemsetAsync(ar.base + from, 0, ar.off - from, s));
+}
 void* Arena::alloc_bytes(size_t bytes)
 {
 	size_t a = (off + 255) & ~size_t(255);

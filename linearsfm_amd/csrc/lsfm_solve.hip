@@ -530,17 +530,17 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	const unsigned long long* tab = sy.tab;
 	const int* hval = sy.hval;
 	const unsigned long long mask = sy.mask;
+	const int ntiles = (NF + SCHUR_TILE - 1) / SCHUR_TILE;
+	ZeroSpan zs(sc);
 	sy.S = sc.alloc<double>((size_t)cnt * 36);
+	unsigned char* fb = sc.alloc<unsigned char>(ntiles + 1); // tiles the panel kernel hands to the per-feature kernel
+	zs.zero(s);
 	sy.E = sc.alloc<double>((size_t)M * 6);
-	dev_zero(ctx, sy.S, (size_t)cnt * 36 * sizeof(double));
 	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
-		const int ntiles = (NF + SCHUR_TILE - 1) / SCHUR_TILE;
-		unsigned char* fb = sc.alloc<unsigned char>(ntiles);
-		dev_zero(ctx, fb, ntiles);
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev2, s));
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
 		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);

@@ -902,10 +902,10 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	}
 	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
 	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
+	ZeroSpan zs(ctx->scratch);
 	double* Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
 	double* PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);
-	dev_zero(ctx, Gpose, (size_t)M * 36 * nh * sizeof(double));
-	dev_zero(ctx, PP, (size_t)B * 3 * 36 * sizeof(double));
+	zs.zero(s);
 	if (M)
 	{
 		if (mono) hipLaunchKernelGGL(k_tr_pose_jac<2>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);

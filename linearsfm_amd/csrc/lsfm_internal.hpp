@@ -88,7 +88,7 @@ struct lsfm_context {
 	lsfm::Arena arena[3];   // rotation: level input / transformed level / joined level
 	lsfm::Arena scratch;    // per-stage work space
 	int cur = 0;
-	size_t arena_bytes = 0;
+	size_t arena_bytes = 0, arena_req = 0; // actual size of each arena / the request it answers (may have been capped)
 	lsfm::PcgOptions pcg;
 	std::string last_error;
 	int* h_pinned = nullptr; // small pinned staging buffer for counters

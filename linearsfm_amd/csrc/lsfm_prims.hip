@@ -1,4 +1,5 @@
 // Context, arenas and the two library primitives used off the hot path (prefix sum, radix sort: rocPRIM).
+#include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -110,13 +111,22 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 
 void lsfm_context::ensure_arenas(size_t bytes_each)
 {
-	if (arena_bytes >= bytes_each && arena[0].base) return;
+	if (arena_req >= bytes_each && arena[0].base) return;
 	LSFM_CHECK_HIP(hipStreamSynchronize(stream));
+	const size_t requested = bytes_each;
+	// the estimate is an upper bound that ignores the merging of common features (an order of magnitude at depth): never
+	// ask for more than a share of what the device has free; a tree that really needs more fails with LSFM_ERR_OOM at
+	// the allocation that overflows its arena
+	arena[0].destroy(); arena[1].destroy(); arena[2].destroy(); scratch.destroy();
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)4 << 30))
+		bytes_each = std::min(bytes_each, (free_b - ((size_t)2 << 30)) / 5);
 	arena[0].init(bytes_each);
 	arena[1].init(bytes_each);
 	arena[2].init(bytes_each);
 	scratch.init(bytes_each);
 	arena_bytes = bytes_each;
+	arena_req = requested;
 }
 
 extern "C" {

@@ -95,6 +95,12 @@ struct lsfm_context {
 	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
 	size_t stage_size = 0, stage_off = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	// side stream: the pattern of S is built there while the caller's right-hand-side kernels run on the main stream.
+	// evA = point of the main stream after which the index arrays of the joint map are complete (recorded by the caller,
+	// pattern_dep set), evB = pattern ready
+	hipStream_t stream2 = nullptr;
+	hipEvent_t evA = nullptr, evB = nullptr;
+	bool pattern_dep = false;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run
 	void ensure_arenas(size_t bytes_each);
 };

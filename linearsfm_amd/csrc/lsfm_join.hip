@@ -340,6 +340,12 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
 		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
 	}
+	// everything the pattern of S needs is enqueued: the solve may build it beside the right-hand sides
+	if (!eP_out && !eF_out)
+	{
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s));
+		ctx->pattern_dep = true;
+	}
 	// ---- right-hand sides ----
 	if (NFY)
 		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);

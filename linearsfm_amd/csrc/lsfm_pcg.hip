@@ -1018,8 +1018,33 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	// pattern -> (copy it to the host) -> numeric assembly K9 enqueued -> symbolic factorisation on the host while K9
 	// runs -> numeric factorisation
-	build_schur_pattern(ctx, io, sy);
-	chol_fetch(ctx, sy, io.d_pose_origin, hin);
+	// The pattern depends on index arrays only.  When the caller marked the point of the main stream where those were
+	// complete (evA) and went on to enqueue its right-hand-side kernels, the pattern is built on the side stream next
+	// to them; the values wait for both.
+	{
+		static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
+		if (side && ctx->pattern_dep)
+		{
+			ctx->pattern_dep = false;
+			LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evA, 0));
+			std::swap(ctx->stream, ctx->stream2);
+			try
+			{
+				build_schur_pattern(ctx, io, sy);
+				chol_fetch(ctx, sy, io.d_pose_origin, hin);
+				LSFM_CHECK_HIP(hipEventRecord(ctx->evB, ctx->stream));
+			}
+			catch (...) { std::swap(ctx->stream, ctx->stream2); throw; }
+			std::swap(ctx->stream, ctx->stream2);
+			LSFM_CHECK_HIP(hipStreamWaitEvent(s, ctx->evB, 0));
+		}
+		else
+		{
+			ctx->pattern_dep = false;
+			build_schur_pattern(ctx, io, sy);
+			chol_fetch(ctx, sy, io.d_pose_origin, hin);
+		}
+	}
 	build_schur_values(ctx, io, sy);
 	LSFM_CHECK_HIP(hipEventRecord(eb, s));
 	double tw0 = wall();

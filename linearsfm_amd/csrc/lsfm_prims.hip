@@ -147,6 +147,9 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		c->device = device;
 		LSFM_CHECK_HIP(hipSetDevice(device));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		c->stage_size = (size_t)16 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
@@ -180,6 +183,9 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
 	if (c->ev3) (void)hipEventDestroy(c->ev3);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	if (c->evA) (void)hipEventDestroy(c->evA);
+	if (c->evB) (void)hipEventDestroy(c->evB);
 	delete c;
 }
 

@@ -798,6 +798,7 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 {
 	hipStream_t s = ctx->stream;
 	const int M = in.M;
+	bool ev_entries = false;
 	if (!in.NF && hook) (void)(*hook)(out); // nothing to redirect, but the consumer still lays out its container
 	if (in.NF)
 	{
@@ -817,6 +818,8 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, finfo, in.fptr, in.W,
 		                   in.photo, KW, Dp, Cp, FD, rd.W, rd.photo, rd.feature, Gsum, Gpose, hubJ, out.W_alias ? 1 : 0, rd.wbase, rd.newf, rd.srcf);
 		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s)); // pose rows of G complete: the U stage may start on the side stream
+		ev_entries = true;
 		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,
 		                   Dp, FD, Gsum, hubJ, rd.wbase, rd.newf, rd.srcf, rd.W, rd.photo, rd.feature, PP);
 		if (ctx->stats)
@@ -835,12 +838,22 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 			                         nf_act * 18 * NH * 8 + nw_pass * (4 + 8 + (out.W_alias ? 0 : 288)) + (double)(in.NF - nf_act) * (16 + 4);
 		}
 	}
+	// U stage: needs the pose rows of G (complete after k_tr_entries) but nothing of the feature epilogue, which runs
+	// on the main stream meanwhile; k_tr_diag needs both
+	static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
+	hipStream_t su = (side && ev_entries) ? ctx->stream2 : s;
+	if (su != s) LSFM_CHECK_HIP(hipStreamWaitEvent(su, ctx->evA, 0));
 	if (in.NU)
-		hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
+		hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, su, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
 		                   Dp, Cp, out.U, out.Ui, out.Uj, Gpose);
 	if (M)
-		hipLaunchKernelGGL(k_tr_poseslots<NH>, dim3((M + 127) / 128), dim3(128), 0, s, M, d_tm, in.pose_map, Dp, Cp, Gpose, out.U, out.Ui,
+		hipLaunchKernelGGL(k_tr_poseslots<NH>, dim3((M + 127) / 128), dim3(128), 0, su, M, d_tm, in.pose_map, Dp, Cp, Gpose, out.U, out.Ui,
 		                   out.Uj, PP);
+	if (su != s)
+	{
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evB, su));
+		LSFM_CHECK_HIP(hipStreamWaitEvent(s, ctx->evB, 0));
+	}
 	hipLaunchKernelGGL(k_tr_diag<NH>, dim3((in.B + 127) / 128), dim3(128), 0, s, in.B, d_tm, PP, out.U);
 }
 

@@ -292,3 +292,29 @@ def test_full_size_properties_without_the_oracle(ctx):
         x = rng.normal(size=6 * M + 3 * int(out["n"]))
         a, b = _quad_form(out, x), _quad_form(back, x)
         assert abs(a - b) / abs(a) < 1e-7, (a, b)
+
+
+def test_error_paths_of_the_c_abi(ctx):
+    """Invalid input comes back as an error code with a message, never as a crash or a silent result: empty set, a pose id
+    that no map holds as transform target, an information matrix that is not positive definite."""
+    from linearsfm_amd import api
+    with pytest.raises(api.LsfmError):
+        ctx.divide_conquer([], False)
+    maps = [oracle_free_dict(m) for m in synth.make_stereo_set(2, 6, 4, seed=3)]
+    with pytest.raises(api.LsfmError, match="target pose id not found"):
+        ctx.transform(maps[0], False, 987654)
+    bad = [dict(m) for m in maps]
+    for b in bad:
+        b["V"] = -np.asarray(b["V"])  # negative-definite feature blocks: the Schur system cannot be positive definite
+        b["U"] = -np.asarray(b["U"])
+    with pytest.raises(api.LsfmError, match="not positive definite"):
+        ctx.divide_conquer(bad, False)
+    # the context stays usable after an error
+    out, stats, rc = ctx.divide_conquer(maps, False)
+    assert rc == 0 and int(out["m"]) == 2
+
+
+def oracle_free_dict(m):
+    """LocalMap -> the dict the ctypes view takes (same fields as pyoracle.localmap_to_dict, without importing the oracle)."""
+    return dict(Ref=m.Ref, FRef=m.Ref, m=m.m, n=m.n, stno=m.stno, stVal=m.stVal, U=m.U, Ui=m.Ui, Uj=m.Uj, W=m.W, photo=m.photo,
+                feature=m.feature, V=m.V, FBlock=m.FBlock)

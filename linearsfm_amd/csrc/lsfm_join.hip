@@ -155,7 +155,7 @@ __global__ void k_join_wcopy(int NW, const double* __restrict__ W, const int* __
 // right-hand side: eF += W^T x_pose, eP += W x_feat (each block with the estimates of the map it came from),
 // Imp.cpp:2770-2786, 2822-2838, 2891-2906.  One lane per W block of the joint map (coalesced); the feature sums go
 // through LDS per run, the pose sums through an LDS table flushed once per work-group.
-#define RHS_TILE 512 /* joint features per work-group */
+#define RHS_TILE 128 /* joint features per work-group */
 __global__ void __launch_bounds__(256)
 k_join_rhs_w(int NFY, const int* __restrict__ fptr_y, const double* __restrict__ Wy, const int* __restrict__ photo_y,
              const int* __restrict__ srcf, const double* __restrict__ pose, const double* __restrict__ feat, double* __restrict__ eP,

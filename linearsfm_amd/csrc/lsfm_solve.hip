@@ -399,7 +399,7 @@ k_spmv(int M, const int* __restrict__ rowptr, const int* __restrict__ colidx, co
 }
 
 // K11 (Imp.cpp:2980-3020); features of carried maps keep their values
-#define BSUB_TILE 512 /* features per work-group */
+#define BSUB_TILE 128 /* features per work-group */
 __global__ void __launch_bounds__(256)
 k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
           const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,

@@ -301,7 +301,7 @@ __global__ void k_tr_gather_counts(const int* __restrict__ KU, const int* __rest
 // contiguous over the wave); a lane per feature walking its run strided the wave's accesses by the run length and
 // needed 340 registers (one wave per SIMD).
 // ---------------------------------------------------------------------------------------------------------
-#define TRE_TILE 256 /* features per work-group: the LDS pose table is flushed once per tile */
+#define TRE_TILE 128 /* features per work-group: the LDS pose table is flushed once per tile */
 #define TRE_ROUND 256 /* W blocks per round = threads */
 
 template <int NH>

@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 # HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 guide
 # prescribes + WRITE_SIZE; separate --pmc runs), averaged over the launches of one tree run.  None = not collected.
 # Source: profiles/r01_pmc_traffic_summary.json (from r01_pmc_{FETCH,WRITE}_SIZE_counter_collection.csv, 3499-map run).
-TRAFFIC = {"schur": 7.529e8, "trf": 1.4901e9}
+TRAFFIC = {"schur": 7.528e8, "trf": 1.4802e9}
 
 
 def cpu_baseline(maps, sample_maps, mono):

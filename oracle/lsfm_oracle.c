@@ -1602,6 +1602,66 @@ static void transform_any(const orc_map* in, int mono, int Ref, int ScaP, int Fi
 	g_t_trans += now_s() - t0;
 }
 
+/* The same tree with the joins of a level on several host threads (OpenMP): the "fair multi-core" CPU figure next to
+ * the single-threaded one (the reference itself is single-threaded).  Pairs of a level are independent
+ * (Imp.cpp:1938-2033); every pair is computed exactly as in orc_divide_conquer, so the result is identical. */
+int orc_divide_conquer_omp(orc_map* LM, int nLocalMapCount, int mono, orc_map* out, int nthreads, double* timing)
+{
+	int L = 0, rc = 0;
+	orc_map G;
+	double t0 = now_s();
+	memset(&G, 0, sizeof G);
+	if (nLocalMapCount == 1) { G = LM[0]; memset(&LM[0], 0, sizeof LM[0]); }
+	while (nLocalMapCount > 1)
+	{
+		const int N2 = nLocalMapCount % 2;
+		const int cnt = (int)(nLocalMapCount / 2.0 + 0.5);
+		orc_map* NEXT = (orc_map*)xcalloc(cnt, sizeof(orc_map));
+		int i;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1) reduction(| : rc)
+#endif
+		for (i = 0; i < cnt; i++)
+		{
+			const int NumLM = (i < cnt - 1 || N2 == 0) ? 2 : 1;
+			orc_map Gi = LM[2 * i];
+			memset(&LM[2 * i], 0, sizeof Gi);
+			if (NumLM == 2)
+			{
+				orc_map End, Joint, *Cur = &LM[2 * i + 1];
+				if (mono) orc_transform_mono(&Gi, Cur->Ref, Cur->ScaP, Cur->Fix, &End); else orc_transform_stereo(&Gi, Cur->Ref, &End);
+				orc_map_free(&Gi);
+				rc |= mono ? orc_join_mono(&End, Cur, &Joint) : orc_join_stereo(&End, Cur, &Joint);
+				Gi = Joint;
+			}
+			if ((i + 1) % 2 == 0 && Gi.Ref > Gi.FRef)
+			{
+				orc_map Tmp;
+				if (mono) orc_transform_mono(&Gi, Gi.FRef, Gi.FScaP, Gi.FFix, &Tmp); else orc_transform_stereo(&Gi, Gi.FRef, &Tmp);
+				orc_map_free(&Gi);
+				Gi = Tmp;
+			}
+			NEXT[i] = Gi;
+		}
+		for (i = 0; i < cnt; i++) LM[i] = NEXT[i];
+		free(NEXT);
+		nLocalMapCount = cnt;
+		L++;
+		if (nLocalMapCount == 1) { G = LM[0]; memset(&LM[0], 0, sizeof G); }
+	}
+	if (g_final_reanchor && G.Ref > G.FRef)
+	{
+		orc_map Tmp;
+		if (mono) orc_transform_mono(&G, G.FRef, G.FScaP, G.FFix, &Tmp); else orc_transform_stereo(&G, G.FRef, &Tmp);
+		orc_map_free(&G);
+		G = Tmp;
+	}
+	*out = G;
+	if (timing) { timing[0] = now_s() - t0; timing[1] = timing[2] = timing[3] = 0; }
+	(void)L;
+	return rc;
+}
+
 /* Imp.cpp:1926-2063 / 6511-6630 */
 int orc_divide_conquer(orc_map* LM, int nLocalMapCount, int mono, orc_map* out, int verbose, double* timing)
 {

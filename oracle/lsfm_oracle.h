@@ -82,6 +82,8 @@ int orc_join_mono(orc_map* End, orc_map* Cur, orc_map* joint);
  * match_hash != 0 replaces the O(n1*n2) std::find feature matching by a sort-based one (same result).
  * timing (optional): [0]=total s, [1]=transform s, [2]=join-assembly s, [3]=solve s */
 int orc_divide_conquer(orc_map* maps, int N, int mono, orc_map* out, int verbose, double* timing);
+/* the same tree, the independent joins of a level on `nthreads` host threads (OpenMP); identical result; timing[0] only */
+int orc_divide_conquer_omp(orc_map* maps, int N, int mono, orc_map* out, int nthreads, double* timing);
 
 /* Imp.cpp:2102-2117 and 7876-7967 (byte-compatible "%lf" files) */
 int orc_save_state(const char* path, const double* st, const int* stno, int n);

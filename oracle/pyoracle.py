@@ -54,6 +54,7 @@ def lib():
         L.orc_join_stereo.argtypes = [P(OrcMap), P(OrcMap), P(OrcMap)]
         L.orc_join_mono.argtypes = [P(OrcMap), P(OrcMap), P(OrcMap)]
         L.orc_divide_conquer.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), C.c_int, dp]
+        L.orc_divide_conquer_omp.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), C.c_int, dp]
         L.orc_set_match_hash.argtypes = [C.c_int]
         L.orc_set_final_reanchor.argtypes = [C.c_int]
         L.free = C.CDLL(None).free
@@ -214,8 +215,9 @@ def schur(j, eP, eF, accumulate_u):
     return out
 
 
-def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True):
-    """Full hierarchical join of a list of map dicts; returns (final map dict, timing[4], rc)."""
+def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True, threads=0):
+    """Full hierarchical join of a list of map dicts; returns (final map dict, timing[4], rc).
+    threads > 0: the independent joins of a level on that many host threads (same result, timing[0] only)."""
     L = lib()
     L.orc_set_match_hash(int(match_hash))
     L.orc_set_final_reanchor(int(final_reanchor))
@@ -225,7 +227,10 @@ def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=T
         arr[k] = dict_to_map(d)
     out = OrcMap()
     timing = (C.c_double * 4)()
-    rc = L.orc_divide_conquer(arr, N, int(mono), C.byref(out), int(verbose), timing)
+    if threads > 0:
+        rc = L.orc_divide_conquer_omp(arr, N, int(mono), C.byref(out), int(threads), timing)
+    else:
+        rc = L.orc_divide_conquer(arr, N, int(mono), C.byref(out), int(verbose), timing)
     res = map_to_dict(out)
     L.orc_map_free(C.byref(out))
     return res, list(timing), rc

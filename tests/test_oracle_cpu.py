@@ -203,3 +203,15 @@ def test_localmap_writer_roundtrip(oracle, tmp_path, mono):
     assert back["Ref"] == out["Ref"] and back["m"] == out["m"] and back["n"] == out["n"]
     if mono:
         assert (back["ScaP"], back["Fix"], back["Sign"]) == (out["ScaP"], out["Fix"], out["Sign"])
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_threaded_oracle_tree_is_identical(oracle, mono):
+    """orc_divide_conquer_omp (the multi-core CPU figure of bench.py) computes every join exactly like the serial tree."""
+    maps = synth.make_mono_set(11, 6, 4, seed=8) if mono else synth.make_stereo_set(13, 6, 5, seed=8)
+    d = [oracle.localmap_to_dict(m) for m in maps]
+    a, _, rc1 = oracle.divide_conquer(d, mono)
+    b, _, rc2 = oracle.divide_conquer(d, mono, threads=3)
+    assert rc1 == 0 and rc2 == 0
+    for k in ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k

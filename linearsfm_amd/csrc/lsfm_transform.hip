@@ -529,7 +529,7 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 }
 
 template <int NH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NH == 1 ? 2 : 1)
 k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const int* __restrict__ fptr,
                const double* __restrict__ Vold, const double* __restrict__ Wold, const int* __restrict__ photo, const double* __restrict__ Dp,
                const double* __restrict__ FD, const double* __restrict__ Gsum, const int* __restrict__ hubJ, const int* __restrict__ wbase,

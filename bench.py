@@ -74,14 +74,13 @@ def main():
 
     from linearsfm_amd import api, synth
 
-    typ, cN, cnpf, cvis = synth.CONFIGS[args.config]
+    typ, cN, cnpf, cvis, cpath = synth.CONFIGS[args.config]
     mono = typ == "Monocular"
     args.maps = args.maps or cN
     args.new_per_frame = args.new_per_frame or cnpf
     args.vis = args.vis or cvis
     # synthetic stand-in set; every rank its own seed (independent map sets)
-    gen = synth.make_mono_set if mono else synth.make_stereo_set
-    maps = gen(args.maps, new_per_frame=args.new_per_frame, vis=args.vis, seed=1000 * rank)
+    _, maps = synth.make_config(args.config, args.maps, seed=1000 * rank, new_per_frame=args.new_per_frame, vis=args.vis)
     ctx = api.Context(local_rank)
     ctx.set_pcg(args.tol, 4)
     tree = ctx.tree_upload(maps, mono)   # PCIe copy, outside the timed region: inputs are resident from here on

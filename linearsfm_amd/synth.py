@@ -102,16 +102,35 @@ def _drot(a, b, g):
 # ----------------------------------------------------------------------------------------------
 # world
 # ----------------------------------------------------------------------------------------------
-def _world(n_frames, new_per_frame, vis, seed):
-    """Camera path + points.  Camera moves in the x-y plane looking along +z, points in a slab above it."""
+GOLDEN_ANGLE = 2.399963229728653
+
+
+def _world(n_frames, new_per_frame, vis, seed, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0), turn=GOLDEN_ANGLE):
+    """Camera path + points.  Camera moves in the x-y plane looking along +z, points in a slab above it.
+
+    lap = 0: an open path that never returns (dead reckoning only; global coordinates of a long set are then so weakly
+    determined that two fp64 evaluations of the same join tree differ visibly -- kept for the small fixtures).
+    lap = P > 0: the path is a sequence of closed laps of P frames that all leave from and return to the same place
+    (circles through the origin, every lap in a new direction), like the real sets, whose trajectories revisit
+    (README.txt:58-60 names sets of up to 3499 local maps that the reference solved).  Points first seen within
+    `home` frames of a lap boundary are re-observed, with probability `revisit`, by the frames at the same phase of the
+    NEXT lap: the same feature id then appears in local maps that are a whole lap apart, and the join that brings the two
+    laps together closes the loop."""
     rng1 = np.random.default_rng(seed + 1)
     rng2 = np.random.default_rng(seed + 2)
     i = np.arange(n_frames)
     step = 0.5
     heading = 0.6 * np.sin(2 * np.pi * i / 257.0) + 0.25 * np.sin(2 * np.pi * i / 61.0)
     pos = np.zeros((n_frames, 3))
-    pos[1:, 0] = np.cumsum(step * np.cos(heading[:-1]))
-    pos[1:, 1] = np.cumsum(step * np.sin(heading[:-1]))
+    if lap > 0:
+        R = step / (2.0 * np.sin(np.pi / lap))             # chord between consecutive frames = step
+        psi = turn * (i // lap)
+        phi = psi + np.pi + 2 * np.pi * (i % lap) / lap
+        pos[:, 0] = R * (np.cos(psi) + np.cos(phi))
+        pos[:, 1] = R * (np.sin(psi) + np.sin(phi))
+    else:
+        pos[1:, 0] = np.cumsum(step * np.cos(heading[:-1]))
+        pos[1:, 1] = np.cumsum(step * np.sin(heading[:-1]))
     pos[:, 2] = 0.3 * np.sin(2 * np.pi * i / 97.0)
 
     def smooth(scale, period, phase):
@@ -126,9 +145,27 @@ def _world(n_frames, new_per_frame, vis, seed):
     npts = starts.shape[0]
     mid = np.clip(starts + (vis - 1) / 2.0, 0, n_frames - 1)
     c_mid = np.stack([np.interp(mid, i, pos[:, d]) for d in range(3)], 1)
-    off = np.stack([rng2.uniform(-3, 3, npts), rng2.uniform(-2.5, 2.5, npts), rng2.uniform(4.0, 12.0, npts)], 1)
+    off = np.stack([rng2.uniform(-3, 3, npts), rng2.uniform(-2.5, 2.5, npts), rng2.uniform(depth[0], depth[1], npts)], 1)
     pts = c_mid + off
-    return pos, Rw, starts, pts
+    # second visibility window of the re-observed points (NEVER = none)
+    starts2 = np.full(npts, NEVER)
+    if lap > 0:
+        rng4 = np.random.default_rng(seed + 4)
+        ph_s = np.mod(starts, lap)
+        near = (starts >= 0) & ((ph_s < home) | (ph_s >= lap - home))
+        pick = near & (rng4.uniform(0, 1, npts) < revisit)
+        starts2[pick] = starts[pick] + lap
+    return pos, Rw, starts, starts2, pts
+
+
+NEVER = -(1 << 40)
+
+
+def _visible(starts, starts2, vis, first, last):
+    """points seen by every frame of [first, last]"""
+    a = (starts <= first) & (starts + vis - 1 >= last)
+    b = (starts2 <= first) & (starts2 + vis - 1 >= last)
+    return np.nonzero(a | b)[0]
 
 
 def _rel_pose(pos, Rw, k, j):
@@ -141,16 +178,18 @@ def _rel_pose(pos, Rw, k, j):
 # ----------------------------------------------------------------------------------------------
 # Stereo
 # ----------------------------------------------------------------------------------------------
-def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_id=1):
-    """n_maps Stereo local maps over n_maps+1 frames (ids first_id..).  ~new_per_frame*(vis-1) features per map."""
+def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_id=1, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0),
+                    turn=GOLDEN_ANGLE):
+    """n_maps Stereo local maps over n_maps+1 frames (ids first_id..).  ~new_per_frame*(vis-1) features per map.
+    lap/home/revisit: see _world (lap = 0: open path)."""
     n_frames = n_maps + 1
-    pos, Rw, starts, pts = _world(n_frames, new_per_frame, vis, seed)
+    pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn)
     rng3 = np.random.default_rng(seed + 3)
     sinv = np.diag(1.0 / np.array([0.01, 0.01, 0.03]) ** 2)
     maps = []
     for k in range(n_maps):
         # points visible in frame k and k+1
-        sel = np.nonzero((starts <= k) & (starts + vis - 1 >= k + 1))[0]
+        sel = _visible(starts, starts2, vis, k, k + 1)
         n = sel.shape[0]
         t, R = _rel_pose(pos, Rw, k, k + 1)
         a, b, g = ypr_from_rot(R)
@@ -181,15 +220,17 @@ def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_
 # ----------------------------------------------------------------------------------------------
 # Mono
 # ----------------------------------------------------------------------------------------------
-def make_mono_set(n_maps, new_per_frame=300, vis=4, seed=0, noise=1e-3, first_id=1):
-    """n_maps Mono local maps over n_maps+2 frames; map k = frames k,k+1,k+2 (Ref=k, ScaP=k+1)."""
+def make_mono_set(n_maps, new_per_frame=300, vis=4, seed=0, noise=1e-3, first_id=1, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0),
+                  turn=GOLDEN_ANGLE):
+    """n_maps Mono local maps over n_maps+2 frames; map k = frames k,k+1,k+2 (Ref=k, ScaP=k+1).
+    lap/home/revisit: see _world (lap = 0: open path)."""
     n_frames = n_maps + 2
-    pos, Rw, starts, pts = _world(n_frames, new_per_frame, vis, seed)
+    pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn)
     rng3 = np.random.default_rng(seed + 3)
     w = 1.0 / (1e-3) ** 2
     maps = []
     for k in range(n_maps):
-        sel = np.nonzero((starts <= k) & (starts + vis - 1 >= k + 2))[0]
+        sel = _visible(starts, starts2, vis, k, k + 2)
         n = sel.shape[0]
         t1, R1 = _rel_pose(pos, Rw, k, k + 1)
         t2, R2 = _rel_pose(pos, Rw, k, k + 2)
@@ -304,20 +345,26 @@ def write_set(dirpath, maps):
         write_localmap(os.path.join(dirpath, f"localmap_{k + 1}.txt"), lm)
 
 
-# name -> (type, N maps, new features per frame, vis)   
+# name -> (type, N maps, new features per frame, vis, path)   (BASELINE.md section 2).  path: keyword arguments of _world --
+# the stand-ins revisit like the real sets do (README.txt:58-60), which is what makes their global coordinates well
+# determined.  Stereo: "flower" -- laps of 120 frames in ever new directions that all start and end at the same place, the
+# frames within 10 frames of a lap boundary re-observe 40 % of the points their predecessors of the previous lap saw.
+# Mono (scale is observable only through shared points, so an open monocular chain drifts far more): laps of 40 frames,
+# every lap slightly turned against the previous one, half of ALL points re-observed one lap later.  Lap boundaries do not
+# coincide with the power-of-two blocks of the join tree.
+FLOWER = dict(lap=120, home=10, revisit=0.4)
+SPIRAL = dict(lap=40, home=20, revisit=0.5, turn=0.15)
 CONFIGS = {
-    "rs90":     ("Monocular", 88, 300, 4),
-    "rs468":    ("Monocular", 466, 300, 4),
-    "nc3500":   ("Stereo", 3499, 130, 5),
-    "synth16k": ("Monocular", 16384, 64, 4),
-    "synth64k": ("Stereo", 65536, 64, 5),
+    "rs90":     ("Monocular", 88, 300, 4, SPIRAL),
+    "rs468":    ("Monocular", 466, 300, 4, SPIRAL),
+    "nc3500":   ("Stereo", 3499, 130, 5, FLOWER),
+    "synth16k": ("Monocular", 16384, 64, 4, SPIRAL),
+    "synth64k": ("Stereo", 65536, 64, 5, FLOWER),
 }
 
 
-def make_config(name, n_maps=None, seed=0):
-    typ, N, npf, vis = CONFIGS[name]
-    if n_maps is not None:
-        N = n_maps
-    if typ == "Stereo":
-        return typ, make_stereo_set(N, npf, vis, seed)
-    return typ, make_mono_set(N, npf, vis, seed)
+def make_config(name, n_maps=None, seed=0, new_per_frame=None, vis=None, path=None):
+    """The named stand-in set (optionally shortened / thinned): returns (type, list of LocalMap)."""
+    typ, N, npf, cvis, cpath = CONFIGS[name]
+    gen = make_stereo_set if typ == "Stereo" else make_mono_set
+    return typ, gen(n_maps or N, new_per_frame or npf, vis or cvis, seed, **(cpath if path is None else path))

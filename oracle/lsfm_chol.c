@@ -56,104 +56,28 @@ static long symbolic_lnz(int n, const int* Cp, const int* Ci, int* parent, int* 
 	return lnz;
 }
 
-/* C = P A P^T, upper part, CSC.  pinv[old] = new */
-static void symperm(int n, const int* Ap, const int* Ai, const double* Ax, const int* pinv, int** Cp_o, int** Ci_o, double** Cx_o)
-{
-	int *Cp = xm((n + 1) * sizeof(int)), *w = calloc(n + 1, sizeof(int)), *Ci;
-	double* Cx;
-	int j, p, i, i2, j2, q;
-	for (j = 0; j < n; j++)
-		for (p = Ap[j]; p < Ap[j + 1]; p++)
-		{
-			i = Ai[p];
-			if (i > j) continue;
-			i2 = pinv ? pinv[i] : i; j2 = pinv ? pinv[j] : j;
-			w[i2 > j2 ? i2 : j2]++;
-		}
-	Cp[0] = 0;
-	for (j = 0; j < n; j++) { Cp[j + 1] = Cp[j] + w[j]; w[j] = Cp[j]; }
-	Ci = xm((Cp[n] + 1) * sizeof(int));
-	Cx = Ax ? xm((Cp[n] + 1) * sizeof(double)) : NULL;
-	for (j = 0; j < n; j++)
-		for (p = Ap[j]; p < Ap[j + 1]; p++)
-		{
-			i = Ai[p];
-			if (i > j) continue;
-			i2 = pinv ? pinv[i] : i; j2 = pinv ? pinv[j] : j;
-			q = w[i2 > j2 ? i2 : j2]++;
-			Ci[q] = i2 < j2 ? i2 : j2;
-			if (Cx) Cx[q] = Ax[p];
-		}
-	free(w);
-	*Cp_o = Cp; *Ci_o = Ci; *Cx_o = Cx;
-}
+#define REAL double
+#define RSQRT sqrt
+#define SUF(name) name##_d
+#include "lsfm_chol_num.inc"
+#undef REAL
+#undef RSQRT
+#undef SUF
+#define REAL long double
+#define RSQRT sqrtl
+#define SUF(name) name##_x
+#include "lsfm_chol_num.inc"
+#undef REAL
+#undef RSQRT
+#undef SUF
 
 int orc_chol_solve(int n, const int* Ap, const int* Ai, const double* Ax, const int* perm, const double* b, double* x, long* lnz_out)
 {
-	int *pinv = NULL, *Cp, *Ci, *parent, *cc, *Lp, *Li, *c, *s, *w;
-	double *Cx, *Lx, *y, *xw;
-	int k, p, i, top, rc = 0;
-	long lnz;
-	if (n == 0) { if (lnz_out) *lnz_out = 0; return 0; }
-	if (perm)
-	{
-		pinv = xm(n * sizeof(int));
-		for (k = 0; k < n; k++) pinv[perm[k]] = k;
-	}
-	symperm(n, Ap, Ai, Ax, pinv, &Cp, &Ci, &Cx);
-	parent = xm(n * sizeof(int)); cc = xm(n * sizeof(int));
-	lnz = symbolic_lnz(n, Cp, Ci, parent, cc);
-	if (lnz_out) *lnz_out = lnz;
-	Lp = xm((n + 1) * sizeof(int)); c = xm(n * sizeof(int));
-	Lp[0] = 0;
-	for (k = 0; k < n; k++) { Lp[k + 1] = Lp[k] + cc[k]; c[k] = Lp[k]; }
-	Li = xm((size_t)lnz * sizeof(int)); Lx = xm((size_t)lnz * sizeof(double));
-	s = xm(n * sizeof(int)); w = xm(n * sizeof(int)); xw = xm(n * sizeof(double));
-	for (k = 0; k < n; k++) { w[k] = -1; xw[k] = 0; }
-	for (k = 0; k < n; k++)
-	{
-		double d, lki;
-		top = ereach(Cp, Ci, k, parent, s, w, n);
-		xw[k] = 0;
-		for (p = Cp[k]; p < Cp[k + 1]; p++)
-			if (Ci[p] <= k) xw[Ci[p]] += Cx[p];   /* += : duplicate entries are summed */
-		d = xw[k]; xw[k] = 0;
-		for (; top < n; top++)
-		{
-			i = s[top];
-			lki = xw[i] / Lx[Lp[i]];
-			xw[i] = 0;
-			for (p = Lp[i] + 1; p < c[i]; p++) xw[Li[p]] -= Lx[p] * lki;
-			d -= lki * lki;
-			p = c[i]++;
-			Li[p] = k; Lx[p] = lki;
-		}
-		if (!(d > 0)) { rc = k + 1; break; }
-		p = c[k]++;
-		Li[p] = k; Lx[p] = sqrt(d);
-	}
-	if (rc == 0)
-	{
-		y = xm(n * sizeof(double));
-		for (k = 0; k < n; k++) y[k] = b[perm ? perm[k] : k];
-		for (k = 0; k < n; k++) /* L y = b */
-		{
-			y[k] /= Lx[Lp[k]];
-			for (p = Lp[k] + 1; p < Lp[k + 1]; p++) y[Li[p]] -= Lx[p] * y[k];
-		}
-		for (k = n - 1; k >= 0; k--) /* L^T x = y */
-		{
-			for (p = Lp[k] + 1; p < Lp[k + 1]; p++) y[k] -= Lx[p] * y[Li[p]];
-			y[k] /= Lx[Lp[k]];
-		}
-		for (k = 0; k < n; k++) x[perm ? perm[k] : k] = y[k];
-		free(y);
-	}
-	else
-		for (k = 0; k < n; k++) x[k] = 0;
-	free(pinv); free(Cp); free(Ci); free(Cx); free(parent); free(cc); free(Lp); free(c); free(Li); free(Lx);
-	free(s); free(w); free(xw);
-	return rc;
+	return chol_solve_d(n, Ap, Ai, Ax, perm, b, x, lnz_out);
+}
+int orc_chol_solve_x(int n, const int* Ap, const int* Ai, const long double* Ax, const int* perm, const long double* b, long double* x, long* lnz_out)
+{
+	return chol_solve_x(n, Ap, Ai, Ax, perm, b, x, lnz_out);
 }
 
 /* Fill-reducing ordering of the block graph.  The Schur matrices of this path are "chain + hubs": every
@@ -203,7 +127,7 @@ void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm)
 				}
 		qsort(d, nb, sizeof *d, cmp_degidx);
 		for (j = 0; j < nb; j++) { perm[j] = d[j].idx; pinv[d[j].idx] = j; }
-		symperm(nb, Ap, Ai, NULL, pinv, &Cp, &Ci, &Cx);
+		symperm_d(nb, Ap, Ai, NULL, pinv, &Cp, &Ci, &Cx);
 		fill = symbolic_lnz(nb, Cp, Ci, parent, cc);
 		free(Cp); free(Ci);
 		if (best_fill < 0 || fill < best_fill) { best_fill = fill; memcpy(best, perm, nb * sizeof(int)); }

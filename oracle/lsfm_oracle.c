@@ -1242,24 +1242,6 @@ void orc_join_assemble_mono(orc_map* End, orc_map* Cur, orc_map* J, double** ePo
 /* ------------------------------------------------------------------------------------------------
  * Schur complement + solve + back-substitution  (Imp.cpp:2119-2378, 6756-7041, 2980-3042)
  * ---------------------------------------------------------------------------------------------- */
-/* Imp.cpp:3022-3042: V^-1, written back symmetrised from the upper triangle of the inverse */
-static void inverse_v(const double* V, double* IV, int n)
-{
-	int i;
-	for (i = 0; i < n; i++)
-	{
-		const double* a = V + (size_t)i * 9;
-		double* o = IV + (size_t)i * 9;
-		double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
-		double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
-		/* inverse = adj/det; (0,1) (0,2) (1,2) entries of the inverse */
-		double i00 = c00 * id, i11 = (a[0] * a[8] - a[2] * a[6]) * id, i22 = (a[0] * a[4] - a[1] * a[3]) * id;
-		double i01 = (a[2] * a[7] - a[1] * a[8]) * id, i02 = (a[1] * a[5] - a[2] * a[4]) * id, i12 = (a[2] * a[3] - a[0] * a[5]) * id;
-		o[0] = i00; o[4] = i11; o[8] = i22;
-		o[1] = o[3] = i01; o[2] = o[6] = i02; o[5] = o[7] = i12;
-	}
-}
-
 static int cmp_int(const void* a, const void* b) { int x = *(const int*)a, y = *(const int*)b; return x < y ? -1 : x > y; }
 
 /* returns index of column j in row i of the block-CRS pattern (sba_crsm_elmidx, Imp.cpp:55-76) */
@@ -1274,15 +1256,37 @@ static int crs_find(const int* rowptr, const int* colidx, int i, int j)
 	return -1;
 }
 
-void orc_schur(const double* eb, const double* ea, const double* U, const double* W, const double* V,
-               const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
-               int accumulate_u, int** rowptr_o, int** colidx_o, double** S_o, double** E_o, double** IV_o)
+int orc_chol_solve_x(int n, const int* Ap, const int* Ai, const long double* Ax, const int* perm, const long double* b,
+                     long double* x, long* lnz_out);
+
+#define REAL double
+#define SUF(name) name##_d
+#define CHOL_SOLVE orc_chol_solve
+#include "lsfm_solve_num.inc"
+#undef REAL
+#undef SUF
+#undef CHOL_SOLVE
+#define REAL long double
+#define SUF(name) name##_x
+#define CHOL_SOLVE orc_chol_solve_x
+#include "lsfm_solve_num.inc"
+#undef REAL
+#undef SUF
+#undef CHOL_SOLVE
+
+/* 0: the solves run in double (the reference's arithmetic); 1: in long double (lsfm_solve_num.inc), results rounded to
+ * double -- the yardstick for telling two fp64 answers apart, never the expected value of a parity test by itself */
+static int g_extended = 0;
+void orc_set_extended(int on) { g_extended = on; }
+
+/* run length of each feature in feature[] (mapPhoto, Imp.cpp:2134-2153) and the block pattern of S (upper): pose pairs
+ * sharing a feature + U pattern.  The reference sets a dense m x m byte mask (Imp.cpp:2131-2205) and scans it into a CRS
+ * index (sba_crsm, Imp.cpp:2190-2205); the same set is built here row by row from a pose->entries index. */
+static void schur_pattern(const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
+                          int** mapPhoto_o, int** rowptr_o, int** colidx_o)
 {
 	int *mapPhoto, *rowptr, *colidx, *pcnt, *pptr, *plist, *mark, *fstart;
-	int i, j, k, ii, jj, l, pos, nuis, p;
-	double *S, *E, *IV, WV[18], sum;
-
-	/* run length of each feature in feature[] (mapPhoto, Imp.cpp:2134-2153) */
+	int i, j, k, nuis, p;
 	mapPhoto = xcalloc(n, sizeof(int));
 	fstart = xmalloc((n + 1) * sizeof(int));
 	{
@@ -1300,8 +1304,6 @@ void orc_schur(const double* eb, const double* ea, const double* U, const double
 		fstart[0] = 0;
 		for (i = 0; i < n; i++) fstart[i + 1] = fstart[i] + mapPhoto[i];
 	}
-	/* block pattern of S (upper): pose pairs sharing a feature + U pattern.  The reference sets a dense m x m
-	 * byte mask (Imp.cpp:2131-2205); the same set is built here row by row from a pose->entries index. */
 	pcnt = xcalloc(m + 1, sizeof(int));
 	for (i = 0; i < nW; i++) pcnt[photo[i] + 1]++;
 	pptr = xmalloc((m + 1) * sizeof(int));
@@ -1357,103 +1359,73 @@ void orc_schur(const double* eb, const double* ea, const double* U, const double
 		rowptr[m] = nuis;
 		free(ucnt); free(uptr); free(ulist); free(tmpcols); free(mark);
 	}
-	free(pcnt); free(pptr); free(plist);
+	free(pcnt); free(pptr); free(plist); free(fstart);
+	*mapPhoto_o = mapPhoto; *rowptr_o = rowptr; *colidx_o = colidx;
+}
 
-	S = xcalloc((size_t)nuis * 36, sizeof(double));
+void orc_schur(const double* eb, const double* ea, const double* U, const double* W, const double* V,
+               const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
+               int accumulate_u, int** rowptr_o, int** colidx_o, double** S_o, double** E_o, double** IV_o)
+{
+	int *mapPhoto, *rowptr, *colidx;
+	double *S, *E, *IV;
+	schur_pattern(Ui, Uj, photo, feature, m, n, nU, nW, &mapPhoto, &rowptr, &colidx);
+	S = xcalloc((size_t)rowptr[m] * 36, sizeof(double));
 	E = xmalloc((size_t)6 * m * sizeof(double));
 	IV = xmalloc((size_t)9 * n * sizeof(double));
-	inverse_v(V, IV, n);
-	/* copy U into S, Imp.cpp:2214-2238 (Stereo '=') / 6854-6878 (Mono '+='); diagonal blocks: upper triangle only */
-	for (i = 0; i < nU; i++)
-	{
-		int a = Ui[i], b = Uj[i];
-		int pos1 = crs_find(rowptr, colidx, a, b);
-		double* ptr2 = S + (size_t)pos1 * 36;
-		const double* ptr1 = U + (size_t)i * 36;
-		if (pos1 < 0) { fprintf(stderr, "oracle: U block (%d,%d) not upper-ordered\n", a, b); exit(1); }
-		for (ii = 0; ii < 6; ii++)
-			for (jj = (a == b ? ii : 0); jj < 6; jj++)
-			{
-				if (accumulate_u) ptr2[ii * 6 + jj] += ptr1[ii * 6 + jj]; else ptr2[ii * 6 + jj] = ptr1[ii * 6 + jj];
-			}
-	}
-	for (i = 0; i < 6 * m; i++) E[i] = ea[i];
-	/* S -= W V^-1 W^T, E -= W V^-1 eb: Imp.cpp:2244-2332 */
-	pos = 0;
-	for (i = 0; i < n; i++)
-	{
-		int numfea = mapPhoto[i];
-		for (j = 0; j < numfea; j++)
-		{
-			int nF1 = feature[pos + j], nP1 = photo[pos + j];
-			const double* ptr1 = W + (size_t)(pos + j) * 18;
-			const double* ptr2 = IV + (size_t)nF1 * 9;
-			double* ptrE = E + nP1 * 6;
-			for (ii = 0; ii < 6; ii++)
-				for (jj = 0; jj < 3; jj++)
-				{
-					for (k = 0, sum = 0.0; k < 3; k++) sum += ptr1[ii * 3 + k] * ptr2[jj * 3 + k]; /* Imp.cpp:2269-2271 */
-					WV[ii * 3 + jj] = sum;
-				}
-			for (k = 0; k < numfea; k++)
-			{
-				int nP2 = photo[pos + k];
-				const double* ptr3 = W + (size_t)(pos + k) * 18;
-				if (nP1 <= nP2)
-				{
-					int pos1 = crs_find(rowptr, colidx, nP1, nP2);
-					double* ptrS = S + (size_t)pos1 * 36;
-					for (ii = 0; ii < 6; ii++)
-						for (jj = (nP1 == nP2 ? ii : 0); jj < 6; jj++)
-						{
-							for (l = 0, sum = 0.0; l < 3; l++) sum += WV[ii * 3 + l] * ptr3[jj * 3 + l];
-							ptrS[ii * 6 + jj] -= sum;
-						}
-				}
-			}
-			{
-				const double* ptr5 = eb + nF1 * 3;
-				for (ii = 0; ii < 6; ii++)
-				{
-					for (jj = 0, sum = 0.0; jj < 3; jj++) sum += WV[ii * 3 + jj] * ptr5[jj];
-					ptrE[ii] -= sum;
-				}
-			}
-		}
-		pos += numfea;
-	}
-	free(mapPhoto); free(fstart);
+	schur_values_d(eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, accumulate_u, mapPhoto, rowptr, colidx, S, E, IV);
+	free(mapPhoto);
 	*rowptr_o = rowptr; *colidx_o = colidx; *S_o = S; *E_o = E; *IV_o = IV;
 }
 
-/* Imp.cpp:2980-3020 */
-static void solve_features(const double* W, const double* IV, const double* eb, const double* dpa, double* dpb,
-                           int n, const int* photo, const int* feature, int nW)
+/* pba_solveFeatures (Imp.cpp:2980-3020) on its own: dpb[3n] from given pose values dpa[6m] and V^-1 */
+void orc_solve_features(const double* W, const double* IV, const double* eb, const double* dpa, double* dpb, int n,
+                        const int* photo, const int* feature, int nW)
 {
-	int i, pos = 0, ii, jj;
-	for (i = 0; i < n; i++)
-	{
-		double eb2[3] = { 0, 0, 0 };
-		const double* ptr2 = IV + (size_t)i * 9;
-		while (pos < nW && feature[pos] == i)
+	solve_features_d(W, IV, eb, dpa, dpb, n, photo, feature, nW);
+}
+
+/* the scalar CSC (upper, stype = 1) the reference hands to CHOLMOD for this system, values in double: what
+ * pba_constructCSSLM / pba_constructCSSGN (Imp.cpp:2451-2498 / 7123-7200) write into m_sparseS from S.  skipblk /
+ * skipfix < 0: Stereo.  Arrays malloc'ed; returns the dimension. */
+int orc_schur_csc(const double* S, const int* rowptr, const int* colidx, int m, int skipblk, int skipfix, int** Sp_o, int** Si_o,
+                  double** Sx_o)
+{
+	const int nuis = rowptr[m];
+	int *cptr = xcalloc(m + 2, sizeof(int)), *crow = xmalloc((nuis + 1) * sizeof(int)), *cpos = xmalloc((nuis + 1) * sizeof(int));
+	int *fill = xcalloc(m + 1, sizeof(int)), *newidx = xmalloc(6 * m * sizeof(int));
+	int *Sp, *Si, i, k, ii, jj, jjj, ns = 0, nz = 0;
+	double* Sx;
+	for (i = 0; i < nuis; i++) cptr[colidx[i] + 1]++;
+	for (i = 0; i < m; i++) cptr[i + 1] += cptr[i];
+	for (i = 0; i < m; i++)
+		for (k = rowptr[i]; k < rowptr[i + 1]; k++)
 		{
-			const double* ptr3 = W + (size_t)pos * 18;
-			const double* ptr4 = dpa + photo[pos] * 6;
-			for (ii = 0; ii < 3; ii++)
+			int c = colidx[k];
+			crow[cptr[c] + fill[c]] = i; cpos[cptr[c] + fill[c]] = k; fill[c]++;
+		}
+	for (i = 0; i < 6 * m; i++) newidx[i] = ((skipblk >= 0 && i / 6 == skipblk) || i == skipfix) ? -1 : ns++;
+	Sp = xmalloc((ns + 1) * sizeof(int)); Si = xmalloc(((size_t)nuis * 36 + 1) * sizeof(int)); Sx = xmalloc(((size_t)nuis * 36 + 1) * sizeof(double));
+	for (ii = 0; ii < m; ii++)
+		for (k = 0; k < 6; k++)
+		{
+			if (newidx[ii * 6 + k] < 0) continue;
+			Sp[newidx[ii * 6 + k]] = nz;
+			for (i = cptr[ii]; i < cptr[ii + 1]; i++)
 			{
-				double sum = 0;
-				for (jj = 0; jj < 6; jj++) sum += ptr3[jj * 3 + ii] * ptr4[jj];
-				eb2[ii] += sum;
+				const double* ptr5 = S + (size_t)cpos[i] * 36;
+				jj = crow[i];
+				for (jjj = 0; jjj < (ii == jj ? k + 1 : 6); jjj++)
+				{
+					if (newidx[jj * 6 + jjj] < 0) continue;
+					Si[nz] = newidx[jj * 6 + jjj]; Sx[nz] = ptr5[jjj * 6 + k]; nz++;
+				}
 			}
-			pos++;
 		}
-		for (ii = 0; ii < 3; ii++)
-		{
-			double sum = 0;
-			for (jj = 0; jj < 3; jj++) sum += ptr2[ii * 3 + jj] * (eb[i * 3 + jj] - eb2[jj]);
-			dpb[i * 3 + ii] = sum;
-		}
-	}
+	Sp[ns] = nz;
+	free(cptr); free(crow); free(cpos); free(fill); free(newidx);
+	*Sp_o = Sp; *Si_o = Si; *Sx_o = Sx;
+	return ns;
 }
 
 /* shared by Stereo (skipblk=-1, skipfix=-1) and Mono (the 6 scalars of block skipblk and scalar skipfix are
@@ -1462,12 +1434,11 @@ static int solve_common(double* stVal, const double* eb, const double* ea, const
                         const double* V, const int* Ui, const int* Uj, const int* photo, const int* feature,
                         int m, int n, int nU, int nW, int accumulate_u, int skipblk, int skipfix, long* stats)
 {
-	int *rowptr, *colidx, *cptr, *crow, *cpos, *newidx, *Sp, *Si, *bperm, *sperm, *bAp, *bAi;
-	double *S, *E, *IV, *Sx, *rhs, *sol;
-	int i, k, ii, jj, jjj, nuis, ns, nz, rc, nb;
+	int *mapPhoto, *rowptr, *colidx, *cptr, *crow, *cpos, *newidx, *bperm, *sperm, *bAp, *bAi;
+	int i, k, jj, nuis, ns, rc, nb;
 	long lnz = 0;
 
-	orc_schur(eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, accumulate_u, &rowptr, &colidx, &S, &E, &IV);
+	schur_pattern(Ui, Uj, photo, feature, m, n, nU, nW, &mapPhoto, &rowptr, &colidx);
 	nuis = rowptr[m];
 	/* column access to the upper block pattern */
 	cptr = xcalloc(m + 2, sizeof(int));
@@ -1492,30 +1463,6 @@ static int solve_common(double* stVal, const double* eb, const double* ea, const
 	{
 		if ((skipblk >= 0 && i / 6 == skipblk) || i == skipfix) newidx[i] = -1; else newidx[i] = ns++;
 	}
-	/* CSC upper (stype=1) as handed to CHOLMOD: pba_constructCSSLM / GN, Imp.cpp:2451-2498 / 7123-7200 */
-	Sp = xmalloc((ns + 1) * sizeof(int));
-	Si = xmalloc(((size_t)nuis * 36 + 1) * sizeof(int));
-	Sx = xmalloc(((size_t)nuis * 36 + 1) * sizeof(double));
-	nz = 0;
-	for (ii = 0; ii < m; ii++)
-		for (k = 0; k < 6; k++)
-		{
-			if (newidx[ii * 6 + k] < 0) continue;
-			Sp[newidx[ii * 6 + k]] = nz;
-			for (i = cptr[ii]; i < cptr[ii + 1]; i++)
-			{
-				const double* ptr5 = S + (size_t)cpos[i] * 36;
-				jj = crow[i];
-				for (jjj = 0; jjj < (ii == jj ? k + 1 : 6); jjj++)
-				{
-					if (newidx[jj * 6 + jjj] < 0) continue;
-					Si[nz] = newidx[jj * 6 + jjj];
-					Sx[nz] = ptr5[jjj * 6 + k];
-					nz++;
-				}
-			}
-		}
-	Sp[ns] = nz;
 	/* ordering: block minimum degree (reference: CHOLMOD block AMD for Stereo, scalar AMD for Mono) */
 	nb = m;
 	bAp = xmalloc((nb + 1) * sizeof(int));
@@ -1529,15 +1476,15 @@ static int solve_common(double* stVal, const double* eb, const double* ea, const
 	for (i = 0; i < nb; i++)
 		for (jj = 0; jj < 6; jj++)
 			if (newidx[bperm[i] * 6 + jj] >= 0) sperm[k++] = newidx[bperm[i] * 6 + jj];
-	rhs = xmalloc((ns + 1) * sizeof(double));
-	sol = xmalloc((ns + 1) * sizeof(double));
-	for (i = 0; i < 6 * m; i++) if (newidx[i] >= 0) rhs[newidx[i]] = E[i];
-	rc = orc_chol_solve(ns, Sp, Si, Sx, sperm, rhs, sol, &lnz);
-	for (i = 0; i < 6 * m; i++) stVal[i] = newidx[i] >= 0 ? sol[newidx[i]] : 0.0; /* Imp.cpp:7010-7021 */
-	solve_features(W, IV, eb, stVal, stVal + 6 * m, n, photo, feature, nW);
+	if (g_extended)
+		rc = solve_system_x(stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, accumulate_u, mapPhoto, rowptr, colidx, cptr, crow,
+		                    cpos, newidx, ns, sperm, &lnz);
+	else
+		rc = solve_system_d(stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, accumulate_u, mapPhoto, rowptr, colidx, cptr, crow,
+		                    cpos, newidx, ns, sperm, &lnz);
 	if (stats) { stats[0] = nuis; stats[1] = lnz; }
-	free(rowptr); free(colidx); free(S); free(E); free(IV); free(cptr); free(crow); free(cpos); free(newidx);
-	free(Sp); free(Si); free(Sx); free(bAp); free(bAi); free(bperm); free(sperm); free(rhs); free(sol);
+	free(mapPhoto); free(rowptr); free(colidx); free(cptr); free(crow); free(cpos); free(newidx);
+	free(bAp); free(bAi); free(bperm); free(sperm);
 	return rc;
 }
 

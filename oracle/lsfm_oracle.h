@@ -74,6 +74,21 @@ void orc_schur(const double* eb, const double* ea, const double* U, const double
                const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
                int accumulate_u, int** rowptr, int** colidx, double** Sval, double** E, double** Vinv);
 
+/* pba_solveFeatures (Imp.cpp:2980-3020) on its own: dpb[3n] from given pose values dpa[6m] and V^-1 (IV) */
+void orc_solve_features(const double* W, const double* IV, const double* eb, const double* dpa, double* dpb, int n,
+                        const int* photo, const int* feature, int nW);
+
+/* the scalar CSC (upper, stype = 1) the reference hands to CHOLMOD, values in double: what pba_constructCSSLM / GN
+ * (Imp.cpp:2451-2498 / 7123-7200) write from S.  skipblk / skipfix < 0: Stereo; Mono: block `Ref` and scalar `Fix` are
+ * left out and the rest renumbered.  Arrays malloc'ed; returns the dimension. */
+int orc_schur_csc(const double* S, const int* rowptr, const int* colidx, int m, int skipblk, int skipfix, int** Sp, int** Si,
+                  double** Sx);
+
+/* on = 1: every Schur complement, LL^T and back-substitution of the calls below runs in long double (64-bit mantissa:
+ * oracle/lsfm_solve_num.inc, lsfm_chol_num.inc -- the same statements compiled for a second type), inputs and outputs
+ * stay fp64.  Yardstick only: it says which of two fp64 answers is nearer the exact solution of the assembled system. */
+void orc_set_extended(int on);
+
 /* full joins: transform is NOT included.  End and Cur are consumed (freed), joint is produced. */
 int orc_join_stereo(orc_map* End, orc_map* Cur, orc_map* joint);
 int orc_join_mono(orc_map* End, orc_map* Cur, orc_map* joint);
@@ -93,6 +108,8 @@ int orc_save_poses(const char* pose_path, const char* feat_path, const int* stno
  * block_perm (length nb) may be NULL.  Returns 0 or the failing column+1. */
 int orc_chol_solve(int n, const int* Ap, const int* Ai, const double* Ax, const int* perm, const double* b,
                    double* x, long* lnz_out);
+int orc_chol_solve_x(int n, const int* Ap, const int* Ai, const long double* Ax, const int* perm, const long double* b,
+                     long double* x, long* lnz_out);
 /* minimum-degree ordering on a symmetric block pattern given as upper CSC (Ap[nb+1], Ai) */
 void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm);
 

@@ -57,6 +57,10 @@ def lib():
         L.orc_divide_conquer_omp.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), C.c_int, dp]
         L.orc_set_match_hash.argtypes = [C.c_int]
         L.orc_set_final_reanchor.argtypes = [C.c_int]
+        L.orc_set_extended.argtypes = [C.c_int]
+        L.orc_schur_csc.argtypes = [dp, ip, ip, C.c_int, C.c_int, C.c_int, P(ip), P(ip), P(dp)]
+        L.orc_schur_csc.restype = C.c_int
+        L.orc_solve_features.argtypes = [dp, dp, dp, dp, dp, C.c_int, ip, ip, C.c_int]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _LIB = L
@@ -170,9 +174,11 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def solve(j, eP, eF, mono, sa=None):
-    """Schur + direct solve + back-substitution on assembled joint arrays; returns (stVal, rc, stats)."""
+def solve(j, eP, eF, mono, sa=None, extended=False):
+    """Schur + direct solve + back-substitution on assembled joint arrays; returns (stVal, rc, stats).
+    extended: the same statements in long double (orc_set_extended), result rounded to fp64."""
     L = lib()
+    L.orc_set_extended(int(extended))
     m, n = int(j["m"]), int(j["n"])
     st = np.zeros(6 * m + 3 * n)
     U = np.ascontiguousarray(j["U"], np.float64); W = np.ascontiguousarray(j["W"], np.float64)
@@ -215,10 +221,41 @@ def schur(j, eP, eF, accumulate_u):
     return out
 
 
-def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True, threads=0):
-    """Full hierarchical join of a list of map dicts; returns (final map dict, timing[4], rc).
-    threads > 0: the independent joins of a level on that many host threads (same result, timing[0] only)."""
+def solve_features(j, IV, eF, dpa):
+    """pba_solveFeatures alone: feature values from given pose values (Imp.cpp:2980-3020)."""
     L = lib()
+    n = int(j["n"])
+    W = np.ascontiguousarray(j["W"], np.float64); IV = np.ascontiguousarray(IV, np.float64)
+    eF = np.ascontiguousarray(eF, np.float64); dpa = np.ascontiguousarray(dpa, np.float64)
+    ph = np.ascontiguousarray(j["photo"], np.int32); fe = np.ascontiguousarray(j["feature"], np.int32)
+    dpb = np.zeros(3 * n)
+    d, i = C.c_double, C.c_int
+    L.orc_solve_features(_p(W, d), _p(IV, d), _p(eF, d), _p(dpa, d), _p(dpb, d), n, _p(ph, i), _p(fe, i), len(ph))
+    return dpb
+
+
+def schur_csc(S, rowptr, colidx, m, skipblk=-1, skipfix=-1):
+    """Scalar CSC (upper) of a block-CRS S as handed to CHOLMOD (pba_constructCSSLM / GN): (Sp, Si, Sx)."""
+    L = lib()
+    S = np.ascontiguousarray(S, np.float64); rowptr = np.ascontiguousarray(rowptr, np.int32)
+    colidx = np.ascontiguousarray(colidx, np.int32)
+    d, i = C.c_double, C.c_int
+    Sp, Si, Sx = C.POINTER(i)(), C.POINTER(i)(), C.POINTER(d)()
+    ns = L.orc_schur_csc(_p(S, d), _p(rowptr, i), _p(colidx, i), int(m), int(skipblk), int(skipfix), C.byref(Sp), C.byref(Si),
+                         C.byref(Sx))
+    sp = _arr(Sp, ns + 1, np.int32)
+    out = (sp, _arr(Si, int(sp[ns]), np.int32), _arr(Sx, int(sp[ns]), np.float64))
+    for p in (Sp, Si, Sx):
+        L.free(p)
+    return out
+
+
+def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True, threads=0, extended=False):
+    """Full hierarchical join of a list of map dicts; returns (final map dict, timing[4], rc).
+    threads > 0: the independent joins of a level on that many host threads (same result, timing[0] only).
+    extended: every solve of the tree in long double (transform and assembly stay fp64: they are pinned to the reference)."""
+    L = lib()
+    L.orc_set_extended(int(extended))
     L.orc_set_match_hash(int(match_hash))
     L.orc_set_final_reanchor(int(final_reanchor))
     N = len(dicts)

@@ -14,10 +14,23 @@
 // symbols left undefined and they are never called (the CLinearSFMImp constructor, which calls
 // cholmod_start, is bypassed by running methods on zeroed raw storage).
 //
+// From the solve stage (Imp.cpp:2119-2378 / 6756-7041) the pieces that do not touch CHOLMOD are public methods and are
+// run for real by the "parts" mode on arrays handed over in a file:
+//     pba_inverseV                          Imp.cpp:3022   V^-1 (Eigen 3x3 inverse, symmetrised write-back)
+//     pba_solveFeatures                     Imp.cpp:2980   back-substitution of the features for given pose values
+//     pba_constructAuxCSS{LM,GN}            Imp.cpp:2529 / 7248   block pattern handed to cholmod_amd
+//     pba_constructCSS{LM,GN}               Imp.cpp:2451 / 7123   scalar CSC (upper) handed to cholmod_factorize; they walk
+//                                           the S blocks through sba_crsm_elmidx (Imp.cpp:55-76, static, reached that way)
+// pba_constructCSS* write through m_sparseS->x: the harness points m_sparseS at a cholmod_sparse STRUCT (vendored header
+// type) whose x is a plain buffer -- no CHOLMOD function is called or replaced.  The Schur loop itself is inline in
+// lmj_solveLinearSFM* between allocations and cholmod_start and cannot be called on its own.
+//
 // Usage:
 //   ref_dump pair  Stereo|Monocular  A.txt B.txt out.bin     transform A to B's frame, assemble join
 //   ref_dump trans Stereo A.txt Ref out.bin
 //   ref_dump trans Monocular A.txt Ref ScaP Fix out.bin
+//   ref_dump parts Stereo|Monocular  in.bin out.bin          in.bin (same tagged format): m n nW V W photo mapPhoto ea eb
+//                                                            dpa rowptr colidx S [Ref ScaP Fix]
 // Output: tagged binary ("name dtype count\n" + raw little-endian payload), read by tests/refdump.py.
 #define private public
 #include "LinearSFMImp.h"
@@ -77,6 +90,90 @@ void CLinearSFMImp::lmj_solveLinearSFMMono(double* stVal, double* eb, double* ea
 	put_d("solve.W", W, 18L * nW); put_i("solve.photo", photo, nW); put_i("solve.feature", feature, nW);
 	put_d("solve.V", V, 9L * n);
 	for (int i = 0; i < 6 * m + 3 * n; i++) stVal[i] = 0.0;
+}
+
+// ---- reader of the tagged binary (the format put_d / put_i write) ------------------------------------------
+struct Blob { char name[128]; char dt[8]; long n; void* p; };
+static int read_blobs(const char* path, Blob* b, int cap)
+{
+	FILE* f = fopen(path, "rb");
+	if (!f) { perror(path); exit(1); }
+	int k = 0;
+	char line[256];
+	while (k < cap && fgets(line, sizeof line, f))
+	{
+		if (sscanf(line, "%127s %7s %ld", b[k].name, b[k].dt, &b[k].n) != 3) break;
+		size_t sz = (b[k].dt[0] == 'f' ? 8 : 4) * (size_t)b[k].n;
+		b[k].p = malloc(sz ? sz : 1);
+		if (sz && fread(b[k].p, 1, sz, f) != sz) { fprintf(stderr, "short read in %s\n", path); exit(1); }
+		k++;
+	}
+	fclose(f);
+	return k;
+}
+static Blob* find_blob(Blob* b, int n, const char* name)
+{
+	for (int i = 0; i < n; i++) if (strcmp(b[i].name, name) == 0) return &b[i];
+	fprintf(stderr, "parts: array %s missing\n", name);
+	exit(1);
+	return NULL;
+}
+#define BD(name) ((double*)find_blob(bl, nb, name)->p)
+#define BI(name) ((int*)find_blob(bl, nb, name)->p)
+
+static void run_parts(CLinearSFMImp* imp, bool mono, const char* inp)
+{
+	static Blob bl[64];
+	int nb = read_blobs(inp, bl, 64);
+	const int m = BI("m")[0], n = BI("n")[0], nW = BI("nW")[0];
+	// pba_inverseV works in place (the reference saves / restores V around it, Imp.cpp:2210-2212, 2365)
+	double* IV = (double*)malloc(sizeof(double) * 9 * (n ? n : 1));
+	memcpy(IV, BD("V"), sizeof(double) * 9 * n);
+	imp->pba_inverseV(IV, m, n);
+	put_d("parts.IV", IV, 9L * n);
+	// pba_solveFeatures(W, IV, ea, eb, dpa, dpb, m, n, mapPhoto, photo)
+	double* dpb = (double*)calloc(3 * (n ? n : 1), sizeof(double));
+	imp->pba_solveFeatures(BD("W"), IV, BD("ea"), BD("eb"), BD("dpa"), dpb, m, n, BI("mapPhoto"), BI("photo"));
+	put_d("parts.dpb", dpb, 3L * n);
+	(void)nW;
+	// the mask and the CRS index the reference's solver builds from it (Imp.cpp:2131-2205): here from the given pattern
+	int *rowptr = BI("rowptr"), *colidx = BI("colidx");
+	const int nuis = rowptr[m];
+	char* smask = (char*)calloc((size_t)m * m, 1);
+	for (int i = 0; i < m; i++) for (int k = rowptr[i]; k < rowptr[i + 1]; k++) smask[(size_t)i * m + colidx[k]] = 1;
+	sba_crsm Sidxij;
+	Sidxij.nr = Sidxij.nc = m; Sidxij.nnz = nuis;
+	Sidxij.val = (int*)malloc(sizeof(int) * (nuis ? nuis : 1));
+	for (int k = 0; k < nuis; k++) Sidxij.val[k] = k;
+	Sidxij.colidx = colidx; Sidxij.rowptr = rowptr;
+	int* Ap = (int*)calloc(m + 2, sizeof(int));
+	int* Aii = (int*)calloc(nuis + 1, sizeof(int));
+	const int dim = mono ? 6 * m - 7 : 6 * m;
+	int* Sp = (int*)calloc(6 * m + 2, sizeof(int));
+	int* Si = (int*)calloc((size_t)nuis * 36 + 1, sizeof(int));
+	double* Sx = (double*)calloc((size_t)nuis * 36 + 1, sizeof(double));
+	cholmod_sparse sp; // the vendored struct only; its x is where pba_constructCSS* write the values
+	memset(&sp, 0, sizeof sp);
+	sp.x = Sx; sp.p = Sp; sp.i = Si;
+	imp->m_sparseS = &sp;
+	if (!mono)
+	{
+		imp->pba_constructAuxCSSLM(Ap, Aii, m, smask);
+		imp->pba_constructCSSLM(Si, Sp, NULL, BD("S"), Sidxij, false, m, smask);
+		put_i("parts.Ap", Ap, m + 1);
+		put_i("parts.Aii", Aii, Ap[m]);
+	}
+	else
+	{
+		const int Ref = BI("Ref")[0], ScaP = BI("ScaP")[0], Fix = BI("Fix")[0];
+		imp->pba_constructAuxCSSGN(Ap, Aii, m, smask, Ref);
+		imp->pba_constructCSSGN(Si, Sp, NULL, BD("S"), Sidxij, false, m, smask, Ref, ScaP, Fix);
+		put_i("parts.Ap", Ap, m);
+		put_i("parts.Aii", Aii, Ap[m - 1]);
+	}
+	put_i("parts.Sp", Sp, dim + 1);
+	put_i("parts.Si", Si, Sp[dim]);
+	put_d("parts.Sx", Sx, Sp[dim]);
 }
 
 int main(int argc, char** argv)
@@ -150,6 +247,7 @@ int main(int argc, char** argv)
 			put_i("joint.FBlock", imp->m_GMap.FBlock, imp->m_GMap.n);
 		}
 	}
+	else if (strcmp(argv[1], "parts") == 0) run_parts(imp, mono, argv[3]);
 	else { fprintf(stderr, "unknown mode %s\n", argv[1]); return 2; }
 	fclose(g_out);
 	return 0;

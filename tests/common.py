@@ -94,19 +94,73 @@ def feat_param_err(stA, stB, stno):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 
 
-def oracle_noise_floor(oracle, dicts, mono, ref_stval, stno):
-    """How far two valid fp64 evaluations of the reference path differ on this input: the oracle re-run with its
-    Cholesky forced to a different (equally valid) elimination order (ORC_ORDER, oracle/lsfm_chol.c).  On long chains
-    the camera systems are so ill-conditioned that this floor, not the implementation, limits any parity number."""
-    import os
-    old = os.environ.get("ORC_ORDER")
-    os.environ["ORC_ORDER"] = "1"
-    try:
-        alt, _, rc = oracle.divide_conquer(dicts, mono)
-    finally:
-        if old is None:
-            os.environ.pop("ORC_ORDER")
-        else:
-            os.environ["ORC_ORDER"] = old
-    assert rc == 0
-    return max(pose_param_err(alt["stVal"], ref_stval, stno), feat_param_err(alt["stVal"], ref_stval, stno))
+def golden_system(z, j):
+    """The system the REAL reference assembled for join j of a golden file and handed to lmj_solveLinearSFM* (captured by
+    oracle/ref_harness.cpp): joint arrays, right-hand sides, Mono call-site arguments."""
+    J = dict(m=int(z[f"join{j}.solve.m"][0]), n=int(z[f"join{j}.solve.n"][0]), U=z[f"join{j}.solve.U"].reshape(-1, 36),
+             W=z[f"join{j}.solve.W"].reshape(-1, 18), V=z[f"join{j}.solve.V"].reshape(-1, 9), Ui=z[f"join{j}.solve.Ui"],
+             Uj=z[f"join{j}.solve.Uj"], photo=z[f"join{j}.solve.photo"], feature=z[f"join{j}.solve.feature"])
+    mono = str(z["type"]) == "Monocular"
+    sa = [int(z[f"join{j}.solve.{k}"][0]) for k in ("Ref", "ScaP", "Fix", "Sign", "FixBlk")] if mono else None
+    return J, z[f"join{j}.solve.ea"], z[f"join{j}.solve.eb"], mono, sa
+
+
+def _inv3_longdouble(M):
+    """[n,3,3] long double inverse by the adjugate"""
+    a = M.astype(np.longdouble)
+    c = np.empty_like(a)
+    c[:, 0, 0] = a[:, 1, 1] * a[:, 2, 2] - a[:, 1, 2] * a[:, 2, 1]
+    c[:, 0, 1] = a[:, 0, 2] * a[:, 2, 1] - a[:, 0, 1] * a[:, 2, 2]
+    c[:, 0, 2] = a[:, 0, 1] * a[:, 1, 2] - a[:, 0, 2] * a[:, 1, 1]
+    c[:, 1, 0] = a[:, 1, 2] * a[:, 2, 0] - a[:, 1, 0] * a[:, 2, 2]
+    c[:, 1, 1] = a[:, 0, 0] * a[:, 2, 2] - a[:, 0, 2] * a[:, 2, 0]
+    c[:, 1, 2] = a[:, 0, 2] * a[:, 1, 0] - a[:, 0, 0] * a[:, 1, 2]
+    c[:, 2, 0] = a[:, 1, 0] * a[:, 2, 1] - a[:, 1, 1] * a[:, 2, 0]
+    c[:, 2, 1] = a[:, 0, 1] * a[:, 2, 0] - a[:, 0, 0] * a[:, 2, 1]
+    c[:, 2, 2] = a[:, 0, 0] * a[:, 1, 1] - a[:, 0, 1] * a[:, 1, 0]
+    det = a[:, 0, 0] * c[:, 0, 0] + a[:, 0, 1] * c[:, 1, 0] + a[:, 0, 2] * c[:, 2, 0]
+    return c / det[:, None, None]
+
+
+def dense_reference_solve(J, ea, eb, mono, sa=None, IV=None):
+    """Expected value of lmj_solveLinearSFM{Stereo,Mono} that owes nothing to the oracle's or the library's solver: the FULL
+    normal equations [[U, W], [W^T, V]] x = [ea; eb] of the assembled system (no Schur complement, no sparse factorisation),
+    solved densely by LAPACK (LU) and refined with residuals in extended precision until the correction is below 1e-17
+    relative -- i.e. the exact solution rounded to fp64.  Mono: the 6 scalars of the reference pose (block sa[0]) and scalar
+    sa[2] (Fix) are removed, their solution is 0 and finally x[Fix] = Sign (Imp.cpp:6981-7026).
+    IV (optional, [n,9]): the output of the reference's own pba_inverseV for this V (fixture `parts.IV`).  The reference
+    eliminates the features with that matrix -- the computed 3x3 inverse, symmetrised from its upper triangle
+    (Imp.cpp:3027-3040) -- as if it were V^-1 exactly; with IV given the feature blocks of the dense system are IV^-1 (in
+    extended precision), so that the expected value is the exact solution of the very system the reference's algebra
+    solves (the two differ by cond(V) * 1e-16, which the camera system of a monocular join amplifies to ~1e-11).
+    Returns the state vector in the reference's layout (6m pose scalars, 3n feature scalars)."""
+    import scipy.linalg as sl
+    from refdump import dense_info
+    m, n = int(J["m"]), int(J["n"])
+    A = dense_info(J)
+    A = np.triu(A) + np.triu(A, 1).T  # the reference reads the upper triangle of a diagonal block only (Imp.cpp:2224-2229)
+    b = np.concatenate([np.asarray(ea, np.float64), np.asarray(eb, np.float64)])
+    keep = np.ones(6 * m + 3 * n, bool)
+    if mono:
+        keep[6 * sa[0]:6 * sa[0] + 6] = False
+        keep[sa[2]] = False
+    Al = A.astype(np.longdouble)
+    if IV is not None:
+        Ve = _inv3_longdouble(np.asarray(IV).reshape(-1, 3, 3))
+        for f in range(n):
+            Al[6 * m + 3 * f:6 * m + 3 * f + 3, 6 * m + 3 * f:6 * m + 3 * f + 3] = Ve[f]
+    Al, bl = Al[np.ix_(keep, keep)], b[keep].astype(np.longdouble)
+    lu = sl.lu_factor(np.asarray(Al, np.float64))
+    x = sl.lu_solve(lu, b[keep])
+    xl = x.astype(np.longdouble)
+    for _ in range(8):
+        r = bl - Al @ xl
+        dx = sl.lu_solve(lu, np.asarray(r, np.float64))
+        xl = xl + dx.astype(np.longdouble)
+        if np.max(np.abs(dx)) <= 1e-17 * np.max(np.abs(x)):
+            break
+    out = np.zeros(6 * m + 3 * n)
+    out[keep] = np.asarray(xl, np.float64)
+    if mono:
+        out[sa[2]] = sa[3]
+    return out

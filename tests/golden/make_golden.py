@@ -15,6 +15,14 @@ and for every re-anchoring transform (LinearSFMImp.cpp:1997-2025, 2039-2063) the
 output.  The solve itself (Schur + CHOLMOD) cannot be run from the reference here (CHOLMOD absent, no stand-in),
 so the state that flows to the next tree level is the ORACLE's solution (oracle/lsfm_oracle.c); the fixture also
 stores that state ("sol") so that other implementations can be compared with the oracle on identical inputs.
+What pins the solve stage instead:
+    dense_sol       the exact solution (rounded to fp64) of the FULL reference-assembled normal equations, by dense LAPACK
+                    LU + extended-precision refinement (tests/common.py dense_reference_solve): no Schur complement, no
+                    sparse factorisation, nothing of the oracle
+    parts.*         outputs of the REAL reference's CHOLMOD-free solve-stage methods on this system (ref_dump parts):
+                    pba_inverseV (IV), pba_solveFeatures (dpb for the pose values parts_in.dpa = dense_sol's poses),
+                    pba_constructAuxCSS{LM,GN} (Ap, Aii) and pba_constructCSS{LM,GN} (Sp, Si, Sx) for the block-CRS
+                    Schur matrix parts_in.{rowptr,colidx,S}
 
 Usage:  python tests/golden/make_golden.py        (from the repo root)
 """
@@ -32,6 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from linearsfm_amd import synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 from refdump import read_dump, sub  # noqa: E402
+from common import dense_reference_solve  # noqa: E402
 
 REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
 MAPKEYS = ("Ref", "FRef", "m", "n", "ScaP", "Fix", "Sign", "FScaP", "FFix", "stno", "stVal", "U", "Ui", "Uj", "W",
@@ -42,6 +51,59 @@ def write_map(path, d, mono):
     g = po.dict_to_map(d)
     po.lib().orc_write_map(path.encode(), int(mono), C.byref(g))
     po.lib().orc_map_free(C.byref(g))
+
+
+def write_blobs(path, arrays):
+    """tagged binary in the format ref_dump writes and reads"""
+    with open(path, "wb") as f:
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            assert a.dtype in (np.float64, np.int32), (name, a.dtype)
+            f.write(f"{name} {'f8' if a.dtype == np.float64 else 'i4'} {a.size}\n".encode())
+            f.write(a.tobytes())
+
+
+def solve_stage_pins(typ, mono, J, eP, eF, sa, sr, store, tag, tmp):
+    """dense_sol + the real reference's CHOLMOD-free solve-stage methods on the reference-assembled system; the oracle's
+    restatement of each piece is checked against them on the spot."""
+    m, n = int(J["m"]), int(J["n"])
+    Jr = dict(m=m, n=n, U=sr["U"], W=sr["W"], V=sr["V"], Ui=sr["Ui"], Uj=sr["Uj"], photo=sr["photo"], feature=sr["feature"])
+    rowptr, colidx, S, E, IV = po.schur(Jr, sr["ea"], sr["eb"], 1 if mono else 0)
+    # first pass: pose values for pba_solveFeatures from the plain dense solve; the stored expected value is then computed
+    # with the reference's own V^-1 (parts.IV), see dense_reference_solve
+    dpa = dense_reference_solve(Jr, sr["ea"], sr["eb"], mono, sa)[:6 * m].copy()
+    if mono:
+        dpa[sa[2]] = 0.0  # pba_solveFeatures runs before stVal[Fix] = Sign (Imp.cpp:7024-7026)
+    mapPhoto = np.bincount(np.asarray(sr["feature"]), minlength=n).astype(np.int32)
+    arrays = dict(m=np.array([m], np.int32), n=np.array([n], np.int32), nW=np.array([len(sr["photo"])], np.int32),
+                  V=sr["V"].ravel(), W=sr["W"].ravel(), photo=np.asarray(sr["photo"], np.int32), mapPhoto=mapPhoto,
+                  ea=sr["ea"], eb=sr["eb"], dpa=dpa, rowptr=rowptr, colidx=colidx, S=S.ravel())
+    if mono:
+        arrays.update(Ref=np.array([sa[0]], np.int32), ScaP=np.array([sa[1]], np.int32), Fix=np.array([sa[2]], np.int32))
+    fi, fo = os.path.join(tmp, "parts_in.bin"), os.path.join(tmp, "parts_out.bin")
+    write_blobs(fi, arrays)
+    subprocess.check_call([REF_DUMP, "parts", typ, fi, fo])
+    P = read_dump(fo)
+    for k, v in P.items():
+        store[f"{tag}.{k}"] = v
+    xd = dense_reference_solve(Jr, sr["ea"], sr["eb"], mono, sa, IV=P["parts.IV"])
+    store[f"{tag}.dense_sol"] = xd
+    for k in ("dpa", "rowptr", "colidx", "S"):
+        store[f"{tag}.parts_in.{k}"] = arrays[k]
+    # the oracle's restatements against the real methods
+    worst = check_close(IV, P["parts.IV"], f"{tag}.IV", 1e-13)
+    worst = max(worst, check_close(po.solve_features(Jr, IV, sr["eb"], dpa), P["parts.dpb"], f"{tag}.dpb", 1e-12))
+    Sp, Si, Sx = po.schur_csc(S, rowptr, colidx, m, sa[0] if mono else -1, sa[2] if mono else -1)
+    assert np.array_equal(Sp, P["parts.Sp"]) and np.array_equal(Si, P["parts.Si"]), tag
+    assert np.array_equal(Sx, P["parts.Sx"]), tag  # a copy of S's entries: bit for bit
+    # oracle's sparse solve and its extended-precision twin against the dense expected value
+    st, rc, _ = po.solve(Jr, sr["ea"], sr["eb"], mono, sa)
+    stx, rcx, _ = po.solve(Jr, sr["ea"], sr["eb"], mono, sa, extended=True)
+    assert rc == 0 and rcx == 0
+    e_d = float(np.max(np.abs(st - xd) / np.maximum(1, np.abs(xd))))
+    e_x = float(np.max(np.abs(stx - xd) / np.maximum(1, np.abs(xd))))
+    assert e_d < 1e-10 and e_x < 1e-11, (tag, e_d, e_x)  # the twin inverts V in long double, dense_sol uses the fp64 parts.IV
+    return worst, e_d, e_x
 
 
 def put(store, prefix, d, keys=None):
@@ -71,6 +133,7 @@ def run(typ, maps, out_path, tmp):
     L = 0
     step = 0
     worst = 0.0
+    worst_solve = [0.0, 0.0]
     while count > 1:
         N2 = count % 2
         count = int(count / 2.0 + 0.5)
@@ -106,6 +169,10 @@ def run(typ, maps, out_path, tmp):
                     worst = max(worst, check_close(x, sr[k], f"{tag}.solve.{k}"))
                 if mono:
                     assert sa == [sr["Ref"], sr["ScaP"], sr["Fix"], sr["Sign"], sr["FixBlk"]], (sa, sr)
+                w2, e_d, e_x = solve_stage_pins(typ, mono, J, eP, eF, sa, sr, store, tag, tmp)
+                worst = max(worst, w2)
+                worst_solve[0] = max(worst_solve[0], e_d)
+                worst_solve[1] = max(worst_solve[1], e_x)
                 st, rc, stats = po.solve(J, eP, eF, mono, sa)
                 assert rc == 0
                 J["stVal"] = st
@@ -122,8 +189,8 @@ def run(typ, maps, out_path, tmp):
     put(store, "result", G, MAPKEYS)
     store["njoins"] = np.array(step)
     np.savez_compressed(out_path, **store)
-    print(f"{out_path}: {step} joins, worst oracle-vs-reference rel err {worst:.2e}, "
-          f"{os.path.getsize(out_path) / 1024:.0f} KiB")
+    print(f"{out_path}: {step} joins, worst oracle-vs-reference rel err {worst:.2e}; oracle solve vs dense LAPACK expected value "
+          f"{worst_solve[0]:.2e} (long double twin {worst_solve[1]:.2e}), {os.path.getsize(out_path) / 1024:.0f} KiB")
 
 
 def reanchor(typ, mono, G, store, tag, tmp):

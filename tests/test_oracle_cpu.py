@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import assert_maps_close, get_map, load_golden, ref_map, rel_err
+from common import assert_maps_close, dense_reference_solve, get_map, golden_system, load_golden, ref_map, rel_err
 from linearsfm_amd import synth
 from refdump import dense_info
 
@@ -38,6 +38,74 @@ def test_oracle_transform_and_assembly_vs_reference(oracle, name):
         st, rc, _ = oracle.solve(J, eP, eF, mono, sa)
         assert rc == 0
         assert rel_err(st, z[f"join{j}.sol"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_oracle_solve_stage_vs_reference_methods_and_dense_lapack(oracle, name):
+    """The solve stage, piece by piece, on every system the REAL reference assembled (22 joins, Stereo and Mono):
+    V^-1, back-substitution and the CSC handed to CHOLMOD against the reference's own pba_inverseV / pba_solveFeatures /
+    pba_constructCSS{LM,GN} / pba_constructAuxCSS{LM,GN} (fixture parts.*, run by oracle/_ref/ref_dump); the Schur
+    complement against a dense numpy evaluation of U - W V^-1 W^T; the solution against the dense LAPACK expected value
+    of the full normal equations (dense_sol: no Schur complement, no sparse factorisation)."""
+    z = load_golden(name)
+    for j in range(int(z["njoins"])):
+        J, ea, eb, mono, sa = golden_system(z, j)
+        m, n = J["m"], J["n"]
+        rowptr, colidx, S, E, IV = oracle.schur(J, ea, eb, 1 if mono else 0)
+        # pba_inverseV
+        assert rel_err(IV, z[f"join{j}.parts.IV"]) < 1e-13
+        # pattern: pba_constructAuxCSS* list the upper blocks column by column
+        assert np.array_equal(rowptr, z[f"join{j}.parts_in.rowptr"]) and np.array_equal(colidx, z[f"join{j}.parts_in.colidx"])
+        cols = [[] for _ in range(m)]
+        for p in range(m):
+            for k in range(rowptr[p], rowptr[p + 1]):
+                cols[colidx[k]].append(p)
+        if mono:  # block `Ref` dropped, later blocks renumbered -1 (Imp.cpp:7248-7280)
+            ref = sa[0]
+            cols = [[r - (r > ref) for r in c if r != ref] for q, c in enumerate(cols) if q != ref]
+        Ap = np.cumsum([0] + [len(c) for c in cols]).astype(np.int32)
+        assert np.array_equal(Ap, z[f"join{j}.parts.Ap"])
+        assert np.array_equal(np.concatenate(cols).astype(np.int32), z[f"join{j}.parts.Aii"])
+        # Schur complement, dense and independent: S = U - sum_f W_f IV_f W_f^T on the upper blocks, E = ea - W IV eb
+        A = np.zeros((6 * m, 6 * m)); Ed = np.array(ea, np.float64)
+        U = J["U"].reshape(-1, 6, 6)
+        for k in range(len(J["Ui"])):
+            a, b = int(J["Ui"][k]), int(J["Uj"][k])
+            A[6 * a:6 * a + 6, 6 * b:6 * b + 6] += U[k]
+        W = J["W"].reshape(-1, 6, 3); IVr = z[f"join{j}.parts.IV"].reshape(-1, 3, 3)
+        ph, fe = J["photo"], J["feature"]
+        for x in range(len(ph)):
+            WV = W[x] @ IVr[fe[x]]
+            Ed[6 * ph[x]:6 * ph[x] + 6] -= WV @ eb[3 * fe[x]:3 * fe[x] + 3]
+            for y in np.nonzero(fe == fe[x])[0]:
+                if ph[x] <= ph[y]:
+                    A[6 * ph[x]:6 * ph[x] + 6, 6 * ph[y]:6 * ph[y] + 6] -= WV @ W[y].T
+        scale = np.abs(A).max()
+        for p in range(m):
+            for k in range(rowptr[p], rowptr[p + 1]):
+                q = colidx[k]
+                got, exp = S[k], A[6 * p:6 * p + 6, 6 * q:6 * q + 6]
+                if p == q:
+                    got, exp = np.triu(got), np.triu(exp)  # diagonal blocks: upper triangle only (Imp.cpp:2224-2229, 2307)
+                assert np.abs(got - exp).max() / scale < 1e-13, (j, p, q)
+        assert rel_err(E, Ed) < 1e-12
+        # pba_constructCSSLM / GN: the scalar CSC handed to cholmod_factorize, a copy of S's entries
+        Sp, Si, Sx = oracle.schur_csc(z[f"join{j}.parts_in.S"], rowptr, colidx, m, sa[0] if mono else -1, sa[2] if mono else -1)
+        assert np.array_equal(Sp, z[f"join{j}.parts.Sp"]) and np.array_equal(Si, z[f"join{j}.parts.Si"])
+        assert np.array_equal(Sx, z[f"join{j}.parts.Sx"])
+        # pba_solveFeatures for the pose values the fixture handed to the reference
+        dpb = oracle.solve_features(J, z[f"join{j}.parts.IV"], eb, z[f"join{j}.parts_in.dpa"])
+        assert rel_err(dpb, z[f"join{j}.parts.dpb"]) < 1e-13
+        # the whole solve against the dense LAPACK expected value, recomputed here and as stored
+        xd = z[f"join{j}.dense_sol"]
+        live = dense_reference_solve(J, ea, eb, mono, sa, IV=z[f"join{j}.parts.IV"])
+        assert np.max(np.abs(live - xd) / np.maximum(1, np.abs(xd))) < 1e-14
+        st, rc, _ = oracle.solve(J, ea, eb, mono, sa)
+        assert rc == 0
+        assert np.max(np.abs(st - xd) / np.maximum(1, np.abs(xd))) < 1e-10
+        stx, rc, _ = oracle.solve(J, ea, eb, mono, sa, extended=True)
+        assert rc == 0
+        assert np.max(np.abs(stx - xd) / np.maximum(1, np.abs(xd))) < 1e-11
 
 
 @pytest.mark.parametrize("name", GOLD)

@@ -82,7 +82,7 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out);
 void lsfm_context_destroy(lsfm_context* ctx);
 /* Solver controls.  rel_tol: the refinement of a system stops when ||E - S x|| <= rel_tol * ||E|| (default 1e-12: the
  * residual level of a direct fp64 solve, which is what the reference computes) or when the true residual stops
- * shrinking; at most 50 refinement steps.  max_it_factor: kept for compatibility, unused. */
+ * shrinking; at most 50 refinement steps.  max_it_factor: accepted and ignored (the iteration cap is fixed). */
 int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor);
 const char* lsfm_last_error(lsfm_context* ctx);
 void* lsfm_stream(lsfm_context* ctx); /* hipStream_t the library launches on */
@@ -130,7 +130,11 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
  * Two phases so that a caller (bench) can time the device part with inputs resident in HBM:
  *   lsfm_tree_upload   copies the N maps to the device (PCIe), returns a handle
  *   lsfm_tree_run      runs the whole tree on the device (this is the region the reference times)
- *   lsfm_tree_download copies the final map back;  lsfm_tree_free releases the handle. */
+ *   lsfm_tree_download copies the final map back;  lsfm_tree_free releases the handle.
+ * Lifetime rule: the result of lsfm_tree_run lives in the CONTEXT's arenas, which every other compute call on the same
+ * context (another tree's upload or run, lsfm_transform_*, lsfm_join_*, lsfm_solve_*) reuses.  Download (or export) a
+ * tree before the context does anything else; a download after such a call fails with LSFM_ERR_ARG instead of
+ * returning overwritten memory.  The resident INPUT maps of a tree are its own: a tree can be run again at any time. */
 typedef struct lsfm_tree lsfm_tree;
 int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_tree** out);
 int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* tree, lsfm_stats* stats);
@@ -140,6 +144,21 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* tree, lsfm_stats* stats);
 int lsfm_tree_set_final_reanchor(lsfm_tree* tree, int on);
 int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* tree);
+/* ---- device-resident hand-off of a tree node (multi-GPU sub-tree sharding; no counterpart in the reference, whose
+ * scheduler keeps every node in one process: m_LMsetS[i] = m_GMapS, Imp.cpp:2032) ---------------------------------
+ * A finished tree's final map is PACKED into one contiguous device buffer (a 128-byte header of ints, then the arrays
+ * with map-local indices, each 256-byte aligned) that the caller owns and may move to another GPU by any means that
+ * moves device bytes (RCCL send/recv, hipMemcpyPeer).  lsfm_tree_upload_dev builds the resident inputs of a new tree
+ * from N such buffers on this context's device -- no host copy of the arrays, only the N headers are read back.
+ *   lsfm_tree_export_size  bytes lsfm_tree_export_dev will write (0: tree not run / overwritten)
+ *   lsfm_tree_export_dev   dst: device memory of >= cap bytes, accessible from the context's device
+ *   lsfm_packed_size       total bytes of a packed map, from the first 128 bytes of it copied to the host (0: not a pack)
+ *   lsfm_tree_upload_dev   packed[k]: device pointer of packed map k (pose origins travel inside the pack) */
+size_t lsfm_tree_export_size(lsfm_context* ctx, lsfm_tree* tree);
+int lsfm_tree_export_dev(lsfm_context* ctx, lsfm_tree* tree, void* dst, size_t cap);
+size_t lsfm_packed_size(const void* host_header128);
+int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, int mono, lsfm_tree** out);
+
 /* convenience: upload + run + download */
 int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_map* out, lsfm_stats* stats);
 

@@ -107,6 +107,97 @@ void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, boo
 	batch_set_offsets(ctx, ar, o);
 }
 
+// ---- packed maps: the hand-off of a tree node between GPUs ---------------------------------------------------------
+size_t pack_layout(PackHeader& h)
+{
+	const size_t m = h.m, n = h.n, nU = h.nU, nW = h.nW;
+	const size_t bytes[12] = { m * 48, n * 24, nU * 288, nW * 144, n * 72, m * 4, m * 4, n * 4, nU * 4, nU * 4, nW * 4, (n + 1) * 4 };
+	size_t o = sizeof(PackHeader);
+	for (int i = 0; i < 12; i++) { h.off[i] = o; o = (o + bytes[i] + 255) & ~(size_t)255; }
+	h.total = o;
+	return o;
+}
+
+__global__ void k_copy_add(const int* __restrict__ src, int n, int add, int* __restrict__ dst)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[i] + add;
+}
+
+// map k of a batch -> one contiguous buffer (indices made local to the map)
+void batch_pack_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, void* dst, size_t cap)
+{
+	hipStream_t s = ctx->stream;
+	PackHeader h;
+	memset(&h, 0, sizeof h);
+	const int po = b.pose_off[k], fo = b.feat_off[k], uo = b.u_off[k], wo = b.w_off[k];
+	h.magic = LSFM_PACK_MAGIC; h.version = 1; h.mono = mono;
+	h.m = b.pose_off[k + 1] - po; h.n = b.feat_off[k + 1] - fo; h.nU = b.u_off[k + 1] - uo; h.nW = b.w_off[k + 1] - wo;
+	h.Ref = b.Ref[k]; h.FRef = b.FRef[k]; h.ScaP = b.ScaP[k]; h.Fix = b.Fix[k]; h.Sign = b.Sign[k]; h.FScaP = b.FScaP[k]; h.FFix = b.FFix[k];
+	if (pack_layout(h) > cap) LSFM_FAIL(LSFM_ERR_ARG, "export buffer too small");
+	if (b.W_alias) LSFM_FAIL(LSFM_ERR_INTERNAL, "cannot pack a batch whose W blocks are aliased");
+	char* d = static_cast<char*>(dst);
+	h2d(ctx, d, &h, sizeof h);
+	auto cp = [&](int slot, const void* src, size_t bytes) {
+		if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(d + h.off[slot], src, bytes, hipMemcpyDeviceToDevice, s));
+	};
+	cp(0, b.pose + (size_t)po * 6, (size_t)h.m * 48); cp(1, b.feat + (size_t)fo * 3, (size_t)h.n * 24);
+	cp(2, b.U + (size_t)uo * 36, (size_t)h.nU * 288); cp(3, b.W + (size_t)wo * 18, (size_t)h.nW * 144);
+	cp(4, b.V + (size_t)fo * 9, (size_t)h.n * 72); cp(5, b.pose_id + po, (size_t)h.m * 4);
+	cp(6, b.pose_origin + po, (size_t)h.m * 4); cp(7, b.feat_id + fo, (size_t)h.n * 4);
+	auto sh = [&](int slot, const int* src, int cnt, int add) {
+		if (cnt) hipLaunchKernelGGL(k_copy_add, dim3((cnt + 255) / 256), dim3(256), 0, s, src, cnt, add, reinterpret_cast<int*>(d + h.off[slot]));
+	};
+	sh(8, b.Ui + uo, h.nU, -po); sh(9, b.Uj + uo, h.nU, -po); sh(10, b.photo + wo, h.nW, -po); sh(11, b.fptr + fo, h.n + 1, -wo);
+	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+// N packed maps (device) -> one batch with global indices in `ar`
+void batch_unpack_maps(lsfm_context* ctx, Arena& ar, const void* const* packed, const PackHeader* hdr, int N, bool mono, DevBatch& o)
+{
+	hipStream_t s = ctx->stream;
+	o = DevBatch();
+	o.B = N;
+	o.pose_off.assign(N + 1, 0); o.feat_off.assign(N + 1, 0); o.u_off.assign(N + 1, 0); o.w_off.assign(N + 1, 0);
+	o.Ref.resize(N); o.FRef.resize(N); o.ScaP.assign(N, 0); o.Fix.assign(N, 0); o.Sign.assign(N, 1); o.FScaP.assign(N, 0); o.FFix.assign(N, 0);
+	for (int k = 0; k < N; k++)
+	{
+		const PackHeader& h = hdr[k];
+		o.pose_off[k + 1] = o.pose_off[k] + h.m; o.feat_off[k + 1] = o.feat_off[k] + h.n;
+		o.u_off[k + 1] = o.u_off[k] + h.nU; o.w_off[k + 1] = o.w_off[k] + h.nW;
+		o.Ref[k] = h.Ref; o.FRef[k] = h.FRef;
+		if (mono) { o.ScaP[k] = h.ScaP; o.Fix[k] = h.Fix; o.Sign[k] = h.Sign; o.FScaP[k] = h.FScaP; o.FFix[k] = h.FFix; }
+	}
+	o.M = o.pose_off[N]; o.NF = o.feat_off[N]; o.NU = o.u_off[N]; o.NW = o.w_off[N];
+	o.pose = ar.alloc<double>((size_t)o.M * 6); o.pose_id = ar.alloc<int>(o.M); o.pose_origin = ar.alloc<int>(o.M);
+	o.feat = ar.alloc<double>((size_t)o.NF * 3); o.feat_id = ar.alloc<int>(o.NF);
+	o.U = ar.alloc<double>((size_t)o.NU * 36); o.Ui = ar.alloc<int>(o.NU); o.Uj = ar.alloc<int>(o.NU);
+	o.W = ar.alloc<double>((size_t)o.NW * 18); o.photo = ar.alloc<int>(o.NW); o.feature = ar.alloc<int>(o.NW);
+	o.fptr = ar.alloc<int>(o.NF + 1); o.V = ar.alloc<double>((size_t)o.NF * 9);
+	for (int k = 0; k < N; k++)
+	{
+		const PackHeader& h = hdr[k];
+		const char* p = static_cast<const char*>(packed[k]);
+		const int po = o.pose_off[k], fo = o.feat_off[k], uo = o.u_off[k], wo = o.w_off[k];
+		auto cp = [&](void* dst, int slot, size_t bytes) {
+			if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(dst, p + h.off[slot], bytes, hipMemcpyDeviceToDevice, s));
+		};
+		cp(o.pose + (size_t)po * 6, 0, (size_t)h.m * 48); cp(o.feat + (size_t)fo * 3, 1, (size_t)h.n * 24);
+		cp(o.U + (size_t)uo * 36, 2, (size_t)h.nU * 288); cp(o.W + (size_t)wo * 18, 3, (size_t)h.nW * 144);
+		cp(o.V + (size_t)fo * 9, 4, (size_t)h.n * 72); cp(o.pose_id + po, 5, (size_t)h.m * 4);
+		cp(o.pose_origin + po, 6, (size_t)h.m * 4); cp(o.feat_id + fo, 7, (size_t)h.n * 4);
+		auto sh = [&](int* dst, int slot, int cnt, int add) {
+			if (cnt) hipLaunchKernelGGL(k_copy_add, dim3((cnt + 255) / 256), dim3(256), 0, s, reinterpret_cast<const int*>(p + h.off[slot]), cnt, add, dst);
+		};
+		sh(o.Ui + uo, 8, h.nU, po); sh(o.Uj + uo, 9, h.nU, po); sh(o.photo + wo, 10, h.nW, po);
+		sh(o.fptr + fo, 11, h.n + (k == N - 1 ? 1 : 0), wo); // the last map also writes fptr[NF] = NW
+	}
+	// feature[] of every W block from the run pointers
+	if (o.NW) hipLaunchKernelGGL(k_fill_segment_ids, dim3((o.NW + 255) / 256), dim3(256), 0, s, o.fptr, o.NF, o.feature, o.NW);
+	LSFM_CHECK_HIP(hipGetLastError());
+	batch_set_offsets(ctx, ar, o);
+}
+
 template <class T> static T* host_alloc(size_t n) { return static_cast<T*>(malloc((n ? n : 1) * sizeof(T))); }
 
 void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, lsfm_map* g)

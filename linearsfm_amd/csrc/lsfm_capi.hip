@@ -17,6 +17,7 @@ struct lsfm_tree {
 	int slot = 0;
 	bool done = false;
 	bool final_reanchor = true;
+	unsigned long long generation = 0; // ctx->generation when the run ended: the result lives in the context's arenas
 };
 
 namespace {
@@ -176,6 +177,8 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		{
 			// level 0 reads the resident inputs where they are (no level writes its input), so a tree can be run repeatedly
 			t->slot = -1;
+			t->done = false;
+			ctx->generation++;
 			ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
 			t->level = t->input;
 			while (t->level.B > 1) run_level(ctx, t, st);
@@ -201,6 +204,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		st->t_total_ms = now_ms() - t0;
 		ctx->stats = nullptr;
 		t->done = true;
+		t->generation = ctx->generation;
 		return st->not_converged ? LSFM_NOT_CONVERGED : LSFM_OK;
 	});
 }
@@ -210,7 +214,78 @@ int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)
 	if (!t || !out) return LSFM_ERR_ARG;
 	return guarded(ctx, [&]() {
 		if (!t->done || t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (t->generation != ctx->generation)
+			LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context (it lives in the context's arenas): "
+			                        "download a tree before the context is used for anything else, or run it again");
 		batch_download_map(ctx, t->level, 0, t->mono, out);
+		return LSFM_OK;
+	});
+}
+
+size_t lsfm_tree_export_size(lsfm_context* ctx, lsfm_tree* t)
+{
+	if (!ctx || !t || !t->done || t->level.B != 1 || t->generation != ctx->generation) return 0;
+	PackHeader h;
+	memset(&h, 0, sizeof h);
+	const DevBatch& b = t->level;
+	h.m = b.M; h.n = b.NF; h.nU = b.NU; h.nW = b.NW;
+	return pack_layout(h);
+}
+
+int lsfm_tree_export_dev(lsfm_context* ctx, lsfm_tree* t, void* dst, size_t cap)
+{
+	if (!t || !dst) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		if (!t->done || t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (t->generation != ctx->generation) LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context");
+		batch_pack_map(ctx, t->level, 0, t->mono, dst, cap);
+		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream)); // the caller hands dst to another library / stream next
+		return LSFM_OK;
+	});
+}
+
+size_t lsfm_packed_size(const void* host_header)
+{
+	if (!host_header) return 0;
+	PackHeader h;
+	memcpy(&h, host_header, sizeof h);
+	if (h.magic != LSFM_PACK_MAGIC || h.version != 1 || h.m < 0 || h.n < 0 || h.nU < 0 || h.nW < 0) return 0;
+	PackHeader c = h;
+	return pack_layout(c) == h.total ? (size_t)h.total : 0;
+}
+
+int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, int mono, lsfm_tree** out)
+{
+	if (!out || !packed || N <= 0) return LSFM_ERR_ARG;
+	*out = nullptr;
+	return guarded(ctx, [&]() {
+		std::vector<PackHeader> hdr(N);
+		size_t nw = 0, nf = 0, nu = 0, m = 0, bytes = 0;
+		for (int k = 0; k < N; k++)
+		{
+			if (!packed[k]) LSFM_FAIL(LSFM_ERR_ARG, "null packed map");
+			LSFM_CHECK_HIP(hipMemcpyAsync(&hdr[k], packed[k], sizeof(PackHeader), hipMemcpyDeviceToHost, ctx->stream));
+		}
+		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		for (int k = 0; k < N; k++)
+		{
+			if (lsfm_packed_size(&hdr[k]) == 0) LSFM_FAIL(LSFM_ERR_ARG, "buffer " + std::to_string(k) + " is not a packed map");
+			if ((hdr[k].mono != 0) != (mono != 0)) LSFM_FAIL(LSFM_ERR_ARG, "packed map of the other camera type");
+			nw += hdr[k].nW; nf += hdr[k].n; nu += hdr[k].nU; m += hdr[k].m; bytes += hdr[k].total;
+		}
+		const size_t L = tree_levels(N) + 1;
+		ctx->ensure_arenas((nw + 2 * L * nf) * 160 * 3 + (nu + 3 * L * m) * 320 * 3 + nf * 400 + ((size_t)256 << 20));
+		lsfm_tree* t = new lsfm_tree();
+		t->mono = mono != 0; t->N = N; t->slot = 0;
+		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
+		try
+		{
+			t->input_arena.init(bytes + (m + nf + nw) * 8 + (size_t)N * 4096 + ((size_t)1 << 20));
+			batch_unpack_maps(ctx, t->input_arena, packed, hdr.data(), N, t->mono, t->input);
+			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		}
+		catch (...) { t->input_arena.destroy(); delete t; throw; }
+		*out = t;
 		return LSFM_OK;
 	});
 }

@@ -95,6 +95,10 @@ struct lsfm_context {
 	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
 	size_t stage_size = 0, stage_off = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipEvent_t evs[4] = { nullptr, nullptr, nullptr, nullptr }; // stage brackets of a solve (owned here: nothing to leak on an error path)
+	// Every entry point that resets or reallocates the arenas bumps this; a finished tree remembers the value it ended with,
+	// and lsfm_tree_download refuses a result that a later call on the same context has overwritten
+	unsigned long long generation = 0;
 	// side stream: the pattern of S is built there while the caller's right-hand-side kernels run on the main stream.
 	// evA = point of the main stream after which the index arrays of the joint map are complete (recorded by the caller,
 	// pattern_dep set), evB = pattern ready
@@ -120,6 +124,19 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes);
 void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, bool mono, DevBatch& out);
 void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, lsfm_map* out);
 void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b); // uploads pose_off / feat_off, fills pose_map / feat_map
+// A map packed into one contiguous device buffer for the hand-off between GPUs (include/lsfm.h): header, then the arrays
+// with map-local indices, each 256-byte aligned.
+struct PackHeader {
+	int magic, version, mono, m, n, nU, nW, Ref, FRef, ScaP, Fix, Sign, FScaP, FFix, pad0, pad1;
+	unsigned long long total;
+	unsigned long long off[12]; // pose feat U W V | pose_id pose_origin feat_id Ui Uj photo fptr
+	unsigned long long pad[11];
+};
+static_assert(sizeof(PackHeader) == 256, "the header is the first 256 bytes of a pack");
+#define LSFM_PACK_MAGIC 0x4d46534c
+size_t pack_layout(PackHeader& h); // fills off[] and total from the counts
+void batch_pack_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, void* dst, size_t cap);
+void batch_unpack_maps(lsfm_context* ctx, Arena& ar, const void* const* packed, const PackHeader* hdr, int N, bool mono, DevBatch& out);
 
 // ---- transform (lsfm_transform.hip): K1-K4 ------------------------------------------------------------------
 // target_ref[b] < 0 ... map b is passed through unchanged; otherwise the pose id the map is re-expressed in

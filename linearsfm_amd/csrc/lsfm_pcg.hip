@@ -1007,9 +1007,8 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
 	const int M = io.M, nseg = io.nseg;
-	hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr, ed = nullptr;
+	hipEvent_t ea = ctx->evs[0], eb = ctx->evs[1], ec = ctx->evs[2], ed = ctx->evs[3];
 	float ms = 0;
-	LSFM_CHECK_HIP(hipEventCreate(&ea)); LSFM_CHECK_HIP(hipEventCreate(&eb)); LSFM_CHECK_HIP(hipEventCreate(&ec)); LSFM_CHECK_HIP(hipEventCreate(&ed));
 	LSFM_CHECK_HIP(hipEventRecord(ea, s));
 	SchurSystem sy;
 	CholDev ch;
@@ -1149,7 +1148,6 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
 		st->max_rel_residual = std::max(st->max_rel_residual, maxrel);
 	}
-	(void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec); (void)hipEventDestroy(ed);
 	return notconv;
 }
 

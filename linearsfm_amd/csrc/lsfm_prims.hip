@@ -111,6 +111,7 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 
 void lsfm_context::ensure_arenas(size_t bytes_each)
 {
+	generation++; // every caller is about to reset the arenas
 	if (arena_req >= bytes_each && arena[0].base) return;
 	LSFM_CHECK_HIP(hipStreamSynchronize(stream));
 	const size_t requested = bytes_each;
@@ -157,6 +158,7 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev1));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev2));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev3));
+		for (auto& e : c->evs) LSFM_CHECK_HIP(hipEventCreate(&e));
 		if (arena_bytes) c->ensure_arenas(arena_bytes);
 	}
 	catch (const lsfm::Error& e)
@@ -182,6 +184,7 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
 	if (c->ev3) (void)hipEventDestroy(c->ev3);
+	for (auto& e : c->evs) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->evA) (void)hipEventDestroy(c->evA);

@@ -142,6 +142,12 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* tree, lsfm_stats* stats);
  * frame of its last join -- what the reference's loop holds for an intermediate tree node; used when the tree is a
  * SUBTREE whose root is joined further by another call (multi-GPU sharding). */
 int lsfm_tree_set_final_reanchor(lsfm_tree* tree, int on);
+/* on = 1 (default): the first lsfm_tree_run of a tree records what depends on its STRUCTURE only (container sizes, block
+ * pattern of every Schur system, ordering / elimination tree / supernodes of its factorisation -- the reference repeats
+ * that analysis in every join, cholmod_analyze_p, Imp.cpp:2440) and later runs of the same resident tree reuse it: they are
+ * enqueued without a host <-> device round trip.  The numeric work of a run is the same either way.  on = 0: every run
+ * analyses from scratch (what a first run costs; lsfm_stats.t_total_ms of the first run reports it too). */
+int lsfm_tree_set_plans(lsfm_tree* tree, int on);
 int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* tree);
 /* ---- device-resident hand-off of a tree node (multi-GPU sub-tree sharding; no counterpart in the reference, whose

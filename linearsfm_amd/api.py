@@ -74,6 +74,13 @@ def lib():
         L.lsfm_tree_upload.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(vp)]
         L.lsfm_tree_run.argtypes = [vp, vp, P(LsfmStats)]
         L.lsfm_tree_set_final_reanchor.argtypes = [vp, C.c_int]
+        L.lsfm_tree_set_plans.argtypes = [vp, C.c_int]
+        L.lsfm_tree_export_size.argtypes = [vp, vp]
+        L.lsfm_tree_export_size.restype = C.c_size_t
+        L.lsfm_tree_export_dev.argtypes = [vp, vp, vp, C.c_size_t]
+        L.lsfm_packed_size.argtypes = [vp]
+        L.lsfm_packed_size.restype = C.c_size_t
+        L.lsfm_tree_upload_dev.argtypes = [vp, P(vp), C.c_int, C.c_int, P(vp)]
         L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
         L.lsfm_tree_free.argtypes = [vp, vp]
         L.lsfm_tree_free.restype = None
@@ -91,7 +98,8 @@ def lib():
 EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_last_error", "lsfm_stream",
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
-           "lsfm_tree_download",
+           "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
+           "lsfm_tree_upload_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench"]
 
@@ -244,6 +252,27 @@ class Context:
 
     def tree_free(self, tree):
         lib().lsfm_tree_free(self._h, tree)
+
+    def tree_set_plans(self, tree, on):
+        lib().lsfm_tree_set_plans(tree, int(on))
+
+    def tree_set_final_reanchor(self, tree, on):
+        lib().lsfm_tree_set_final_reanchor(tree, int(on))
+
+    # ---- device-resident hand-off of a tree node (multi-GPU sub-tree sharding) ---------------------------
+    def tree_export_size(self, tree):
+        return int(lib().lsfm_tree_export_size(self._h, tree))
+
+    def tree_export_dev(self, tree, dev_ptr, cap):
+        """Packs the final map of a finished tree into caller-owned device memory (e.g. a torch uint8 CUDA tensor)."""
+        self._check(lib().lsfm_tree_export_dev(self._h, tree, C.c_void_p(int(dev_ptr)), int(cap)), "lsfm_tree_export_dev")
+
+    def tree_upload_dev(self, dev_ptrs, mono):
+        """A new tree whose resident inputs are the packed maps at the given device addresses (no host copy)."""
+        arr = (C.c_void_p * len(dev_ptrs))(*[C.c_void_p(int(p)) for p in dev_ptrs])
+        t = C.c_void_p()
+        self._check(lib().lsfm_tree_upload_dev(self._h, arr, len(dev_ptrs), int(mono), C.byref(t)), "lsfm_tree_upload_dev")
+        return t
 
     def divide_conquer(self, maps, mono, final_reanchor=True):
         t = self.tree_upload(maps, mono)

@@ -18,6 +18,10 @@ struct lsfm_tree {
 	bool done = false;
 	bool final_reanchor = true;
 	unsigned long long generation = 0; // ctx->generation when the run ended: the result lives in the context's arenas
+	// what the first run leaves for the next ones (structure only: the resident inputs never change): one plan per tree
+	// level + one for the final re-anchoring transform
+	std::vector<LevelPlan> plans;
+	bool use_plans = true;
 };
 
 namespace {
@@ -31,6 +35,10 @@ double now_ms()
 template <class F> int guarded(lsfm_context* ctx, F&& f)
 {
 	if (!ctx) return LSFM_ERR_ARG;
+	struct Reset { // per-call state that must not outlive the call (sinks of deferred timings point into the caller's frame)
+		lsfm_context* c;
+		~Reset() { c->timed.clear(); c->ev_next = 0; c->plan = nullptr; }
+	} reset{ ctx };
 	try
 	{
 		if (hipSetDevice(ctx->device) != hipSuccess) return LSFM_ERR_NO_DEVICE;
@@ -67,8 +75,9 @@ int tree_levels(int N)
 }
 
 // one level: transform the maps that need it, then join the pairs
-void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
+void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 {
+	ctx->plan = (t->use_plans && level < (int)t->plans.size()) ? &t->plans[level] : nullptr;
 	DevBatch& X = t->level;
 	const int B = X.B, npairs = B / 2;
 	std::vector<int> tref(B, -1), tscap(B, 0), tfix(B, 0);
@@ -83,7 +92,9 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 		// ... and End is expressed in Cur's frame (Imp.cpp:1964 / 6549)
 		tref[e] = cref; tscap[e] = cscap; tfix[e] = cfix; ntr++;
 	}
-	const double t0 = now_ms();
+	// stage times from events on the stream (a warm level is only enqueued: host clocks say nothing about it)
+	hipEvent_t e_t0 = ctx->pool_event(), e_t1 = ctx->pool_event(), e_t2 = ctx->pool_event();
+	LSFM_CHECK_HIP(hipEventRecord(e_t0, ctx->stream));
 	// three arenas in rotation: X (this level; slot -1 = the resident inputs, never written) stays alive until the join
 	// is done, because the W blocks of the maps the transform passes through are read from X, not copied (W_alias)
 	const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3, sm = t->slot < 0 ? 1 : (t->slot + 2) % 3;
@@ -92,11 +103,10 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	other.reset();
 	mine.reset();
 	DevBatch Xt, Y;
-	double t1;
 	if (t->mono)
 	{
 		transform_batch(ctx, other, X, tref, tscap, tfix, true, Xt, true);
-		t1 = now_ms();
+		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
 	}
 	else
@@ -105,27 +115,25 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 		// W stage), and the transform's block kernel writes every W' block straight to its place in the joint map
 		JoinState js;
 		const size_t smark = ctx->scratch.mark();
-		double hook_ms = 0;
 		std::function<TrRedirect(DevBatch&)> hook = [&](DevBatch& mid) {
-			const double a = now_ms();
 			join_stereo_prepare(ctx, mine, mid, Y, js);
 			TrRedirect rd;
 			rd.wbase = js.wbase; rd.newf = js.newf; rd.W = Y.W; rd.photo = Y.photo; rd.feature = Y.feature; rd.srcf = js.srcf;
-			hook_ms = now_ms() - a;
 			return rd;
 		};
-		transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook);
-		t1 = now_ms() - hook_ms;
+		transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); // (the join's layout kernels run inside)
+		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		js.smark = smark; // everything of this level goes at once
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
 	}
-	double t2 = now_ms();
+	LSFM_CHECK_HIP(hipEventRecord(e_t2, ctx->stream));
+	ctx->plan = nullptr;
 	t->level = Y;
 	t->slot = sm;
 	if (st)
 	{
-		st->t_transform_ms += t1 - t0;
-		st->t_join_ms += (t2 - t1);
+		ctx->defer_time(e_t0, e_t1, &st->t_transform_ms);
+		ctx->defer_time(e_t1, e_t2, &st->t_join_ms);
 		st->levels++; st->joins += npairs; st->transforms += ntr;
 	}
 }
@@ -162,6 +170,45 @@ int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, l
 	});
 }
 
+// one pass over the tree; with valid plans nothing in here waits for the device before the final synchronisation
+static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
+{
+	// level 0 reads the resident inputs where they are (no level writes its input), so a tree can be run repeatedly
+	t->slot = -1;
+	t->done = false;
+	ctx->generation++;
+	ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
+	ctx->stage_off = 0; // the stream is idle: the staging ring starts over
+	LSFM_CHECK_HIP(hipMemsetAsync(ctx->d_run, 0, sizeof(RunStatsDev), ctx->stream));
+	t->level = t->input;
+	const int nlev = tree_levels(t->N);
+	if ((int)t->plans.size() != nlev + 1) t->plans.assign(nlev + 1, LevelPlan());
+	int level = 0;
+	while (t->level.B > 1) run_level(ctx, t, st, level++);
+	// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
+	DevBatch& X = t->level;
+	if (t->final_reanchor && X.B == 1 && X.Ref[0] > X.FRef[0])
+	{
+		std::vector<int> tref(1, X.FRef[0]), tscap(1, X.FScaP[0]), tfix(1, X.FFix[0]);
+		const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3;
+		Arena& other = ctx->arena[so];
+		other.reset();
+		DevBatch Xt;
+		hipEvent_t e0 = ctx->pool_event(), e1 = ctx->pool_event();
+		LSFM_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+		ctx->plan = t->use_plans ? &t->plans[nlev] : nullptr;
+		transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt);
+		if (ctx->plan) ctx->plan->valid = true;
+		ctx->plan = nullptr;
+		LSFM_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+		ctx->defer_time(e0, e1, &st->t_transform_ms);
+		st->transforms++;
+		t->level = Xt;
+		t->slot = so;
+	}
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
 int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 {
 	if (!t) return LSFM_ERR_ARG;
@@ -169,44 +216,50 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		lsfm_stats local;
 		memset(&local, 0, sizeof local);
 		lsfm_stats* st = stats ? stats : &local;
-		memset(st, 0, sizeof *st);
 		ctx->stats = st;
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-		const double t0 = now_ms();
 		try
 		{
-			// level 0 reads the resident inputs where they are (no level writes its input), so a tree can be run repeatedly
-			t->slot = -1;
-			t->done = false;
-			ctx->generation++;
-			ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
-			t->level = t->input;
-			while (t->level.B > 1) run_level(ctx, t, st);
-			// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
-			DevBatch& X = t->level;
-			if (t->final_reanchor && X.B == 1 && X.Ref[0] > X.FRef[0])
+			for (int attempt = 0;; attempt++)
 			{
-				std::vector<int> tref(1, X.FRef[0]), tscap(1, X.FScaP[0]), tfix(1, X.FFix[0]);
-				const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3;
-				Arena& other = ctx->arena[so];
-				other.reset();
-				DevBatch Xt;
-				const double a = now_ms();
-				transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt);
-				st->t_transform_ms += now_ms() - a;
-				st->transforms++;
-				t->level = Xt;
-				t->slot = so;
+				memset(st, 0, sizeof *st);
+				ctx->timed.clear(); ctx->ev_next = 0;
+				const double t0 = now_ms();
+				tree_pass(ctx, t, st);
+				st->t_total_ms = now_ms() - t0;
+				// what the warm levels left in the device accumulators instead of stopping for it
+				RunStatsDev rs;
+				LSFM_CHECK_HIP(hipMemcpy(&rs, ctx->d_run, sizeof rs, hipMemcpyDeviceToHost));
+				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
+				if (rs.chol_err)
+					LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
+				if (rs.not_converged && attempt == 0)
+				{
+					// a planned run enqueues the refinement steps the first run needed; if a system asks for more this time,
+					// drop the plans and run the levels the slow way again (reads the state of every step back)
+					t->plans.clear();
+					continue;
+				}
+				st->not_converged += rs.not_converged;
+				st->max_rel_residual = std::max(st->max_rel_residual, rs.max_rel_residual);
+				break;
 			}
-			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+			ctx->flush_times();
 		}
 		catch (...) { ctx->stats = nullptr; throw; }
-		st->t_total_ms = now_ms() - t0;
 		ctx->stats = nullptr;
 		t->done = true;
 		t->generation = ctx->generation;
 		return st->not_converged ? LSFM_NOT_CONVERGED : LSFM_OK;
 	});
+}
+
+int lsfm_tree_set_plans(lsfm_tree* t, int on)
+{
+	if (!t) return LSFM_ERR_ARG;
+	t->use_plans = on != 0;
+	if (!on) t->plans.clear();
+	return LSFM_OK;
 }
 
 int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,30 @@ struct DevBatch {
 
 struct PcgOptions { double rel_tol = 1e-12; int max_it_factor = 4; };
 
+// What the first run of a tree level leaves behind for the next runs of the SAME resident tree.  Everything here is
+// structure: it depends on the labels, the index arrays and the join tree of the uploaded local maps, which no run
+// changes -- sizes the host needs to carve the next container (the first run reads them back from the device: a
+// round trip each), the block pattern of S with its hash index, the ordering / elimination structure / supernode
+// groups of the factorisation (the reference redoes its symbolic analysis in every join: cholmod_analyze_p,
+// Imp.cpp:2440; here it is done once per tree shape).  With a valid plan a level is enqueued without a single
+// host <-> device synchronisation.
+struct LevelPlan {
+	bool valid = false;
+	std::vector<int> tr_cnt;     // transform: kept-block prefix values at the map boundaries (U then W)
+	std::vector<int> tr_sign;    // Mono: sign of the new scale of every transformed map
+	std::vector<int> join_rb;    // join: ranks of the unmatched features at the map boundaries
+	std::shared_ptr<void> solve; // pattern of S + symbolic factorisation + iteration count (lsfm_pcg.hip)
+};
+
+// per-run accumulators on the device, read back once at the end of a run (a warm level does not stop for them)
+struct RunStatsDev {
+	int chol_err;          // 1 + block column of a non-positive pivot (first one wins)
+	int not_converged;     // systems left above the residual bound
+	int tr_err;            // 1 + map whose transform target was not found
+	int pad;
+	double max_rel_residual;
+};
+
 } // namespace lsfm
 
 struct lsfm_context {
@@ -106,6 +131,17 @@ struct lsfm_context {
 	hipEvent_t evA = nullptr, evB = nullptr;
 	bool pattern_dep = false;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run
+	lsfm::LevelPlan* plan = nullptr; // plan of the tree level being run (null: stage-level calls, nothing is recorded or reused)
+	bool warm() const { return plan && plan->valid; }
+	lsfm::RunStatsDev* d_run = nullptr; // device accumulators of the current run
+	// timing of stages without stopping for them: events from a pool, elapsed times added to their sinks by flush_times()
+	std::vector<hipEvent_t> ev_pool;
+	size_t ev_next = 0;
+	struct Timed { hipEvent_t a, b; double* sink; };
+	std::vector<Timed> timed;
+	hipEvent_t pool_event();
+	void defer_time(hipEvent_t a, hipEvent_t b, double* sink) { timed.push_back(Timed{ a, b, sink }); }
+	void flush_times(); // after the stream has been synchronised
 	void ensure_arenas(size_t bytes_each);
 };
 

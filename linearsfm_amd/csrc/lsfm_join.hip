@@ -255,7 +255,12 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	int* d_rb = ctx->scratch.alloc<int>(B + 1);
 	hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, R, in.d_feat_off, B + 1, d_rb);
 	std::vector<int> rb(B + 1);
-	d2h_ints(ctx, d_rb, rb.data(), B + 1);
+	if (ctx->warm()) rb = ctx->plan->join_rb; // known from an earlier run of the same tree
+	else
+	{
+		d2h_ints(ctx, d_rb, rb.data(), B + 1);
+		if (ctx->plan) ctx->plan->join_rb = rb;
+	}
 
 	out = DevBatch();
 	out.B = G; out.M = in.M; out.NU = in.NU; out.NW = in.NW;
@@ -365,10 +370,12 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	io.ea = eP; io.eb = eF; io.x0 = in.pose; io.d_fixed = nullptr; io.d_pose_origin = out.pose_origin;
 	io.x_pose = out.pose; io.x_feat = out.feat;
 	io.seg_rows = seg_rows;
+	const bool warm = ctx->warm();
 	int rc = solve_batch(ctx, io);
-	LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s)); // a warm level is only enqueued: its scratch is reused in stream order
 	ctx->scratch.release(st.smark);
 	if (rc > 0 && ctx->stats) ctx->stats->not_converged += rc;
+	if (ctx->plan && !eP_out && !eF_out) ctx->plan->valid = true; // every stage of the level has left its structure behind
 }
 
 void join_batch_stereo(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, double* eP_out, double* eF_out)

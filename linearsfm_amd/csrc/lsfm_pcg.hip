@@ -59,6 +59,15 @@ struct CholDev {
 	std::vector<int> tlevel_nsmall;    // host: the first tlevel_nsmall[l] tasks of level l fit LDS whole (small-task kernels)
 	std::vector<int> tlevel_small_lds; // host: dynamic LDS bytes of the level's small-task launches
 	std::vector<int> tlevel_outer;     // host: largest number of deferred update pairs of a column of the level
+	// supernode groups: the columns above the leaf tasks, cut into runs of <= CHOL_GS consecutive columns of one
+	// fundamental supernode (same rows below the run), ordered by group level (children before parents)
+	int ngroups = 0;
+	int *grp_c0 = nullptr, *grp_s = nullptr, *grp_nr = nullptr; // [ngroups] first column, columns, rows below the run
+	std::vector<int> glevel_ptr;    // host: groups of level l = [glevel_ptr[l], glevel_ptr[l+1])
+	std::vector<int> glevel_maxnr;  // host: most rows below a run of the level
+	int* blob = nullptr;    // all index arrays above are slices of this one allocation
+	size_t blob_ints = 0;
+	double* Gd = nullptr;   // parking area of the factored diagonal blocks of one group level: SN_GD doubles per group
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
 	int* d_err = nullptr;
@@ -589,6 +598,320 @@ __global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int
 	else chol_factor_task_global(blockIdx.x, task_ptr, task_cols, col_nin, colptr, rowidx, L, Dinv, err);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Supernode groups: the factorisation above the leaf tasks.  With a path that revisits, the separators of the
+// dissection are 20-70 poses wide and every separator column has 100-300 blocks below it: walking such a chain
+// column by column in one work-group (the round-1 scheme) left the chip idle -- 27 ms for the top join of the
+// NC3500-like set.  A group is a run of s <= CHOL_GS consecutive columns of one fundamental supernode: column c0+t
+// holds [its diagonal block, the s-1-t later columns of the run, the nr common rows below the run], so block
+// (row i of the common rows, column t) sits at colptr[c0+t] + (s-t) + i: the run is a dense trapezoid in the block
+// storage as it is.  Per group level (children before parents) two launches:
+//   k_sn_panel   every work-group factors the s x s diagonal blocks in LDS (redundantly: the other CUs would idle)
+//                and solves its 16 block rows of the panel against them:  X = A L_dd^-T
+//   k_sn_update  one lane per pair (a >= b) of common rows: block (r_a, r_b) -= sum_t X[a,t] X[b,t]^T, left through LDS
+//                as contiguous atomics (groups of one level share ancestors)
+// ---------------------------------------------------------------------------------------------------------------
+#define CHOL_GS 16
+#define SN_RB 16                    /* block rows of the panel per work-group */
+#define SN_XS (6 * CHOL_GS + 1)     /* odd row stride of the panel rows in LDS */
+#define SN_THREADS 256               /* 96 lanes own rows; the rest is there to keep more loads in flight */
+#define SN_LD 8                      /* loads in flight per lane in the copy loops (a dependent load costs ~1.5 us) */
+#define SN_GD (CHOL_GS * (CHOL_GS + 1) / 2 * 36) /* doubles per group in the parking area of the diagonal blocks */
+// 1 / sqrt(x) without the ~300-cycle IEEE sqrt + divide chains (they sat on the critical path of every column step):
+// hardware estimate + three Newton steps (full double precision up to an ulp or two -- the factor is a preconditioner
+// under iterative refinement)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+	double r = __builtin_amdgcn_rsq(x);
+	const double h = 0.5 * x;
+	r = r * fma(-h * r, r, 1.5);
+	r = r * fma(-h * r, r, 1.5);
+	r = r * fma(-h * r, r, 1.5);
+	return r;
+}
+__device__ __forceinline__ int sn_idx(int s, int u, int t) { return t * s - t * (t - 1) / 2 + (u - t); }
+
+// Dense s x s (blocks) Cholesky of the run's diagonal part, one lane per scalar row, left-looking by block columns: for
+// block column t every lane i >= 6t forms  a[c] = A[i][6t+c] - sum_{j<6t} L[i][j] L[6t+c][j]  (own row from LDS with an
+// odd stride, the six pivot rows broadcast); the six lanes of the block's own rows publish theirs as the 6x6 diagonal block
+// D, everybody factors D in registers (56 flops: cheaper than a second barrier-separated phase) and finishes its row.
+// Two barriers per block column instead of the ~6 of the block-by-block walk, no idle lanes: ~15 us for 96 x 96 instead
+// of ~65.  The panel rows X = A L_dd^-T are the same recurrence on rows below the diagonal part, streamed without barriers.
+__global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
+                                                          const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Dinv, int* err,
+                                                          double* __restrict__ Gd)
+{
+	__shared__ double Ls[6 * CHOL_GS * SN_XS]; // L_dd, dense scalar rows
+	__shared__ double Xs[6 * SN_RB * SN_XS];   // the panel rows of this work-group
+	__shared__ double sD[36];
+	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
+	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
+	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	const int i0 = blockIdx.y * SN_RB;
+	if (blockIdx.y > 0 && i0 >= nr) return;
+	const int tid = threadIdx.x, nt = blockDim.x;
+	const int nb = s * (s + 1) / 2, n6 = 6 * s;
+	// where every block of the run's diagonal part sits in the block storage / in the dense rows (one lane per block)
+	for (int t = tid; t < s; t += nt) sCol[t] = colptr[c0 + t];
+	__syncthreads();
+	for (int e = tid; e < nb; e += nt)
+	{
+		int t = 0;
+		while (sn_idx(s, s - 1, t) < e) t++; // column of packed block e (s <= 16: a short scan)
+		const int u = t + (e - sn_idx(s, t, t));
+		sSrc[e] = (sCol[t] + (u - t)) * 36;
+		sDst[e] = 6 * u * SN_XS + 6 * t;
+	}
+	__syncthreads();
+	for (int base = 0; base < nb * 36; base += nt * SN_LD)
+	{
+		double v[SN_LD];
+#pragma unroll
+		for (int i = 0; i < SN_LD; i++)
+		{
+			const int q = base + i * nt + tid, e = q / 36;
+			if (q < nb * 36) v[i] = L[(size_t)sSrc[e] + (q - e * 36)];
+		}
+#pragma unroll
+		for (int i = 0; i < SN_LD; i++)
+		{
+			const int q = base + i * nt + tid, e = q / 36, w = q - e * 36;
+			if (q < nb * 36) Ls[sDst[e] + (w / 6) * SN_XS + w % 6] = v[i];
+		}
+	}
+	// the panel rows of this work-group: block (il, t) at colptr[c0 + t] + (s - t) + i0 + il
+	const int nrows = max(0, min(SN_RB, nr - i0));
+	for (int base = 0; base < nrows * s * 36; base += nt * SN_LD)
+	{
+		double v[SN_LD];
+#pragma unroll
+		for (int i = 0; i < SN_LD; i++)
+		{
+			const int q = base + i * nt + tid, blk = q / 36, il = blk / s, t = blk - il * s;
+			if (q < nrows * s * 36) v[i] = L[(size_t)(sCol[t] + (s - t) + i0 + il) * 36 + (q - blk * 36)];
+		}
+#pragma unroll
+		for (int i = 0; i < SN_LD; i++)
+		{
+			const int q = base + i * nt + tid, blk = q / 36, w = q - blk * 36, il = blk / s, t = blk - il * s;
+			if (q < nrows * s * 36) Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6] = v[i];
+		}
+	}
+	__syncthreads();
+	bool bad = false;
+	for (int t = 0; t < s; t++)
+	{
+		const int k0 = 6 * t;
+		double a[6];
+		const bool mine = tid >= k0 && tid < n6;
+		if (mine)
+		{
+			const double* xi = &Ls[tid * SN_XS];
+#pragma unroll
+			for (int c = 0; c < 6; c++) a[c] = xi[k0 + c];
+			for (int v = 0; v < t; v++) // block by block: 42 LDS reads in flight, then 36 multiply-adds
+			{
+				double xv[6];
+#pragma unroll
+				for (int k = 0; k < 6; k++) xv[k] = xi[6 * v + k];
+#pragma unroll
+				for (int c = 0; c < 6; c++)
+				{
+					const double* lr = &Ls[(k0 + c) * SN_XS + 6 * v];
+#pragma unroll
+					for (int k = 0; k < 6; k++) a[c] = fma(-xv[k], lr[k], a[c]);
+				}
+			}
+			if (tid < k0 + 6)
+#pragma unroll
+				for (int c = 0; c < 6; c++) sD[(tid - k0) * 6 + c] = a[c];
+		}
+		__syncthreads();
+		if (mine)
+		{
+			// 6x6 Cholesky of D (lower triangle of the symmetric block), by every lane; di[k] = 1 / L_kk
+			double d[21], di[6];
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+#pragma unroll
+				for (int c = 0; c <= r; c++) d[r * (r + 1) / 2 + c] = sD[r * 6 + c];
+#pragma unroll
+			for (int k = 0; k < 6; k++)
+			{
+				double pv = d[k * (k + 1) / 2 + k];
+				if (!(pv > 0)) { bad = true; pv = 1.0; }
+				di[k] = fast_rsqrt(pv);
+				d[k * (k + 1) / 2 + k] = pv * di[k];
+#pragma unroll
+				for (int r = k + 1; r < 6; r++) d[r * (r + 1) / 2 + k] *= di[k];
+#pragma unroll
+				for (int r = k + 1; r < 6; r++)
+#pragma unroll
+					for (int c = k + 1; c <= r; c++) d[r * (r + 1) / 2 + c] -= d[r * (r + 1) / 2 + k] * d[c * (c + 1) / 2 + k];
+			}
+			double* xo = &Ls[tid * SN_XS + k0];
+			if (tid < k0 + 6)
+			{
+				// a row of the diagonal block itself: row (tid - k0) of the factor, zeros above the diagonal
+				// (static indices only: a run-time index into d[] would put the whole array into scratch memory)
+				const int r = tid - k0;
+#pragma unroll
+				for (int rr = 0; rr < 6; rr++)
+					if (rr == r)
+					{
+#pragma unroll
+						for (int c = 0; c < 6; c++) xo[c] = c <= rr ? d[rr * (rr + 1) / 2 + c] : 0.0;
+						sInvD[k0 + rr] = di[rr];
+					}
+			}
+			else
+			{
+#pragma unroll
+				for (int c = 0; c < 6; c++)
+				{
+					double v = a[c];
+#pragma unroll
+					for (int k = 0; k < c; k++) v = fma(-a[k], d[c * (c + 1) / 2 + k], v);
+					a[c] = v * di[c];
+				}
+#pragma unroll
+				for (int c = 0; c < 6; c++) xo[c] = a[c];
+			}
+		}
+		__syncthreads();
+	}
+	if (bad && tid == 0) atomicExch(err, 1 + c0);
+	// inverse of every diagonal 6x6 factor (the triangular solves use it): lane (t, c) solves L_tt x = e_c
+	if (tid < n6)
+	{
+		const int t = tid / 6, c = tid - 6 * t;
+		const double* dg = &Ls[(6 * t) * SN_XS + 6 * t];
+		double x[6];
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+		{
+			double v = r == c ? 1.0 : 0.0;
+#pragma unroll
+			for (int k = 0; k < r; k++) v = fma(-dg[r * SN_XS + k], x[k], v);
+			x[r] = v * sInvD[6 * t + r];
+		}
+#pragma unroll
+		for (int r = 0; r < 6; r++) Dinv[(size_t)(c0 + t) * 36 + r * 6 + c] = r >= c ? x[r] : 0.0; // every work-group writes the same values
+	}
+	// the factored diagonal blocks are parked (the other work-groups of the group may still be reading the unfactored
+	// ones from L); k_sn_update puts them in place
+	if (blockIdx.y == 0)
+		for (int q = tid; q < nb * 36; q += nt)
+		{
+			const int e = q / 36, w = q - e * 36;
+			Gd[(size_t)g * SN_GD + q] = Ls[sDst[e] + (w / 6) * SN_XS + w % 6];
+		}
+	if (nrows <= 0) return;
+	// X = A L_dd^-T, one scalar row per lane, no barriers: L_dd is final
+	if (tid < 6 * nrows)
+	{
+		double* x = &Xs[tid * SN_XS];
+		for (int t = 0; t < s; t++)
+		{
+			const int k0 = 6 * t;
+			double a[6];
+#pragma unroll
+			for (int c = 0; c < 6; c++) a[c] = x[k0 + c];
+			for (int v = 0; v < t; v++)
+			{
+				double xv[6];
+#pragma unroll
+				for (int k = 0; k < 6; k++) xv[k] = x[6 * v + k];
+#pragma unroll
+				for (int c = 0; c < 6; c++)
+				{
+					const double* lr = &Ls[(k0 + c) * SN_XS + 6 * v];
+#pragma unroll
+					for (int k = 0; k < 6; k++) a[c] = fma(-xv[k], lr[k], a[c]);
+				}
+			}
+			const double* dg = &Ls[k0 * SN_XS + k0];
+#pragma unroll
+			for (int c = 0; c < 6; c++)
+			{
+				double v = a[c];
+#pragma unroll
+				for (int k = 0; k < c; k++) v = fma(-a[k], dg[c * SN_XS + k], v);
+				a[c] = v * sInvD[k0 + c];
+			}
+#pragma unroll
+			for (int c = 0; c < 6; c++) x[k0 + c] = a[c];
+		}
+	}
+	__syncthreads();
+	for (int q = tid; q < nrows * s * 36; q += nt)
+	{
+		const int blk = q / 36, w = q - blk * 36, il = blk / s, t = blk - il * s;
+		L[(size_t)(sCol[t] + (s - t) + i0 + il) * 36 + w] = Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+	}
+}
+
+__global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
+                                                           const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
+                                                           const double* __restrict__ Gd)
+{
+	__shared__ double sT[SN_THREADS * 37];
+	__shared__ int spos[SN_THREADS];
+	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	const int npairs = nr * (nr + 1) / 2;
+	const int tid = threadIdx.x;
+	if (blockIdx.y == 0)
+	{
+		const int nb = s * (s + 1) / 2;
+		for (int q = tid; q < nb * 36; q += SN_THREADS)
+		{
+			const int e = q / 36;
+			int t = 0;
+			while (sn_idx(s, s - 1, t) < e) t++;
+			const int u = t + (e - sn_idx(s, t, t));
+			L[(size_t)(colptr[c0 + t] + (u - t)) * 36 + (q - e * 36)] = Gd[(size_t)g * SN_GD + q];
+		}
+	}
+	const int rows0 = colptr[c0 + s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
+	for (int base = blockIdx.y * SN_THREADS; base < npairs; base += gridDim.y * SN_THREADS)
+	{
+		const int pr = base + tid;
+		int pos = -1;
+		if (pr < npairs)
+		{
+			int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+			while (a * (a + 1) / 2 > pr) a--;
+			while ((a + 1) * (a + 2) / 2 <= pr) a++;
+			const int b = pr - a * (a + 1) / 2;
+			double T[36];
+			zero<36>(T);
+			for (int t = 0; t < s; t++)
+			{
+				const size_t cb = (size_t)colptr[c0 + t] + (s - t);
+				double La[36], Lb[36];
+				ld<36>(La, L + (cb + a) * 36);
+				ld<36>(Lb, L + (cb + b) * 36);
+				mmt<6, 6, 6, true>(La, Lb, T);
+			}
+			const int ra = rowidx[rows0 + a], rb = rowidx[rows0 + b];
+			const int cbk = colptr[rb], nbk = colptr[rb + 1] - cbk;
+			pos = cbk + (a - b);
+			if (!(a - b < nbk && rowidx[pos] == ra)) pos = find_row(rowidx, cbk, cbk + nbk, ra);
+			for (int q = 0; q < 36; q++) sT[tid * 37 + q] = T[q];
+		}
+		spos[tid] = pos;
+		__syncthreads();
+		for (int idx = tid; idx < SN_THREADS * 36; idx += SN_THREADS)
+		{
+			const int p = idx / 36, q = idx - p * 36;
+			const int ps = spos[p];
+			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[p * 37 + q]);
+		}
+		__syncthreads();
+	}
+}
+
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
                           double* __restrict__ v)
 {
@@ -640,6 +963,61 @@ static void chol_fetch(lsfm_context* ctx, const SchurSystem& sy, const int* d_or
 	if (d_origin) LSFM_CHECK_HIP(hipMemcpyAsync(in.origin.data(), d_origin, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	else std::iota(in.origin.begin(), in.origin.end(), 0);
 	d2h(ctx, in.keys.data(), sy.upper_keys, (size_t)nnzb * sizeof(unsigned long long));
+}
+
+// value arrays of a factorisation (per run; the index arrays may come from a plan)
+static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
+{
+	Arena& sc = ctx->scratch;
+	ch.L = sc.alloc<double>((size_t)ch.nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)ch.M * 36);
+	int most = 1;
+	for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++) most = std::max(most, ch.glevel_ptr[l + 1] - ch.glevel_ptr[l]);
+	ch.Gd = sc.alloc<double>((size_t)most * (CHOL_GS * (CHOL_GS + 1) / 2 * 36));
+	dev_zero(ctx, ch.L, (size_t)ch.nnzL * 36 * sizeof(double));
+}
+
+// What a first solve of a tree level leaves for the next runs of the same tree (LevelPlan::solve): the block pattern of S
+// with its hash index and the whole symbolic factorisation, in one device allocation of their own.
+struct SolvePlan {
+	SchurSystem sy; // index members only (S, E, IV are per run)
+	CholDev ch;     // index members + host vectors (L, Dinv, Gd, d_err are per run)
+	int its = 1;    // refinement steps the first run needed
+	char* mem = nullptr;
+	~SolvePlan() { if (mem) (void)hipFree(mem); }
+};
+static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSystem& sy, const CholDev& ch, int its)
+{
+	auto sp = std::make_shared<SolvePlan>();
+	const size_t M = sy.M, nnzb = sy.nnzb, cap = (size_t)sy.mask + 1;
+	struct Item { const void* src; size_t bytes; void** dst; };
+	SolvePlan& P = *sp;
+	P.sy = sy; P.ch = ch; P.its = its;
+	P.sy.S = nullptr; P.sy.E = nullptr; P.sy.IV = nullptr;
+	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr;
+	std::vector<Item> items = {
+		{ sy.rowptr, (M + 1) * 4, (void**)&P.sy.rowptr }, { sy.colidx, (nnzb + 1) * 4, (void**)&P.sy.colidx },
+		{ sy.upper_keys, nnzb * 8, (void**)&P.sy.upper_keys }, { sy.longrows, (M + 1) * 4, (void**)&P.sy.longrows },
+		{ sy.d_nlong, 4, (void**)&P.sy.d_nlong }, { sy.tab, cap * 8, (void**)&P.sy.tab }, { sy.hval, cap * 4, (void**)&P.sy.hval },
+		{ ch.blob, ch.blob_ints * 4, (void**)&P.ch.blob },
+	};
+	size_t total = 0;
+	for (const Item& it : items) total += (it.bytes + 255) & ~(size_t)255;
+	LSFM_CHECK_HIP(hipMalloc((void**)&P.mem, total + 256));
+	size_t off = 0;
+	for (const Item& it : items)
+	{
+		if (it.bytes) LSFM_CHECK_HIP(hipMemcpyAsync(P.mem + off, it.src, it.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+		*it.dst = P.mem + off;
+		off += (it.bytes + 255) & ~(size_t)255;
+	}
+	// the factorisation's index arrays are slices of the blob
+	const ptrdiff_t shift = (char*)P.ch.blob - (char*)ch.blob;
+	auto rebase = [&](int*& p) { if (p) p = (int*)((char*)p + shift); };
+	rebase(P.ch.colptr); rebase(P.ch.rowidx); rebase(P.ch.perm); rebase(P.ch.pinv); rebase(P.ch.order); rebase(P.ch.task_cols);
+	rebase(P.ch.task_ptr); rebase(P.ch.col_task); rebase(P.ch.col_lpos); rebase(P.ch.col_nin); rebase(P.ch.grp_c0); rebase(P.ch.grp_s);
+	rebase(P.ch.grp_nr);
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+	return sp;
 }
 
 static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHostIn& in, CholDev& ch)
@@ -816,6 +1194,38 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 			const int no = ccount[j] - 1 - m, l = tlev[task[j]];
 			ch.tlevel_outer[l] = std::max(ch.tlevel_outer[l], no * (no + 1) / 2);
 		}
+		// ---- supernode groups over the large columns (the factorisation above the leaf tasks) ----
+		{
+			std::vector<int> grp(M, -1), gc0, gs, glev;
+			for (int j = 0; j < M; j++)
+			{
+				if (size[j] <= task_x) continue;
+				const bool join = j > 0 && size[j - 1] > task_x && parent[j - 1] == j && ccount[j - 1] == ccount[j] + 1 && gs[grp[j - 1]] < CHOL_GS;
+				if (join) { grp[j] = grp[j - 1]; gs[grp[j]]++; }
+				else { grp[j] = (int)gc0.size(); gc0.push_back(j); gs.push_back(1); glev.push_back(0); }
+			}
+			const int ng = (int)gc0.size();
+			int ngl = 0;
+			for (int g = 0; g < ng; g++) // ascending first column: children before parents
+			{
+				const int pj = parent[gc0[g] + gs[g] - 1];
+				if (pj >= 0) glev[grp[pj]] = std::max(glev[grp[pj]], glev[g] + 1);
+				ngl = std::max(ngl, glev[g] + 1);
+			}
+			std::vector<int> gl_count(ngl + 1, 0), gfill(ngl, 0), o_c0(ng), o_s(ng), o_nr(ng);
+			for (int g = 0; g < ng; g++) gl_count[glev[g] + 1]++;
+			for (int l = 0; l < ngl; l++) gl_count[l + 1] += gl_count[l];
+			ch.glevel_maxnr.assign(ngl, 0);
+			for (int g = 0; g < ng; g++)
+			{
+				const int at = gl_count[glev[g]] + gfill[glev[g]]++;
+				o_c0[at] = gc0[g]; o_s[at] = gs[g]; o_nr[at] = ccount[gc0[g] + gs[g] - 1] - 1;
+				ch.glevel_maxnr[glev[g]] = std::max(ch.glevel_maxnr[glev[g]], o_nr[at]);
+			}
+			ch.ngroups = ng;
+			ch.glevel_ptr = gl_count;
+			pack(&ch.grp_c0, o_c0); pack(&ch.grp_s, o_s); pack(&ch.grp_nr, o_nr);
+		}
 		pack(&ch.col_nin, nin); pack(&ch.col_task, ctask); pack(&ch.col_lpos, clpos); pack(&ch.task_cols, tcols); pack(&ch.task_ptr, tptr);
 	}
 	pack(&ch.colptr, colptr); pack(&ch.rowidx, rowidx); pack(&ch.perm, perm); pack(&ch.pinv, pinv); pack(&ch.order, order);
@@ -823,11 +1233,11 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 		int* d_blob = sc.alloc<int>(blob.size());
 		h2d(ctx, d_blob, blob.data(), blob.size() * sizeof(int));
 		for (auto& pd : blob_dst) *pd.first = d_blob + pd.second;
+		ch.blob = d_blob; ch.blob_ints = blob.size();
 	}
-	ch.L = sc.alloc<double>((size_t)nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)M * 36);
+	chol_alloc_values(ctx, ch);
 	ch.d_err = sc.alloc<int>(1);
 	dev_zero(ctx, ch.d_err, sizeof(int));
-	dev_zero(ctx, ch.L, (size_t)nnzL * 36 * sizeof(double));
 }
 
 static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch)
@@ -836,8 +1246,10 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	if (sy.nnzb)
 		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, s, sy.nnzb, sy.upper_keys, sy.S, ch.pinv, ch.colptr, ch.rowidx,
 		                   fixed, ch.L);
+	static const bool groups = !getenv("LSFM_NO_GROUPS");
 	for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
 	{
+		if (groups && l > 0) break; // the chains above the leaf tasks go by supernode groups below
 		const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
 		if (!n) continue;
 		static const bool use_small = !getenv("LSFM_NO_SMALL_TASKS");
@@ -847,6 +1259,17 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
 		if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 	}
+	if (groups)
+		for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++)
+		{
+			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0, mnr = ch.glevel_maxnr[l];
+			if (!ng) continue;
+			hipLaunchKernelGGL(k_sn_panel, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+			                   ch.colptr, ch.L, ch.Dinv, ch.d_err, ch.Gd);
+			const long np = (long)mnr * (mnr + 1) / 2;
+			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_THREADS - 1) / SN_THREADS, 2048))), dim3(SN_THREADS), 0, s,
+			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Gd);
+		}
 }
 
 // z = (L L^T)^-1 r in the original numbering, rz_dot[seg] += r . z
@@ -1002,26 +1425,60 @@ __global__ void k_pcg_reset(int nseg, int cur, PcgSeg* seg)
 	g.pAp = 0; g.rr = 0; g.rz[cur] = 0; // rz[cur] is the accumulator of the next iteration
 }
 
+// per-system outcome of a level into the run's device accumulators (a warm level does not stop to read them)
+__global__ void k_pcg_run_stats(int nseg, const PcgSeg* __restrict__ seg, RunStatsDev* run)
+{
+	int g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= nseg || !seg[g].active) return;
+	const PcgSeg& fin = seg[nseg + g];
+	const double rel = fin.ee > 0 ? sqrt(fin.rr / fin.ee) : 0.0;
+	if (!(rel < 1e-8) || (seg[g].done != 1 && !(rel < 1e-9))) atomicAdd(&run->not_converged, 1);
+	// max of non-negative doubles = max of their bit patterns
+	atomicMax(reinterpret_cast<unsigned long long*>(&run->max_rel_residual), (unsigned long long)__double_as_longlong(rel == rel ? rel : 1e300));
+}
+__global__ void k_chol_err_to_run(const int* err, RunStatsDev* run)
+{
+	if (*err && !run->chol_err) run->chol_err = *err;
+}
+
 int solve_batch(lsfm_context* ctx, const SolveIO& io)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
 	const int M = io.M, nseg = io.nseg;
-	hipEvent_t ea = ctx->evs[0], eb = ctx->evs[1], ec = ctx->evs[2], ed = ctx->evs[3];
-	float ms = 0;
+	LevelPlan* lp = ctx->plan;
+	SolvePlan* sp = lp ? static_cast<SolvePlan*>(lp->solve.get()) : nullptr;
+	const bool warm = sp != nullptr; // pattern + symbolic factorisation known from an earlier run of the same tree level
+	hipEvent_t ea = ctx->pool_event(), eb = ctx->pool_event(), ec = ctx->pool_event(), ed = ctx->pool_event();
 	LSFM_CHECK_HIP(hipEventRecord(ea, s));
 	SchurSystem sy;
 	CholDev ch;
 	CholHostIn hin;
 	const bool dbg = getenv("LSFM_DEBUG") != nullptr;
 	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	// pattern -> (copy it to the host) -> numeric assembly K9 enqueued -> symbolic factorisation on the host while K9
-	// runs -> numeric factorisation
-	// The pattern depends on index arrays only.  When the caller marked the point of the main stream where those were
-	// complete (evA) and went on to enqueue its right-hand-side kernels, the pattern is built on the side stream next
-	// to them; the values wait for both.
+	double tw0 = 0, tw1 = 0;
+	int* d_err = nullptr;
+	if (warm)
 	{
+		ctx->pattern_dep = false;
+		sy = sp->sy;
+		ch = sp->ch;
+		schur_vinv(ctx, io, sy);
+		build_schur_values(ctx, io, sy);
+		LSFM_CHECK_HIP(hipEventRecord(eb, s));
+		chol_alloc_values(ctx, ch);
+		d_err = ch.d_err = sc.alloc<int>(1);
+		dev_zero(ctx, d_err, sizeof(int));
+	}
+	else
+	{
+		// pattern -> (copy it to the host) -> numeric assembly K9 enqueued -> symbolic factorisation on the host while K9
+		// runs -> numeric factorisation
+		// The pattern depends on index arrays only.  When the caller marked the point of the main stream where those were
+		// complete (evA) and went on to enqueue its right-hand-side kernels, the pattern is built on the side stream next
+		// to them; the values wait for both.
 		static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
+		schur_vinv(ctx, io, sy);
 		if (side && ctx->pattern_dep)
 		{
 			ctx->pattern_dep = false;
@@ -1043,13 +1500,13 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			build_schur_pattern(ctx, io, sy);
 			chol_fetch(ctx, sy, io.d_pose_origin, hin);
 		}
+		build_schur_values(ctx, io, sy);
+		LSFM_CHECK_HIP(hipEventRecord(eb, s));
+		tw0 = wall();
+		chol_analyse(ctx, sy, hin, ch);
+		tw1 = wall();
+		d_err = ch.d_err;
 	}
-	build_schur_values(ctx, io, sy);
-	LSFM_CHECK_HIP(hipEventRecord(eb, s));
-	double tw0 = wall();
-	chol_analyse(ctx, sy, hin, ch);
-	double tw1 = wall();
-	schur_values_stats(ctx, io, sy);
 	chol_factor(ctx, sy, io.d_fixed, ch);
 	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
 	double tw2 = wall();
@@ -1080,12 +1537,21 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipLaunchKernelGGL(k_copy, dim3(nbe), dim3(256), 0, s, nscal, z, p);
 	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
 	dev_zero(ctx, Ap, nscal * sizeof(double));
-	int cerr = d2h_int(ctx, ch.d_err);
-	if (cerr) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
+	if (warm) hipLaunchKernelGGL(k_chol_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run); // reported at the end of the run
+	else
+	{
+		int cerr = d2h_int(ctx, d_err);
+		if (cerr) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
+	}
 
+	// One refinement step: x += alpha p, true residual, convergence test per system (converged systems freeze), then the
+	// preconditioner for the next step.  A first run reads the number of finished systems back after every step; a warm
+	// run enqueues the steps the first run needed -- the device-side tests still freeze what is done, and whether every
+	// system ended below its bound is read once at the end of the whole run.
 	const int maxit = 50;
-	int its = 0, ndone = d2h_int(ctx, d_misc + 1);
-	while (ndone < nseg && its < maxit)
+	int its = 0, ndone = warm ? 0 : d2h_int(ctx, d_misc + 1);
+	const int planned = warm ? sp->its : maxit;
+	while ((warm ? its < planned : (ndone < nseg && its < maxit)))
 	{
 		const int cur = its & 1;
 		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
@@ -1095,8 +1561,12 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		// the test comes before the preconditioner: the apply for a residual that already passed would be wasted
 		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, seg, d_misc + 1);
 		its++;
-		ndone = d2h_int(ctx, d_misc + 1);
-		if (ndone >= nseg) break;
+		if (warm) { if (its >= planned) break; }
+		else
+		{
+			ndone = d2h_int(ctx, d_misc + 1);
+			if (ndone >= nseg) break;
+		}
 		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
 		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);
 		hipLaunchKernelGGL(k_pcg_reset, dim3(nbs), dim3(128), 0, s, nseg, cur, seg);
@@ -1104,26 +1574,42 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	if (dbg)
 	{
 		LSFM_CHECK_HIP(hipStreamSynchronize(s));
-		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d task levels=%d | analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
-		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, (int)ch.tlevel_ptr.size() - 1, tw1 - tw0, tw2 - tw1, its, wall() - tw2);
+		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d task levels=%d group levels=%d %s| analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
+		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, (int)ch.tlevel_ptr.size() - 1, (int)ch.glevel_ptr.size() - 1, warm ? "(plan) " : "", tw1 - tw0, tw2 - tw1, its, wall() - tw2);
 	}
 	// ---- true residual, statistics; one SpMV launch timed with HIP events on this stream.  Nothing here waits for
-	// the device before the back-substitution is enqueued: the per-system sums come back in one copy at the end ----
+	// the device before the back-substitution is enqueued ----
 	const int nsample = 1;
-	float sp_ms = 0;
 	PcgSeg* seg2 = seg + nseg; // zeroed accumulators of the final residual
 	dev_zero(ctx, Ap, nscal * sizeof(double));
-	LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
+	hipEvent_t es0 = ctx->pool_event(), es1 = ctx->pool_event();
+	LSFM_CHECK_HIP(hipEventRecord(es0, s));
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
-	LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+	LSFM_CHECK_HIP(hipEventRecord(es1, s));
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg2, 1);
 	LSFM_CHECK_HIP(hipEventRecord(ec, s));
 	launch_backsub(ctx, io, sy, x);
 	LSFM_CHECK_HIP(hipGetLastError());
 	LSFM_CHECK_HIP(hipEventRecord(ed, s));
+	if (ctx->stats)
+	{
+		lsfm_stats* st = ctx->stats;
+		ctx->defer_time(ea, eb, &st->t_schur_ms);
+		ctx->defer_time(eb, ec, &st->t_pcg_ms);
+		ctx->defer_time(ec, ed, &st->t_backsub_ms);
+		ctx->defer_time(es0, es1, &st->spmv_ms);
+		st->pcg_iterations += its;
+		st->spmv_launches += nsample;
+		st->spmv_bytes += nsample * spmv_bytes(sy);
+		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
+	}
+	if (warm)
+	{
+		hipLaunchKernelGGL(k_pcg_run_stats, dim3(nbs), dim3(128), 0, s, nseg, seg, ctx->d_run);
+		return 0; // the outcome is read at the end of the run (lsfm_tree_run)
+	}
 	std::vector<PcgSeg> hs2(2 * (size_t)nseg);
 	d2h(ctx, hs2.data(), seg, sizeof(PcgSeg) * 2 * nseg); // synchronises
-	LSFM_CHECK_HIP(hipEventElapsedTime(&sp_ms, ctx->ev0, ctx->ev1));
 	int notconv = 0;
 	double maxrel = 0;
 	for (int g = 0; g < nseg; g++)
@@ -1135,19 +1621,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		// converged = stopped by the tolerance, or stopped by stagnation with a residual a direct solve would also leave
 		if (!(rel < 1e-8) || (hs2[g].done != 1 && !(rel < 1e-9))) notconv++;
 	}
-	if (ctx->stats)
-	{
-		lsfm_stats* st = ctx->stats;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); st->t_schur_ms += ms;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, eb, ec)); st->t_pcg_ms += ms;
-		LSFM_CHECK_HIP(hipEventElapsedTime(&ms, ec, ed)); st->t_backsub_ms += ms;
-		st->pcg_iterations += its;
-		st->spmv_launches += nsample;
-		st->spmv_ms += sp_ms;
-		st->spmv_bytes += nsample * spmv_bytes(sy);
-		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
-		st->max_rel_residual = std::max(st->max_rel_residual, maxrel);
-	}
+	if (ctx->stats) ctx->stats->max_rel_residual = std::max(ctx->stats->max_rel_residual, maxrel);
+	// what depends on the structure only stays with the tree level for its next runs
+	if (lp && !lp->solve && notconv == 0) lp->solve = solve_plan_store(ctx, sy, ch, std::max(its, 1));
 	return notconv;
 }
 

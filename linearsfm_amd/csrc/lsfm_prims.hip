@@ -109,6 +109,28 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 
 } // namespace lsfm
 
+hipEvent_t lsfm_context::pool_event()
+{
+	if (ev_next == ev_pool.size())
+	{
+		hipEvent_t e = nullptr;
+		LSFM_CHECK_HIP(hipEventCreate(&e));
+		ev_pool.push_back(e);
+	}
+	return ev_pool[ev_next++];
+}
+void lsfm_context::flush_times()
+{
+	for (const Timed& t : timed)
+	{
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && t.sink) *t.sink += ms;
+	}
+	timed.clear();
+	ev_next = 0;
+	(void)hipGetLastError();
+}
+
 void lsfm_context::ensure_arenas(size_t bytes_each)
 {
 	generation++; // every caller is about to reset the arenas
@@ -152,13 +174,15 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
-		c->stage_size = (size_t)16 << 20;
+		c->stage_size = (size_t)64 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev0));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev1));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev2));
 		LSFM_CHECK_HIP(hipEventCreate(&c->ev3));
 		for (auto& e : c->evs) LSFM_CHECK_HIP(hipEventCreate(&e));
+		LSFM_CHECK_HIP(hipMalloc((void**)&c->d_run, sizeof(lsfm::RunStatsDev)));
+		LSFM_CHECK_HIP(hipMemset(c->d_run, 0, sizeof(lsfm::RunStatsDev)));
 		if (arena_bytes) c->ensure_arenas(arena_bytes);
 	}
 	catch (const lsfm::Error& e)
@@ -185,6 +209,8 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
 	if (c->ev3) (void)hipEventDestroy(c->ev3);
 	for (auto& e : c->evs) if (e) (void)hipEventDestroy(e);
+	for (auto& e : c->ev_pool) if (e) (void)hipEventDestroy(e);
+	if (c->d_run) (void)hipFree(c->d_run);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->evA) (void)hipEventDestroy(c->evA);

@@ -21,8 +21,8 @@ namespace lsfm {
 #define PM_PASS 16
 #define PM_K (3 * PM_PASS)
 #define PM_KS (PM_K + 1) /* odd row stride: the 16 rows x 2 k of a half-wave fall into distinct LDS banks */
-#define PM_SMAX 32
-#define PM_ROWS (6 * PM_SMAX)
+#define PM_SMAX 32      /* slots of the common variant: 256 threads, two work-groups per CU */
+#define PM_SMAX_BIG 48  /* slots of the variant for the tiles that exceed it: 1024 threads (16 waves share the 171 output tiles) */
 #define PM_HASH 64
 #define PM_THREADS 256
 #define PM_MAXE 4096 /* W blocks of the tile whose slot is kept in LDS (one byte each); later ones probe the hash again */
@@ -49,22 +49,23 @@ __device__ __forceinline__ int pn_hash_find(const unsigned long long* __restrict
 	return -1;
 }
 
+template <int SMAX>
 struct PmShared {
 	int hkey[PM_HASH];
 	int hslot[PM_HASH];
-	int pose_of[PM_SMAX];
+	int pose_of[SMAX];
 	int nslots, bad;
 	int fp[PM_PASS + 1];
 	double Ls[PM_PASS * 6]; // l00 l10 l11 l20 l21 l22 of V^-1 = L L^T
 	double ys[PM_K];        // L^T eb
-	double P[PM_ROWS * PM_KS];
+	double P[6 * SMAX * PM_KS];
 	unsigned char eslot[PM_MAXE]; // slot of the tile's W blocks, filled once: the passes do not touch photo[] again
 };
 
-// T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + 4 t; slots past the last
-// tile recompute tile (0,0) and are dropped)
-template <int T>
-__device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
+// T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + NW t over its NW waves; slots
+// past the last tile recompute tile (0,0) and are dropped)
+template <int T, int SMAX, int THREADS>
+__device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                         const double* __restrict__ W, const double* __restrict__ IV, const double* __restrict__ eb,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
@@ -77,7 +78,7 @@ __device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, in
 #pragma unroll
 	for (int t = 0; t < T; t++)
 	{
-		const int q = wave + 4 * t;
+		const int q = wave + (THREADS / 64) * t;
 		int i = 0, j = 0;
 		if (q < ntile)
 		{
@@ -123,7 +124,7 @@ __device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, in
 	{
 		const int nf = min(PM_PASS, f1 - p0);
 		__syncthreads(); // the previous pass is fully consumed
-		for (int q = tid; q < NT * 16 * PM_KS; q += PM_THREADS) sh.P[q] = 0.0;
+		for (int q = tid; q < NT * 16 * PM_KS; q += THREADS) sh.P[q] = 0.0;
 		if (tid <= nf) sh.fp[tid] = fptr[p0 + tid];
 		if (tid < PM_PASS)
 		{
@@ -215,7 +216,7 @@ __device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, in
 	}
 	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair, in the (now free) panel ----
 	int* pslot = reinterpret_cast<int*>(sh.P);
-	for (int q = tid; q < ns * ns; q += PM_THREADS)
+	for (int q = tid; q < ns * ns; q += THREADS)
 	{
 		const int si = q / ns, sj = q - si * ns;
 		pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
@@ -257,12 +258,16 @@ __device__ __forceinline__ void pm_body(PmShared& sh, int ns, int f0, int f1, in
 	if (tid < rows && eacc != 0.0) atomic_add_f64(E + (size_t)sh.pose_of[tid / 6] * 6 + tid % 6, eacc);
 }
 
-__global__ void __launch_bounds__(PM_THREADS, 2)
+// `only` == nullptr: every tile; tiles with more than SMAX poses are flagged in `fallback`.  `only` != nullptr (the second
+// pass with the larger variant): just the flagged tiles; a tile it can take is un-flagged, the rest stays for k_schur_w.
+template <int SMAX, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 2 : 1)
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
               const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-              double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
+              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only)
 {
-	__shared__ PmShared sh;
+	if (only && !only[blockIdx.x]) return;
+	__shared__ PmShared<SMAX> sh;
 	const int tid = threadIdx.x;
 	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
 	const int jb = fptr[f0], je = fptr[f1];
@@ -270,11 +275,12 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 	if (tid == 0) { sh.nslots = 0; sh.bad = 0; }
 	__syncthreads();
 	// ---- the tile's poses -> slots ----
-	for (int j = jb + tid; j < je; j += PM_THREADS)
+	for (int j = jb + tid; j < je; j += THREADS)
 	{
 		const int key = photo[j];
 		unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-		for (int probe = 0; probe < PM_HASH; probe++)
+		int probe = 0;
+		for (; probe < PM_HASH; probe++)
 		{
 			const int cur = sh.hkey[h];
 			if (cur == key) break;
@@ -285,6 +291,7 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			}
 			h = (h + 1) & (PM_HASH - 1);
 		}
+		if (probe == PM_HASH) sh.bad = 2; // table full: more than PM_HASH distinct poses
 		if (j - jb < PM_MAXE) sh.eslot[j - jb] = (unsigned char)h; // table position now, slot number once slots are dealt
 	}
 	__syncthreads();
@@ -292,26 +299,36 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 	{
 		const int id = atomicAdd(&sh.nslots, 1);
 		sh.hslot[tid] = id;
-		if (id < PM_SMAX) sh.pose_of[id] = sh.hkey[tid];
+		if (id < SMAX) sh.pose_of[id] = sh.hkey[tid];
 	}
 	__syncthreads();
 	const int ns = sh.nslots;
-	if (ns > PM_SMAX)
+	if (ns > SMAX || sh.bad == 2)
 	{
-		// more than PM_HASH distinct poses also ends here: the table is then full, nslots = PM_HASH > PM_SMAX
 		if (tid == 0) fallback[blockIdx.x] = 1;
 		return;
 	}
-	for (int e = tid; e < je - jb && e < PM_MAXE; e += PM_THREADS) sh.eslot[e] = (unsigned char)sh.hslot[sh.eslot[e]];
+	if (only && tid == 0) fallback[blockIdx.x] = 0; // taken here (pm_body flags it again if a V^-1 has no Cholesky factor)
+	for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = (unsigned char)sh.hslot[sh.eslot[e]];
 	// (visible to the passes through the barrier at the top of the first pass)
-	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + 3) >> 2; // tiles per wave, uniform
-#define PM_GO(T) pm_body<T>(sh, ns, f0, f1, jb, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
-	if (tpw <= 1) PM_GO(1);
-	else if (tpw <= 3) PM_GO(3);
-	else if (tpw <= 6) PM_GO(6);
-	else if (tpw <= 9) PM_GO(9);
-	else if (tpw <= 14) PM_GO(14);
-	else PM_GO(20);
+	constexpr int NW = THREADS / 64;
+	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
+#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
+	if (THREADS == 256)
+	{
+		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 3) PM_GO(3);
+		else if (tpw <= 6) PM_GO(6);
+		else if (tpw <= 9) PM_GO(9);
+		else if (tpw <= 14) PM_GO(14);
+		else PM_GO(20);
+	}
+	else
+	{
+		if (tpw <= 6) PM_GO(6);
+		else if (tpw <= 9) PM_GO(9);
+		else PM_GO(11);
+	}
 #undef PM_GO
 }
 
@@ -320,9 +337,13 @@ int schur_panel_tile() { return PM_TILE; }
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback)
 {
-	if (NF)
-		hipLaunchKernelGGL(k_schur_panel, dim3((NF + PM_TILE - 1) / PM_TILE), dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val,
-		                   mask, S, E, fallback);
+	if (!NF) return;
+	const dim3 grid((NF + PM_TILE - 1) / PM_TILE);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E,
+	                   fallback, (const unsigned char*)nullptr);
+	// the tiles that exceed 32 poses (a path that revisits: the frames of two laps + the hub poses of every level)
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback,
+	                   (const unsigned char*)fallback);
 }
 
 } // namespace lsfm

@@ -471,6 +471,13 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 	sy.d_nlong = nl;
 }
 
+// K7: V^-1 of every feature (values: once per run)
+void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+{
+	sy.IV = ctx->scratch.alloc<double>((size_t)io.NF * 9);
+	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, sy.IV);
+}
+
 // Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
@@ -478,8 +485,6 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	Arena& sc = ctx->scratch;
 	const int M = io.M, NF = io.NF;
 	sy.M = M;
-	sy.IV = sc.alloc<double>((size_t)NF * 9);
-	if (NF) hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.V, sy.IV);
 	int* d_flags = sc.alloc<int>(4); // [0] overflow, [1] count, [2] mirrored count
 	size_t cap = 1024;
 	// S has little more than U's pattern (the W-induced pairs are mostly hub links that U already holds): 4x head room over
@@ -541,25 +546,21 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev2, s));
+		hipEvent_t e2 = nullptr, e3 = nullptr;
+		if (ctx->stats) { e2 = ctx->pool_event(); e3 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(e2, s)); }
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
 		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev3, s));
+		if (ctx->stats)
+		{
+			LSFM_CHECK_HIP(hipEventRecord(e3, s));
+			ctx->defer_time(e2, e3, &ctx->stats->schur_ms);
+			ctx->stats->schur_launches++;
+			// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
+			ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)io.NF * (72 + 24 + 4) + (double)sy.nnzb * 288 + (double)io.M * 48;
+		}
 	}
 	LSFM_CHECK_HIP(hipGetLastError());
-}
-
-void schur_values_stats(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy)
-{
-	if (!ctx->stats || !io.NF) return;
-	float t = 0;
-	LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev3));
-	LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev2, ctx->ev3));
-	ctx->stats->schur_launches++;
-	ctx->stats->schur_ms += t;
-	// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
-	ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)io.NF * (72 + 24 + 4) + (double)sy.nnzb * 288 + (double)io.M * 48;
 }
 
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,

@@ -20,7 +20,7 @@ struct SchurSystem {
 
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
-void schur_values_stats(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy);
+void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int nmir = -1);
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed, const double* dotw,
                  const int* pose_seg, double* dot, int dot_stride);

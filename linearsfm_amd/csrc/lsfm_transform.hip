@@ -814,21 +814,19 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		TrRedirect rd;
 		if (hook) rd = (*hook)(out);
 		if (!rd.W) { rd = TrRedirect(); rd.wbase = out.fptr; rd.W = out.W; rd.photo = out.photo; rd.feature = out.feature; }
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s)); // the events bracket k_tr_entries alone
+		hipEvent_t e0 = nullptr, e1 = nullptr; // the events bracket k_tr_entries alone; read at the end of the run
+		if (ctx->stats) { e0 = ctx->pool_event(); e1 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(e0, s)); }
 		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, finfo, in.fptr, in.W,
 		                   in.photo, KW, Dp, Cp, FD, rd.W, rd.photo, rd.feature, Gsum, Gpose, hubJ, out.W_alias ? 1 : 0, rd.wbase, rd.newf, rd.srcf);
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(e1, s));
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s)); // pose rows of G complete: the U stage may start on the side stream
 		ev_entries = true;
 		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,
 		                   Dp, FD, Gsum, hubJ, rd.wbase, rd.newf, rd.srcf, rd.W, rd.photo, rd.feature, PP);
 		if (ctx->stats)
 		{
-			float t = 0;
-			LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
-			LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+			ctx->defer_time(e0, e1, &ctx->stats->trf_ms);
 			ctx->stats->trf_launches++;
-			ctx->stats->trf_ms += t;
 			// k_tr_entries, every input and output once.  Blocks of transformed maps: W block + photo + kept-rank in, W' block
 			// + photo' + feature' out (the blocks to the hub poses are not written here); per feature of a transformed map
 			// D_f/C_f + record + run pointer in, the W^T C sums out.  Blocks of pass-through maps: photo in, photo' + feature'
@@ -858,6 +856,19 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 }
 
 __global__ void k_set_last(int* p, int idx, int v) { p[idx] = v; }
+// the output offsets of every map (known to the host once the kept-block counts are) into the device copy of the map records,
+// which keeps what the device computed (hub indices, parameters)
+__global__ void k_tr_patch(TMap* tm, const int4* __restrict__ offs, int B)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= B) return;
+	const int4 o = offs[b];
+	tm[b].kU0 = o.x; tm[b].kW0 = o.y; tm[b].U0n = o.z; tm[b].W0n = o.w;
+}
+__global__ void k_tr_err_to_run(const int* err, RunStatsDev* run)
+{
+	if (*err && !run->tr_err) run->tr_err = *err;
+}
 
 void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
                      const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out,
@@ -940,11 +951,19 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	int* d_cnt = ctx->scratch.alloc<int>(2 * (B + 1));
 	h2d(ctx, d_uoff, in.u_off.data(), (B + 1) * sizeof(int));
 	h2d(ctx, d_woff, in.w_off.data(), (B + 1) * sizeof(int));
-	hipLaunchKernelGGL(k_tr_gather_counts, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, d_uoff, d_woff, B, d_cnt);
+	LevelPlan* plan = ctx->plan;
+	const bool warm = ctx->warm();
 	std::vector<int> cnt(2 * (B + 1));
-	d2h_ints(ctx, d_cnt, cnt.data(), cnt.size());
-	int err = d2h_int(ctx, d_err);
-	if (err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(err - 1));
+	if (warm) cnt = plan->tr_cnt; // the structure of this level is known from an earlier run of the same tree: no round trip
+	else
+	{
+		hipLaunchKernelGGL(k_tr_gather_counts, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, d_uoff, d_woff, B, d_cnt);
+		d2h_ints(ctx, d_cnt, cnt.data(), cnt.size());
+		int err = d2h_int(ctx, d_err);
+		if (err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(err - 1));
+		if (plan) plan->tr_cnt = cnt;
+	}
+	if (warm && ctx->d_run) hipLaunchKernelGGL(k_tr_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run);
 	out.u_off.assign(B + 1, 0); out.w_off.assign(B + 1, 0);
 	for (int b = 0; b < B; b++)
 	{
@@ -972,16 +991,25 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		out.d_alias = d_alias;
 		out.W_alias = in.W;
 	}
-	// second upload keeps what the device computed (hub indices, parameters): patch only the offset fields
+	// the offsets go into the device copy of the map records (a kernel: the copy keeps what the device computed)
 	{
-		std::vector<TMap> dev(B);
-		d2h(ctx, dev.data(), d_tm, sizeof(TMap) * B);
-		for (int b = 0; b < B; b++)
+		std::vector<int4> offs(B);
+		for (int b = 0; b < B; b++) offs[b] = make_int4(tm[b].kU0, tm[b].kW0, tm[b].U0n, tm[b].W0n);
+		int4* d_offs = ctx->scratch.alloc<int4>(B);
+		h2d(ctx, d_offs, offs.data(), sizeof(int4) * B);
+		hipLaunchKernelGGL(k_tr_patch, dim3((B + 127) / 128), dim3(128), 0, s, d_tm, d_offs, B);
+	}
+	if (mono)
+	{
+		// Imp.cpp:3241-3244: the sign of the new scale is part of the map record the caller keeps
+		if (warm) { for (int b = 0; b < B; b++) if (tm[b].active) out.Sign[b] = plan->tr_sign[b]; }
+		else
 		{
-			dev[b].kU0 = tm[b].kU0; dev[b].kW0 = tm[b].kW0; dev[b].U0n = tm[b].U0n; dev[b].W0n = tm[b].W0n;
-			if (mono && dev[b].active > 0) out.Sign[b] = dev[b].sign1; // Imp.cpp:3241-3244
+			std::vector<TMap> dev(B);
+			d2h(ctx, dev.data(), d_tm, sizeof(TMap) * B);
+			for (int b = 0; b < B; b++) if (dev[b].active > 0) out.Sign[b] = dev[b].sign1;
+			if (plan) plan->tr_sign = out.Sign;
 		}
-		h2d(ctx, d_tm, dev.data(), sizeof(TMap) * B);
 	}
 	out.U = ar.alloc<double>((size_t)out.NU * 36); out.Ui = ar.alloc<int>(out.NU); out.Uj = ar.alloc<int>(out.NU);
 	if (!hook) { out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW); }
@@ -998,8 +1026,9 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act, hook);
 	LSFM_CHECK_HIP(hipGetLastError());
 	(void)any;
-	// scratch is released by the caller's next stage only after these launches are ordered on the stream
-	LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	// Scratch is released for the caller's next stage: everything that touches it is ordered on the main stream (the side
+	// stream's part rejoins it through evB above).  A first run also stops here so that a failure surfaces at its stage.
+	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s));
 	if (!hook) ctx->scratch.release(smark); // with a hook its allocations outlive this call: the caller releases
 }
 

@@ -280,6 +280,97 @@ def test_subtree_sharding_on_device_equals_single_tree(ctx, mono):
     assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-8
 
 
+@pytest.mark.parametrize("mono", [False, True])
+def test_repeated_runs_of_a_resident_tree(ctx, mono):
+    """lsfm_tree_run on the same upload: the first run analyses every level (container sizes, pattern of S, symbolic
+    factorisation) and leaves that with the tree; the next runs reuse it and are enqueued without host round trips; with
+    plans switched off every run analyses again.  All three give the same map (summation order of atomics aside)."""
+    from linearsfm_amd import api
+    maps = synth.make_mono_set(90, 20, 4, seed=21, **synth.SPIRAL) if mono else synth.make_stereo_set(300, 20, 5, seed=21, lap=50)
+    t = ctx.tree_upload(maps, mono)
+    try:
+        s1, rc1 = ctx.tree_run(t)
+        a = ctx.tree_download(t)
+        s2, rc2 = ctx.tree_run(t)
+        b = ctx.tree_download(t)
+        s3, rc3 = ctx.tree_run(t)
+        c = ctx.tree_download(t)
+        ctx.tree_set_plans(t, False)
+        s4, rc4 = ctx.tree_run(t)
+        d = ctx.tree_download(t)
+    finally:
+        ctx.tree_free(t)
+    assert rc1 == rc2 == rc3 == rc4 == 0
+    for s in (s1, s2, s3, s4):
+        assert s["not_converged"] == 0 and s["max_rel_residual"] < 1e-9, s
+    for other in (b, c, d):
+        assert np.array_equal(other["stno"], a["stno"])
+        for k in ("Ui", "Uj", "photo", "feature"):
+            assert np.array_equal(other[k], a[k]), k
+        assert pose_param_err(other["stVal"], a["stVal"], a["stno"]) < 1e-9
+        assert feat_param_err(other["stVal"], a["stVal"], a["stno"]) < 1e-9
+        for k in ("U", "W", "V"):
+            assert rel_err(other[k], a[k]) < 1e-7, k  # atomics: the summation order differs from run to run
+
+
+def test_a_result_overwritten_by_a_later_call_is_refused(ctx):
+    """A finished tree's map lives in the context's arenas: after any other compute call on the context a download must
+    fail with a message instead of handing back overwritten memory; running the tree again makes it available again."""
+    from linearsfm_amd import api
+    maps = synth.make_stereo_set(6, 5, 4, seed=2)
+    t = ctx.tree_upload(maps, False)
+    try:
+        ctx.tree_run(t)
+        ctx.transform(maps[0].__dict__, False, maps[0].Ref + 1)  # another call on the same context
+        with pytest.raises(api.LsfmError, match="overwritten"):
+            ctx.tree_download(t)
+        assert ctx.tree_export_size(t) == 0
+        ctx.tree_run(t)
+        out = ctx.tree_download(t)
+        assert int(out["m"]) == 6
+    finally:
+        ctx.tree_free(t)
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_device_resident_handoff_of_subtree_roots(ctx, mono):
+    """lsfm_tree_export_dev / lsfm_tree_upload_dev: two sub-trees, their roots packed into device buffers (torch tensors, as
+    the multi-GPU scheduler holds them), a third tree built from the two buffers without a host copy of the arrays --
+    equal to the single tree over all maps."""
+    import torch
+    from linearsfm_amd.distributed import shard_bounds
+    N = 24
+    maps = synth.make_mono_set(N, 8, 4, seed=33, **synth.SPIRAL) if mono else synth.make_stereo_set(N, 6, 5, seed=33, lap=10, home=3)
+    dicts = [dict(m.__dict__) for m in maps]
+    single, _, rc = ctx.divide_conquer(dicts, mono)
+    assert rc == 0
+    _, bounds = shard_bounds(N, 2)
+    bufs = []
+    for r, (lo, hi) in enumerate(bounds):
+        part = [dict(d, pose_origin=np.full(int(d["m"]), lo + k, np.int32)) for k, d in enumerate(dicts[lo:hi])]
+        t = ctx.tree_upload(part, mono)
+        ctx.tree_set_final_reanchor(t, r % 2 == 1)
+        _, rc = ctx.tree_run(t)
+        assert rc == 0
+        nbytes = ctx.tree_export_size(t)
+        assert nbytes > 256
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+        ctx.tree_export_dev(t, buf.data_ptr(), nbytes)
+        ctx.tree_free(t)
+        bufs.append(buf)
+    torch.cuda.synchronize()
+    t = ctx.tree_upload_dev([b.data_ptr() for b in bufs], mono)
+    _, rc = ctx.tree_run(t)
+    merged = ctx.tree_download(t)
+    ctx.tree_free(t)
+    assert rc == 0
+    assert np.array_equal(merged["stno"], single["stno"])
+    for k in ("Ui", "Uj", "photo", "feature"):
+        assert np.array_equal(merged[k], single[k]), k
+    assert pose_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-9
+    assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-9
+
+
 @pytest.mark.parametrize("m,band,hubs", [(700, 3, 2), (700, 80, 5), (300, 299, 0), (64, 1, 1), (1, 0, 0)])
 def test_spmv_long_rows_and_wide_bands(ctx, m, band, hubs):
     """k_spmv paths: hub rows longer than a tile's budget (taken by the tiles that own their columns), bands wider than

@@ -164,6 +164,10 @@ size_t lsfm_tree_export_size(lsfm_context* ctx, lsfm_tree* tree);
 int lsfm_tree_export_dev(lsfm_context* ctx, lsfm_tree* tree, void* dst, size_t cap);
 size_t lsfm_packed_size(const void* host_header128);
 int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, int mono, lsfm_tree** out);
+/* new VALUES for the resident inputs of a tree made by lsfm_tree_upload_dev: N packed maps with the same sizes (and, by
+ * contract, the same labels and index arrays) as the ones it was built from -- the next step of a scheduler that joins
+ * the same sub-tree roots again.  Keeps the tree's allocations and its plans (lsfm_tree_set_plans). */
+int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* tree, const void* const* packed, int N);
 
 /* convenience: upload + run + download */
 int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_map* out, lsfm_stats* stats);

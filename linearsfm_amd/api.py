@@ -81,6 +81,7 @@ def lib():
         L.lsfm_packed_size.argtypes = [vp]
         L.lsfm_packed_size.restype = C.c_size_t
         L.lsfm_tree_upload_dev.argtypes = [vp, P(vp), C.c_int, C.c_int, P(vp)]
+        L.lsfm_tree_reload_dev.argtypes = [vp, vp, P(vp), C.c_int]
         L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
         L.lsfm_tree_free.argtypes = [vp, vp]
         L.lsfm_tree_free.restype = None
@@ -99,7 +100,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
-           "lsfm_tree_upload_dev",
+           "lsfm_tree_upload_dev", "lsfm_tree_reload_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench"]
 
@@ -189,6 +190,11 @@ class Context:
 
     def stream(self):
         return lib().lsfm_stream(self._h)
+
+    def tree_reload_dev(self, tree, dev_ptrs):
+        """New values (same structure) for the resident inputs of a tree made by tree_upload_dev; plans are kept."""
+        arr = (C.c_void_p * len(dev_ptrs))(*[C.c_void_p(int(p)) for p in dev_ptrs])
+        self._check(lib().lsfm_tree_reload_dev(self._h, tree, arr, len(dev_ptrs)), "lsfm_tree_reload_dev")
 
     # ---- the reference's three scheduler-facing methods -------------------------------------------------
     def transform(self, d, mono, Ref, ScaP=0, Fix=0):

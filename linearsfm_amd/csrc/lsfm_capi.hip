@@ -343,6 +343,34 @@ int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, in
 	});
 }
 
+int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* t, const void* const* packed, int N)
+{
+	if (!t || !packed || N != t->N) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		std::vector<PackHeader> hdr(N);
+		for (int k = 0; k < N; k++)
+		{
+			if (!packed[k]) LSFM_FAIL(LSFM_ERR_ARG, "null packed map");
+			LSFM_CHECK_HIP(hipMemcpyAsync(&hdr[k], packed[k], sizeof(PackHeader), hipMemcpyDeviceToHost, ctx->stream));
+		}
+		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		const DevBatch& b = t->input;
+		for (int k = 0; k < N; k++)
+		{
+			const PackHeader& h = hdr[k];
+			if (lsfm_packed_size(&h) == 0 || (h.mono != 0) != t->mono || h.m != b.pose_off[k + 1] - b.pose_off[k] || h.n != b.feat_off[k + 1] - b.feat_off[k] ||
+			    h.nU != b.u_off[k + 1] - b.u_off[k] || h.nW != b.w_off[k + 1] - b.w_off[k])
+				LSFM_FAIL(LSFM_ERR_ARG, "packed map " + std::to_string(k) + " does not have the sizes of the tree's resident map (reload keeps the structure)");
+		}
+		ctx->generation++;
+		t->done = false;
+		t->input_arena.reset(); // same sizes, same order: every array lands where it was
+		batch_unpack_maps(ctx, t->input_arena, packed, hdr.data(), N, t->mono, t->input);
+		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		return LSFM_OK;
+	});
+}
+
 int lsfm_tree_set_final_reanchor(lsfm_tree* t, int on)
 {
 	if (!t) return LSFM_ERR_ARG;

@@ -179,15 +179,16 @@ def _rel_pose(pos, Rw, k, j):
 # Stereo
 # ----------------------------------------------------------------------------------------------
 def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_id=1, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0),
-                    turn=GOLDEN_ANGLE):
+                    turn=GOLDEN_ANGLE, only=None):
     """n_maps Stereo local maps over n_maps+1 frames (ids first_id..).  ~new_per_frame*(vis-1) features per map.
-    lap/home/revisit: see _world (lap = 0: open path)."""
+    lap/home/revisit: see _world (lap = 0: open path).  only = (lo, hi): just the maps lo..hi-1 of the set (each map draws
+    its noise from its own generator, so a slice equals the corresponding part of the whole set)."""
     n_frames = n_maps + 1
     pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn)
-    rng3 = np.random.default_rng(seed + 3)
     sinv = np.diag(1.0 / np.array([0.01, 0.01, 0.03]) ** 2)
     maps = []
-    for k in range(n_maps):
+    for k in range(*(only or (0, n_maps))):
+        rng3 = np.random.default_rng([seed + 3, k])
         # points visible in frame k and k+1
         sel = _visible(starts, starts2, vis, k, k + 1)
         n = sel.shape[0]
@@ -221,15 +222,15 @@ def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_
 # Mono
 # ----------------------------------------------------------------------------------------------
 def make_mono_set(n_maps, new_per_frame=300, vis=4, seed=0, noise=1e-3, first_id=1, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0),
-                  turn=GOLDEN_ANGLE):
+                  turn=GOLDEN_ANGLE, only=None):
     """n_maps Mono local maps over n_maps+2 frames; map k = frames k,k+1,k+2 (Ref=k, ScaP=k+1).
-    lap/home/revisit: see _world (lap = 0: open path)."""
+    lap/home/revisit: see _world (lap = 0: open path); only = (lo, hi): just that slice of the set."""
     n_frames = n_maps + 2
     pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn)
-    rng3 = np.random.default_rng(seed + 3)
     w = 1.0 / (1e-3) ** 2
     maps = []
-    for k in range(n_maps):
+    for k in range(*(only or (0, n_maps))):
+        rng3 = np.random.default_rng([seed + 3, k])
         sel = _visible(starts, starts2, vis, k, k + 2)
         n = sel.shape[0]
         t1, R1 = _rel_pose(pos, Rw, k, k + 1)
@@ -363,8 +364,9 @@ CONFIGS = {
 }
 
 
-def make_config(name, n_maps=None, seed=0, new_per_frame=None, vis=None, path=None):
-    """The named stand-in set (optionally shortened / thinned): returns (type, list of LocalMap)."""
+def make_config(name, n_maps=None, seed=0, new_per_frame=None, vis=None, path=None, only=None):
+    """The named stand-in set (optionally shortened / thinned, or just the slice `only` = (lo, hi) of it): returns
+    (type, list of LocalMap)."""
     typ, N, npf, cvis, cpath = CONFIGS[name]
     gen = make_stereo_set if typ == "Stereo" else make_mono_set
-    return typ, gen(n_maps or N, new_per_frame or npf, vis or cvis, seed, **(cpath if path is None else path))
+    return typ, gen(n_maps or N, new_per_frame or npf, vis or cvis, seed, only=only, **(cpath if path is None else path))

@@ -102,7 +102,7 @@ def solve_stage_pins(typ, mono, J, eP, eF, sa, sr, store, tag, tmp):
     assert rc == 0 and rcx == 0
     e_d = float(np.max(np.abs(st - xd) / np.maximum(1, np.abs(xd))))
     e_x = float(np.max(np.abs(stx - xd) / np.maximum(1, np.abs(xd))))
-    assert e_d < 1e-10 and e_x < 1e-11, (tag, e_d, e_x)  # the twin inverts V in long double, dense_sol uses the fp64 parts.IV
+    assert e_d < 1e-10 and e_x < 1e-10, (tag, e_d, e_x)  # the twin inverts V in long double, dense_sol uses the fp64 parts.IV
     return worst, e_d, e_x
 
 

@@ -1,5 +1,6 @@
-"""world_size-2 (and 3) gloo tests of the multi-GPU scheduling (linearsfm_amd/distributed.py) on CPU.  The compute back
-end here is the oracle (tests only); on the GPU box the same scheduler drives the HIP library."""
+"""world_size-2 / 3 / 4 gloo tests of the multi-GPU schedule (linearsfm_amd/distributed.py: blocks = sub-trees, pairwise
+merge rounds on log2(G) ranks) on CPU.  The compute back end here is the oracle (tests only); on the GPU box the same
+schedule (merge_schedule) drives the HIP library with device-resident hand-off (ShardedTree, tests/test_gpu_sharded.py)."""
 import os
 import socket
 
@@ -9,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from linearsfm_amd import synth
-from linearsfm_amd.distributed import shard_bounds, sharded_divide_conquer
+from linearsfm_amd.distributed import merge_schedule, shard_bounds, sharded_divide_conquer
 
 
 def _free_port():
@@ -43,7 +44,8 @@ def _worker(rank, world, port, n_maps, mono, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_maps,mono", [(2, 8, False), (2, 7, False), (3, 11, False), (2, 6, True)])
+@pytest.mark.parametrize("world,n_maps,mono", [(2, 8, False), (2, 7, False), (3, 11, False), (2, 6, True), (4, 13, False), (4, 16, True),
+                                               (4, 5, False)])
 def test_subtree_sharding_equals_serial_tree(oracle, world, n_maps, mono):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -51,7 +53,7 @@ def test_subtree_sharding_equals_serial_tree(oracle, world, n_maps, mono):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_maps, mono, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=180)
+    got = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -69,3 +71,24 @@ def test_shard_bounds_are_subtrees():
         assert size & (size - 1) == 0 and size * w >= n
         assert b[0][0] == 0 and max(h for _, h in b) == n
         assert all(lo % size == 0 or lo == n for lo, _ in b)
+
+
+def test_merge_schedule_is_a_binary_tree():
+    """Every rank but 0 sends exactly once, to the rank that merges it in that round; the last merge is on rank 0 and is
+    re-anchored; the re-anchoring of an intermediate node follows the parity of its index at its level."""
+    for world in (1, 2, 3, 4, 5, 8):
+        nonempty = [True] * world
+        sends, merges = {}, {}
+        for r in range(world):
+            for act in merge_schedule(r, world, nonempty):
+                (sends if act[0] == "send" else merges).setdefault(r, []).append(act)
+        assert sorted(sends) == list(range(1, world))
+        for r, (a,) in sends.items():
+            _, peer, j = a
+            assert any(m[1] == r and m[2] == j for m in merges[peer])
+        if world > 1:
+            last = merges[0][-1]
+            assert last[3] is True
+            for r, acts in merges.items():
+                for _, peer, j, reanchor in acts[:-1] if r == 0 else acts:
+                    assert reanchor == ((r >> (j + 1)) % 2 == 1)

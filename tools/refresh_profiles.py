@@ -1,35 +1,63 @@
 #!/usr/bin/env python3
-"""Copies the rocprofv3 / bench outputs of one gpurun_out/<dir> into profiles/ (round 1 names) and prints the HBM traffic
-per launch (FETCH_SIZE doubled as MI355X_MICROARCH prescribes for gfx950, + WRITE_SIZE; KB -> bytes).
-usage: python tools/refresh_profiles.py gpurun_out/r01e"""
+"""Copies the rocprofv3 / bench outputs of one gpurun_out/<dir> into profiles/ and writes the HBM traffic summary bench.py reads
+(FETCH_SIZE doubled as MI355X_MICROARCH prescribes for gfx950, + WRITE_SIZE; KB -> bytes; separate --pmc passes).
+usage: python tools/refresh_profiles.py gpurun_out/<dir> <round tag, e.g. r02> <config, e.g. nc3500> <trees in the profiled run>"""
 import collections
 import csv
 import glob
 import json
+import os
 import shutil
+import sqlite3
 import sys
 
-src = sys.argv[1]
-out = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"{src}/pmc_{c}/*/*counter_collection.csv")[0]
-    shutil.copy(f, f"profiles/r01_pmc_{c}_counter_collection.csv")
+src, tag, config, trees = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+
+
+def short(n):
+    n = n.replace("void ", "").split("(")[0]
+    return n.split("::")[-1].split("<")[0]
+
+
+def counter(name):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        agg[n][0] += 1
-        agg[n][1] += float(r["Counter_Value"])
-    out[c] = agg
-names = sorted(out["FETCH_SIZE"], key=lambda n: -(2 * out["FETCH_SIZE"][n][1] + out["WRITE_SIZE"][n][1]))[:12]
-res = {}
+    files = glob.glob(f"{src}/pmc_{name}/**/*counter_collection.csv", recursive=True)
+    if files:
+        shutil.copy(files[0], f"profiles/{tag}_pmc_{name}_counter_collection_{config}.csv")
+        for r in csv.DictReader(open(files[0])):
+            agg[short(r["Kernel_Name"])][0] += 1
+            agg[short(r["Kernel_Name"])][1] += float(r["Counter_Value"])
+        return agg
+    dbs = glob.glob(f"{src}/pmc_{name}/**/*.db", recursive=True)
+    con = sqlite3.connect(dbs[0])
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    view = "counters_collection" if "counters_collection" in tabs else [t for t in tabs if "counter" in t.lower()][0]
+    cols = [d[0] for d in cur.execute(f"select * from {view} limit 1").description]
+    kn = [c for c in cols if "kernel" in c.lower() and "name" in c.lower()][0]
+    val = [c for c in cols if c.lower() in ("value", "counter_value")][0]
+    rows = list(cur.execute(f"select {kn}, {val} from {view}"))
+    with open(f"profiles/{tag}_pmc_{name}_per_kernel_{config}.csv", "w") as f:
+        f.write("Kernel_Name,Counter_Value\n")
+        for k, v in rows:
+            f.write(f"\"{k}\",{v}\n")
+            agg[short(k)][0] += 1
+            agg[short(k)][1] += float(v)
+    return agg
+
+
+out = {c: counter(c) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+names = sorted(out["FETCH_SIZE"], key=lambda n: -(2 * out["FETCH_SIZE"][n][1] + out["WRITE_SIZE"][n][1]))
+per_launch, detail, total = {}, {}, 0.0
 for n in names:
     cnt, fk, wk = out["FETCH_SIZE"][n][0], out["FETCH_SIZE"][n][1], out["WRITE_SIZE"][n][1]
-    hbm = (2 * fk + wk) * 1024 / cnt
-    res[n] = dict(launches=cnt, fetch_KB_raw_total=fk, write_KB_total=wk, hbm_bytes_per_launch_corrected=hbm)
-    print(f"{n[:44]:44s} n={cnt:4d} -> {hbm / 1e6:8.1f} MB/launch")
-json.dump(res, open("profiles/r01_pmc_traffic_summary.json", "w"), indent=1)
-shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], "profiles/r01_bench_nc3500_kernel_stats.csv")
-open("profiles/r01_bench_default.json", "w").write([l for l in open(f"{src}/bench_default.log") if l.startswith("{")][0])
-open("profiles/r01_bench_under_rocprof.json", "w").write([l for l in open(f"{src}/bench_prof.log") if l.startswith("{")][0])
-d = json.load(open("profiles/r01_bench_default.json"))
-print(d["value"], d["device_breakdown_ms"], d["roofline"]["achieved"], d["roofline"]["frac"], d["cpu_baseline"]["value"])
+    hbm = (2 * fk + wk) * 1024
+    total += hbm
+    per_launch[n] = hbm / max(cnt, 1)
+    detail[n] = dict(launches=cnt, fetch_KB_raw_total=fk, write_KB_total=wk, hbm_bytes_per_launch_corrected=hbm / max(cnt, 1))
+for n in names[:14]:
+    print(f"{n[:44]:44s} n={detail[n]['launches']:5d} -> {per_launch[n] / 1e6:8.1f} MB/launch")
+res = dict(config=config, trees_in_profiled_run=trees, bytes_per_tree=total / trees, per_launch=per_launch, kernels=detail,
+           source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --config {config}; FETCH_SIZE doubled (gfx950), KB -> bytes")
+json.dump(res, open(f"profiles/{tag}_pmc_traffic_summary_{config}.json", "w"), indent=1)
+print("HBM bytes per tree: %.2f GB" % (total / trees / 1e9))

@@ -637,16 +637,20 @@ __device__ __forceinline__ int sn_idx(int s, int u, int t) { return t * s - t * 
 // odd stride, the six pivot rows broadcast); the six lanes of the block's own rows publish theirs as the 6x6 diagonal block
 // D, everybody factors D in registers (56 flops: cheaper than a second barrier-separated phase) and finishes its row.
 // Two barriers per block column instead of the ~6 of the block-by-block walk, no idle lanes: ~15 us for 96 x 96 instead
-// of ~65.  The panel rows X = A L_dd^-T are the same recurrence on rows below the diagonal part, streamed without barriers.
+// of ~65.  The panel rows X = A L_dd^-T are the same recurrence on rows below the diagonal part: other waves of the work-group
+// carry them along, block column by block column, on their own SIMDs.
 __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Dinv, int* err,
                                                           double* __restrict__ Gd)
 {
-	__shared__ double Ls[6 * CHOL_GS * SN_XS]; // L_dd, dense scalar rows
-	__shared__ double Xs[6 * SN_RB * SN_XS];   // the panel rows of this work-group
+	// rows 0 .. 6 GS - 1: L_dd (dense scalar rows); rows 6 GS ..: the panel rows of this work-group.  Lanes 0..95 own the
+	// diagonal rows, lanes 128..223 (two other waves, other SIMDs) the panel rows: the same recurrence, in step
+	__shared__ double Ms[(6 * CHOL_GS + 6 * SN_RB) * SN_XS];
 	__shared__ double sD[36];
 	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
+	double* const Ls = Ms;
+	double* const Xs = Ms + 6 * CHOL_GS * SN_XS;
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
 	const int i0 = blockIdx.y * SN_RB;
 	if (blockIdx.y > 0 && i0 >= nr) return;
@@ -664,50 +668,49 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		sDst[e] = 6 * u * SN_XS + 6 * t;
 	}
 	__syncthreads();
-	for (int base = 0; base < nb * 36; base += nt * SN_LD)
-	{
-		double v[SN_LD];
-#pragma unroll
-		for (int i = 0; i < SN_LD; i++)
-		{
-			const int q = base + i * nt + tid, e = q / 36;
-			if (q < nb * 36) v[i] = L[(size_t)sSrc[e] + (q - e * 36)];
-		}
-#pragma unroll
-		for (int i = 0; i < SN_LD; i++)
-		{
-			const int q = base + i * nt + tid, e = q / 36, w = q - e * 36;
-			if (q < nb * 36) Ls[sDst[e] + (w / 6) * SN_XS + w % 6] = v[i];
-		}
-	}
-	// the panel rows of this work-group: block (il, t) at colptr[c0 + t] + (s - t) + i0 + il
+	// blocks -> dense rows, two doubles per load, SN_LD loads in flight per lane (a dependent load costs ~1.5 us)
 	const int nrows = max(0, min(SN_RB, nr - i0));
-	for (int base = 0; base < nrows * s * 36; base += nt * SN_LD)
+	const int nd2 = nb * 18, np2 = nrows * s * 18; // pairs of doubles: diagonal part, panel rows
+	for (int base = 0; base < nd2 + np2; base += nt * SN_LD)
 	{
-		double v[SN_LD];
+		double2 v[SN_LD];
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
-			const int q = base + i * nt + tid, blk = q / 36, il = blk / s, t = blk - il * s;
-			if (q < nrows * s * 36) v[i] = L[(size_t)(sCol[t] + (s - t) + i0 + il) * 36 + (q - blk * 36)];
+			const int q = base + i * nt + tid;
+			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const double2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
+			else if (q < nd2 + np2)
+			{
+				const int qq = q - nd2, blk = qq / 18, il = blk / s, t = blk - il * s;
+				v[i] = *reinterpret_cast<const double2*>(L + (size_t)(sCol[t] + (s - t) + i0 + il) * 36 + 2 * (qq - blk * 18));
+			}
 		}
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
-			const int q = base + i * nt + tid, blk = q / 36, w = q - blk * 36, il = blk / s, t = blk - il * s;
-			if (q < nrows * s * 36) Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6] = v[i];
+			const int q = base + i * nt + tid;
+			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * SN_XS + w % 6]; d[0] = v[i].x; d[1] = v[i].y; }
+			else if (q < nd2 + np2)
+			{
+				const int qq = q - nd2, blk = qq / 18, w = 2 * (qq - blk * 18), il = blk / s, t = blk - il * s;
+				double* d = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+				d[0] = v[i].x; d[1] = v[i].y;
+			}
 		}
 	}
 	__syncthreads();
+	// row of Ms this lane owns (-1: none)
+	const int ri = tid < 6 * CHOL_GS ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? 6 * CHOL_GS + (tid - 128) : -1);
+	const bool panel_lane = ri >= 6 * CHOL_GS && (ri - 6 * CHOL_GS) < 6 * nrows;
 	bool bad = false;
 	for (int t = 0; t < s; t++)
 	{
 		const int k0 = 6 * t;
 		double a[6];
-		const bool mine = tid >= k0 && tid < n6;
+		const bool mine = panel_lane || (ri >= k0 && ri < n6);
 		if (mine)
 		{
-			const double* xi = &Ls[tid * SN_XS];
+			const double* xi = &Ms[ri * SN_XS];
 #pragma unroll
 			for (int c = 0; c < 6; c++) a[c] = xi[k0 + c];
 			for (int v = 0; v < t; v++) // block by block: 42 LDS reads in flight, then 36 multiply-adds
@@ -723,9 +726,9 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 					for (int k = 0; k < 6; k++) a[c] = fma(-xv[k], lr[k], a[c]);
 				}
 			}
-			if (tid < k0 + 6)
+			if (ri < k0 + 6)
 #pragma unroll
-				for (int c = 0; c < 6; c++) sD[(tid - k0) * 6 + c] = a[c];
+				for (int c = 0; c < 6; c++) sD[(ri - k0) * 6 + c] = a[c];
 		}
 		__syncthreads();
 		if (mine)
@@ -750,12 +753,12 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 #pragma unroll
 					for (int c = k + 1; c <= r; c++) d[r * (r + 1) / 2 + c] -= d[r * (r + 1) / 2 + k] * d[c * (c + 1) / 2 + k];
 			}
-			double* xo = &Ls[tid * SN_XS + k0];
-			if (tid < k0 + 6)
+			double* xo = &Ms[ri * SN_XS + k0];
+			if (ri < k0 + 6)
 			{
-				// a row of the diagonal block itself: row (tid - k0) of the factor, zeros above the diagonal
+				// a row of the diagonal block itself: row (ri - k0) of the factor, zeros above the diagonal
 				// (static indices only: a run-time index into d[] would put the whole array into scratch memory)
-				const int r = tid - k0;
+				const int r = ri - k0;
 #pragma unroll
 				for (int rr = 0; rr < 6; rr++)
 					if (rr == r)
@@ -807,57 +810,23 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			const int e = q / 36, w = q - e * 36;
 			Gd[(size_t)g * SN_GD + q] = Ls[sDst[e] + (w / 6) * SN_XS + w % 6];
 		}
-	if (nrows <= 0) return;
-	// X = A L_dd^-T, one scalar row per lane, no barriers: L_dd is final
-	if (tid < 6 * nrows)
+	// the solved panel rows X = A L_dd^-T go back to their blocks
+	for (int q = tid; q < np2; q += nt)
 	{
-		double* x = &Xs[tid * SN_XS];
-		for (int t = 0; t < s; t++)
-		{
-			const int k0 = 6 * t;
-			double a[6];
-#pragma unroll
-			for (int c = 0; c < 6; c++) a[c] = x[k0 + c];
-			for (int v = 0; v < t; v++)
-			{
-				double xv[6];
-#pragma unroll
-				for (int k = 0; k < 6; k++) xv[k] = x[6 * v + k];
-#pragma unroll
-				for (int c = 0; c < 6; c++)
-				{
-					const double* lr = &Ls[(k0 + c) * SN_XS + 6 * v];
-#pragma unroll
-					for (int k = 0; k < 6; k++) a[c] = fma(-xv[k], lr[k], a[c]);
-				}
-			}
-			const double* dg = &Ls[k0 * SN_XS + k0];
-#pragma unroll
-			for (int c = 0; c < 6; c++)
-			{
-				double v = a[c];
-#pragma unroll
-				for (int k = 0; k < c; k++) v = fma(-a[k], dg[c * SN_XS + k], v);
-				a[c] = v * sInvD[k0 + c];
-			}
-#pragma unroll
-			for (int c = 0; c < 6; c++) x[k0 + c] = a[c];
-		}
-	}
-	__syncthreads();
-	for (int q = tid; q < nrows * s * 36; q += nt)
-	{
-		const int blk = q / 36, w = q - blk * 36, il = blk / s, t = blk - il * s;
-		L[(size_t)(sCol[t] + (s - t) + i0 + il) * 36 + w] = Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+		const int blk = q / 18, w = 2 * (q - blk * 18), il = blk / s, t = blk - il * s;
+		const double* x = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+		*reinterpret_cast<double2*>(L + (size_t)(sCol[t] + (s - t) + i0 + il) * 36 + w) = make_double2(x[0], x[1]);
 	}
 }
 
+#define SN_KS 4                      /* lanes per pair of rows in k_sn_update: each takes every 4th column of the run */
+#define SN_PAIRS (SN_THREADS / SN_KS)
 __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
                                                            const double* __restrict__ Gd)
 {
-	__shared__ double sT[SN_THREADS * 37];
-	__shared__ int spos[SN_THREADS];
+	__shared__ double sT[SN_PAIRS * 37];
+	__shared__ int spos[SN_PAIRS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
 	const int npairs = nr * (nr + 1) / 2;
 	const int tid = threadIdx.x;
@@ -874,10 +843,12 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 		}
 	}
 	const int rows0 = colptr[c0 + s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
-	for (int base = blockIdx.y * SN_THREADS; base < npairs; base += gridDim.y * SN_THREADS)
+	const int pl = tid / SN_KS, sub = tid - pl * SN_KS; // pair of this lane inside the round, its share of the columns
+	for (int base = blockIdx.y * SN_PAIRS; base < npairs; base += gridDim.y * SN_PAIRS)
 	{
-		const int pr = base + tid;
-		int pos = -1;
+		for (int q = tid; q < SN_PAIRS * 37; q += SN_THREADS) sT[q] = 0.0;
+		__syncthreads();
+		const int pr = base + pl;
 		if (pr < npairs)
 		{
 			int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
@@ -886,7 +857,8 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 			const int b = pr - a * (a + 1) / 2;
 			double T[36];
 			zero<36>(T);
-			for (int t = 0; t < s; t++)
+			// a dependent chain of s block loads per pair cost ~2 us each: four lanes share the chain, their sums meet in LDS
+			for (int t = sub; t < s; t += SN_KS)
 			{
 				const size_t cb = (size_t)colptr[c0 + t] + (s - t);
 				double La[36], Lb[36];
@@ -894,15 +866,20 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 				ld<36>(Lb, L + (cb + b) * 36);
 				mmt<6, 6, 6, true>(La, Lb, T);
 			}
-			const int ra = rowidx[rows0 + a], rb = rowidx[rows0 + b];
-			const int cbk = colptr[rb], nbk = colptr[rb + 1] - cbk;
-			pos = cbk + (a - b);
-			if (!(a - b < nbk && rowidx[pos] == ra)) pos = find_row(rowidx, cbk, cbk + nbk, ra);
-			for (int q = 0; q < 36; q++) sT[tid * 37 + q] = T[q];
+			if (sub < s)
+				for (int q = 0; q < 36; q++) lds_add_f64(&sT[pl * 37 + q], T[q]);
+			if (sub == 0)
+			{
+				const int ra = rowidx[rows0 + a], rb = rowidx[rows0 + b];
+				const int cbk = colptr[rb], nbk = colptr[rb + 1] - cbk;
+				int pos = cbk + (a - b);
+				if (!(a - b < nbk && rowidx[pos] == ra)) pos = find_row(rowidx, cbk, cbk + nbk, ra);
+				spos[pl] = pos;
+			}
 		}
-		spos[tid] = pos;
+		else if (sub == 0) spos[pl] = -1;
 		__syncthreads();
-		for (int idx = tid; idx < SN_THREADS * 36; idx += SN_THREADS)
+		for (int idx = tid; idx < SN_PAIRS * 36; idx += SN_THREADS)
 		{
 			const int p = idx / 36, q = idx - p * 36;
 			const int ps = spos[p];
@@ -1267,7 +1244,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			hipLaunchKernelGGL(k_sn_panel, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
 			                   ch.colptr, ch.L, ch.Dinv, ch.d_err, ch.Gd);
 			const long np = (long)mnr * (mnr + 1) / 2;
-			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_THREADS - 1) / SN_THREADS, 2048))), dim3(SN_THREADS), 0, s,
+			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
 			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Gd);
 		}
 }

@@ -76,5 +76,7 @@ def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono):
         for k in ("Ui", "Uj", "photo", "feature"):
             assert np.array_equal(got[k], single[k]), k
         assert got["Ref"] == single["Ref"] and got["FRef"] == single["FRef"]
-        assert pose_param_err(got["stVal"], single["stVal"], single["stno"]) < 1e-9
-        assert feat_param_err(got["stVal"], single["stVal"], single["stno"]) < 1e-9
+        # same tree shape, same joins; the elimination order of a merged system and the summation order of atomics may differ
+        tol = 1e-8 if mono else 1e-9
+        assert pose_param_err(got["stVal"], single["stVal"], single["stno"]) < tol
+        assert feat_param_err(got["stVal"], single["stVal"], single["stno"]) < tol

@@ -16,7 +16,10 @@ src, tag, config, trees = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]
 
 def short(n):
     n = n.replace("void ", "").split("(")[0]
-    return n.split("::")[-1].split("<")[0]
+    base = n.split("::")[-1].split("<")[0]
+    if base == "k_schur_panel" and "<48" in n:
+        return "k_schur_panel_48"  # the pass over the tiles the 32-slot variant flagged (most work-groups leave at once)
+    return base
 
 
 def counter(name):
@@ -61,3 +64,13 @@ res = dict(config=config, trees_in_profiled_run=trees, bytes_per_tree=total / tr
            source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --config {config}; FETCH_SIZE doubled (gfx950), KB -> bytes")
 json.dump(res, open(f"profiles/{tag}_pmc_traffic_summary_{config}.json", "w"), indent=1)
 print("HBM bytes per tree: %.2f GB" % (total / trees / 1e9))
+st = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
+if st:
+    shutil.copy(st[0], f"profiles/{tag}_bench_{config}_kernel_stats.csv")
+for name, dst in (("bench_default.log", f"profiles/{tag}_bench_default.json"), ("bench_prof.log", f"profiles/{tag}_bench_under_rocprof.json")):
+    if os.path.exists(f"{src}/{name}"):
+        lines = [l for l in open(f"{src}/{name}") if l.startswith("{")]
+        if lines:
+            open(dst, "w").write(lines[0])
+for f in glob.glob(f"{src}/full_parity_*.json"):
+    shutil.copy(f, f"profiles/{tag}_{os.path.basename(f)}")

@@ -67,6 +67,7 @@ struct CholDev {
 	std::vector<int> glevel_maxnr;  // host: most rows below a run of the level
 	int* blob = nullptr;    // all index arrays above are slices of this one allocation
 	size_t blob_ints = 0;
+	double* wv = nullptr;   // [M*6] forward-solve results of the group columns (lsfm_pcg.hip k_sn_fwd / k_sn_bwd)
 	double* Gd = nullptr;   // parking area of the factored diagonal blocks of one group level: SN_GD doubles per group
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
@@ -889,6 +890,175 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Triangular solves by supernode group (the columns above the leaf tasks; the leaf sub-trees keep k_chol_fwd/bwd_tasks).
+// One work-group per group, one launch per group level.  Forward: y_g = L_dd^-1 v_g by the row-owner recurrence on the
+// dense rows of L_dd in LDS (two barriers per block column), then v[r_i] -= X[i,:] y_g for the common rows, four lanes per
+// row.  y_g goes to a second vector (another group of the level may still be adding to v_g's neighbours; nobody reads
+// v_g after its own level).  Backward: z = y_g - X^T x[rows], x_g = L_dd^-T z, written into v.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sn_load_diag(int s, int c0, const int* __restrict__ colptr, const double* __restrict__ L, double* Ls, int* sSrc,
+                                             int* sDst, int* sCol)
+{
+	const int tid = threadIdx.x, nt = blockDim.x, nb = s * (s + 1) / 2;
+	for (int t = tid; t < s; t += nt) sCol[t] = colptr[c0 + t];
+	__syncthreads();
+	for (int e = tid; e < nb; e += nt)
+	{
+		int t = 0;
+		while (sn_idx(s, s - 1, t) < e) t++;
+		const int u = t + (e - sn_idx(s, t, t));
+		sSrc[e] = (sCol[t] + (u - t)) * 36;
+		sDst[e] = 6 * u * SN_XS + 6 * t;
+	}
+	__syncthreads();
+	const int nd2 = nb * 18;
+	for (int base = 0; base < nd2; base += nt * SN_LD)
+	{
+		double2 v[SN_LD];
+#pragma unroll
+		for (int i = 0; i < SN_LD; i++)
+		{
+			const int q = base + i * nt + tid;
+			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const double2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
+		}
+#pragma unroll
+		for (int i = 0; i < SN_LD; i++)
+		{
+			const int q = base + i * nt + tid;
+			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * SN_XS + w % 6]; d[0] = v[i].x; d[1] = v[i].y; }
+		}
+	}
+	__syncthreads();
+}
+
+__global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
+                                                        const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
+                                                        const double* __restrict__ Dinv, double* __restrict__ v, double* __restrict__ w)
+{
+	__shared__ double Ls[6 * CHOL_GS * SN_XS];
+	__shared__ double sDi[CHOL_GS * 36];
+	__shared__ double sA[6], sY[6 * CHOL_GS];
+	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
+	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	const int tid = threadIdx.x, n6 = 6 * s;
+	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = Dinv[(size_t)c0 * 36 + q];
+	double acc = tid < n6 ? v[(size_t)c0 * 6 + tid] : 0.0;
+	sn_load_diag(s, c0, colptr, L, Ls, sSrc, sDst, sCol);
+	for (int t = 0; t < s; t++)
+	{
+		const int k0 = 6 * t;
+		if (tid >= k0 && tid < k0 + 6) sA[tid - k0] = acc;
+		__syncthreads();
+		if (tid >= k0 && tid < k0 + 6)
+		{
+			const int c = tid - k0;
+			double y = 0.0;
+			for (int k = 0; k <= c; k++) y = fma(sDi[t * 36 + c * 6 + k], sA[k], y);
+			sY[tid] = y;
+		}
+		__syncthreads();
+		if (tid >= k0 + 6 && tid < n6)
+		{
+			const double* lr = &Ls[tid * SN_XS + k0];
+#pragma unroll
+			for (int k = 0; k < 6; k++) acc = fma(-lr[k], sY[k0 + k], acc);
+		}
+	}
+	if (tid < n6) w[(size_t)c0 * 6 + tid] = sY[tid];
+	// the common rows: v[r_i] -= sum_t X[i,t] y_t, four lanes per row (each every 4th column of the run)
+	const int rows0 = colptr[c0 + s - 1] + 1;
+	const int sub = tid & 3;
+	for (int i = tid >> 2; i < nr; i += SN_THREADS / 4)
+	{
+		double o[6] = { 0, 0, 0, 0, 0, 0 };
+		for (int t = sub; t < s; t += 4)
+		{
+			const double* blk = L + ((size_t)sCol[t] + (s - t) + i) * 36;
+			double b[36];
+			ld<36>(b, blk);
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+#pragma unroll
+				for (int k = 0; k < 6; k++) o[r] = fma(b[r * 6 + k], sY[6 * t + k], o[r]);
+		}
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+		{
+			o[r] += __shfl_xor(o[r], 1, LSFM_WAVE);
+			o[r] += __shfl_xor(o[r], 2, LSFM_WAVE);
+		}
+		if (sub == 0)
+		{
+			double* dst = v + (size_t)rowidx[rows0 + i] * 6;
+#pragma unroll
+			for (int r = 0; r < 6; r++) atomic_add_f64(dst + r, -o[r]);
+		}
+	}
+}
+
+__global__ void __launch_bounds__(SN_THREADS) k_sn_bwd(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
+                                                        const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
+                                                        const double* __restrict__ Dinv, double* __restrict__ v, const double* __restrict__ w)
+{
+	__shared__ double Ls[6 * CHOL_GS * SN_XS];
+	__shared__ double sDi[CHOL_GS * 36];
+	__shared__ double sA[6], sZ[6 * CHOL_GS], sX[6 * CHOL_GS];
+	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
+	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	const int tid = threadIdx.x, n6 = 6 * s;
+	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = Dinv[(size_t)c0 * 36 + q];
+	if (tid < n6) sZ[tid] = w[(size_t)c0 * 6 + tid];
+	sn_load_diag(s, c0, colptr, L, Ls, sSrc, sDst, sCol); // (ends with a barrier: sZ, sDi, sCol visible)
+	// z -= X^T x over the common rows (all final: they belong to higher levels), four lanes per row
+	const int rows0 = colptr[c0 + s - 1] + 1;
+	const int sub = tid & 3;
+	for (int i = tid >> 2; i < nr; i += SN_THREADS / 4)
+	{
+		const double* xr = v + (size_t)rowidx[rows0 + i] * 6;
+		double x6[6];
+		ld<6>(x6, xr);
+		for (int t = sub; t < s; t += 4)
+		{
+			const double* blk = L + ((size_t)sCol[t] + (s - t) + i) * 36;
+			double b[36];
+			ld<36>(b, blk);
+#pragma unroll
+			for (int c = 0; c < 6; c++)
+			{
+				double o = 0.0;
+#pragma unroll
+				for (int r = 0; r < 6; r++) o = fma(b[r * 6 + c], x6[r], o);
+				lds_add_f64(&sZ[6 * t + c], -o);
+			}
+		}
+	}
+	__syncthreads();
+	// x_g = L_dd^-T z: lane (t, c) owns column 6t + c, block columns from the last to the first
+	double acc = tid < n6 ? sZ[tid] : 0.0;
+	for (int t = s - 1; t >= 0; t--)
+	{
+		const int k0 = 6 * t;
+		if (tid >= k0 && tid < k0 + 6) sA[tid - k0] = acc;
+		__syncthreads();
+		if (tid >= k0 && tid < k0 + 6)
+		{
+			const int c = tid - k0;
+			double x = 0.0;
+			for (int k = c; k < 6; k++) x = fma(sDi[t * 36 + k * 6 + c], sA[k], x);
+			sX[tid] = x;
+		}
+		__syncthreads();
+		if (tid < k0)
+		{
+#pragma unroll
+			for (int k = 0; k < 6; k++) acc = fma(-Ls[(k0 + k) * SN_XS + tid], sX[k0 + k], acc);
+		}
+	}
+	if (tid < n6) v[(size_t)c0 * 6 + tid] = sX[tid];
+}
+
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
                           double* __restrict__ v)
 {
@@ -947,6 +1117,7 @@ static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
 {
 	Arena& sc = ctx->scratch;
 	ch.L = sc.alloc<double>((size_t)ch.nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)ch.M * 36);
+	ch.wv = sc.alloc<double>((size_t)ch.M * 6);
 	int most = 1;
 	for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++) most = std::max(most, ch.glevel_ptr[l + 1] - ch.glevel_ptr[l]);
 	ch.Gd = sc.alloc<double>((size_t)most * (CHOL_GS * (CHOL_GS + 1) / 2 * 36));
@@ -970,7 +1141,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	SolvePlan& P = *sp;
 	P.sy = sy; P.ch = ch; P.its = its;
 	P.sy.S = nullptr; P.sy.E = nullptr; P.sy.IV = nullptr;
-	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr;
+	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr;
 	std::vector<Item> items = {
 		{ sy.rowptr, (M + 1) * 4, (void**)&P.sy.rowptr }, { sy.colidx, (nnzb + 1) * 4, (void**)&P.sy.colidx },
 		{ sy.upper_keys, nnzb * 8, (void**)&P.sy.upper_keys }, { sy.longrows, (M + 1) * 4, (void**)&P.sy.longrows },
@@ -1259,6 +1430,28 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 	static const bool task_solve = !getenv("LSFM_LEVEL_SOLVE");
 	int task_max = 0;
 	for (int m : ch.tlevel_maxsize) task_max = std::max(task_max, m);
+	static const bool group_solve = !getenv("LSFM_NO_GROUPS") && !getenv("LSFM_TASK_SOLVE");
+	if (task_solve && group_solve && !ch.tlevel_ptr.empty() && (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL <= 56 * 1024)
+	{
+		// leaf sub-trees (task level 0) by task, everything above them by supernode group
+		const int n0 = ch.tlevel_ptr.size() > 1 ? ch.tlevel_ptr[1] - ch.tlevel_ptr[0] : 0;
+		const size_t lds0 = (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL + 8;
+		const int ngl = (int)ch.glevel_ptr.size() - 1;
+		if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+		for (int l = 0; l < ngl; l++)
+		{
+			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
+			if (ng) hipLaunchKernelGGL(k_sn_fwd, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Dinv, v, ch.wv);
+		}
+		for (int l = ngl - 1; l >= 0; l--)
+		{
+			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
+			if (ng) hipLaunchKernelGGL(k_sn_bwd, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Dinv, v, ch.wv);
+		}
+		if (n0) hipLaunchKernelGGL(k_chol_bwd_tasks, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
+		return;
+	}
 	if (task_solve && (size_t)task_max * CHOL_TASK_LDS_PER_COL <= 56 * 1024) // a task's per-column data must fit LDS; else one launch per tree level
 	{
 		const int ntl = (int)ch.tlevel_ptr.size() - 1;

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <numeric>
+#include <queue>
 
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
@@ -1178,19 +1179,67 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 	std::vector<int> blob;
 	std::vector<std::pair<int**, size_t>> blob_dst;
 	auto pack = [&](int** dst, const std::vector<int>& v) { blob_dst.emplace_back(dst, blob.size()); blob.insert(blob.end(), v.begin(), v.end()); };
-	std::vector<int> deg(M, 0), sep(M, 0);
-	for (int e = 0; e < nnzb; e++)
+	// Separators of the dissection: the edges that cross the cut of tree level l (the two poses come from different
+	// halves of a level-l node: bitlen(origin_p ^ origin_q) = l) must lose an endpoint to that level's separator.  From the
+	// top level down, over the edges no higher separator covers yet, a greedy vertex cover: the pose with the most
+	// uncovered crossing edges first (hub poses, then ONE side of a loop closure -- taking the higher-degree endpoint
+	// edge by edge, as round 1 did, put both sides of a closure in: 72 instead of 41 poses in the top separator of the
+	// NC3500-like set, elimination tree 330 instead of 227 columns high, 2.6 instead of 1.7 GFLOP).
+	std::vector<int> sep(M, 0);
 	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p != q) { deg[p]++; deg[q]++; }
-	}
-	for (int e = 0; e < nnzb; e++)
-	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p == q) continue;
-		const int l = bitlen((unsigned)(origin[p] ^ origin[q]));
-		const int v = (deg[p] > deg[q] || (deg[p] == deg[q] && p > q)) ? p : q;
-		if (l > sep[v]) sep[v] = l;
+		std::vector<std::vector<std::pair<int, int>>> lev_edges(34);
+		for (int e = 0; e < nnzb; e++)
+		{
+			const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+			if (p != q) lev_edges[bitlen((unsigned)(origin[p] ^ origin[q]))].emplace_back(p, q);
+		}
+		std::vector<int> cdeg(M, 0), start(M + 1, 0), adj;
+		std::vector<char> covered;
+		for (int l = 33; l >= 1; l--)
+		{
+			const auto& es = lev_edges[l];
+			if (es.empty()) continue;
+			// uncovered edges of the level, as a CSR adjacency with edge ids
+			std::vector<std::pair<int, int>> live;
+			for (const auto& pq : es) if (sep[pq.first] < l && sep[pq.second] < l) live.push_back(pq);
+			if (live.empty()) continue;
+			std::vector<int> verts;
+			for (const auto& pq : live) { if (!cdeg[pq.first]++) verts.push_back(pq.first); if (!cdeg[pq.second]++) verts.push_back(pq.second); }
+			std::sort(verts.begin(), verts.end());
+			int tot = 0;
+			for (int v : verts) { start[v] = tot; tot += cdeg[v]; }
+			adj.assign(tot, 0);
+			std::vector<int> fillv(verts.size(), 0);
+			auto vpos = [&](int v) { return (int)(std::lower_bound(verts.begin(), verts.end(), v) - verts.begin()); };
+			for (int e = 0; e < (int)live.size(); e++)
+			{
+				const int a = live[e].first, b = live[e].second;
+				adj[start[a] + fillv[vpos(a)]++] = e;
+				adj[start[b] + fillv[vpos(b)]++] = e;
+			}
+			covered.assign(live.size(), 0);
+			std::vector<int> cur(verts.size());
+			std::priority_queue<std::pair<int, int>> heap; // (uncovered crossing edges, pose): lazy deletion
+			for (size_t i = 0; i < verts.size(); i++) { cur[i] = cdeg[verts[i]]; heap.emplace(cur[i], verts[i]); }
+			while (!heap.empty())
+			{
+				const auto top = heap.top();
+				heap.pop();
+				const int v = top.second, iv = vpos(v);
+				if (top.first != cur[iv] || cur[iv] <= 0) continue; // stale entry
+				sep[v] = l;
+				for (int t = start[v]; t < start[v] + cdeg[v]; t++)
+				{
+					const int e = adj[t];
+					if (covered[e]) continue;
+					covered[e] = 1;
+					const int w = live[e].first == v ? live[e].second : live[e].first, iw = vpos(w);
+					if (--cur[iw] > 0) heap.emplace(cur[iw], w);
+				}
+				cur[iv] = 0;
+			}
+			for (int v : verts) cdeg[v] = 0;
+		}
 	}
 	std::vector<int> perm(M), pinv(M);
 	std::iota(perm.begin(), perm.end(), 0);

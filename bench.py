@@ -24,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+# fp64 matrix peak: the guide lists FP32 matrix = FP32 vector = 157.3 TFLOP/s (64 FLOP/clk/SIMD); v_mfma_f64_16x16x4_f64 runs at half
+# that rate (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz) = 78.6 TFLOP/s, AMD's dense FP64 matrix figure for MI355X
+F64_MFMA_PEAK_TFLOPS = 78.6
 METRIC_NAMES = {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular", "rs90": "RS90-like monocular",
                 "synth16k": "synthetic 16k monocular", "synth64k": "synthetic 64k stereo"}
 
@@ -152,6 +155,8 @@ def main():
             kern[key] = dict(name=name, total_ms=acc.get(f"{key}_ms", 0.0) / args.steps, launches_per_step=acc.get(f"{key}_launches", 0) / args.steps,
                              avg_ms=acc.get(f"{key}_ms", 0.0) / n, avg_bytes=acc.get(f"{key}_bytes", 0.0) / n)
             kern[key]["gbs"] = kern[key]["avg_bytes"] / (kern[key]["avg_ms"] * 1e-3) / 1e9 if kern[key]["avg_ms"] > 0 else 0.0
+        kern["schur"]["avg_flops"] = acc.get("schur_flops", 0.0) / max(1, acc.get("schur_launches", 0))
+        kern["schur"]["tflops"] = kern["schur"]["avg_flops"] / (kern["schur"]["avg_ms"] * 1e-3) / 1e12 if kern["schur"]["avg_ms"] > 0 else 0.0
         dom = max(("schur", "trf"), key=lambda k: kern[k]["total_ms"])
         pmc = pmc_traffic(args.config) if (world == 1 and not args.maps) else None
         traffic = None
@@ -187,22 +192,35 @@ def main():
             "pcg_iterations_per_step": acc.get("pcg_iterations", 0) / args.steps,
             "max_rel_residual": (stats or {}).get("max_rel_residual"),
             "not_converged": (stats or {}).get("not_converged"),
-            "roofline": {"bound": "hbm", "kernel": kern[dom]["name"], "achieved": kern[dom]["gbs"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_bytes_per_launch": kern[dom]["avg_bytes"],
-                         "launches_per_step": kern[dom]["launches_per_step"],
-                         "note": "one launch per tree level (12 levels + final re-anchoring); average over all of them, small "
-                                 "low-level launches included; algorithmic bytes = every input and output moved once "
-                                 "(DESIGN.md); traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/ for this "
-                                 "configuration, null when none is kept"},
+            "roofline": ({"bound": "hbm", "kernel": kern[dom]["name"], "achieved": kern[dom]["gbs"],
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                          "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_bytes_per_launch": kern[dom]["avg_bytes"],
+                          "launches_per_step": kern[dom]["launches_per_step"],
+                          "note": "one launch per tree level (12 levels + final re-anchoring); average over all of them, small "
+                                  "low-level launches included; algorithmic bytes = every input and output moved once "
+                                  "(DESIGN.md); traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/ for this "
+                                  "configuration, null when none is kept"} if dom == "trf" else
+                         {"bound": "mfma", "kernel": kern[dom]["name"], "achieved": kern[dom]["tflops"], "peak": F64_MFMA_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                          "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_flops_per_launch": kern[dom]["avg_flops"],
+                          "hbm_view": {"algorithmic_bytes_per_launch": kern[dom]["avg_bytes"], "achieved_GBps": kern[dom]["gbs"],
+                                       "frac_of_hbm_peak": kern[dom]["gbs"] / HBM_PEAK_GBS},
+                          "launches_per_step": kern[dom]["launches_per_step"],
+                          "note": "K9 is the one real contraction of the path: a tile's contribution to S is P P^T on v_mfma_f64_16x16x4_f64. "
+                                  "ALGORITHMIC flops per feature with k W blocks: k (108 + 36) + k (k + 1) / 2 * 216 (Imp.cpp:2260-2328) -- "
+                                  "the zero blocks the dense panel also multiplies are not counted; ~17 flop per HBM byte at the top "
+                                  "levels, where the fp64 matrix rate binds, latency at the low ones; one launch per tree level, average "
+                                  "over all of them; traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/"}),
             "whole_step_hbm": whole,
             "cg_spmv": {"algorithmic_GBps": kern["spmv"]["gbs"], "frac_of_hbm_peak": kern["spmv"]["gbs"] / HBM_PEAK_GBS,
                         "avg_launch_ms": kern["spmv"]["avg_ms"], "matrix_MB_top_level": (stats or {}).get("spmv_nnzb_upper_last", 0) * 288 / 1e6,
                         "note": "cache-resident on this configuration: the Schur matrix of a level is <= ~20 MB (L2 / Infinity Cache), the "
                                 "launch is latency-bound and -- with the exact factor as preconditioner -- runs ~5 times per level; the "
                                 "kernel's HBM-streaming rate is measured by tools/spmv_bench.py on matrices of 1 GB+"},
-            "kernels": {k: {"avg_launch_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"], "ms_per_step": v["total_ms"],
-                            "launches_per_step": v["launches_per_step"]} for k, v in kern.items()},
+            "kernels": {k: {"avg_launch_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"], "frac_of_hbm_peak": v["gbs"] / HBM_PEAK_GBS,
+                            "ms_per_step": v["total_ms"], "launches_per_step": v["launches_per_step"],
+                            **({"algorithmic_TFLOPs": v["tflops"], "frac_of_f64_mfma_peak": v["tflops"] / F64_MFMA_PEAK_TFLOPS} if k == "schur" else {})}
+                        for k, v in kern.items()},
         }
         if args.cpu_baseline and world == 1:  # the CPU leg runs at N=1 only, on the same set
             from oracle import pyoracle as po

@@ -73,6 +73,9 @@ typedef struct lsfm_stats {
 	 * those launches */
 	long schur_launches, trf_launches;
 	double schur_ms, schur_bytes, trf_ms, trf_bytes;
+	/* algorithmic flops of the K9 launches: per feature with k W blocks, k (108 + 36) for W V^-1 and the right-hand side and
+	 * k (k + 1) / 2 * 216 for the pose pairs (Imp.cpp:2260-2328) -- at the top levels K9 is bound by the fp64 matrix rate */
+	double schur_flops;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */

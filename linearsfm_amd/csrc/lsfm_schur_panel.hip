@@ -260,8 +260,11 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 
 // `only` == nullptr: every tile; tiles with more than SMAX poses are flagged in `fallback`.  `only` != nullptr (the second
 // pass with the larger variant): just the flagged tiles; a tile it can take is un-flagged, the rest stays for k_schur_w.
+// SMAX = 8 / 16: for levels whose systems have at most that many poses (the bottom of the tree: thousands of tiny joins).
+// A tile is then all latency -- hashing, eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
+// work-groups share a CU instead of 2.
 template <int SMAX, int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 2 : 1)
+__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 6 : (SMAX <= 16 ? 3 : 2)))
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
               const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
               double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only)
@@ -314,7 +317,18 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 	constexpr int NW = THREADS / 64;
 	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
 #define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
-	if (THREADS == 256)
+	if constexpr (SMAX <= 8)
+	{
+		if (tpw <= 1) PM_GO(1);
+		else PM_GO(2); // 48 rows: 6 tiles over 4 waves
+	}
+	else if constexpr (SMAX <= 16)
+	{
+		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 3) PM_GO(3);
+		else PM_GO(6); // 96 rows: 21 tiles over 4 waves
+	}
+	else if constexpr (THREADS == 256)
 	{
 		if (tpw <= 1) PM_GO(1);
 		else if (tpw <= 3) PM_GO(3);
@@ -335,10 +349,24 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 int schur_panel_tile() { return PM_TILE; }
 
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
-                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback)
+                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
+                        int max_poses_per_system)
 {
 	if (!NF) return;
 	const dim3 grid((NF + PM_TILE - 1) / PM_TILE);
+	// no tile can be seen by more poses than its system has
+	if (max_poses_per_system <= 8)
+	{
+		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback,
+		                   (const unsigned char*)nullptr);
+		return;
+	}
+	if (max_poses_per_system <= 16)
+	{
+		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback,
+		                   (const unsigned char*)nullptr);
+		return;
+	}
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E,
 	                   fallback, (const unsigned char*)nullptr);
 	// the tiles that exceed 32 poses (a path that revisits: the frames of two laps + the hub poses of every level)

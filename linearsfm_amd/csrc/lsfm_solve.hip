@@ -118,6 +118,17 @@ k_pat_insert_w(int NF, const int* __restrict__ fptr, const int* __restrict__ pho
 	}
 }
 
+// sum over the features of (run length)^2: the pose pairs of K9 (for its algorithmic flop count)
+__global__ void k_sum_run_squares(int NF, const int* __restrict__ fptr, unsigned long long* out)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long v = 0;
+	if (f < NF) { const unsigned long long k = (unsigned long long)(fptr[f + 1] - fptr[f]); v = k * k; }
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, LSFM_WAVE);
+	if ((threadIdx.x & (LSFM_WAVE - 1)) == 0 && v) atomicAdd(out, v);
+}
+
 __global__ void k_pat_compact(size_t cap, const unsigned long long* __restrict__ tab, unsigned long long* __restrict__ list, int* __restrict__ count)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,6 +497,9 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	const int M = io.M, NF = io.NF;
 	sy.M = M;
 	int* d_flags = sc.alloc<int>(4); // [0] overflow, [1] count, [2] mirrored count
+	unsigned long long* d_k2 = sc.alloc<unsigned long long>(1);
+	dev_zero(ctx, d_k2, sizeof(unsigned long long));
+	if (NF) hipLaunchKernelGGL(k_sum_run_squares, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, d_k2);
 	size_t cap = 1024;
 	// S has little more than U's pattern (the W-induced pairs are mostly hub links that U already holds): 4x head room over
 	// NU + 8 M entries; the loop below grows the table if a level needs more
@@ -506,7 +520,14 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		hipLaunchKernelGGL(k_pat_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, cap, tab, list, d_flags + 1);
 		int fl[2];
 		d2h_ints(ctx, d_flags, fl, 2);
-		if (!fl[0] && (size_t)fl[1] * 2 <= cap) { sy.nnzb = fl[1]; break; }
+		if (!fl[0] && (size_t)fl[1] * 2 <= cap)
+		{
+			sy.nnzb = fl[1];
+			unsigned long long k2 = 0;
+			d2h(ctx, &k2, d_k2, sizeof k2);
+			sy.k9_flops = (double)io.NW * 144.0 + ((double)k2 + (double)io.NW) * 0.5 * 216.0;
+			break;
+		}
 		sc.release(mk);
 		cap <<= 2;
 		if (attempt > 10) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur pattern hash table kept overflowing");
@@ -549,7 +570,9 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		hipEvent_t e2 = nullptr, e3 = nullptr;
 		if (ctx->stats) { e2 = ctx->pool_event(); e3 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(e2, s)); }
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
-		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
+		int most = 0;
+		for (int r : io.seg_rows) most = std::max(most, r);
+		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb, most);
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
 		if (ctx->stats)
 		{
@@ -558,6 +581,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			ctx->stats->schur_launches++;
 			// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
 			ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)io.NF * (72 + 24 + 4) + (double)sy.nnzb * 288 + (double)io.M * 48;
+			ctx->stats->schur_flops += sy.k9_flops;
 		}
 	}
 	LSFM_CHECK_HIP(hipGetLastError());

@@ -16,6 +16,7 @@ struct SchurSystem {
 	const unsigned long long* tab = nullptr; // pose pair -> block of S (open addressing), values in hval
 	const int* hval = nullptr;
 	unsigned long long mask = 0;
+	double k9_flops = 0; // algorithmic flops of the numeric Schur complement of this system (structure only)
 };
 
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
@@ -26,7 +27,8 @@ void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, doub
                  const int* pose_seg, double* dot, int dot_stride);
 double spmv_bytes(const SchurSystem& sy);
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
-                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback);
+                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
+                        int max_poses_per_system);
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);
 
 } // namespace lsfm

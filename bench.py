@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1, help="1: time the oracle on the SAME set on the host cores (N=1 only); 0: skip")
     ap.add_argument("--cpu-max-maps", type=int, default=4096, help="sets larger than this time the oracle on their first maps only")
     ap.add_argument("--tol", type=float, default=1e-12, help="relative residual at which the refinement of a system stops (library default)")
+    ap.add_argument("--mixed", action="store_true", help="Cholesky preconditioner kept and applied in fp32, fp64 residual correction (BASELINE configs[4])")
     ap.add_argument("--no-plans", action="store_true", help="every step analyses from scratch (what a first run costs)")
     args = ap.parse_args()
 
@@ -101,6 +102,7 @@ def main():
     _, block = synth.make_config(args.config, n_maps, seed=0, new_per_frame=npf, vis=vis, only=(lo, hi))
     ctx = api.Context(local_rank)
     ctx.set_pcg(args.tol, 4)
+    ctx.set_precision(args.mixed)
     tree = ShardedTree(ctx, block, lo, n_maps, mono)   # PCIe copy, outside the timed region: inputs are resident from here on
     if args.no_plans:
         if tree.block_tree is not None:
@@ -177,7 +179,7 @@ def main():
             "higher_is_better": False,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not args.mixed else "f64 (S, right-hand side, iterate, residual) + f32 (Cholesky preconditioner)",
             "data": "synthetic",
             "config": {"workload": f"{args.config} stand-in ({typ}): {n_maps} local maps, {npf} new features/frame visible in {vis} "
                                    f"frames, camera path {cpath}, {out['m']} poses / {out['n']} features in the final map",

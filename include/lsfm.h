@@ -87,6 +87,13 @@ void lsfm_context_destroy(lsfm_context* ctx);
  * residual level of a direct fp64 solve, which is what the reference computes) or when the true residual stops
  * shrinking; at most 50 refinement steps.  max_it_factor: accepted and ignored (the iteration cap is fixed). */
 int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor);
+/* Precision of the preconditioner.  mode 0 (default): fp64 throughout, the reference's arithmetic.  mode 1, "mixed": the
+ * Cholesky factor of every camera system is kept and applied in fp32 (half the bytes of the triangular solves; the
+ * factorisation itself runs in fp64 and is rounded once -- an fp32 elimination breaks down on these matrices), while S,
+ * the right-hand side, the iterate and the residual r = E - S x stay fp64: every refinement step corrects against the
+ * fp64 residual, and the stopping rule is the same relative residual as in mode 0, reached in more steps (2-3 instead
+ * of 1).  BASELINE.json configs[4]. */
+int lsfm_set_precision(lsfm_context* ctx, int mode);
 const char* lsfm_last_error(lsfm_context* ctx);
 void* lsfm_stream(lsfm_context* ctx); /* hipStream_t the library launches on */
 

@@ -18,6 +18,12 @@ __device__ __forceinline__ void ld(double* dst, const double* __restrict__ src)
 	for (int i = 0; i < N; i++) dst[i] = src[i];
 }
 template <int N>
+__device__ __forceinline__ void ld(double* dst, const float* __restrict__ src) // an fp32 copy widened on load
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) dst[i] = (double)src[i];
+}
+template <int N>
 __device__ __forceinline__ void st(double* __restrict__ dst, const double* src)
 {
 #pragma unroll

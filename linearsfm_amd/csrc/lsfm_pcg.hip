@@ -68,6 +68,7 @@ struct CholDev {
 	std::vector<int> glevel_maxnr;  // host: most rows below a run of the level
 	int* blob = nullptr;    // all index arrays above are slices of this one allocation
 	size_t blob_ints = 0;
+	float *Lf = nullptr, *Dinvf = nullptr; // mixed precision: the factor rounded to fp32 for the triangular solves (null: fp64)
 	double* wv = nullptr;   // [M*6] forward-solve results of the group columns (lsfm_pcg.hip k_sn_fwd / k_sn_bwd)
 	double* Gd = nullptr;   // parking area of the factored diagonal blocks of one group level: SN_GD doubles per group
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
@@ -368,8 +369,9 @@ __global__ void __launch_bounds__(CHOL_OUT_THREADS) k_chol_update_outer(const in
 // LDS per task column: its slice of v (6), the inverse pivot block (36) and three ints (column, first block, count):
 // everything a column step needs except the sub-diagonal blocks themselves is fetched side by side before the walk
 #define CHOL_TASK_LDS_PER_COL (6 * 8 + 36 * 8 + 3 * 4)
+template <class FT>
 __device__ __forceinline__ void chol_task_stage(int b, int e, const int* __restrict__ task_cols, const int* __restrict__ colptr,
-                                                const double* __restrict__ Dinv, const double* __restrict__ v, double* lv, double* sD, int* sj,
+                                                const FT* __restrict__ Dinv, const double* __restrict__ v, double* lv, double* sD, int* sj,
                                                 int* sc0, int* sn)
 {
 	const int tid = threadIdx.x, nt = blockDim.x, nc = e - b;
@@ -381,13 +383,14 @@ __device__ __forceinline__ void chol_task_stage(int b, int e, const int* __restr
 		sc0[q] = c0; sn[q] = colptr[j + 1] - c0 - 1;
 	}
 	for (int q = tid; q < nc * 6; q += nt) lv[q] = v[(size_t)task_cols[b + q / 6] * 6 + q % 6];
-	for (int q = tid; q < nc * 36; q += nt) sD[q] = Dinv[(size_t)task_cols[b + q / 36] * 36 + q % 36];
+	for (int q = tid; q < nc * 36; q += nt) sD[q] = (double)Dinv[(size_t)task_cols[b + q / 36] * 36 + q % 36];
 	__syncthreads();
 }
+template <class FT>
 __global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                          const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
-                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
-                                                         const double* __restrict__ Dinv, double* __restrict__ v)
+                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
+                                                         const FT* __restrict__ Dinv, double* __restrict__ v)
 {
 	extern __shared__ double lds[];
 	__shared__ double sy[6];
@@ -413,9 +416,9 @@ __global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ 
 		for (int w = tid; w < n * 6; w += nt)
 		{
 			const int en = c0 + 1 + w / 6, r = w % 6;
-			const double* blk = L + (size_t)en * 36 + r * 6;
+			const FT* blk = L + (size_t)en * 36 + r * 6;
 			double s = 0;
-			for (int q = 0; q < 6; q++) s = fma(blk[q], sy[q], s);
+			for (int q = 0; q < 6; q++) s = fma((double)blk[q], sy[q], s);
 			const int i = rowidx[en];
 			if (col_task[i] == me) lds_add_f64(&lv[col_lpos[i] * 6 + r], -s);
 			else atomic_add_f64(v + (size_t)i * 6 + r, -s);
@@ -424,10 +427,11 @@ __global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ 
 	}
 	for (int q = tid; q < nc * 6; q += nt) v[(size_t)sj[q / 6] * 6 + q % 6] = lv[q];
 }
+template <class FT>
 __global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                          const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
-                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
-                                                         const double* __restrict__ Dinv, double* __restrict__ v)
+                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
+                                                         const FT* __restrict__ Dinv, double* __restrict__ v)
 {
 	extern __shared__ double lds[];
 	__shared__ double red[256];
@@ -447,17 +451,17 @@ __global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ 
 		if (g < ng)
 			for (int en = g; en < n; en += ng)
 			{
-				const double* blk = L + (size_t)(c0 + 1 + en) * 36;
+				const FT* blk = L + (size_t)(c0 + 1 + en) * 36;
 				const int i = rowidx[c0 + 1 + en];
 				if (col_task[i] == me)
 				{
 					const double* xi = &lv[col_lpos[i] * 6];
-					for (int r = 0; r < 6; r++) s = fma(blk[r * 6 + c], xi[r], s);
+					for (int r = 0; r < 6; r++) s = fma((double)blk[r * 6 + c], xi[r], s);
 				}
 				else
 				{
 					const double* xi = v + (size_t)i * 6;
-					for (int r = 0; r < 6; r++) s = fma(blk[r * 6 + c], xi[r], s);
+					for (int r = 0; r < 6; r++) s = fma((double)blk[r * 6 + c], xi[r], s);
 				}
 			}
 		red[tid] = (g < ng) ? s : 0.0;
@@ -899,7 +903,11 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 // row.  y_g goes to a second vector (another group of the level may still be adding to v_g's neighbours; nobody reads
 // v_g after its own level).  Backward: z = y_g - X^T x[rows], x_g = L_dd^-T z, written into v.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sn_load_diag(int s, int c0, const int* __restrict__ colptr, const double* __restrict__ L, double* Ls, int* sSrc,
+template <class FT> struct SnPair;
+template <> struct SnPair<double> { typedef double2 T; };
+template <> struct SnPair<float> { typedef float2 T; };
+template <class FT>
+__device__ __forceinline__ void sn_load_diag(int s, int c0, const int* __restrict__ colptr, const FT* __restrict__ L, double* Ls, int* sSrc,
                                              int* sDst, int* sCol)
 {
 	const int tid = threadIdx.x, nt = blockDim.x, nb = s * (s + 1) / 2;
@@ -917,26 +925,27 @@ __device__ __forceinline__ void sn_load_diag(int s, int c0, const int* __restric
 	const int nd2 = nb * 18;
 	for (int base = 0; base < nd2; base += nt * SN_LD)
 	{
-		double2 v[SN_LD];
+		typename SnPair<FT>::T v[SN_LD];
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
 			const int q = base + i * nt + tid;
-			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const double2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
+			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const typename SnPair<FT>::T*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
 		}
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
 			const int q = base + i * nt + tid;
-			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * SN_XS + w % 6]; d[0] = v[i].x; d[1] = v[i].y; }
+			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * SN_XS + w % 6]; d[0] = (double)v[i].x; d[1] = (double)v[i].y; }
 		}
 	}
 	__syncthreads();
 }
 
+template <class FT>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
-                                                        const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
-                                                        const double* __restrict__ Dinv, double* __restrict__ v, double* __restrict__ w)
+                                                        const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
+                                                        const FT* __restrict__ Dinv, double* __restrict__ v, double* __restrict__ w)
 {
 	__shared__ double Ls[6 * CHOL_GS * SN_XS];
 	__shared__ double sDi[CHOL_GS * 36];
@@ -944,7 +953,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ g
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
 	const int tid = threadIdx.x, n6 = 6 * s;
-	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = Dinv[(size_t)c0 * 36 + q];
+	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = (double)Dinv[(size_t)c0 * 36 + q];
 	double acc = tid < n6 ? v[(size_t)c0 * 6 + tid] : 0.0;
 	sn_load_diag(s, c0, colptr, L, Ls, sSrc, sDst, sCol);
 	for (int t = 0; t < s; t++)
@@ -976,7 +985,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ g
 		double o[6] = { 0, 0, 0, 0, 0, 0 };
 		for (int t = sub; t < s; t += 4)
 		{
-			const double* blk = L + ((size_t)sCol[t] + (s - t) + i) * 36;
+			const FT* blk = L + ((size_t)sCol[t] + (s - t) + i) * 36;
 			double b[36];
 			ld<36>(b, blk);
 #pragma unroll
@@ -999,9 +1008,10 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ g
 	}
 }
 
+template <class FT>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_bwd(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
-                                                        const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ L,
-                                                        const double* __restrict__ Dinv, double* __restrict__ v, const double* __restrict__ w)
+                                                        const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
+                                                        const FT* __restrict__ Dinv, double* __restrict__ v, const double* __restrict__ w)
 {
 	__shared__ double Ls[6 * CHOL_GS * SN_XS];
 	__shared__ double sDi[CHOL_GS * 36];
@@ -1009,7 +1019,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_bwd(const int* __restrict__ g
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
 	const int tid = threadIdx.x, n6 = 6 * s;
-	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = Dinv[(size_t)c0 * 36 + q];
+	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = (double)Dinv[(size_t)c0 * 36 + q];
 	if (tid < n6) sZ[tid] = w[(size_t)c0 * 6 + tid];
 	sn_load_diag(s, c0, colptr, L, Ls, sSrc, sDst, sCol); // (ends with a barrier: sZ, sDi, sCol visible)
 	// z -= X^T x over the common rows (all final: they belong to higher levels), four lanes per row
@@ -1022,7 +1032,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_bwd(const int* __restrict__ g
 		ld<6>(x6, xr);
 		for (int t = sub; t < s; t += 4)
 		{
-			const double* blk = L + ((size_t)sCol[t] + (s - t) + i) * 36;
+			const FT* blk = L + ((size_t)sCol[t] + (s - t) + i) * 36;
 			double b[36];
 			ld<36>(b, blk);
 #pragma unroll
@@ -1058,6 +1068,12 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_bwd(const int* __restrict__ g
 		}
 	}
 	if (tid < n6) v[(size_t)c0 * 6 + tid] = sX[tid];
+}
+
+__global__ void k_to_float(size_t n, const double* __restrict__ a, float* __restrict__ b)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) b[i] = (float)a[i];
 }
 
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
@@ -1130,7 +1146,8 @@ static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
 struct SolvePlan {
 	SchurSystem sy; // index members only (S, E, IV are per run)
 	CholDev ch;     // index members + host vectors (L, Dinv, Gd, d_err are per run)
-	int its = 1;    // refinement steps the first run needed
+	int its = 1;    // refinement steps the first run needed ...
+	bool mixed = false; // ... with the preconditioner in this precision
 	char* mem = nullptr;
 	~SolvePlan() { if (mem) (void)hipFree(mem); }
 };
@@ -1140,9 +1157,9 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	const size_t M = sy.M, nnzb = sy.nnzb, cap = (size_t)sy.mask + 1;
 	struct Item { const void* src; size_t bytes; void** dst; };
 	SolvePlan& P = *sp;
-	P.sy = sy; P.ch = ch; P.its = its;
+	P.sy = sy; P.ch = ch; P.its = its; P.mixed = ch.Lf != nullptr;
 	P.sy.S = nullptr; P.sy.E = nullptr; P.sy.IV = nullptr;
-	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr;
+	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr; P.ch.Lf = nullptr; P.ch.Dinvf = nullptr;
 	std::vector<Item> items = {
 		{ sy.rowptr, (M + 1) * 4, (void**)&P.sy.rowptr }, { sy.colidx, (nnzb + 1) * 4, (void**)&P.sy.colidx },
 		{ sy.upper_keys, nnzb * 8, (void**)&P.sy.upper_keys }, { sy.longrows, (M + 1) * 4, (void**)&P.sy.longrows },
@@ -1486,18 +1503,23 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		const int n0 = ch.tlevel_ptr.size() > 1 ? ch.tlevel_ptr[1] - ch.tlevel_ptr[0] : 0;
 		const size_t lds0 = (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL + 8;
 		const int ngl = (int)ch.glevel_ptr.size() - 1;
-		if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
-		for (int l = 0; l < ngl; l++)
-		{
-			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
-			if (ng) hipLaunchKernelGGL(k_sn_fwd, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Dinv, v, ch.wv);
-		}
-		for (int l = ngl - 1; l >= 0; l--)
-		{
-			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
-			if (ng) hipLaunchKernelGGL(k_sn_bwd, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Dinv, v, ch.wv);
-		}
-		if (n0) hipLaunchKernelGGL(k_chol_bwd_tasks, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+		auto sweep = [&](auto tag, const auto* Lx, const auto* Dx) {
+			typedef decltype(tag) FT;
+			if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
+			for (int l = 0; l < ngl; l++)
+			{
+				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
+				if (ng) hipLaunchKernelGGL(k_sn_fwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Lx, Dx, v, ch.wv);
+			}
+			for (int l = ngl - 1; l >= 0; l--)
+			{
+				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
+				if (ng) hipLaunchKernelGGL(k_sn_bwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Lx, Dx, v, ch.wv);
+			}
+			if (n0) hipLaunchKernelGGL(k_chol_bwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
+		};
+		if (ch.Lf) sweep(float(), (const float*)ch.Lf, (const float*)ch.Dinvf); // mixed precision: the factor applied in fp32
+		else sweep(double(), (const double*)ch.L, (const double*)ch.Dinv);
 		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
 		return;
 	}
@@ -1507,12 +1529,12 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		for (int l = 0; l < ntl; l++)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 		}
 		for (int l = ntl - 1; l >= 0; l--)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 		}
 		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
 		return;
@@ -1727,6 +1749,16 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		d_err = ch.d_err;
 	}
 	chol_factor(ctx, sy, io.d_fixed, ch);
+	const bool mixed = ctx->pcg.mixed;
+	if (mixed)
+	{
+		// mixed precision (BASELINE configs[4]): the factor is rounded to fp32 once and applied from there; S, E, x and the
+		// residual stay fp64 -- every refinement step corrects against r = E - S x in fp64
+		const size_t nl = (size_t)ch.nnzL * 36, nd = (size_t)ch.M * 36;
+		ch.Lf = sc.alloc<float>(nl); ch.Dinvf = sc.alloc<float>(nd);
+		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, nl, ch.L, ch.Lf);
+		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, nd, ch.Dinv, ch.Dinvf);
+	}
 	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
 	double tw2 = wall();
 	int* d_misc = sc.alloc<int>(4); // [1] ndone
@@ -1768,9 +1800,10 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	// run enqueues the steps the first run needed -- the device-side tests still freeze what is done, and whether every
 	// system ended below its bound is read once at the end of the whole run.
 	const int maxit = 50;
-	int its = 0, ndone = warm ? 0 : d2h_int(ctx, d_misc + 1);
-	const int planned = warm ? sp->its : maxit;
-	while ((warm ? its < planned : (ndone < nseg && its < maxit)))
+	const bool planned_run = warm && sp->mixed == mixed; // the step count was recorded with the preconditioner in this precision
+	int its = 0, ndone = planned_run ? 0 : d2h_int(ctx, d_misc + 1);
+	const int planned = planned_run ? sp->its : maxit;
+	while ((planned_run ? its < planned : (ndone < nseg && its < maxit)))
 	{
 		const int cur = its & 1;
 		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
@@ -1780,7 +1813,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		// the test comes before the preconditioner: the apply for a residual that already passed would be wasted
 		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, seg, d_misc + 1);
 		its++;
-		if (warm) { if (its >= planned) break; }
+		if (planned_run) { if (its >= planned) break; }
 		else
 		{
 			ndone = d2h_int(ctx, d_misc + 1);
@@ -1824,6 +1857,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	}
 	if (warm)
 	{
+		if (!planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; } // the precision changed: the count was re-learnt
 		hipLaunchKernelGGL(k_pcg_run_stats, dim3(nbs), dim3(128), 0, s, nseg, seg, ctx->d_run);
 		return 0; // the outcome is read at the end of the run (lsfm_tree_run)
 	}

@@ -226,6 +226,13 @@ int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor)
 	return LSFM_OK;
 }
 
+int lsfm_set_precision(lsfm_context* ctx, int mode)
+{
+	if (!ctx || (mode != 0 && mode != 1)) return LSFM_ERR_ARG;
+	ctx->pcg.mixed = mode == 1;
+	return LSFM_OK;
+}
+
 const char* lsfm_last_error(lsfm_context* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 void* lsfm_stream(lsfm_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

@@ -313,6 +313,38 @@ def test_repeated_runs_of_a_resident_tree(ctx, mono):
             assert rel_err(other[k], a[k]) < 1e-7, k  # atomics: the summation order differs from run to run
 
 
+@pytest.mark.parametrize("mono,N", [(False, 1500), (True, 200)])
+def test_mixed_precision_preconditioner_vs_fp64(ctx, mono, N):
+    """lsfm_set_precision(1) (BASELINE.json configs[4]): the Cholesky factor kept and applied in fp32, S / E / x / residual in
+    fp64.  Every refinement step corrects against the fp64 residual r = E - S x and the stopping rule is unchanged, so the
+    result agrees with the fp64 path far inside the 1e-6 of the task -- it just takes more steps."""
+    maps = synth.make_mono_set(N, 20, 4, seed=51, **synth.SPIRAL) if mono else synth.make_stereo_set(N, 20, 5, seed=51, **synth.FLOWER)
+    t = ctx.tree_upload(maps, mono)
+    try:
+        s64, rc = ctx.tree_run(t)
+        assert rc == 0
+        a = ctx.tree_download(t)
+        ctx.set_precision(True)
+        s32, rc = ctx.tree_run(t)   # structure from the plan, step counts re-learnt for the fp32 factor
+        assert rc == 0
+        b = ctx.tree_download(t)
+        s32b, rc = ctx.tree_run(t)  # and now planned
+        assert rc == 0
+        c = ctx.tree_download(t)
+    finally:
+        ctx.set_precision(False)
+        ctx.tree_free(t)
+    for s in (s64, s32, s32b):
+        assert s["not_converged"] == 0 and s["max_rel_residual"] < 1e-9, s
+    assert s32["pcg_iterations"] > s64["pcg_iterations"]
+    for other in (b, c):
+        assert np.array_equal(other["stno"], a["stno"])
+        assert pose_param_err(other["stVal"], a["stVal"], a["stno"]) < 1e-7
+        assert feat_param_err(other["stVal"], a["stVal"], a["stno"]) < 1e-7
+    print(f"mixed vs fp64: pose {pose_param_err(b['stVal'], a['stVal'], a['stno']):.2e}, steps {s32['pcg_iterations']} vs {s64['pcg_iterations']}, "
+          f"max rel residual {s32['max_rel_residual']:.2e}")
+
+
 def test_a_result_overwritten_by_a_later_call_is_refused(ctx):
     """A finished tree's map lives in the context's arenas: after any other compute call on the context a download must
     fail with a message instead of handing back overwritten memory; running the tree again makes it available again."""

@@ -93,6 +93,7 @@ struct LevelPlan {
 	std::vector<int> tr_cnt;     // transform: kept-block prefix values at the map boundaries (U then W)
 	std::vector<int> tr_sign;    // Mono: sign of the new scale of every transformed map
 	std::vector<int> join_rb;    // join: ranks of the unmatched features at the map boundaries
+	std::vector<int> join_uo, join_wo; // Mono join: kept-U prefix at the map boundaries, W offsets of the joint maps
 	std::shared_ptr<void> solve; // pattern of S + symbolic factorisation + iteration count (lsfm_pcg.hip)
 };
 

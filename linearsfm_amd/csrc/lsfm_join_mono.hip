@@ -303,10 +303,15 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	dev_exclusive_scan(ctx, removed, R, M);
 	LSFM_CHECK_HIP(hipMemcpyAsync(prior, in.pose, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	hipLaunchKernelGGL(k_mono_wrap, dim3((G + 127) / 128), dim3(128), 0, s, G, d_mg, prior);
-	d2h(ctx, mg.data(), d_mg, sizeof(MGroup) * G);
-	for (int g = 0; g < G; g++)
-		if (mg[g].pair && (mg[g].P1 < 0 || mg[g].P2 < 0 || mg[g].C1 < 0 || mg[g].C2 < 0))
-			LSFM_FAIL(LSFM_ERR_ARG, "Mono join: shared reference / scale pose missing in pair " + std::to_string(g));
+	LevelPlan* plan = ctx->plan;
+	const bool warm = ctx->warm(); // the structure of this level is known from an earlier run of the same tree: no round trips
+	if (!warm)
+	{
+		d2h(ctx, mg.data(), d_mg, sizeof(MGroup) * G);
+		for (int g = 0; g < G; g++)
+			if (mg[g].pair && (mg[g].P1 < 0 || mg[g].P2 < 0 || mg[g].C1 < 0 || mg[g].C2 < 0))
+				LSFM_FAIL(LSFM_ERR_ARG, "Mono join: shared reference / scale pose missing in pair " + std::to_string(g));
+	}
 	const int MY = M - 2 * npair;
 
 	// ---- common features (K5), same as Stereo ----
@@ -320,7 +325,12 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	int* d_rb = sc.alloc<int>(B + 1);
 	hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, RF, in.d_feat_off, B + 1, d_rb);
 	std::vector<int> rb(B + 1);
-	d2h_ints(ctx, d_rb, rb.data(), B + 1);
+	if (warm) rb = plan->join_rb;
+	else
+	{
+		d2h_ints(ctx, d_rb, rb.data(), B + 1);
+		if (plan) plan->join_rb = rb;
+	}
 
 	out = DevBatch();
 	out.B = G; out.M = MY;
@@ -373,8 +383,13 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 		int* d_uo = sc.alloc<int>(B + 1);
 		int* d_ui = sc.alloc<int>(B + 1);
 		h2d(ctx, d_ui, in.u_off.data(), (B + 1) * sizeof(int));
-		hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, d_ui, B + 1, d_uo);
-		d2h_ints(ctx, d_uo, uo.data(), B + 1);
+		if (warm) uo = plan->join_uo;
+		else
+		{
+			hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, d_ui, B + 1, d_uo);
+			d2h_ints(ctx, d_uo, uo.data(), B + 1);
+			if (plan) plan->join_uo = uo;
+		}
 	}
 	out.NU = uo[B];
 	for (int g = 0; g <= G; g++) out.u_off[g] = uo[std::min(2 * g, B)];
@@ -405,8 +420,13 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 		int* d_fo = sc.alloc<int>(G + 1);
 		int* d_wo = sc.alloc<int>(G + 1);
 		h2d(ctx, d_fo, out.feat_off.data(), (G + 1) * sizeof(int));
-		hipLaunchKernelGGL(k_gather_at, dim3((G + 1 + 127) / 128), dim3(128), 0, s, out.fptr, d_fo, G + 1, d_wo);
-		d2h_ints(ctx, d_wo, out.w_off.data(), G + 1);
+		if (warm) out.w_off = plan->join_wo;
+		else
+		{
+			hipLaunchKernelGGL(k_gather_at, dim3((G + 1 + 127) / 128), dim3(128), 0, s, out.fptr, d_fo, G + 1, d_wo);
+			d2h_ints(ctx, d_wo, out.w_off.data(), G + 1);
+			if (plan) plan->join_wo = out.w_off;
+		}
 	}
 	out.NW = out.w_off[G];
 	out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW);
@@ -434,9 +454,10 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	io.seg_rows = seg_rows;
 	int rc = solve_batch(ctx, io);
 	hipLaunchKernelGGL(k_mono_finish, dim3((G + 127) / 128), dim3(128), 0, s, G, d_mg, pnew, out.pose);
-	LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s)); // a warm level is only enqueued: its scratch is reused in stream order
 	sc.release(smark);
 	if (rc > 0 && ctx->stats) ctx->stats->not_converged += rc;
+	if (plan && !eP_out && !eF_out) plan->valid = true; // every stage of the level has left its structure behind
 }
 
 } // namespace lsfm

@@ -28,7 +28,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 # that rate (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz) = 78.6 TFLOP/s, AMD's dense FP64 matrix figure for MI355X
 F64_MFMA_PEAK_TFLOPS = 78.6
 METRIC_NAMES = {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular", "rs90": "RS90-like monocular",
-                "synth16k": "synthetic 16k monocular", "synth64k": "synthetic 64k stereo"}
+                "synth16k": "synthetic 16k monocular", "synth64k": "synthetic 64k stereo",
+                "spmv-stream": "CG SpMV stand-alone on a 1.4 GB Schur-like matrix"}
 
 
 def pmc_traffic(config):
@@ -42,6 +43,44 @@ def pmc_traffic(config):
         return json.load(open(files[-1]))
     except Exception:
         return None
+
+
+def spmv_stream(args, ctx, rank, world, torch, dist, synth_mod):
+    """--config spmv-stream: the CG's SpMV kernel (K10a, k_spmv) alone on a Schur-like matrix too large for the caches
+    (pose chain with 12 neighbours + 12 dense hub rows, 262 144 poses, 1.38 GB of upper blocks).  On the tree configurations S
+    is <= ~20 MB and the launch is latency-bound, so this line is where the kernel's HBM streaming rate is measured.
+    A step = one launch; every rank runs its own replica (no exchange: "replicas only"), value = sum of the ranks' rates."""
+    m, band, hubs = args.maps or 262144, 12, 12
+    rp32, colidx, val = synth_mod.schur_like_matrix(m, band, hubs, seed=0)
+    x = np.random.default_rng(1).normal(size=6 * m)
+    if args.warmup:
+        ctx.spmv_bench(rp32, colidx, val, x, reps=args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    # lsfm_spmv_bench uploads (untimed), then brackets `reps` launches with HIP events on the library's stream
+    y, ms, by = ctx.spmv_bench(rp32, colidx, val, x, reps=args.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    gbs = by / (ms * 1e-3) / 1e9
+    tm = torch.tensor([gbs, ms], dtype=torch.float64, device="cuda")
+    mx = tm.clone()
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        line = {"metric": "CG-SpMV HBM GB/s (6x6-block symmetric SpMV of the Schur system, stand-alone)", "value": float(tm[0].item()),
+                "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(mx[1].item()),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"spmv-stream: {m} poses, band {band} + {hubs} hub rows, {len(colidx)} upper 6x6 blocks "
+                                       f"({len(colidx) * 288 / 1e6:.0f} MB)", "replicas": world,
+                           "value_definition": "algorithmic bytes of one launch (nnzb*(288+4) + 4(m+1) + 96 m, SURVEY 8d) / average "
+                                               "launch time (HIP events around the timed launches), summed over the replicas",
+                           "host_wall_s_including_upload": wall},
+                "roofline": {"bound": "hbm", "kernel": "k_spmv (K10a)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by}}
+        print(json.dumps(line))
 
 
 def cpu_baseline(dicts, mono):
@@ -90,6 +129,14 @@ def main():
 
     from linearsfm_amd import api, synth
     from linearsfm_amd.distributed import ShardedTree, shard_bounds
+
+    if args.config == "spmv-stream":
+        ctx = api.Context(local_rank)
+        spmv_stream(args, ctx, rank, world, torch, dist, synth)
+        ctx.close()
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(0)
 
     typ, cN, cnpf, cvis, cpath = synth.CONFIGS[args.config]
     mono = typ == "Monocular"

@@ -94,6 +94,11 @@ int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor);
  * fp64 residual, and the stopping rule is the same relative residual as in mode 0, reached in more steps (2-3 instead
  * of 1).  BASELINE.json configs[4]. */
 int lsfm_set_precision(lsfm_context* ctx, int mode);
+/* Which kernel multiplies by the Schur matrix in the CG.  0 (default): by size -- a matrix that stays in L2 / Infinity
+ * Cache (every level of the named configurations) is multiplied from a row-sorted list of both orientations of its
+ * blocks, a larger one streams its upper blocks from HBM once.  1: always the streaming kernel.  2: always the list.
+ * A measurement / test knob; it applies to the systems analysed after the call (a recorded plan keeps its choice). */
+int lsfm_set_spmv_variant(lsfm_context* ctx, int variant);
 const char* lsfm_last_error(lsfm_context* ctx);
 void* lsfm_stream(lsfm_context* ctx); /* hipStream_t the library launches on */
 

@@ -60,6 +60,7 @@ def lib():
         L.lsfm_context_destroy.restype = None
         L.lsfm_set_pcg.argtypes = [vp, C.c_double, C.c_int]
         L.lsfm_set_precision.argtypes = [vp, C.c_int]
+        L.lsfm_set_spmv_variant.argtypes = [vp, C.c_int]
         L.lsfm_last_error.argtypes = [vp]
         L.lsfm_last_error.restype = C.c_char_p
         L.lsfm_stream.argtypes = [vp]
@@ -98,7 +99,7 @@ def lib():
     return _LIB
 
 
-EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_set_precision", "lsfm_last_error", "lsfm_stream",
+EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_set_precision", "lsfm_set_spmv_variant", "lsfm_last_error", "lsfm_stream",
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
@@ -193,6 +194,10 @@ class Context:
     def set_precision(self, mixed):
         """False: fp64 throughout.  True: the Cholesky preconditioner kept and applied in fp32, residual correction in fp64."""
         self._check(lib().lsfm_set_precision(self._h, 1 if mixed else 0), "lsfm_set_precision")
+
+    def set_spmv_variant(self, variant):
+        """0: by size (default); 1: always the kernel that streams the upper blocks once; 2: always the row-sorted list."""
+        self._check(lib().lsfm_set_spmv_variant(self._h, int(variant)), "lsfm_set_spmv_variant")
 
     def stream(self):
         return lib().lsfm_stream(self._h)

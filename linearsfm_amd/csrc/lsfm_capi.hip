@@ -540,7 +540,7 @@ int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* coli
 {
 	if (!rowptr || !colidx || !val || !x || !y || m <= 0) return LSFM_ERR_ARG;
 	return guarded(ctx, [&]() {
-		ctx->ensure_arenas(((size_t)rowptr[m] * 400 + (size_t)m * 1000) * 2 + ((size_t)64 << 20));
+		ctx->ensure_arenas(((size_t)rowptr[m] * 480 + (size_t)m * 1000) * 2 + ((size_t)64 << 20));
 		ctx->scratch.reset();
 		return spmv_external(ctx, m, rowptr, colidx, val, x, y, reps, avg_ms, algorithmic_bytes);
 	});

@@ -79,7 +79,7 @@ struct DevBatch {
 	const int* d_alias = nullptr;
 };
 
-struct PcgOptions { double rel_tol = 1e-12; int max_it_factor = 4; bool mixed = false; };
+struct PcgOptions { double rel_tol = 1e-12; int max_it_factor = 4; bool mixed = false; int spmv_variant = 0; };
 
 // What the first run of a tree level leaves behind for the next runs of the SAME resident tree.  Everything here is
 // structure: it depends on the labels, the index arrays and the join tree of the uploaded local maps, which no run

@@ -1165,6 +1165,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 		{ sy.upper_keys, nnzb * 8, (void**)&P.sy.upper_keys }, { sy.longrows, (M + 1) * 4, (void**)&P.sy.longrows },
 		{ sy.d_nlong, 4, (void**)&P.sy.d_nlong }, { sy.tab, cap * 8, (void**)&P.sy.tab }, { sy.hval, cap * 4, (void**)&P.sy.hval },
 		{ ch.blob, ch.blob_ints * 4, (void**)&P.ch.blob },
+		{ sy.gent, sy.gent ? nnzb * 16 : 0, (void**)&P.sy.gent }, { sy.goth, sy.goth ? nnzb * 8 : 0, (void**)&P.sy.goth },
 	};
 	size_t total = 0;
 	for (const Item& it : items) total += (it.bytes + 255) & ~(size_t)255;
@@ -1173,7 +1174,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	for (const Item& it : items)
 	{
 		if (it.bytes) LSFM_CHECK_HIP(hipMemcpyAsync(P.mem + off, it.src, it.bytes, hipMemcpyDeviceToDevice, ctx->stream));
-		*it.dst = P.mem + off;
+		*it.dst = it.src ? P.mem + off : nullptr;
 		off += (it.bytes + 255) & ~(size_t)255;
 	}
 	// the factorisation's index arrays are slices of the blob

@@ -233,6 +233,13 @@ int lsfm_set_precision(lsfm_context* ctx, int mode)
 	return LSFM_OK;
 }
 
+int lsfm_set_spmv_variant(lsfm_context* ctx, int variant)
+{
+	if (!ctx || variant < 0 || variant > 2) return LSFM_ERR_ARG;
+	ctx->pcg.spmv_variant = variant;
+	return LSFM_OK;
+}
+
 const char* lsfm_last_error(lsfm_context* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 void* lsfm_stream(lsfm_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

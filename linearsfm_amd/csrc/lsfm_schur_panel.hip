@@ -25,9 +25,27 @@ namespace lsfm {
 #define PM_SMAX_BIG 48  /* slots of the variant for the tiles that exceed it: 1024 threads (16 waves share the 171 output tiles) */
 #define PM_HASH 64
 #define PM_THREADS 256
-#define PM_MAXE 4096 /* W blocks of the tile whose slot is kept in LDS (one byte each); later ones probe the hash again */
+#define PM_MAXE 3584 /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 per feature on average); later ones probe the hash again */
+#define PM_BF 352   /* >= rows held in registers per pass / 6 (4 x 256 or 2 x 1024) */
+#define PM_DUP 0x80  /* eslot: a block whose (pose, feature) an earlier block of the tile already holds */
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Profiling aid (make K9_TIMING=1; tools/k9_phase_times.py): lane 0 of every work-group adds up the shader clocks it
+// spends in each phase of a tile and leaves the sums in g_k9_t.  Compiled out otherwise.
+#ifdef LSFM_K9_TIMING
+__device__ unsigned long long g_k9_t[64]; // 16 per variant (8 / 16 / 32 / 48 slots)
+#define K9T_DECL unsigned long long k9acc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long k9t_prev = __builtin_readcyclecounter()
+#define K9T(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); k9acc[i] += n_ - k9t_prev; k9t_prev = n_; } while (0)
+#define K9T_BASE (SMAX <= 8 ? 0 : (SMAX <= 16 ? 16 : (SMAX <= 32 ? 32 : 48)))
+#define K9T_FLUSH(a, b) do { if (threadIdx.x == 0) for (int i_ = (a); i_ < (b); i_++) atomicAdd(&g_k9_t[K9T_BASE + i_], k9acc[i_]); } while (0)
+#define K9T_COUNT(ns, T) do { if (threadIdx.x == 0) { atomicAdd(&g_k9_t[K9T_BASE + 8], 1ull); atomicAdd(&g_k9_t[K9T_BASE + 9], (unsigned long long)(ns)); atomicAdd(&g_k9_t[K9T_BASE + 10], (unsigned long long)(T)); } } while (0)
+#else
+#define K9T_DECL do { } while (0)
+#define K9T(i) do { } while (0)
+#define K9T_FLUSH(a, b) do { } while (0)
+#define K9T_COUNT(ns, T) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned long long pn_mix64(unsigned long long x)
 {
@@ -55,22 +73,23 @@ struct PmShared {
 	int hslot[PM_HASH];
 	int pose_of[SMAX];
 	int nslots, bad;
-	int fp[PM_PASS + 1];
-	double Ls[PM_PASS * 6]; // l00 l10 l11 l20 l21 l22 of V^-1 = L L^T
-	double ys[PM_K];        // L^T eb
+	unsigned char bf[PM_BF]; // block of the pass -> its feature (the first PM_BF blocks; later ones search the run pointers)
+	int fpt[PM_TILE + 1]; // run pointers of the tile's features: the prefetch of a pass must not wait for them first
+	double ly[PM_PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
 	double P[6 * SMAX * PM_KS];
-	unsigned char eslot[PM_MAXE]; // slot of the tile's W blocks, filled once: the passes do not touch photo[] again
+	unsigned char eslot[PM_MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
 };
 
 // T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + NW t over its NW waves; slots
 // past the last tile recompute tile (0,0) and are dropped)
 template <int T, int SMAX, int THREADS>
 __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
-                                        const double* __restrict__ W, const double* __restrict__ IV, const double* __restrict__ eb,
+                                        const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
+	K9T_DECL;
 	const int rows = 6 * ns, NT = (rows + 15) >> 4, ntile = NT * (NT + 1) / 2;
 	int ti[T], tj[T], offA[T], offB[T]; // wave-uniform
 	const int lbase = (lane & 15) * PM_KS + (lane >> 4);
@@ -95,110 +114,141 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		acc[t] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
 	}
 	double eacc = 0.0;
-	// W rows of the next pass are fetched into registers before the MFMA loop of the current one: the staging after the
-	// barrier then works on LDS only (measured: staging with the global loads inside cost 4.5 of K9's 9.5 ms)
-	// Staging is by feature: 16 lanes per feature of the pass walk the rows of its blocks (3 doubles each, consecutive
-	// lanes on consecutive rows), so a lane knows its feature without searching the run pointers.
-	constexpr int PF = T <= 9 ? 8 : (T <= 14 ? 2 : 1); // rows per lane held in flight (register budget of the variant)
-	const int sfl = tid >> 4, sl16 = tid & 15;
+	// Everything a pass reads from memory is fetched into registers before the MFMA loop of the pass before it, and none of
+	// it behind a dependent load: the run pointers of the tile sit in LDS, the W rows of a pass are ONE contiguous range
+	// (row w of the pass = 3 doubles at W[18 qb0 + 3 w]: consecutive lanes, consecutive 24 bytes, whatever the lengths of
+	// the 16 runs are), (L, y) of its features 144 contiguous doubles (k_vinv leaves them per feature: no square roots or
+	// divisions here).  Between the barriers a pass then works on LDS only: the feature of a row is found in the pass's run
+	// pointers, its L read from the staged copy.  (Measured before: staging with the global loads inside 4.5 of K9's 9.5 ms;
+	// the per-pass Cholesky of V^-1 behind a dependent load a quarter of a tile; 16 lanes per feature -- a feature seen by
+	// more than 10 poses went back to memory inside the staging -- a third of it.)
+	constexpr int PF = THREADS != 256 ? 2 : (T <= 9 ? 4 : (T <= 14 ? 3 : 2)); // rows per lane in flight: 4 x 256 rows = 10.6 poses per feature on average
 	double pw[PF][3];
+	double lyv = 0.0;
+	int qb0 = 0, R = 0;
 	auto prefetch = [&](int p0n) {
 		const int nfn = min(PM_PASS, f1 - p0n);
-		if (sfl < nfn)
-		{
-			const int qbn = fptr[p0n + sfl], nrown = (fptr[p0n + sfl + 1] - qbn) * 6;
+		qb0 = sh.fpt[p0n - f0];
+		R = (sh.fpt[p0n - f0 + nfn] - qb0) * 6;
+		lyv = 0.0;
+		if (tid < nfn * 9) lyv = LY[(size_t)p0n * 9 + tid];
+		const double* wb = W + (size_t)qb0 * 18;
 #pragma unroll
-			for (int i = 0; i < PF; i++)
-			{
-				const int w = sl16 + 16 * i;
-				if (w < nrown)
-				{
-					const double* wr = W + (size_t)qbn * 18 + (size_t)w * 3; // row r of block e: (qb + e) * 18 + 3 r
-					pw[i][0] = wr[0]; pw[i][1] = wr[1]; pw[i][2] = wr[2];
-				}
-			}
+		for (int i = 0; i < PF; i++)
+		{
+			const int w = tid + THREADS * i;
+			if (w < R) { pw[i][0] = wb[3 * (size_t)w]; pw[i][1] = wb[3 * (size_t)w + 1]; pw[i][2] = wb[3 * (size_t)w + 2]; }
 		}
 	};
 	if (f0 < f1) prefetch(f0);
 	for (int p0 = f0; p0 < f1; p0 += PM_PASS)
 	{
-		const int nf = min(PM_PASS, f1 - p0);
+		const int nf = min(PM_PASS, f1 - p0), pb = p0 - f0;
+		K9T(5);
 		__syncthreads(); // the previous pass is fully consumed
+		K9T(1);
 		for (int q = tid; q < NT * 16 * PM_KS; q += THREADS) sh.P[q] = 0.0;
-		if (tid <= nf) sh.fp[tid] = fptr[p0 + tid];
-		if (tid < PM_PASS)
+		if (tid < PM_PASS * 9)
 		{
-			double l[6] = { 0, 0, 0, 0, 0, 0 }, y[3] = { 0, 0, 0 };
-			if (tid < nf)
-			{
-				const double* a = IV + (size_t)(p0 + tid) * 9;
-				const double* e = eb + (size_t)(p0 + tid) * 3;
-				const double d0 = a[0];
-				l[0] = sqrt(d0);
-				l[1] = a[3] / l[0];
-				l[3] = a[6] / l[0];
-				const double d1 = a[4] - l[1] * l[1];
-				l[2] = sqrt(d1);
-				l[4] = (a[7] - l[3] * l[1]) / l[2];
-				const double d2 = a[8] - l[3] * l[3] - l[4] * l[4];
-				l[5] = sqrt(d2);
-				if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) sh.bad = 1;
-				y[0] = l[0] * e[0] + l[1] * e[1] + l[3] * e[2];
-				y[1] = l[2] * e[1] + l[4] * e[2];
-				y[2] = l[5] * e[2];
-			}
-			for (int q = 0; q < 6; q++) sh.Ls[tid * 6 + q] = l[q];
-			for (int q = 0; q < 3; q++) sh.ys[tid * 3 + q] = y[q];
+			sh.ly[tid] = lyv; // zero for the features past the end of the tile
+			if (tid < nf * 9 && tid % 9 == 0 && !(lyv == lyv)) sh.bad = 1; // k_vinv: V^-1 of this feature has no Cholesky factor
+		}
+		if (tid < nf)
+		{
+			const int a = sh.fpt[pb + tid] - qb0, b = min(sh.fpt[pb + tid + 1] - qb0, PM_BF);
+			for (int e = a; e < b; e++) sh.bf[e] = (unsigned char)tid;
 		}
 		__syncthreads();
-		// stage P = W L
-		if (sfl < nf)
+		K9T(2);
+#ifdef LSFM_K9_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // what is left of the prefetch's latency, apart from the staging itself
+		K9T(7);
+#endif
+		// stage P = W L: first blocks of their (pose, feature) pair with plain stores; the repeats (and the blocks past the
+		// LDS slot list) wait for the barrier and are added
+		bool later = false;
+		const double* wb = W + (size_t)qb0 * 18;
+		auto stage = [&](int w, double w0, double w1, double w2, bool second) {
+			const int e = w / 6, r = w - 6 * e, j = qb0 + e;
+			int sl, dup = 1;
+			if (j - jb < PM_MAXE) { sl = sh.eslot[j - jb]; dup = sl & PM_DUP; sl &= PM_DUP - 1; }
+			else
+			{
+				if (!second) { later = true; return; }
+				const int key = photo[j];
+				unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+				while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+				sl = sh.hslot[h];
+			}
+			if (!second && dup) { later = true; return; }
+			if (second && !dup) return;
+			int lo = 0;
+			if (e < PM_BF) lo = sh.bf[e];
+			else
+			{
+				int hi = nf - 1; // feature of block j: the last run of the pass that starts at or before it
+				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sh.fpt[pb + mid] <= j) lo = mid; else hi = mid - 1; }
+			}
+			const double* l = &sh.ly[lo * 9];
+			double* d = &sh.P[(6 * sl + r) * PM_KS + 3 * lo];
+			const double v0 = w0 * l[0] + w1 * l[1] + w2 * l[3], v1 = w1 * l[2] + w2 * l[4], v2 = w2 * l[5];
+			if (!second)
+			{
+				d[0] = v0; d[1] = v1; d[2] = v2;
+			}
+			else
+			{
+				__hip_atomic_fetch_add(d + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_add(d + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_add(d + 2, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		};
+#pragma unroll
+		for (int i = 0; i < PF; i++)
 		{
-			const int qb = sh.fp[sfl], nrow = (sh.fp[sfl + 1] - qb) * 6;
-			const double* l = &sh.Ls[sfl * 6];
-			const double l0 = l[0], l1 = l[1], l2 = l[2], l3 = l[3], l4 = l[4], l5 = l[5];
-			auto stage = [&](int w, double w0, double w1, double w2) {
-				const int e = w / 6, r = w - 6 * e, j = qb + e;
-				int sl;
-				if (j - jb < PM_MAXE) sl = sh.eslot[j - jb];
-				else
-				{
-					const int key = photo[j];
-					unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-					while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
-					sl = sh.hslot[h];
-				}
-				double* d = &sh.P[(6 * sl + r) * PM_KS + 3 * sfl];
-				// two blocks of one (pose, feature) add up, as in the reference's pair loop: atomics
-				__hip_atomic_fetch_add(d + 0, w0 * l0 + w1 * l1 + w2 * l3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_add(d + 1, w1 * l2 + w2 * l4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_add(d + 2, w2 * l5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			};
+			const int w = tid + THREADS * i;
+			if (w < R) stage(w, pw[i][0], pw[i][1], pw[i][2], false);
+		}
+		for (int w = tid + THREADS * PF; w < R; w += THREADS) stage(w, wb[3 * (size_t)w], wb[3 * (size_t)w + 1], wb[3 * (size_t)w + 2], false);
+		K9T(3);
+		if (__syncthreads_or(later))
+		{
 #pragma unroll
 			for (int i = 0; i < PF; i++)
 			{
-				const int w = sl16 + 16 * i;
-				if (w < nrow) stage(w, pw[i][0], pw[i][1], pw[i][2]);
+				const int w = tid + THREADS * i;
+				if (w < R) stage(w, pw[i][0], pw[i][1], pw[i][2], true);
 			}
-			for (int w = sl16 + 16 * PF; w < nrow; w += 16)
-			{
-				const double* wr = W + (size_t)qb * 18 + (size_t)w * 3;
-				stage(w, wr[0], wr[1], wr[2]);
-			}
+			for (int w = tid + THREADS * PF; w < R; w += THREADS) stage(w, wb[3 * (size_t)w], wb[3 * (size_t)w + 1], wb[3 * (size_t)w + 2], true);
+			__syncthreads();
 		}
-		__syncthreads();
+		K9T(4);
 		if (p0 + PM_PASS < f1) prefetch(p0 + PM_PASS);
-		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328
+		else { R = 0; lyv = 0.0; }
+		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328 (the panel and y are zero past the pass's last feature: constant trip count,
+		// the LDS reads of a row in flight together -- as a 48-step dependent loop this was a third of the pass)
 		if (tid < rows)
 		{
 			const double* pr = &sh.P[tid * PM_KS];
-			double s = 0.0;
-			for (int k = 0; k < 3 * nf; k++) s = fma(pr[k], sh.ys[k], s);
-			eacc -= s;
+			double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 1
+			for (int k0 = 0; k0 < PM_K; k0 += 8)
+#pragma unroll
+				for (int k = k0; k < k0 + 8; k += 4)
+				{
+					s0 = fma(pr[k], sh.ly[(k / 3) * 9 + 6 + k % 3], s0);
+					s1 = fma(pr[k + 1], sh.ly[((k + 1) / 3) * 9 + 6 + (k + 1) % 3], s1);
+					s2 = fma(pr[k + 2], sh.ly[((k + 2) / 3) * 9 + 6 + (k + 2) % 3], s2);
+					s3 = fma(pr[k + 3], sh.ly[((k + 3) / 3) * 9 + 6 + (k + 3) % 3], s3);
+				}
+			eacc -= (s0 + s1) + (s2 + s3);
 		}
-		// P P^T, four feature columns per MFMA: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15]
-		const int nks = (3 * nf + 3) >> 2;
-		for (int ks = 0; ks < nks; ks++)
+		K9T(11);
+		// P P^T, four feature columns per MFMA: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15].
+		// Always the full PM_K columns (zero past the last feature); the T tiles of a step are independent chains
+		constexpr int UNR = T <= 1 ? PM_K / 4 : (T <= 3 ? 4 : (T <= 6 ? 2 : 1));
+#pragma unroll UNR
+		for (int ks = 0; ks < PM_K / 4; ks++)
 		{
 #pragma unroll
 			for (int t = 0; t < T; t++)
@@ -208,7 +258,9 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			}
 		}
 	}
+	K9T(5);
 	__syncthreads();
+	K9T(1);
 	if (sh.bad)
 	{
 		if (tid == 0) fallback[blockIdx.x] = 1;
@@ -256,6 +308,10 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		}
 	}
 	if (tid < rows && eacc != 0.0) atomic_add_f64(E + (size_t)sh.pose_of[tid / 6] * 6 + tid % 6, eacc);
+	K9T(6);
+	K9T_FLUSH(1, 8);
+	K9T_FLUSH(11, 12);
+	K9T_COUNT(ns, T);
 }
 
 // `only` == nullptr: every tile; tiles with more than SMAX poses are flagged in `fallback`.  `only` != nullptr (the second
@@ -264,19 +320,21 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 // A tile is then all latency -- hashing, eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
 // work-groups share a CU instead of 2.
 template <int SMAX, int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 6 : (SMAX <= 16 ? 3 : 2)))
-k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
-              const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : (SMAX <= 16 ? 3 : 2)))
+k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
+              const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
               double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only)
 {
 	if (only && !only[blockIdx.x]) return;
+	K9T_DECL;
 	__shared__ PmShared<SMAX> sh;
 	const int tid = threadIdx.x;
 	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
-	const int jb = fptr[f0], je = fptr[f1];
+	for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
 	if (tid < PM_HASH) { sh.hkey[tid] = -1; sh.hslot[tid] = -1; }
 	if (tid == 0) { sh.nslots = 0; sh.bad = 0; }
 	__syncthreads();
+	const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
 	// ---- the tile's poses -> slots ----
 	for (int j = jb + tid; j < je; j += THREADS)
 	{
@@ -312,11 +370,31 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		return;
 	}
 	if (only && tid == 0) fallback[blockIdx.x] = 0; // taken here (pm_body flags it again if a V^-1 has no Cholesky factor)
+	// slot numbers; and which blocks repeat a (pose, feature) pair of the tile.  The joins keep both blocks when a feature
+	// was seen from the hub pose on either side (the reference concatenates, Imp.cpp:1277; its pair loop adds them up): the
+	// first block of a pair is staged with plain stores, the repeats are added after it -- an LDS atomic add of a double
+	// costs ~4 clocks per LANE on this chip, and as the only way into the panel it was 40 % of the kernel
 	for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = (unsigned char)sh.hslot[sh.eslot[e]];
+	__syncthreads();
+	if (tid < f1 - f0)
+	{
+		// one lane per feature walks its run: a slot it has met before marks a repeat
+		unsigned long long seen = 0ull;
+		const int a = sh.fpt[tid] - jb, b = min(sh.fpt[tid + 1] - jb, PM_MAXE);
+		for (int e = a; e < b; e++)
+		{
+			const int sl = sh.eslot[e];
+			const unsigned long long bit = 1ull << sl;
+			if (seen & bit) sh.eslot[e] = (unsigned char)(sl | PM_DUP);
+			seen |= bit;
+		}
+	}
 	// (visible to the passes through the barrier at the top of the first pass)
+	K9T(0);
+	K9T_FLUSH(0, 1);
 	constexpr int NW = THREADS / 64;
 	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
-#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback)
+#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback)
 	if constexpr (SMAX <= 8)
 	{
 		if (tpw <= 1) PM_GO(1);
@@ -348,7 +426,16 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 
 int schur_panel_tile() { return PM_TILE; }
 
-void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
+#ifdef LSFM_K9_TIMING
+extern "C" void lsfm_debug_k9(unsigned long long* out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9_t), sizeof(unsigned long long) * 64);
+	if (reset) { unsigned long long z[64] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k9_t), z, sizeof(z)); }
+}
+#endif
+
+void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
                         int max_poses_per_system)
 {
@@ -357,20 +444,24 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	// no tile can be seen by more poses than its system has
 	if (max_poses_per_system <= 8)
 	{
-		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback,
+		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 		                   (const unsigned char*)nullptr);
 		return;
 	}
 	if (max_poses_per_system <= 16)
 	{
-		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback,
+		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 		                   (const unsigned char*)nullptr);
 		return;
 	}
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E,
-	                   fallback, (const unsigned char*)nullptr);
-	// the tiles that exceed 32 poses (a path that revisits: the frames of two laps + the hub poses of every level)
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, IV, eb, tab, val, mask, S, E, fallback,
+	// By tile, not by level: most tiles of the upper levels are seen by a dozen poses (12.1 on average on the NC3500-like
+	// set) and fit the 16-slot variant, which is three work-groups to a CU instead of two and a third less work per pass;
+	// the tiles it flags go to the 32-slot variant, what that one flags to the 48-slot one, the rest to k_schur_w
+	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
+	                   (const unsigned char*)nullptr);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E,
+	                   fallback, (const unsigned char*)fallback);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 	                   (const unsigned char*)fallback);
 }
 

@@ -22,7 +22,10 @@ namespace lsfm {
 
 static const unsigned long long HEMPTY = ~0ull;
 
-__global__ void k_vinv(int NF, const double* __restrict__ V, double* __restrict__ IV)
+// also what the panel kernel of K9 needs per feature: V^-1 = L L^T (l00 l10 l11 l20 l21 l22) and y = L^T eb, so that its
+// passes find them ready instead of running a Cholesky with square roots and divisions on a dependent load each;
+// l00 = NaN marks a V^-1 without a Cholesky factor (the tile then goes to k_schur_w)
+__global__ void k_vinv(int NF, const double* __restrict__ V, const double* __restrict__ eb, double* __restrict__ IV, double* __restrict__ LY)
 {
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
@@ -30,6 +33,22 @@ __global__ void k_vinv(int NF, const double* __restrict__ V, double* __restrict_
 	ld<9>(a, V + (size_t)f * 9);
 	inv3_sym(a, o);
 	st<9>(IV + (size_t)f * 9, o);
+	const double* e = eb + (size_t)f * 3;
+	double l[9];
+	const double d0 = o[0];
+	l[0] = sqrt(d0);
+	l[1] = o[3] / l[0];
+	l[3] = o[6] / l[0];
+	const double d1 = o[4] - l[1] * l[1];
+	l[2] = sqrt(d1);
+	l[4] = (o[7] - l[3] * l[1]) / l[2];
+	const double d2 = o[8] - l[3] * l[3] - l[4] * l[4];
+	l[5] = sqrt(d2);
+	l[6] = l[0] * e[0] + l[1] * e[1] + l[3] * e[2];
+	l[7] = l[2] * e[1] + l[4] * e[2];
+	l[8] = l[5] * e[2];
+	if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) l[0] = __builtin_nan("");
+	st<9>(LY + (size_t)f * 9, l);
 }
 
 // ---- hash set of block coordinates ------------------------------------------------------------------------
@@ -275,6 +294,7 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 #define SPW 64   /* rows of the window after the tile */
 #define SP_LONG 256
 #define SP_FAR 64
+#define SPMV_CACHED_BYTES ((size_t)96 << 20) /* a matrix up to this size is multiplied by k_spmv_gather (stays in L2 / Infinity Cache) */
 __global__ void k_spmv_long_rows(int M, const int* __restrict__ rowptr, int* __restrict__ nlong, int* __restrict__ longrows)
 {
 	int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -409,6 +429,123 @@ k_spmv(int M, const int* __restrict__ rowptr, const int* __restrict__ colidx, co
 	if (dotw) wave_scatter_add<1>(dot + (size_t)seg * dot_stride, &w, any);
 }
 
+// ---- K10a, cache-resident variant ------------------------------------------------------------------------------
+// The Schur matrix of a tree level is at most a few tens of MB: it stays in L2 / Infinity Cache between the handful of
+// products a level needs, so reading a block twice costs no HBM traffic, and with a path that revisits the band
+// assumption of k_spmv (q - p small, a few hub rows) no longer holds -- at the top of the NC3500-like tree the windowed
+// kernel spent 130 us per product walking ~100 "long" rows in every work-group.  Here both orientations of every block
+// are listed once, sorted by the row they contribute to (structure only: built with the pattern, kept by the plan):
+// entry = (target row << 32 | block << 1 | transposed), other[e] = the pose whose x it multiplies.  The product is a
+// segmented sum over that list: 8 entries per 8-lane group (lane r < 6 = scalar row r), 256 entries per work-group,
+// summed in an LDS window over the work-group's rows (at most 256: every row holds its diagonal block) and flushed with
+// one atomic per touched scalar -- perfectly balanced whatever the row lengths are.  y must be zero on entry.
+#define SPG_EPG 8
+#define SPG_ENT (32 * SPG_EPG) /* entries per work-group of 256 lanes */
+__global__ void k_spmv_gather_keys(int nnzb, const unsigned long long* __restrict__ upper_keys, unsigned long long* __restrict__ ent,
+                                   int* __restrict__ oth)
+{
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nnzb) return;
+	const unsigned long long key = upper_keys[k];
+	const unsigned p = (unsigned)(key >> 32), q = (unsigned)(key & 0xffffffffull);
+	ent[k] = ((unsigned long long)p << 32) | ((unsigned)k << 1);
+	oth[k] = (int)q;
+	// the mirrored part of an off-diagonal block; diagonal blocks leave a hole that sorts to the end
+	ent[(size_t)nnzb + k] = p != q ? (((unsigned long long)q << 32) | ((unsigned)k << 1) | 1u) : ~0ull;
+	oth[(size_t)nnzb + k] = (int)p;
+}
+__global__ void __launch_bounds__(256)
+k_spmv_gather(int M, int nent, const unsigned long long* __restrict__ ent, const int* __restrict__ oth, const double* __restrict__ S,
+              const double* __restrict__ x, double* __restrict__ y, const unsigned char* __restrict__ fixed, const double* __restrict__ dotw,
+              const int* __restrict__ pose_seg, double* __restrict__ dot, int dot_stride)
+{
+	__shared__ double ywin[SPG_ENT * 6];
+	const int tid = threadIdx.x, g = tid >> 3, r = tid & 7;
+	const int eb = blockIdx.x * SPG_ENT;
+	const int row0 = (int)(ent[eb] >> 32); // first entry of the work-group: never a hole while eb < number of real entries
+	for (int i = tid; i < SPG_ENT * 6; i += 256) ywin[i] = 0.0;
+	__syncthreads();
+	const int e0 = eb + g * SPG_EPG;
+	if (r < 6 && e0 < nent && row0 >= 0)
+	{
+		unsigned long long key[SPG_EPG];
+		int ot[SPG_EPG];
+#pragma unroll
+		for (int i = 0; i < SPG_EPG; i++)
+		{
+			const bool in = e0 + i < nent;
+			key[i] = in ? ent[e0 + i] : ~0ull;
+			ot[i] = in ? oth[e0 + i] : 0;
+		}
+		double sum[SPG_EPG];
+#pragma unroll
+		for (int i = 0; i < SPG_EPG; i++)
+		{
+			sum[i] = 0.0;
+			if (key[i] == ~0ull) continue;
+			const unsigned kk = (unsigned)(key[i] & 0xffffffffull);
+			const double* blk = S + (size_t)(kk >> 1) * 36;
+			const double* xo = x + (size_t)ot[i] * 6;
+			double s = 0.0;
+			if (kk & 1u)
+			{
+#pragma unroll
+				for (int j = 0; j < 6; j++) s = fma(blk[j * 6 + r], xo[j], s);
+			}
+			else
+			{
+#pragma unroll
+				for (int j = 0; j < 6; j++) s = fma(blk[r * 6 + j], xo[j], s);
+			}
+			sum[i] = s;
+		}
+		auto put = [&](int row, double v) {
+			if (row - row0 < SPG_ENT) { lds_add_f64(&ywin[(row - row0) * 6 + r], v); return; }
+			// a row without any block of its own between row0 and here (no diagonal block: not a Schur system, but stay correct)
+			if (fixed && fixed[(size_t)row * 6 + r]) return;
+			atomic_add_f64(y + (size_t)row * 6 + r, v);
+			if (dotw) atomic_add_f64(dot + (size_t)pose_seg[row] * dot_stride, dotw[(size_t)row * 6 + r] * v);
+		};
+		int cur = -1;
+		double acc = 0.0;
+#pragma unroll
+		for (int i = 0; i < SPG_EPG; i++)
+		{
+			if (key[i] == ~0ull) continue;
+			const int row = (int)(key[i] >> 32);
+			if (row != cur)
+			{
+				if (cur >= 0) put(cur, acc);
+				cur = row; acc = 0.0;
+			}
+			acc += sum[i];
+		}
+		if (cur >= 0) put(cur, acc);
+	}
+	__syncthreads();
+	double w = 0.0;
+	int seg = 0;
+	bool any = false;
+	if (row0 >= 0)
+		for (int i = tid; i < SPG_ENT * 6; i += 256)
+		{
+			const int t = row0 + i / 6;
+			const double v = ywin[i];
+			if (t < M && v != 0.0 && !(fixed && fixed[(size_t)t * 6 + i % 6]))
+			{
+				atomic_add_f64(y + (size_t)t * 6 + i % 6, v);
+				if (dotw)
+				{
+					const int sg = pose_seg[t];
+					if (any && sg != seg) { atomic_add_f64(dot + (size_t)seg * dot_stride, w); w = 0.0; }
+					seg = sg; any = true;
+					w = fma(dotw[(size_t)t * 6 + i % 6], v, w);
+				}
+			}
+		}
+	if (dotw) wave_scatter_add<1>(dot + (size_t)seg * dot_stride, &w, any);
+}
+
 // K11 (Imp.cpp:2980-3020); features of carried maps keep their values
 #define BSUB_TILE 128 /* features per work-group */
 __global__ void __launch_bounds__(256)
@@ -480,13 +617,25 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 	dev_zero(ctx, nl, sizeof(int));
 	if (M) hipLaunchKernelGGL(k_spmv_long_rows, dim3((M + 255) / 256), dim3(256), 0, s, M, sy.rowptr, nl, sy.longrows);
 	sy.d_nlong = nl;
+	// a matrix that stays in the caches: the list of both orientations sorted by target row (k_spmv_gather)
+	sy.gent = nullptr; sy.goth = nullptr;
+	const int variant = ctx->pcg.spmv_variant;
+	if (cnt && variant != 1 && (variant == 2 || (size_t)cnt * 288 <= SPMV_CACHED_BYTES))
+	{
+		unsigned long long* ent = sc.alloc<unsigned long long>((size_t)2 * cnt);
+		int* oth = sc.alloc<int>((size_t)2 * cnt);
+		hipLaunchKernelGGL(k_spmv_gather_keys, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, sorted_upper, ent, oth);
+		dev_sort_pairs_u64(ctx, ent, oth, (size_t)2 * cnt, 64);
+		sy.gent = ent; sy.goth = oth;
+	}
 }
 
 // K7: V^-1 of every feature (values: once per run)
 void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
 	sy.IV = ctx->scratch.alloc<double>((size_t)io.NF * 9);
-	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, sy.IV);
+	sy.LY = ctx->scratch.alloc<double>((size_t)io.NF * 9);
+	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY);
 }
 
 // Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only
@@ -572,7 +721,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
 		int most = 0;
 		for (int r : io.seg_rows) most = std::max(most, r);
-		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb, most);
+		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, sy.S, sy.E, fb, most);
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
 		if (ctx->stats)
 		{
@@ -590,9 +739,17 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed,
                  const double* dotw, const int* pose_seg, double* dot, int dot_stride)
 {
-	if (sy.M)
-		hipLaunchKernelGGL(k_spmv, dim3((sy.M + SPT - 1) / SPT), dim3(256), 0, ctx->stream, sy.M, sy.rowptr, sy.colidx, sy.d_nlong, sy.longrows, sy.S, x, y,
-		                   fixed, dotw, pose_seg, dot, dot_stride);
+	if (!sy.M) return;
+	if (sy.gent)
+	{
+		// holes (the mirrored slots of the diagonal blocks) sort to the end: 2 nnzb - (diagonal blocks) real entries, at most 2 nnzb - 1
+		const int nent = 2 * sy.nnzb;
+		hipLaunchKernelGGL(k_spmv_gather, dim3((nent + SPG_ENT - 1) / SPG_ENT), dim3(256), 0, ctx->stream, sy.M, nent, sy.gent, sy.goth, sy.S, x, y, fixed,
+		                   dotw, pose_seg, dot, dot_stride);
+		return;
+	}
+	hipLaunchKernelGGL(k_spmv, dim3((sy.M + SPT - 1) / SPT), dim3(256), 0, ctx->stream, sy.M, sy.rowptr, sy.colidx, sy.d_nlong, sy.longrows, sy.S, x, y,
+	                   fixed, dotw, pose_seg, dot, dot_stride);
 }
 
 // algorithmic bytes of one SpMV on the upper-block storage: blocks + column indices + row pointers + x and y

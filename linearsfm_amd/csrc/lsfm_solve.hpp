@@ -11,8 +11,13 @@ struct SchurSystem {
 	double* S = nullptr;                           // [nnzb*36]
 	double* E = nullptr;                           // [M*6]
 	double* IV = nullptr;                          // [NF*9]
+	double* LY = nullptr;                          // [NF*9] Cholesky factor of V^-1 (6) and L^T eb (3) per feature, for K9's panel kernel
 	int* longrows = nullptr;        // rows with more than SP_LONG blocks (hub poses), *d_nlong of them
 	const int* d_nlong = nullptr;
+	// cache-resident matrices: both orientations of every block sorted by the row they contribute to (k_spmv_gather);
+	// 2 nnzb slots, the holes of the diagonal blocks (~0) at the end; null for a matrix that streams from HBM (k_spmv)
+	const unsigned long long* gent = nullptr;
+	const int* goth = nullptr;
 	const unsigned long long* tab = nullptr; // pose pair -> block of S (open addressing), values in hval
 	const int* hval = nullptr;
 	unsigned long long mask = 0;
@@ -26,7 +31,7 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed, const double* dotw,
                  const int* pose_seg, double* dot, int dot_stride);
 double spmv_bytes(const SchurSystem& sy);
-void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb,
+void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
                         int max_poses_per_system);
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);

@@ -147,6 +147,9 @@ class ShardedTree:
         size = torch.tensor([buf.numel()], dtype=torch.int64, device=self.device if self.gpu_direct else "cpu")
         dist.send(size, dst=dst, group=self.group)
         dist.send(buf if self.gpu_direct else buf.cpu(), dst=dst, group=self.group)
+        if self.gpu_direct:
+            # the next run() packs into the same buffer on the library's own stream, which knows nothing of RCCL's: wait here
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _recv(self, src, slot):
         size = torch.zeros(1, dtype=torch.int64, device=self.device if self.gpu_direct else "cpu")

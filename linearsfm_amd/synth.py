@@ -370,3 +370,30 @@ def make_config(name, n_maps=None, seed=0, new_per_frame=None, vis=None, path=No
     typ, N, npf, cvis, cpath = CONFIGS[name]
     gen = make_stereo_set if typ == "Stereo" else make_mono_set
     return typ, gen(n_maps or N, new_per_frame or npf, vis or cvis, seed, only=only, **(cpath if path is None else path))
+
+
+def schur_like_matrix(m, band=12, hubs=12, seed=0):
+    """Upper-block CSR pattern + values of a Schur-like 6x6-block symmetric matrix for the stand-alone SpMV measurements
+    (bench.py --config spmv-stream, tools/spmv_bench.py): a pose chain with `band` neighbours plus `hubs` dense hub columns,
+    like S at the top of a join tree.  Returns (rowptr int32 [m+1], colidx int32 [nnzb] sorted within a row, val [nnzb, 36])."""
+    rng = np.random.default_rng(seed)
+    hub = np.sort(rng.choice(m, size=min(hubs, m), replace=False))
+    p = np.arange(m)
+    nb = np.minimum(m, p + band + 1) - p                     # chain part of row p: columns p .. p+band
+    cnt_h = np.zeros(m, np.int64)
+    for h in hub:                                            # hub h lies beyond the band of the rows p < h - band
+        cnt_h[:max(0, h - band)] += 1
+    rowptr = np.concatenate([[0], np.cumsum(nb + cnt_h)]).astype(np.int64)
+    assert rowptr[-1] < 2**31
+    colidx = np.empty(rowptr[-1], np.int32)
+    base = rowptr[:-1]
+    for d in range(band + 1):
+        rows = p[p + d < m]
+        colidx[base[rows] + d] = rows + d
+    fill = nb.copy()
+    for h in hub:                                            # ascending hubs keep a row's columns sorted
+        rows = p[:max(0, h - band)]
+        colidx[base[rows] + fill[rows]] = h
+        fill[rows] += 1
+    val = rng.normal(size=(len(colidx), 36))
+    return rowptr.astype(np.int32), colidx, val

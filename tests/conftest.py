@@ -24,6 +24,15 @@ def _has_gpu():
 @pytest.fixture(scope="session")
 def ctx():
     """HIP context of the product library; fails loudly (no fallback) when the device or the library is missing."""
+    # torch brings its own copy of the HIP runtime: where a test also hands torch device buffers to the library (as
+    # bench.py and ShardedTree do), torch initialises first, like there -- a second runtime that comes up after the
+    # library's has been seen to find no device on some boxes
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from linearsfm_amd import api
     c = api.Context(0)
     yield c

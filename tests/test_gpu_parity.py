@@ -150,7 +150,10 @@ def test_tree_stereo_vs_oracle(ctx, oracle, N, npf, vis, seed, lap):
         assert rel_err(got[k], exp[k]) < TREE_TOL, k
 
 
-def test_spmv_kernel_vs_dense(ctx):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_spmv_kernel_vs_dense(ctx, variant):
+    """variant 1: k_spmv (upper blocks streamed once); 2: k_spmv_gather (row-sorted list of both orientations, what the
+    cache-resident systems of the trees use)."""
     rng = np.random.default_rng(0)
     m = 300
     rows = []
@@ -171,7 +174,11 @@ def test_spmv_kernel_vs_dense(ctx):
             A[6 * p:6 * p + 6, 6 * q:6 * q + 6] = val[k]
             A[6 * q:6 * q + 6, 6 * p:6 * p + 6] = val[k].T
     x = rng.normal(size=6 * m)
-    y, ms, by = ctx.spmv_bench(rowptr, colidx, val, x, reps=5)
+    ctx.set_spmv_variant(variant)
+    try:
+        y, ms, by = ctx.spmv_bench(rowptr, colidx, val, x, reps=5)
+    finally:
+        ctx.set_spmv_variant(0)
     assert np.max(np.abs(y - A @ x)) / np.max(np.abs(A @ x)) < 1e-12
     assert ms > 0 and by > 0
 
@@ -403,9 +410,10 @@ def test_device_resident_handoff_of_subtree_roots(ctx, mono):
     assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-9
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("m,band,hubs", [(700, 3, 2), (700, 80, 5), (300, 299, 0), (64, 1, 1), (1, 0, 0)])
-def test_spmv_long_rows_and_wide_bands(ctx, m, band, hubs):
-    """k_spmv paths: hub rows longer than a tile's budget (taken by the tiles that own their columns), bands wider than
+def test_spmv_long_rows_and_wide_bands(ctx, m, band, hubs, variant):
+    """Both SpMV kernels (variant 1 / 2, see test_spmv_kernel_vs_dense).  k_spmv paths: hub rows longer than a tile's budget (taken by the tiles that own their columns), bands wider than
     the LDS window of y (far-row table / global adds), a dense matrix, tiny systems."""
     rng = np.random.default_rng(m + band)
     hub = set(int(h) for h in rng.choice(m, size=min(hubs, m), replace=False)) if hubs else set()
@@ -426,7 +434,11 @@ def test_spmv_long_rows_and_wide_bands(ctx, m, band, hubs):
             A[6 * p:6 * p + 6, 6 * q:6 * q + 6] = val[k]
             A[6 * q:6 * q + 6, 6 * p:6 * p + 6] = val[k].T
     x = rng.normal(size=6 * m)
-    y, ms, by = ctx.spmv_bench(rowptr, colidx, val, x, reps=2)
+    ctx.set_spmv_variant(variant)
+    try:
+        y, ms, by = ctx.spmv_bench(rowptr, colidx, val, x, reps=2)
+    finally:
+        ctx.set_spmv_variant(0)
     ref = A @ x
     assert np.max(np.abs(y - ref)) / np.max(np.abs(ref)) < 1e-12
 

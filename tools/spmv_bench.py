@@ -10,20 +10,11 @@ import sys
 import numpy as np
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from linearsfm_amd import api  # noqa: E402
+from linearsfm_amd import api, synth  # noqa: E402
 
 
 def matrix(m, band=12, hubs=12, seed=0):
-    rng = np.random.default_rng(seed)
-    hub = np.sort(rng.choice(m, size=min(hubs, m), replace=False))
-    cols, rowptr = [], [0]
-    for p in range(m):
-        c = set(range(p, min(m, p + band + 1))) | {int(h) for h in hub if h >= p}
-        cols.append(np.array(sorted(c), np.int32))
-        rowptr.append(rowptr[-1] + len(c))
-    colidx = np.concatenate(cols)
-    val = rng.normal(size=(len(colidx), 36))
-    return np.array(rowptr, np.int32), colidx, val
+    return synth.schur_like_matrix(m, band, hubs, seed)
 
 
 def main():

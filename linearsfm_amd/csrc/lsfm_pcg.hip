@@ -645,13 +645,18 @@ __device__ __forceinline__ int sn_idx(int s, int u, int t) { return t * s - t * 
 // Two barriers per block column instead of the ~6 of the block-by-block walk, no idle lanes: ~15 us for 96 x 96 instead
 // of ~65.  The panel rows X = A L_dd^-T are the same recurrence on rows below the diagonal part: other waves of the work-group
 // carry them along, block column by block column, on their own SIMDs.
+// fv != null: the forward substitution of ONE right-hand side rides along (the first preconditioner application of a
+// level, known before the factorisation starts): fv_g^T is one more panel row, so the recurrence leaves y_g = L_dd^-1 fv_g
+// in it, and every work-group takes X y_g off fv at its common rows -- what k_sn_fwd does in a launch of its own per
+// group level (25 of them at the top join).  y_g goes to fw for the backward substitution.
 __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Dinv, int* err,
-                                                          double* __restrict__ Gd)
+                                                          double* __restrict__ Gd, const int* __restrict__ rowidx, double* __restrict__ fv,
+                                                          double* __restrict__ fw)
 {
 	// rows 0 .. 6 GS - 1: L_dd (dense scalar rows); rows 6 GS ..: the panel rows of this work-group.  Lanes 0..95 own the
 	// diagonal rows, lanes 128..223 (two other waves, other SIMDs) the panel rows: the same recurrence, in step
-	__shared__ double Ms[(6 * CHOL_GS + 6 * SN_RB) * SN_XS];
+	__shared__ double Ms[(6 * CHOL_GS + 6 * SN_RB + 1) * SN_XS]; // + the row of the right-hand side
 	__shared__ double sD[36];
 	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
@@ -704,10 +709,12 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			}
 		}
 	}
+	constexpr int XR = 6 * CHOL_GS + 6 * SN_RB; // row of the right-hand side, owned by lane 128 + 6 SN_RB
+	if (fv && tid < n6) Ms[XR * SN_XS + tid] = fv[(size_t)c0 * 6 + tid];
 	__syncthreads();
 	// row of Ms this lane owns (-1: none)
-	const int ri = tid < 6 * CHOL_GS ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? 6 * CHOL_GS + (tid - 128) : -1);
-	const bool panel_lane = ri >= 6 * CHOL_GS && (ri - 6 * CHOL_GS) < 6 * nrows;
+	const int ri = tid < 6 * CHOL_GS ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? 6 * CHOL_GS + (tid - 128) : ((fv && tid == 128 + 6 * SN_RB) ? XR : -1));
+	const bool panel_lane = ri >= 6 * CHOL_GS && ((ri - 6 * CHOL_GS) < 6 * nrows || ri == XR);
 	bool bad = false;
 	for (int t = 0; t < s; t++)
 	{
@@ -791,6 +798,19 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		__syncthreads();
 	}
 	if (bad && tid == 0) atomicExch(err, 1 + c0);
+	if (fv)
+	{
+		const double* yg = &Ms[XR * SN_XS];
+		if (blockIdx.y == 0 && tid < n6) fw[(size_t)c0 * 6 + tid] = yg[tid];
+		if (panel_lane && ri != XR)
+		{
+			const double* xr = &Ms[ri * SN_XS];
+			double o0 = 0.0, o1 = 0.0;
+			for (int k = 0; k + 1 < n6; k += 2) { o0 = fma(xr[k], yg[k], o0); o1 = fma(xr[k + 1], yg[k + 1], o1); } // n6 is even
+			const int pr = ri - 6 * CHOL_GS, il = pr / 6, r = pr - 6 * il;
+			atomic_add_f64(fv + (size_t)rowidx[sCol[s - 1] + 1 + i0 + il] * 6 + r, -(o0 + o1));
+		}
+	}
 	// inverse of every diagonal 6x6 factor (the triangular solves use it): lane (t, c) solves L_tt x = e_c
 	if (tid < n6)
 	{
@@ -1455,7 +1475,16 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 	dev_zero(ctx, ch.d_err, sizeof(int));
 }
 
-static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch)
+// the supernode-group path of the triangular solves applies (chol_apply): the forward substitution can ride on the factorisation
+static bool chol_group_solve(const CholDev& ch)
+{
+	static const bool on = !getenv("LSFM_LEVEL_SOLVE") && !getenv("LSFM_NO_GROUPS") && !getenv("LSFM_TASK_SOLVE") && !getenv("LSFM_NO_FUSED_FWD");
+	return on && !ch.tlevel_ptr.empty() && (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL <= 56 * 1024;
+}
+
+// fwd_v != null (chol_group_solve(ch) holds): a right-hand side in elimination order; on return it holds what the forward
+// substitution leaves (leaf columns in place, group columns in ch.wv) -- chol_apply(..., fwd_done) does the rest
+static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch, double* fwd_v = nullptr)
 {
 	hipStream_t s = ctx->stream;
 	if (sy.nnzb)
@@ -1474,13 +1503,20 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
 		if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
 	}
+	if (fwd_v)
+	{
+		// the leaf sub-trees are factored: their part of the forward substitution, before the groups take theirs
+		const int n0 = ch.tlevel_ptr.size() > 1 ? ch.tlevel_ptr[1] - ch.tlevel_ptr[0] : 0;
+		const size_t lds0 = (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL + 8;
+		if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, (const double*)ch.L, (const double*)ch.Dinv, fwd_v);
+	}
 	if (groups)
 		for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++)
 		{
 			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0, mnr = ch.glevel_maxnr[l];
 			if (!ng) continue;
 			hipLaunchKernelGGL(k_sn_panel, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-			                   ch.colptr, ch.L, ch.Dinv, ch.d_err, ch.Gd);
+			                   ch.colptr, ch.L, ch.Dinv, ch.d_err, ch.Gd, ch.rowidx, fwd_v, ch.wv);
 			const long np = (long)mnr * (mnr + 1) / 2;
 			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
 			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Gd);
@@ -1488,12 +1524,18 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 }
 
 // z = (L L^T)^-1 r in the original numbering, rz_dot[seg] += r . z
+static void chol_perm_in(lsfm_context* ctx, const CholDev& ch, const double* r, const unsigned char* fixed, double* v)
+{
+	const size_t ns = (size_t)ch.M * 6;
+	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ch.M, ch.perm, r, fixed, v);
+}
+
+// fwd_done: v already went through the forward substitution (chol_factor with fwd_v)
 static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, double* v, double* z, const unsigned char* fixed, const int* pose_seg,
-                       double* dot, int dot_stride)
+                       double* dot, int dot_stride, bool fwd_done = false)
 {
 	hipStream_t s = ctx->stream;
-	const size_t ns = (size_t)ch.M * 6;
-	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, ch.M, ch.perm, r, fixed, v);
+	if (!fwd_done) chol_perm_in(ctx, ch, r, fixed, v);
 	static const bool task_solve = !getenv("LSFM_LEVEL_SOLVE");
 	int task_max = 0;
 	for (int m : ch.tlevel_maxsize) task_max = std::max(task_max, m);
@@ -1506,8 +1548,8 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		const int ngl = (int)ch.glevel_ptr.size() - 1;
 		auto sweep = [&](auto tag, const auto* Lx, const auto* Dx) {
 			typedef decltype(tag) FT;
-			if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
-			for (int l = 0; l < ngl; l++)
+			if (n0 && !fwd_done) hipLaunchKernelGGL(k_chol_fwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
+			for (int l = 0; l < ngl && !fwd_done; l++)
 			{
 				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
 				if (ng) hipLaunchKernelGGL(k_sn_fwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Lx, Dx, v, ch.wv);
@@ -1749,23 +1791,10 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		tw1 = wall();
 		d_err = ch.d_err;
 	}
-	chol_factor(ctx, sy, io.d_fixed, ch);
-	const bool mixed = ctx->pcg.mixed;
-	if (mixed)
-	{
-		// mixed precision (BASELINE configs[4]): the factor is rounded to fp32 once and applied from there; S, E, x and the
-		// residual stay fp64 -- every refinement step corrects against r = E - S x in fp64
-		const size_t nl = (size_t)ch.nnzL * 36, nd = (size_t)ch.M * 36;
-		ch.Lf = sc.alloc<float>(nl); ch.Dinvf = sc.alloc<float>(nd);
-		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, nl, ch.L, ch.Lf);
-		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, nd, ch.Dinv, ch.Dinvf);
-	}
-	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
-	double tw2 = wall();
+	// ---- CG set-up first: the residual of the starting point is the right-hand side of the first preconditioner
+	// application, whose forward substitution rides on the factorisation (k_sn_panel) ----
 	int* d_misc = sc.alloc<int>(4); // [1] ndone
 	dev_zero(ctx, d_misc, 4 * sizeof(int));
-
-	// ---- CG ----
 	std::vector<PcgSeg> hseg(nseg);
 	{
 		int row = 0;
@@ -1785,7 +1814,22 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	dev_zero(ctx, Ap, nscal * sizeof(double));
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 1);
-	chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[0], SEG_STRIDE);
+	const bool mixed = ctx->pcg.mixed;
+	const bool fused_fwd = !mixed && chol_group_solve(ch); // (mixed: the factor is applied from its fp32 copy, made after the factorisation)
+	if (fused_fwd) chol_perm_in(ctx, ch, r, io.d_fixed, v);
+	chol_factor(ctx, sy, io.d_fixed, ch, fused_fwd ? v : nullptr);
+	if (mixed)
+	{
+		// mixed precision (BASELINE configs[4]): the factor is rounded to fp32 once and applied from there; S, E, x and the
+		// residual stay fp64 -- every refinement step corrects against r = E - S x in fp64
+		const size_t nl = (size_t)ch.nnzL * 36, nd = (size_t)ch.M * 36;
+		ch.Lf = sc.alloc<float>(nl); ch.Dinvf = sc.alloc<float>(nd);
+		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, nl, ch.L, ch.Lf);
+		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, nd, ch.Dinv, ch.Dinvf);
+	}
+	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
+	double tw2 = wall();
+	chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[0], SEG_STRIDE, fused_fwd);
 	hipLaunchKernelGGL(k_copy, dim3(nbe), dim3(256), 0, s, nscal, z, p);
 	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
 	dev_zero(ctx, Ap, nscal * sizeof(double));

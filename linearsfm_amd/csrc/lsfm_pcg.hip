@@ -1457,6 +1457,27 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 				o_c0[at] = gc0[g]; o_s[at] = gs[g]; o_nr[at] = ccount[gc0[g] + gs[g] - 1] - 1;
 				ch.glevel_maxnr[glev[g]] = std::max(ch.glevel_maxnr[glev[g]], o_nr[at]);
 			}
+			if (getenv("LSFM_DEBUG") && ng > 50)
+			{
+				// what relaxed amalgamation would buy: chains of groups (parent of a group's last column = first column of the next group)
+				int hist[CHOL_GS + 1] = { 0 };
+				for (int g = 0; g < ng; g++) hist[gs[g]]++;
+				fprintf(stderr, "[lsfm] groups %d, group levels %d, sizes:", ng, ngl);
+				for (int q = 1; q <= CHOL_GS; q++) fprintf(stderr, " %d", hist[q]);
+				long fills[6] = { 0 }; // boundaries j-1 | j inside a parent-child chain (parent[j-1] == j), by the fill a merge needs
+				for (int j = 1; j < M; j++)
+				{
+					if (size[j] <= task_x || size[j - 1] <= task_x || parent[j - 1] != j || grp[j] == grp[j - 1]) continue;
+					const int fill = ccount[j] + 1 - ccount[j - 1];
+					fills[fill <= 0 ? 0 : (fill <= 2 ? 1 : (fill <= 8 ? 2 : (fill <= 32 ? 3 : (fill <= 128 ? 4 : 5))))]++;
+				}
+				fprintf(stderr, " | chain boundaries by fill 0:%ld <=2:%ld <=8:%ld <=32:%ld <=128:%ld more:%ld\n", fills[0], fills[1], fills[2], fills[3], fills[4], fills[5]);
+				std::vector<int> per_level(ngl, 0);
+				for (int g = 0; g < ng; g++) per_level[glev[g]]++;
+				fprintf(stderr, "[lsfm] groups per level:");
+				for (int l = 0; l < ngl; l++) fprintf(stderr, " %d", per_level[l]);
+				fprintf(stderr, "\n");
+			}
 			ch.ngroups = ng;
 			ch.glevel_ptr = gl_count;
 			pack(&ch.grp_c0, o_c0); pack(&ch.grp_s, o_s); pack(&ch.grp_nr, o_nr);

@@ -58,6 +58,14 @@ for n in names:
     total += hbm
     per_launch[n] = hbm / max(cnt, 1)
     detail[n] = dict(launches=cnt, fetch_KB_raw_total=fk, write_KB_total=wk, hbm_bytes_per_launch_corrected=hbm / max(cnt, 1))
+# bench.py's K9 "launch" is one Schur assembly of a level: the panel variants (16 / 32 / 48 slots, by tile) and k_schur_w for
+# the tiles none of them takes are launched together, once per level -- count the step, not the kernels
+if "k_schur_w" in detail and "k_schur_panel" in detail:
+    steps = detail["k_schur_w"]["launches"]
+    k9 = sum(detail[n]["hbm_bytes_per_launch_corrected"] * detail[n]["launches"] for n in ("k_schur_panel", "k_schur_panel_48", "k_schur_w") if n in detail)
+    per_launch["k_schur_panel"] = k9 / max(steps, 1)
+    detail["k_schur_panel"]["hbm_bytes_per_level_all_variants"] = per_launch["k_schur_panel"]
+    detail["k_schur_panel"]["levels"] = steps
 for n in names[:14]:
     print(f"{n[:44]:44s} n={detail[n]['launches']:5d} -> {per_launch[n] / 1e6:8.1f} MB/launch")
 res = dict(config=config, trees_in_profiled_run=trees, bytes_per_tree=total / trees, per_launch=per_launch, kernels=detail,

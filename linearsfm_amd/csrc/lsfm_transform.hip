@@ -373,6 +373,25 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 	for (int s = 0; s < NH; s++) st<18>(fd + 9 + 18 * s, Cf[s]);
 }
 
+// Profiling aid (make K9_TIMING=1; tools/tr_phase_times.py): lane 0 of every work-group adds up the shader clocks it spends
+// in each phase of a round.  Compiled out otherwise.
+#ifdef LSFM_K9_TIMING
+__device__ unsigned long long g_tr_t[16];
+#define TRT_DECL unsigned long long tracc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long trprev = __builtin_readcyclecounter()
+#define TRT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); tracc[i] += n_ - trprev; trprev = n_; } while (0)
+#define TRT_FLUSH() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_tr_t[i_], tracc[i_]); atomicAdd(&g_tr_t[12], 1ull); } } while (0)
+extern "C" void lsfm_debug_tr(unsigned long long* out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tr_t), sizeof(unsigned long long) * 16);
+	if (reset) { unsigned long long z[16] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tr_t), z, sizeof(z)); }
+}
+#else
+#define TRT_DECL do { } while (0)
+#define TRT(i) do { } while (0)
+#define TRT_FLUSH() do { } while (0)
+#endif
+
 template <int NH>
 __global__ void __launch_bounds__(TRE_ROUND, NH == 1 ? 3 : 2)
 k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restrict__ fptr,
@@ -386,15 +405,19 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 	__shared__ double gvals[NH * GCAP * 36];
 	__shared__ double sT[TRE_ROUND * 18];
 	__shared__ int sFp[TRE_TILE + 1];
+	__shared__ unsigned char sAct[TRE_TILE]; // finfo.x of the tile's features (the feature sums asked memory for it every round)
 	const int tid = threadIdx.x;
+	TRT_DECL;
 	const int f0 = blockIdx.x * TRE_TILE, f1 = min(f0 + TRE_TILE, NF), nft = f1 - f0;
 	for (int i = tid; i < GCAP; i += TRE_ROUND) gkeys[i] = -1;
 	for (int i = tid; i < NH * GCAP * 36; i += TRE_ROUND) gvals[i] = 0.0;
 	for (int i = tid; i <= nft; i += TRE_ROUND) sFp[i] = fptr[f0 + i];
+	for (int i = tid; i < nft; i += TRE_ROUND) sAct[i] = finfo[f0 + i].x != 0;
 	__syncthreads();
 	int la = 0; // first feature (tile-local) of the round
 	int pf_j = -1, pf_f = 0, pf_k = 0, pf_kw = 0, pf_wb = 0, pf_lab = 0;
 	int4 pf_fi = make_int4(0, 0, 0, 0);
+	TRT(0);
 	while (la < nft)
 	{
 		// a round = whole features from la on with at most TRE_ROUND blocks; a longer feature is walked in chunks
@@ -411,6 +434,10 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 			const int ce1 = min(ce0 + TRE_ROUND, e1);
 			const int j = ce0 + tid;
 			const bool have = j < ce1;
+			TRT(1); // round set-up (search of the round's end)
+#ifdef LSFM_K9_TIMING
+			if (tid == 0) tracc[11]++;
+#endif
 			bool act = false;
 			int f = 0, k = 0, sl = -1;
 			double W[18];
@@ -470,6 +497,7 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 					sl = lds_slot(gkeys, GCAP, k);
 				}
 			}
+			TRT(2); // own block: index, W load, W' = D^T W D, store
 			// the index data of this lane's block in the NEXT round (it starts where this one ends): the loads fly during the
 			// reductions below instead of heading the next round's dependent chain
 			{
@@ -483,6 +511,7 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 					pf_fi = finfo[pf_f]; pf_k = photo[jn]; pf_kw = KW[jn]; pf_wb = wbase[pf_f]; pf_lab = newf ? newf[pf_f] : pf_f;
 				}
 			}
+			TRT(3); // prefetch issue
 #pragma unroll
 			for (int s = 0; s < NH; s++)
 			{
@@ -494,6 +523,7 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 					mtm<6, 3, 6, true>(W, Ck, T); // share of G_s,f: W^T C_s,k   [3x6]
 					st<18>(&sT[tid * 18], T);
 					ld<18>(Cf, fd + 9 + 18 * s);
+					TRT(5); // C_k load, W^T C_k, C_f load
 					// pose row of G_s: W C_s,f   [6x6], one row at a time
 					double* gl = sl >= 0 ? &gvals[(s * GCAP + sl) * 36] : nullptr;
 					double* gg = Gpose + (size_t)s * M * 36 + (size_t)k * 36;
@@ -506,19 +536,23 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 							if (gl) lds_add_f64(gl + r * 6 + c, v); else atomic_add_f64(gg + r * 6 + c, v);
 						}
 				}
+				TRT(8); // pose rows: 36 LDS atomic adds
 				__syncthreads();
+				TRT(6);
 				// per feature sums of the W^T C_s,k rows of this chunk (the rows of inactive maps are never read)
 				for (int idx = tid; idx < (lb - la) * 18; idx += TRE_ROUND)
 				{
 					const int fl = la + idx / 18, q = idx % 18;
 					const int r0 = max(sFp[fl], ce0) - ce0, r1 = min(sFp[fl + 1], ce1) - ce0;
-					if (!finfo[f0 + fl].x) continue;
+					if (!sAct[fl]) continue;
 					double sum = 0.0;
 					for (int r = r0; r < r1; r++) sum += sT[r * 18 + q];
 					double* g = Gsum + (size_t)(f0 + fl) * TW + 18 * s + q;
 					if (sFp[fl] >= ce0) *g = sum; else if (r1 > r0) *g += sum; // first chunk of the feature stores
 				}
+				TRT(7); // feature sums
 				__syncthreads();
+				TRT(6);
 			}
 			if (ce1 >= e1) break;
 		}
@@ -526,6 +560,8 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 	}
 #pragma unroll
 	for (int s = 0; s < NH; s++) tile_flush<36>(gkeys, gvals + s * GCAP * 36, GCAP, Gpose + (size_t)s * M * 36);
+	TRT(9);
+	TRT_FLUSH();
 }
 
 template <int NH>

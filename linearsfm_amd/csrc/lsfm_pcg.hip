@@ -1186,7 +1186,10 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 		{ sy.d_nlong, 4, (void**)&P.sy.d_nlong }, { sy.tab, cap * 8, (void**)&P.sy.tab }, { sy.hval, cap * 4, (void**)&P.sy.hval },
 		{ ch.blob, ch.blob_ints * 4, (void**)&P.ch.blob },
 		{ sy.gent, sy.gent ? nnzb * 16 : 0, (void**)&P.sy.gent }, { sy.goth, sy.goth ? nnzb * 8 : 0, (void**)&P.sy.goth },
+		{ sy.k9.ns, sy.k9.ns ? (size_t)sy.k9_tiles * 4 : 0, (void**)&P.sy.k9.ns }, { sy.k9.pose, sy.k9.pose ? (size_t)sy.k9_tiles * 48 * 4 : 0, (void**)&P.sy.k9.pose },
+		{ sy.k9.eslot, sy.k9.eslot ? (size_t)sy.k9_NW : 0, (void**)&P.sy.k9.eslot },
 	};
+	P.sy.k9.record = 0;
 	size_t total = 0;
 	for (const Item& it : items) total += (it.bytes + 255) & ~(size_t)255;
 	LSFM_CHECK_HIP(hipMalloc((void**)&P.mem, total + 256));

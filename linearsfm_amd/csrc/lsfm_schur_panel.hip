@@ -86,7 +86,8 @@ template <int T, int SMAX, int THREADS>
 __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                         const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-                                        double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback)
+                                        double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback,
+                                        const unsigned char* __restrict__ ces)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
 	K9T_DECL;
@@ -175,10 +176,14 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			else
 			{
 				if (!second) { later = true; return; }
-				const int key = photo[j];
-				unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-				while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
-				sl = sh.hslot[h];
+				if (ces) sl = ces[j] & (PM_DUP - 1); // the plan's copy (no hash table was built)
+				else
+				{
+					const int key = photo[j];
+					unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+					while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+					sl = sh.hslot[h];
+				}
 			}
 			if (!second && dup) { later = true; return; }
 			if (second && !dup) return;
@@ -314,6 +319,45 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	K9T_COUNT(ns, T);
 }
 
+// the variant of pm_body for the tile's number of 16x16 output tiles per wave
+template <int SMAX, int THREADS>
+__device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
+                                      const double* __restrict__ W, const double* __restrict__ LY, const unsigned long long* __restrict__ tab,
+                                      const int* __restrict__ val, unsigned long long mask, double* __restrict__ S, double* __restrict__ E,
+                                      unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces)
+{
+	constexpr int NW = THREADS / 64;
+	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
+#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces)
+	if constexpr (SMAX <= 8)
+	{
+		if (tpw <= 1) PM_GO(1);
+		else PM_GO(2); // 48 rows: 6 tiles over 4 waves
+	}
+	else if constexpr (SMAX <= 16)
+	{
+		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 3) PM_GO(3);
+		else PM_GO(6); // 96 rows: 21 tiles over 4 waves
+	}
+	else if constexpr (THREADS == 256)
+	{
+		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 3) PM_GO(3);
+		else if (tpw <= 6) PM_GO(6);
+		else if (tpw <= 9) PM_GO(9);
+		else if (tpw <= 14) PM_GO(14);
+		else PM_GO(20);
+	}
+	else
+	{
+		if (tpw <= 6) PM_GO(6);
+		else if (tpw <= 9) PM_GO(9);
+		else PM_GO(11);
+	}
+#undef PM_GO
+}
+
 // `only` == nullptr: every tile; tiles with more than SMAX poses are flagged in `fallback`.  `only` != nullptr (the second
 // pass with the larger variant): just the flagged tiles; a tile it can take is un-flagged, the rest stays for k_schur_w.
 // SMAX = 8 / 16: for levels whose systems have at most that many poses (the bottom of the tree: thousands of tiny joins).
@@ -323,13 +367,32 @@ template <int SMAX, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : (SMAX <= 16 ? 3 : 2)))
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
               const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only)
+              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only, K9Cache kc)
 {
 	if (only && !only[blockIdx.x]) return;
 	K9T_DECL;
 	__shared__ PmShared<SMAX> sh;
 	const int tid = threadIdx.x;
 	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
+	// ---- a later run of the same resident tree: the tile's slots are structure, kept by the plan of the level ----
+	if (kc.ns && !kc.record)
+	{
+		const int cns = kc.ns[blockIdx.x];
+		if (cns < 0 || cns > SMAX)
+		{
+			if (tid == 0) fallback[blockIdx.x] = 1; // another variant's tile (-1: no panel variant took it)
+			return;
+		}
+		for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
+		if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)blockIdx.x * PM_SMAX_BIG + tid];
+		if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
+		__syncthreads();
+		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
+		for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+		if (only && tid == 0) fallback[blockIdx.x] = 0;
+		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot);
+		return;
+	}
 	for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
 	if (tid < PM_HASH) { sh.hkey[tid] = -1; sh.hslot[tid] = -1; }
 	if (tid == 0) { sh.nslots = 0; sh.bad = 0; }
@@ -389,39 +452,30 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			seen |= bit;
 		}
 	}
+	if (kc.ns && kc.record)
+	{
+		// first run of a resident tree: leave the tile's slots for the later ones (the blocks past the LDS list too)
+		__syncthreads();
+		if (tid == 0) kc.ns[blockIdx.x] = ns;
+		if (tid < ns) kc.pose[(size_t)blockIdx.x * PM_SMAX_BIG + tid] = sh.pose_of[tid];
+		for (int e = tid; e < je - jb; e += THREADS)
+		{
+			unsigned char v;
+			if (e < PM_MAXE) v = sh.eslot[e];
+			else
+			{
+				const int key = photo[jb + e];
+				unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+				while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+				v = (unsigned char)(sh.hslot[h] | PM_DUP); // added after the first blocks, like a repeat
+			}
+			kc.eslot[jb + e] = v;
+		}
+	}
 	// (visible to the passes through the barrier at the top of the first pass)
 	K9T(0);
 	K9T_FLUSH(0, 1);
-	constexpr int NW = THREADS / 64;
-	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
-#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback)
-	if constexpr (SMAX <= 8)
-	{
-		if (tpw <= 1) PM_GO(1);
-		else PM_GO(2); // 48 rows: 6 tiles over 4 waves
-	}
-	else if constexpr (SMAX <= 16)
-	{
-		if (tpw <= 1) PM_GO(1);
-		else if (tpw <= 3) PM_GO(3);
-		else PM_GO(6); // 96 rows: 21 tiles over 4 waves
-	}
-	else if constexpr (THREADS == 256)
-	{
-		if (tpw <= 1) PM_GO(1);
-		else if (tpw <= 3) PM_GO(3);
-		else if (tpw <= 6) PM_GO(6);
-		else if (tpw <= 9) PM_GO(9);
-		else if (tpw <= 14) PM_GO(14);
-		else PM_GO(20);
-	}
-	else
-	{
-		if (tpw <= 6) PM_GO(6);
-		else if (tpw <= 9) PM_GO(9);
-		else PM_GO(11);
-	}
-#undef PM_GO
+	k9_go<SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, (const unsigned char*)nullptr);
 }
 
 int schur_panel_tile() { return PM_TILE; }
@@ -437,7 +491,7 @@ extern "C" void lsfm_debug_k9(unsigned long long* out, int reset)
 
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
-                        int max_poses_per_system)
+                        int max_poses_per_system, K9Cache kc)
 {
 	if (!NF) return;
 	const dim3 grid((NF + PM_TILE - 1) / PM_TILE);
@@ -445,24 +499,24 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	if (max_poses_per_system <= 8)
 	{
 		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-		                   (const unsigned char*)nullptr);
+		                   (const unsigned char*)nullptr, kc);
 		return;
 	}
 	if (max_poses_per_system <= 16)
 	{
 		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-		                   (const unsigned char*)nullptr);
+		                   (const unsigned char*)nullptr, kc);
 		return;
 	}
 	// By tile, not by level: most tiles of the upper levels are seen by a dozen poses (12.1 on average on the NC3500-like
 	// set) and fit the 16-slot variant, which is three work-groups to a CU instead of two and a third less work per pass;
 	// the tiles it flags go to the 32-slot variant, what that one flags to the 48-slot one, the rest to k_schur_w
 	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-	                   (const unsigned char*)nullptr);
+	                   (const unsigned char*)nullptr, kc);
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E,
-	                   fallback, (const unsigned char*)fallback);
+	                   fallback, (const unsigned char*)fallback, kc);
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-	                   (const unsigned char*)fallback);
+	                   (const unsigned char*)fallback, kc);
 }
 
 } // namespace lsfm

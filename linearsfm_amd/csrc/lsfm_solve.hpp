@@ -4,6 +4,16 @@
 
 namespace lsfm {
 
+// What K9's panel kernel works out per tile of 128 features from index arrays alone (which poses see the tile = its slots,
+// the slot of every W block, which blocks repeat a (pose, feature) pair): recorded by the first run of a resident tree,
+// read by the later ones instead of hashing the tile's poses again.  ns[tile] = -1: no panel variant takes the tile.
+struct K9Cache {
+	int* ns = nullptr;            // [tiles]
+	int* pose = nullptr;          // [tiles * 48]
+	unsigned char* eslot = nullptr; // [NW]
+	int record = 0;
+};
+
 struct SchurSystem {
 	int M = 0, nnzb = 0;
 	int *rowptr = nullptr, *colidx = nullptr;      // upper block CSR (diagonal block first in every row)
@@ -21,6 +31,8 @@ struct SchurSystem {
 	const unsigned long long* tab = nullptr; // pose pair -> block of S (open addressing), values in hval
 	const int* hval = nullptr;
 	unsigned long long mask = 0;
+	K9Cache k9;      // per-tile structure of K9 (null: every run works it out)
+	int k9_tiles = 0, k9_NW = 0;
 	double k9_flops = 0; // algorithmic flops of the numeric Schur complement of this system (structure only)
 };
 
@@ -33,7 +45,7 @@ void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, doub
 double spmv_bytes(const SchurSystem& sy);
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
-                        int max_poses_per_system);
+                        int max_poses_per_system, K9Cache kc);
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);
 
 } // namespace lsfm

@@ -74,3 +74,21 @@ def test_cli_level_scheduled_solves_and_info_export(oracle, tmp_path):
         assert np.array_equal(info["stno"], exp["stno"]) and np.array_equal(info["photo"], exp["photo"])
         for k in ("U", "W", "V"):
             assert np.max(np.abs(np.asarray(info[k]) - np.asarray(exp[k]))) / np.max(np.abs(np.asarray(exp[k]))) < 1e-6, (tag, k)
+
+
+def test_cli_forward_substitution_inside_and_outside_the_factorisation(tmp_path):
+    """The first preconditioner application of a level takes its forward substitution inside the supernodal factorisation
+    (right-hand side as one more panel row of k_sn_panel); LSFM_NO_FUSED_FWD=1 runs it as launches of its own (k_sn_fwd), the
+    path a second refinement step takes.  A path that revisits (lap=50) gives separators wide enough for supernode groups."""
+    maps = synth.make_stereo_set(200, 20, 5, seed=77, lap=50)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    out = {}
+    for tag, env in (("fused", {}), ("apart", {"LSFM_NO_FUSED_FWD": "1"})):
+        s = str(tmp_path / f"{tag}_full.txt")
+        subprocess.run([exe, "-path", str(d), "-num", "200", "-type", "Stereo", "-full", s], capture_output=True, text=True, check=True,
+                       env=dict(os.environ, **env))
+        out[tag] = _table(s)
+    assert np.array_equal(out["fused"][:, 0], out["apart"][:, 0])
+    assert np.max(np.abs(out["fused"][:, 1] - out["apart"][:, 1]) / np.maximum(1.0, np.abs(out["apart"][:, 1]))) < 1e-9

@@ -183,6 +183,38 @@ def test_spmv_kernel_vs_dense(ctx, variant):
     assert ms > 0 and by > 0
 
 
+def test_spmv_list_kernel_row_without_diagonal_block(ctx):
+    """k_spmv_gather sums in an LDS window over the rows of a work-group, sized on every row owning at least its diagonal
+    block; a row that owns nothing for more than a window's length takes the direct path (not a Schur system, but correct)."""
+    rng = np.random.default_rng(5)
+    m = 700
+    rowptr, colidx = [0], []
+    for p in range(m):
+        cols = [] if 10 <= p < 400 else [p]          # 390 rows in a row without any block of their own ...
+        if p == 5:
+            cols += list(range(10, 650, 3))           # ... but reached through the mirrored part of row 5's blocks
+        colidx += sorted(set(cols))
+        rowptr.append(len(colidx))
+    val = rng.normal(size=(len(colidx), 6, 6))
+    A = np.zeros((6 * m, 6 * m))
+    k = 0
+    for p in range(m):
+        for k in range(rowptr[p], rowptr[p + 1]):
+            q = colidx[k]
+            if p == q:
+                val[k] = val[k] + val[k].T
+            A[6 * p:6 * p + 6, 6 * q:6 * q + 6] = val[k]
+            A[6 * q:6 * q + 6, 6 * p:6 * p + 6] = val[k].T
+    x = rng.normal(size=6 * m)
+    ctx.set_spmv_variant(2)
+    try:
+        y, _, _ = ctx.spmv_bench(rowptr, colidx, val, x, reps=2)
+    finally:
+        ctx.set_spmv_variant(0)
+    ref = A @ x
+    assert np.max(np.abs(y - ref)) / np.max(np.abs(ref)) < 1e-12
+
+
 def test_no_device_no_fallback_message():
     from linearsfm_amd import api
     with pytest.raises(api.LsfmError):

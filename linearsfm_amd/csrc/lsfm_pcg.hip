@@ -1175,6 +1175,15 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 {
 	auto sp = std::make_shared<SolvePlan>();
 	const size_t M = sy.M, nnzb = sy.nnzb, cap = (size_t)sy.mask + 1;
+	if (getenv("LSFM_DEBUG") && sy.k9.ns && sy.k9_tiles > 0)
+	{
+		// census of the Schur tiles by the number of poses that see them (negative: no panel variant took the tile)
+		std::vector<int> h(sy.k9_tiles);
+		d2h(ctx, h.data(), sy.k9.ns, sizeof(int) * h.size());
+		int b16 = 0, b32 = 0, b48 = 0, b64 = 0, b96 = 0, more = 0;
+		for (int v : h) { const int n = v < 0 ? -v : v; (n <= 16 ? b16 : n <= 32 ? b32 : n <= 48 ? b48 : n <= 64 ? b64 : n <= 96 ? b96 : more)++; }
+		fprintf(stderr, "[lsfm] Schur tiles by poses: <=16 %d, <=32 %d, <=48 %d, <=64 %d, <=96 %d, more (or > 64 distinct: hash full) %d\n", b16, b32, b48, b64, b96, more);
+	}
 	struct Item { const void* src; size_t bytes; void** dst; };
 	SolvePlan& P = *sp;
 	P.sy = sy; P.ch = ch; P.its = its; P.mixed = ch.Lf != nullptr;
@@ -1186,7 +1195,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 		{ sy.d_nlong, 4, (void**)&P.sy.d_nlong }, { sy.tab, cap * 8, (void**)&P.sy.tab }, { sy.hval, cap * 4, (void**)&P.sy.hval },
 		{ ch.blob, ch.blob_ints * 4, (void**)&P.ch.blob },
 		{ sy.gent, sy.gent ? nnzb * 16 : 0, (void**)&P.sy.gent }, { sy.goth, sy.goth ? nnzb * 8 : 0, (void**)&P.sy.goth },
-		{ sy.k9.ns, sy.k9.ns ? (size_t)sy.k9_tiles * 4 : 0, (void**)&P.sy.k9.ns }, { sy.k9.pose, sy.k9.pose ? (size_t)sy.k9_tiles * 48 * 4 : 0, (void**)&P.sy.k9.pose },
+		{ sy.k9.ns, sy.k9.ns ? (size_t)sy.k9_tiles * 4 : 0, (void**)&P.sy.k9.ns }, { sy.k9.pose, sy.k9.pose ? (size_t)sy.k9_tiles * 64 * 4 : 0, (void**)&P.sy.k9.pose },
 		{ sy.k9.eslot, sy.k9.eslot ? (size_t)sy.k9_NW : 0, (void**)&P.sy.k9.eslot },
 	};
 	P.sy.k9.record = 0;

@@ -23,6 +23,7 @@ namespace lsfm {
 #define PM_KS (PM_K + 1) /* odd row stride: the 16 rows x 2 k of a half-wave fall into distinct LDS banks */
 #define PM_SMAX 32      /* slots of the common variant: 256 threads, two work-groups per CU */
 #define PM_SMAX_BIG 48  /* slots of the variant for the tiles that exceed it: 1024 threads (16 waves share the 171 output tiles) */
+#define PM_SMAX_MAX 64  /* the widest panel: the same 1024 threads take its 300 output tiles in two sweeps over the tile's passes */
 #define PM_HASH 64
 #define PM_THREADS 256
 #define PM_MAXE 3584 /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 per feature on average); later ones probe the hash again */
@@ -87,7 +88,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
                                         const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback,
-                                        const unsigned char* __restrict__ ces)
+                                        const unsigned char* __restrict__ ces, int q0 = 0, bool first_sweep = true)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
 	K9T_DECL;
@@ -98,7 +99,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 #pragma unroll
 	for (int t = 0; t < T; t++)
 	{
-		const int q = wave + (THREADS / 64) * t;
+		const int q = q0 + wave + (THREADS / 64) * t; // (a sweep of the widest variant starts at output tile q0)
 		int i = 0, j = 0;
 		if (q < ntile)
 		{
@@ -232,7 +233,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		else { R = 0; lyv = 0.0; }
 		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328 (the panel and y are zero past the pass's last feature: constant trip count,
 		// the LDS reads of a row in flight together -- as a 48-step dependent loop this was a third of the pass)
-		if (tid < rows)
+		if (first_sweep && tid < rows)
 		{
 			const double* pr = &sh.P[tid * PM_KS];
 			double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -353,7 +354,15 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 	{
 		if (tpw <= 6) PM_GO(6);
 		else if (tpw <= 9) PM_GO(9);
-		else PM_GO(11);
+		else if (tpw <= 11 || SMAX <= PM_SMAX_BIG) PM_GO(11);
+		else if constexpr (SMAX > PM_SMAX_BIG)
+		{
+			// 49 to 64 poses (Mono far up a deep tree: two hub blocks per feature and level): up to 300 output tiles, more
+			// accumulators than 16 waves hold -- two sweeps over the tile's passes, ten output tiles per wave each
+			pm_body<10, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, 0, true);
+			if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
+			pm_body<10, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, 10 * (THREADS / 64), false);
+		}
 	}
 #undef PM_GO
 }
@@ -384,7 +393,7 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			return;
 		}
 		for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
-		if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)blockIdx.x * PM_SMAX_BIG + tid];
+		if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid];
 		if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
 		__syncthreads();
 		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
@@ -429,7 +438,11 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 	const int ns = sh.nslots;
 	if (ns > SMAX || sh.bad == 2)
 	{
-		if (tid == 0) fallback[blockIdx.x] = 1;
+		if (tid == 0)
+		{
+			fallback[blockIdx.x] = 1;
+			if (kc.ns && kc.record) kc.ns[blockIdx.x] = sh.bad == 2 ? -1000 : -ns; // (a larger variant that takes the tile overwrites this)
+		}
 		return;
 	}
 	if (only && tid == 0) fallback[blockIdx.x] = 0; // taken here (pm_body flags it again if a V^-1 has no Cholesky factor)
@@ -457,7 +470,7 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		// first run of a resident tree: leave the tile's slots for the later ones (the blocks past the LDS list too)
 		__syncthreads();
 		if (tid == 0) kc.ns[blockIdx.x] = ns;
-		if (tid < ns) kc.pose[(size_t)blockIdx.x * PM_SMAX_BIG + tid] = sh.pose_of[tid];
+		if (tid < ns) kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid] = sh.pose_of[tid];
 		for (int e = tid; e < je - jb; e += THREADS)
 		{
 			unsigned char v;
@@ -516,6 +529,8 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E,
 	                   fallback, (const unsigned char*)fallback, kc);
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
+	                   (const unsigned char*)fallback, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 	                   (const unsigned char*)fallback, kc);
 }
 

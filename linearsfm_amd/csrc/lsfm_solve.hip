@@ -725,7 +725,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		if (!sy.k9.ns && ctx->plan)
 		{
 			sy.k9.ns = sc.alloc<int>(ntiles + 1);
-			sy.k9.pose = sc.alloc<int>((size_t)ntiles * 48 + 1);
+			sy.k9.pose = sc.alloc<int>((size_t)ntiles * 64 + 1);
 			sy.k9.eslot = sc.alloc<unsigned char>((size_t)io.NW + 1);
 			sy.k9.record = 1;
 			sy.k9_tiles = ntiles; sy.k9_NW = io.NW;

@@ -9,7 +9,7 @@ namespace lsfm {
 // read by the later ones instead of hashing the tile's poses again.  ns[tile] = -1: no panel variant takes the tile.
 struct K9Cache {
 	int* ns = nullptr;            // [tiles]
-	int* pose = nullptr;          // [tiles * 48]
+	int* pose = nullptr;          // [tiles * 64]
 	unsigned char* eslot = nullptr; // [NW]
 	int record = 0;
 };

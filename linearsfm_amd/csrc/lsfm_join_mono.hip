@@ -249,6 +249,119 @@ __global__ void k_mono_w_fill(int NFY, const int* __restrict__ srcE, const int* 
 	tile_flush<6>(ekeys, evals, ECAP, eP);
 }
 
+// ---- the same in two steps (the default): where every source block goes is index work, one lane per joint feature as above
+// but ints only; the blocks themselves -- 144 bytes each -- are then moved one lane per SOURCE block, consecutive lanes
+// on consecutive blocks, with the right-hand-side parts summed per source feature through LDS (tile_runs).  One lane per
+// feature walking its 9-40 blocks, 144-byte loads a run length apart, was 7 % of an RS468-like tree. ----
+#define MW_DROP (-1)            /* P1 / C1 block: gone, no contribution */
+#define MW_SUMMED (-2)          /* Cur's block to C2: added into End's block to P2, contributes to the right-hand sides */
+#define MW_TARGET (1 << 30)     /* End's last block to P2 of a feature whose Cur run holds C2 blocks: it adds them */
+__global__ void k_mono_w_index(int NFY, const int* __restrict__ srcE, const int* __restrict__ srcC, const int* __restrict__ fptr,
+                               const int* __restrict__ photo, const int* __restrict__ feat_map_y, const MGroup* __restrict__ grp,
+                               const int* __restrict__ pnew, const int* __restrict__ fptr_y, int* __restrict__ photo_y,
+                               int* __restrict__ feature_y, int* __restrict__ dst, int* __restrict__ jf)
+{
+	const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+	if (nf >= NFY) return;
+	const MGroup& g = grp[feat_map_y[nf]];
+	int pos = fptr_y[nf], flpos = -1, flj = -1;
+	bool summed = false;
+	for (int side = 0; side < 2; side++)
+	{
+		const int f = side ? srcC[nf] : srcE[nf];
+		if (f < 0) continue;
+		jf[f] = nf;
+		for (int j = fptr[f]; j < fptr[f + 1]; j++)
+		{
+			const int k = photo[j];
+			if (g.pair && (k == g.P1 || k == g.C1)) { dst[j] = MW_DROP; continue; }
+			if (side == 1 && g.pair && k == g.C2 && flpos >= 0) { dst[j] = MW_SUMMED; summed = true; continue; }
+			if (side == 0 && g.pair && k == g.P2) { flpos = pos; flj = j; }
+			dst[j] = pos;
+			photo_y[pos] = pnew[k]; feature_y[pos] = nf;
+			pos++;
+		}
+	}
+	if (summed) dst[flj] |= MW_TARGET;
+}
+
+#define MWC_TILE 128 /* source features per work-group */
+__global__ void __launch_bounds__(256)
+k_mono_w_copy(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const int* __restrict__ feat_map_src,
+              const double* __restrict__ W_alias, const int* __restrict__ alias, const int* __restrict__ dst, const int* __restrict__ jf,
+              const int* __restrict__ srcC, const int* __restrict__ feat_map_y, const MGroup* __restrict__ grp, const int* __restrict__ pnew,
+              const double* __restrict__ prior, const double* __restrict__ feat, double* __restrict__ Wy, double* __restrict__ eP,
+              double* __restrict__ eF)
+{
+	constexpr int ECAP = 128;
+	__shared__ int ekeys[ECAP];
+	__shared__ double evals[ECAP * 6];
+	__shared__ int sFp[MWC_TILE + 1];
+	__shared__ double sT[256 * 3];
+	const int f0 = blockIdx.x * MWC_TILE, nft = min(MWC_TILE, NF - f0);
+	for (int i = threadIdx.x; i < ECAP; i += blockDim.x) ekeys[i] = -1;
+	for (int i = threadIdx.x; i < ECAP * 6; i += blockDim.x) evals[i] = 0.0;
+	for (int i = threadIdx.x; i <= nft; i += blockDim.x) sFp[i] = fptr[f0 + i];
+	__syncthreads();
+	// blocks of a map the transform passed through are still in the transform's input
+	auto block_of = [&](int f, int j) -> const double* {
+		const int delta = alias ? alias[feat_map_src[f]] : INT_MIN;
+		return (delta != INT_MIN ? W_alias + (ptrdiff_t)delta * 18 : W) + (size_t)j * 18;
+	};
+	tile_runs<3>(nft, sFp, sT,
+		[&](int j, int fl, double* out) {
+			out[0] = 0.0; out[1] = 0.0; out[2] = 0.0;
+			const int d = dst[j];
+			if (d == MW_DROP) return;
+			const int f = f0 + fl, k = photo[j], kn = pnew[k];
+			double w[18];
+			ld<18>(w, block_of(f, j));
+			if (d >= 0)
+			{
+				const int pos = d & ~MW_TARGET;
+				if (d & MW_TARGET)
+				{
+					// End's block to P2: Cur's block(s) to C2 of the same joint feature are summed into it (Imp.cpp:7619-7700)
+					const int nf = jf[f], fc = srcC[nf], C2 = grp[feat_map_y[nf]].C2;
+					double sum[18];
+					ld<18>(sum, w);
+					for (int j2 = fptr[fc]; j2 < fptr[fc + 1]; j2++)
+						if (photo[j2] == C2)
+						{
+							double w2[18];
+							ld<18>(w2, block_of(fc, j2));
+							for (int q = 0; q < 18; q++) sum[q] += w2[q];
+						}
+					st<18>(Wy + (size_t)pos * 18, sum);
+				}
+				else st<18>(Wy + (size_t)pos * 18, w);
+			}
+			// right-hand sides: the block times ITS map's estimates (eP += W x_f, eF += W^T x_p)
+			const double* xf = feat + (size_t)f * 3;
+			const double* xp = prior + (size_t)k * 6;
+			const int es = lds_slot(ekeys, ECAP, kn);
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+			{
+				const double y = w[3 * r] * xf[0] + w[3 * r + 1] * xf[1] + w[3 * r + 2] * xf[2];
+				if (es >= 0) lds_add_f64(&evals[es * 6 + r], y); else atomic_add_f64(eP + (size_t)kn * 6 + r, y);
+			}
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+			{
+				double sacc = 0.0;
+#pragma unroll
+				for (int r = 0; r < 6; r++) sacc = fma(w[3 * r + c], xp[r], sacc);
+				out[c] = sacc;
+			}
+		},
+		[&](int fl, int q, double sum, bool) {
+			const int nf = jf[f0 + fl];
+			if (nf >= 0 && sum != 0.0) atomic_add_f64(eF + (size_t)nf * 3 + q, sum); // End's and Cur's run of a joint feature both land here
+		});
+	tile_flush<6>(ekeys, evals, ECAP, eP); // tile_runs ends with a barrier
+}
+
 __global__ void k_mono_fixed(int G, const MGroup* __restrict__ grp, const int* __restrict__ pnew, unsigned char* __restrict__ fixed)
 {
 	int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,9 +543,22 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	}
 	out.NW = out.w_off[G];
 	out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW);
-	if (NFY)
+	static const bool one_lane_per_feature = getenv("LSFM_MONO_FILL_BY_FEATURE") != nullptr; // the round-1 kernel, kept for comparison
+	if (NFY && one_lane_per_feature)
 		hipLaunchKernelGGL(k_mono_w_fill, dim3((NFY + 127) / 128), dim3(128), 0, s, NFY, srcE, srcC, in.fptr, in.photo, in.W, out.feat_map, d_mg,
 		                   pnew, prior, in.feat, out.fptr, out.W, out.photo, out.feature, eP, eF, in.feat_map, in.W_alias, in.d_alias);
+	else if (NFY)
+	{
+		int* dst = sc.alloc<int>((size_t)in.NW + 1);
+		int* jf = sc.alloc<int>((size_t)in.NF + 1);
+		LSFM_CHECK_HIP(hipMemsetAsync(dst, 0xff, sizeof(int) * (size_t)in.NW, s)); // MW_DROP for blocks no joint feature claims
+		LSFM_CHECK_HIP(hipMemsetAsync(jf, 0xff, sizeof(int) * (size_t)in.NF, s));
+		hipLaunchKernelGGL(k_mono_w_index, dim3((NFY + 255) / 256), dim3(256), 0, s, NFY, srcE, srcC, in.fptr, in.photo, out.feat_map, d_mg, pnew, out.fptr,
+		                   out.photo, out.feature, dst, jf);
+		if (in.NF)
+			hipLaunchKernelGGL(k_mono_w_copy, dim3((in.NF + MWC_TILE - 1) / MWC_TILE), dim3(256), 0, s, in.NF, in.fptr, in.photo, in.W, in.feat_map,
+			                   in.W_alias, in.d_alias, dst, jf, srcC, out.feat_map, d_mg, pnew, prior, in.feat, out.W, eP, eF);
+	}
 	LSFM_CHECK_HIP(hipGetLastError());
 	if (eP_out) d2h(ctx, eP_out, eP, (size_t)MY * 6 * sizeof(double));
 	if (eF_out) d2h(ctx, eF_out, eF, (size_t)NFY * 3 * sizeof(double));

@@ -10,6 +10,7 @@
 //   * the solve removes 7 scalars: the reference pose and the gauge-fixed translation of the scale pose
 //     (lmj_solveLinearSFMMono, Imp.cpp:6981-7026), then sets stVal[Fix] = Sign.
 #include <climits>
+#include <cstdlib>
 
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"

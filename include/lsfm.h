@@ -205,6 +205,12 @@ int lsfm_save_poses(const char* pose_path, const char* feat_path, const int* stn
 int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val,
                     const double* x, double* y, int reps, double* avg_ms, double* algorithmic_bytes);
 
+/* Measurement only: how fast this chip moves nblocks 6x3 blocks of W (144 bytes each) from one array to another with the
+ * access pattern of the W kernels -- mode 0: one lane per block, the block as 18 doubles (lane stride 144 bytes, what
+ * k_tr_entries / k_join_rhs_w / k_backsub do); mode 1: one lane per block, nine 16-byte loads; mode 2: consecutive lanes
+ * on consecutive 16 bytes (the stream copy).  avg_ms over reps launches (HIP events); bytes moved = 2 * 144 * nblocks. */
+int lsfm_wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,7 @@ def lib():
         L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
+        L.lsfm_wstream_bench.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, dp]
         _LIB = L
     return _LIB
 
@@ -105,7 +106,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
-           "lsfm_spmv_bench"]
+           "lsfm_spmv_bench", "lsfm_wstream_bench"]
 
 
 def _c(a, dtype):
@@ -311,6 +312,16 @@ class Context:
                                           _ptr(x, C.c_double), _ptr(y, C.c_double), int(reps), C.byref(ms), C.byref(by)),
                     "lsfm_spmv_bench")
         return y, ms.value, by.value
+
+
+def _wstream(self, nblocks, mode, reps=10):
+    """ms per launch of the W access-pattern copy (lsfm_wstream_bench)."""
+    ms = C.c_double()
+    self._check(lib().lsfm_wstream_bench(self._h, int(nblocks), int(mode), int(reps), C.byref(ms)), "lsfm_wstream_bench")
+    return ms.value
+
+
+Context.wstream_bench = _wstream
 
 
 def read_localmap(path, mono):

@@ -1,6 +1,7 @@
 // Host maps (reference layout, Imp.h:75-178) <-> device batch (flat SoA with global indices).
 #include <cstdlib>
 
+#include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
 
 namespace lsfm {
@@ -233,6 +234,58 @@ void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, 
 	d2h(ctx, g->V, b.V + (size_t)fo * 9, (size_t)n * 9 * sizeof(double));
 	d2h(ctx, fptr.data(), b.fptr + fo, (n + 1) * sizeof(int));
 	for (int i = 0; i < n; i++) g->FBlock[i] = fptr[i] - wo;
+}
+
+// ---- measurement: the W access patterns against the stream copy (lsfm_wstream_bench) ------------------------------
+__global__ void __launch_bounds__(256) k_wstream_block18(long long n, const double* __restrict__ a, double* __restrict__ b)
+{
+	const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	double w[18];
+	ld<18>(w, a + j * 18);
+	st<18>(b + j * 18, w);
+}
+__global__ void __launch_bounds__(256) k_wstream_block9x16(long long n, const double2* __restrict__ a, double2* __restrict__ b)
+{
+	const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	double2 w[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) w[i] = a[j * 9 + i];
+#pragma unroll
+	for (int i = 0; i < 9; i++) b[j * 9 + i] = w[i];
+}
+__global__ void __launch_bounds__(256) k_wstream_linear(long long n2, const double2* __restrict__ a, double2* __restrict__ b)
+{
+	// four 16-byte pieces per lane, consecutive lanes on consecutive pieces
+	const long long base = (long long)blockIdx.x * blockDim.x * 4 + threadIdx.x;
+	double2 w[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) if (base + (long long)i * blockDim.x < n2) w[i] = a[base + (long long)i * blockDim.x];
+#pragma unroll
+	for (int i = 0; i < 4; i++) if (base + (long long)i * blockDim.x < n2) b[base + (long long)i * blockDim.x] = w[i];
+}
+int wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps, double* avg_ms)
+{
+	hipStream_t s = ctx->stream;
+	double* a = ctx->scratch.alloc<double>((size_t)nblocks * 18);
+	double* b = ctx->scratch.alloc<double>((size_t)nblocks * 18);
+	LSFM_CHECK_HIP(hipMemsetAsync(a, 0, (size_t)nblocks * 144, s));
+	float total = 0;
+	for (int k = 0; k < reps + 2; k++)
+	{
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev0, s));
+		if (mode == 0) hipLaunchKernelGGL(k_wstream_block18, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, nblocks, a, b);
+		else if (mode == 1) hipLaunchKernelGGL(k_wstream_block9x16, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, nblocks, (const double2*)a, (double2*)b);
+		else hipLaunchKernelGGL(k_wstream_linear, dim3((unsigned)((nblocks * 9 + 1023) / 1024)), dim3(256), 0, s, nblocks * 9, (const double2*)a, (double2*)b);
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev1, s));
+		LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+		float t = 0;
+		LSFM_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+		if (k >= 2) total += t;
+	}
+	*avg_ms = total / reps;
+	return LSFM_OK;
 }
 
 } // namespace lsfm

@@ -546,4 +546,14 @@ int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* coli
 	});
 }
 
+int lsfm_wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps, double* avg_ms)
+{
+	if (nblocks <= 0 || mode < 0 || mode > 2 || reps <= 0 || !avg_ms) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas((size_t)nblocks * 144 * 2 + ((size_t)64 << 20));
+		ctx->scratch.reset();
+		return wstream_bench(ctx, nblocks, mode, reps, avg_ms);
+	});
+}
+
 } // extern "C"

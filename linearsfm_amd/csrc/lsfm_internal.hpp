@@ -223,4 +223,5 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io);
 int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,
                   double* avg_ms, double* bytes);
 
+int wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps, double* avg_ms); // measurement: W access patterns vs stream copy
 } // namespace lsfm

@@ -258,6 +258,22 @@ k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map
 	st<36>(Dp + (size_t)k * 36, D);
 	st<36>(Cp + (size_t)k * 36, C1);
 	if (NH == 2) st<36>(Cp + (size_t)M * 36 + (size_t)k * 36, C2);
+	if (NH == 1)
+	{
+		// Stereo, every pose but the hub: D_k = [R 0; 0 DD2_k], C_k = [-R T_k; 0 DD_k] with R the map's rotation (which a W
+		// block's feature record holds too) -- 27 pose-dependent numbers instead of 72.  k_tr_entries gathers these: the
+		// two 288-byte gathers per W block were what its time went with (doubling them doubled it).
+		double* pj = Cp + (size_t)M * 36 + (size_t)k * 27;
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+			{
+				pj[3 * r + c] = D[6 * (3 + r) + 3 + c];
+				pj[9 + 3 * r + c] = C1[6 * r + 3 + c];
+				pj[18 + 3 * r + c] = C1[6 * (3 + r) + 3 + c];
+			}
+	}
 }
 
 __global__ void k_tr_flags(const int* __restrict__ Ui, const int* __restrict__ Uj, int NU, const int* __restrict__ photo, int NW,
@@ -438,7 +454,7 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 #ifdef LSFM_K9_TIMING
 			if (tid == 0) tracc[11]++;
 #endif
-			bool act = false;
+			bool act = false, is_hub = false;
 			int f = 0, k = 0, sl = -1;
 			double W[18];
 			const double* fd = nullptr;
@@ -474,13 +490,34 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 					ld<18>(W, Wold + (size_t)j * 18);
 					fd = FD + (size_t)f * (9 + TW);
 					const bool hub = (k == fi.y) || (NH == 2 && k == fi.z);
+					is_hub = hub;
 					if (!hub)
 					{
 						// W' = D_k^T W D_f at its new place: after the feature's hub block(s), old order kept
-						double Dk[36], T1[18], Df[9], Wn[18];
-						ld<36>(Dk, Dp + (size_t)k * 36);
-						mtm<6, 6, 3, false>(Dk, W, T1);
+						double T1[18], Df[9], Wn[18];
 						ld<9>(Df, fd);
+						if constexpr (NH == 1)
+						{
+							// D_k = [R 0; 0 DD2_k], R = D_f (Stereo): the same sums as the 6x6 product, without its zero terms
+							double DD2[9];
+							ld<9>(DD2, Cp + (size_t)M * 36 + (size_t)k * 27);
+#pragma unroll
+							for (int i = 0; i < 3; i++)
+#pragma unroll
+								for (int j = 0; j < 3; j++)
+								{
+									double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+									for (int q = 0; q < 3; q++) { s0 = fma(Df[3 * q + i], W[3 * q + j], s0); s1 = fma(DD2[3 * q + i], W[3 * (3 + q) + j], s1); }
+									T1[3 * i + j] = s0; T1[3 * (3 + i) + j] = s1;
+								}
+						}
+						else
+						{
+							double Dk[36];
+							ld<36>(Dk, Dp + (size_t)k * 36);
+							mtm<6, 6, 3, false>(Dk, W, T1);
+						}
 						mm<6, 3, 3, false>(T1, Df, Wn);
 						const int pos = wb + fi.w + kw;
 						st<18>(Wn_ + (size_t)pos * 18, Wn);
@@ -517,10 +554,37 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 			{
 				if (act)
 				{
-					double Ck[36], T[18], Cf[18];
-					ld<36>(Ck, Cp + (size_t)s * M * 36 + (size_t)k * 36);
+					double T[18], Cf[18];
 					zero<18>(T);
-					mtm<6, 3, 6, true>(W, Ck, T); // share of G_s,f: W^T C_s,k   [3x6]
+					if constexpr (NH == 1)
+					{
+						// C_k = [-R T_k; 0 DD_k] (zero for the hub pose): W^T C_k from the 18 packed numbers and R = D_f
+						if (!is_hub)
+						{
+							double R[9], TK[9], DDk[9];
+							ld<9>(R, fd);
+							ld<9>(TK, Cp + (size_t)M * 36 + (size_t)k * 27 + 9);
+							ld<9>(DDk, Cp + (size_t)M * 36 + (size_t)k * 27 + 18);
+#pragma unroll
+							for (int i = 0; i < 3; i++)
+#pragma unroll
+								for (int j = 0; j < 3; j++)
+								{
+									double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+									for (int q = 0; q < 3; q++) { s0 = fma(W[3 * q + i], -R[3 * q + j], s0); s1 = fma(W[3 * q + i], TK[3 * q + j], s1); }
+#pragma unroll
+									for (int q = 0; q < 3; q++) s1 = fma(W[3 * (3 + q) + i], DDk[3 * q + j], s1);
+									T[6 * i + j] = s0; T[6 * i + 3 + j] = s1;
+								}
+						}
+					}
+					else
+					{
+						double Ck[36];
+						ld<36>(Ck, Cp + (size_t)s * M * 36 + (size_t)k * 36);
+						mtm<6, 3, 6, true>(W, Ck, T); // share of G_s,f: W^T C_s,k   [3x6]
+					}
 					st<18>(&sT[tid * 18], T);
 					ld<18>(Cf, fd + 9 + 18 * s);
 					TRT(5); // C_k load, W^T C_k, C_f load
@@ -961,7 +1025,8 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		hipLaunchKernelGGL(k_tr_params2, dim3((B + 127) / 128), dim3(128), 0, s, out.pose, d_tm, B);
 	}
 	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
-	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
+	// Stereo: + the 27 pose-dependent entries of (D_k, C_k) packed per pose, for k_tr_entries (after the one C section)
+	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh + (nh == 1 ? (size_t)M * 27 : 0));
 	ZeroSpan zs(ctx->scratch);
 	double* Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
 	double* PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);

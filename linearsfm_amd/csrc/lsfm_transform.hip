@@ -274,6 +274,21 @@ k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map
 				pj[18 + 3 * r + c] = C1[6 * (3 + r) + 3 + c];
 			}
 	}
+	else
+	{
+		// Mono: every one of D_k, C1_k, C2_k is [tl tr; 0 br] (the hub poses' D collects the C terms and keeps that shape; C2 is
+		// its top-left block alone): 63 numbers instead of 108
+		double* pj = Cp + (size_t)M * 72 + (size_t)k * 63;
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+			{
+				pj[3 * r + c] = D[6 * r + c]; pj[9 + 3 * r + c] = D[6 * r + 3 + c]; pj[18 + 3 * r + c] = D[6 * (3 + r) + 3 + c];
+				pj[27 + 3 * r + c] = C1[6 * r + c]; pj[36 + 3 * r + c] = C1[6 * r + 3 + c]; pj[45 + 3 * r + c] = C1[6 * (3 + r) + 3 + c];
+				pj[54 + 3 * r + c] = C2[6 * r + c];
+			}
+	}
 }
 
 __global__ void k_tr_flags(const int* __restrict__ Ui, const int* __restrict__ Uj, int NU, const int* __restrict__ photo, int NW,
@@ -514,9 +529,21 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 						}
 						else
 						{
-							double Dk[36];
-							ld<36>(Dk, Dp + (size_t)k * 36);
-							mtm<6, 6, 3, false>(Dk, W, T1);
+							// D_k = [tl tr; 0 br]: the sums of the 6x6 product in its order, without the zero terms
+							double Dt[27];
+							ld<27>(Dt, Cp + (size_t)M * 72 + (size_t)k * 63);
+#pragma unroll
+							for (int i = 0; i < 3; i++)
+#pragma unroll
+								for (int j = 0; j < 3; j++)
+								{
+									double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+									for (int q = 0; q < 3; q++) { s0 = fma(Dt[3 * q + i], W[3 * q + j], s0); s1 = fma(Dt[9 + 3 * q + i], W[3 * q + j], s1); }
+#pragma unroll
+									for (int q = 0; q < 3; q++) s1 = fma(Dt[18 + 3 * q + i], W[3 * (3 + q) + j], s1);
+									T1[3 * i + j] = s0; T1[3 * (3 + i) + j] = s1;
+								}
 						}
 						mm<6, 3, 3, false>(T1, Df, Wn);
 						const int pos = wb + fi.w + kw;
@@ -581,9 +608,30 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 					}
 					else
 					{
-						double Ck[36];
-						ld<36>(Ck, Cp + (size_t)s * M * 36 + (size_t)k * 36);
-						mtm<6, 3, 6, true>(W, Ck, T); // share of G_s,f: W^T C_s,k   [3x6]
+						// share of G_s,f: W^T C_s,k [3x6] with C1_k = [tl tr; 0 br], C2_k = [tl 0; 0 0]
+						const double* pc = Cp + (size_t)M * 72 + (size_t)k * 63 + (s == 0 ? 27 : 54);
+						double Ct[27];
+						ld<9>(Ct, pc);
+						if (s == 0) ld<18>(Ct + 9, pc + 9);
+#pragma unroll
+						for (int i = 0; i < 3; i++)
+#pragma unroll
+							for (int j = 0; j < 3; j++)
+							{
+								double s0 = 0.0;
+#pragma unroll
+								for (int q = 0; q < 3; q++) s0 = fma(W[3 * q + i], Ct[3 * q + j], s0);
+								T[6 * i + j] = s0;
+								if (s == 0)
+								{
+									double s1 = 0.0;
+#pragma unroll
+									for (int q = 0; q < 3; q++) s1 = fma(W[3 * q + i], Ct[9 + 3 * q + j], s1);
+#pragma unroll
+									for (int q = 0; q < 3; q++) s1 = fma(W[3 * (3 + q) + i], Ct[18 + 3 * q + j], s1);
+									T[6 * i + 3 + j] = s1;
+								}
+							}
 					}
 					st<18>(&sT[tid * 18], T);
 					ld<18>(Cf, fd + 9 + 18 * s);
@@ -1026,7 +1074,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	}
 	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
 	// Stereo: + the 27 pose-dependent entries of (D_k, C_k) packed per pose, for k_tr_entries (after the one C section)
-	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh + (nh == 1 ? (size_t)M * 27 : 0));
+	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh + (nh == 1 ? (size_t)M * 27 : (size_t)M * 63));
 	ZeroSpan zs(ctx->scratch);
 	double* Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
 	double* PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);

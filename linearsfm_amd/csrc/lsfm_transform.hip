@@ -581,15 +581,15 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 			{
 				if (act)
 				{
-					double T[18], Cf[18];
+					double T[18], Cf[18], R[9];
 					zero<18>(T);
 					if constexpr (NH == 1)
 					{
 						// C_k = [-R T_k; 0 DD_k] (zero for the hub pose): W^T C_k from the 18 packed numbers and R = D_f
+						ld<9>(R, fd);
 						if (!is_hub)
 						{
-							double R[9], TK[9], DDk[9];
-							ld<9>(R, fd);
+							double TK[9], DDk[9];
 							ld<9>(TK, Cp + (size_t)M * 36 + (size_t)k * 27 + 9);
 							ld<9>(DDk, Cp + (size_t)M * 36 + (size_t)k * 27 + 18);
 #pragma unroll
@@ -634,7 +634,15 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 							}
 					}
 					st<18>(&sT[tid * 18], T);
-					ld<18>(Cf, fd + 9 + 18 * s);
+					if constexpr (NH == 1)
+					{
+						// C_f = [-R | T_f] (k_tr_feat_pre): R is in registers already, only the feature's own 9 numbers are fetched
+#pragma unroll
+						for (int m = 0; m < 3; m++)
+#pragma unroll
+							for (int c = 0; c < 3; c++) { Cf[6 * m + c] = -R[3 * m + c]; Cf[6 * m + 3 + c] = fd[9 + 6 * m + 3 + c]; }
+					}
+					else ld<18>(Cf, fd + 9 + 18 * s);
 					TRT(5); // C_k load, W^T C_k, C_f load
 					// pose row of G_s: W C_s,f   [6x6], one row at a time
 					double* gl = sl >= 0 ? &gvals[(s * GCAP + sl) * 36] : nullptr;

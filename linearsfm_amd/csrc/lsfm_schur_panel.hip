@@ -1,16 +1,25 @@
 // K9, panel formulation on the matrix cores: S(p,q) -= sum_f W_pf V_f^-1 W_qf^T and E_p -= sum_f W_pf V_f^-1 eb_f
 // (Imp.cpp:2244-2332).
 //
-// A tile of PM_TILE consecutive features is observed by a small set of poses (its ~12 hub poses plus the few frames
-// that see it): at most PM_SMAX "slots".  With V_f^-1 = L_f L_f^T the tile's contribution is a dense symmetric rank-k
+// A tile of PM_TILE consecutive features is observed by a small set of poses (the hub poses of the levels below plus the
+// few frames that see it): its "slots".  With V_f^-1 = L_f L_f^T the tile's contribution is a dense symmetric rank-k
 // update  P P^T,  P = [ W_sf L_f ]  (rows = 6 * slot + r, columns = 3 * feature + c, absent blocks zero), i.e. a real
 // contraction over the 3 * PM_TILE feature columns: the panel is staged PM_PASS features at a time in LDS and the
 // 16x16 tiles of the upper block triangle of P P^T are accumulated with v_mfma_f64_16x16x4_f64, the tiles dealt round
-// robin to the four waves of the work-group.  No lane idles on an absent pose pair, the LDS traffic is two doubles per
-// lane per 1024 multiply-adds, and every touched block of S leaves the work-group once.  The right-hand side part is
-// the panel times y = L^T eb, one panel row per lane.
-// Tiles with more than PM_SMAX poses (sub-map boundaries at the top of the tree can exceed it) or with a V^-1 that has
-// no Cholesky factor are flagged and handled by the per-feature kernel k_schur_w.
+// robin to the waves of the work-group.  No lane idles on an absent pose pair and every touched block of S leaves the
+// work-group once.  The right-hand side part is the panel times y = L^T eb, one panel row per lane.
+//
+// Variants by the number of slots of a tile (launch_schur_panel): 8 / 16 / 32 slots with 256 threads (4 / 3 / 2
+// work-groups per CU), 48 and 64 slots with 1024 threads (one work-group per CU; 64: the output tiles in two sweeps over
+// the tile's passes).  A variant flags the tiles that exceed it for the next one; what exceeds 64 poses, or holds a V^-1
+// without a Cholesky factor, goes to the per-feature kernel k_schur_w.
+//
+// A pass works on LDS only between its barriers: the W rows of a pass (ONE contiguous range), and per feature L and y
+// (k_vinv leaves them), are fetched into registers during the MFMA phase of the pass before; first blocks of a
+// (pose, feature) pair are staged with plain stores, repeats -- the joins keep both blocks of a feature seen from the hub
+// pose on either side -- with LDS atomics after a barrier that passes without repeats skip.  What a tile works out from
+// index arrays alone (its poses, the slot of every block, the repeats) is recorded by the first run of a resident tree
+// (K9Cache) and read by the later ones.  DESIGN.md section 3 "Inside a tile" has the measurements behind each of these.
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
 #include "lsfm_solve.hpp"
@@ -26,7 +35,7 @@ namespace lsfm {
 #define PM_SMAX_MAX 64  /* the widest panel: the same 1024 threads take its 300 output tiles in two sweeps over the tile's passes */
 #define PM_HASH 64
 #define PM_THREADS 256
-#define PM_MAXE 3584 /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 per feature on average); later ones probe the hash again */
+#define PM_MAXE 3584 /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 per feature on average); later ones are added after the first blocks */
 #define PM_BF 352   /* >= rows held in registers per pass / 6 (4 x 256 or 2 x 1024) */
 #define PM_DUP 0x80  /* eslot: a block whose (pose, feature) an earlier block of the tile already holds */
 

@@ -124,7 +124,10 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		offB[t] = 16 * j * PM_KS;
 		acc[t] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
 	}
-	double eacc = 0.0;
+	constexpr int NE = ((6 * SMAX + 15) / 16 + THREADS / 64 - 1) / (THREADS / 64); // 16-row strips of the panel per wave
+	double eacc[NE];
+#pragma unroll
+	for (int i = 0; i < NE; i++) eacc[i] = 0.0;
 	// Everything a pass reads from memory is fetched into registers before the MFMA loop of the pass before it, and none of
 	// it behind a dependent load: the run pointers of the tile sit in LDS, the W rows of a pass are ONE contiguous range
 	// (row w of the pass = 3 doubles at W[18 qb0 + 3 w]: consecutive lanes, consecutive 24 bytes, whatever the lengths of
@@ -240,23 +243,35 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		K9T(4);
 		if (p0 + PM_PASS < f1) prefetch(p0 + PM_PASS);
 		else { R = 0; lyv = 0.0; }
-		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328 (the panel and y are zero past the pass's last feature: constant trip count,
-		// the LDS reads of a row in flight together -- as a 48-step dependent loop this was a third of the pass)
-		if (first_sweep && tid < rows)
+		K9T(12);
+		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328.  By 16-row strips over ALL the waves: lane (row l & 15 of the strip, quarter
+		// l >> 4 of the 48 columns) sums 12 products, two shuffles add the quarters up -- 24 LDS reads a lane instead of the 96 of
+		// one lane per panel row, which only the first wave or two took part in (a quarter of a 16-slot tile's clocks).  The
+		// panel and y are zero past the pass's last feature and past the tile's rows: no bounds in the loop.
+		if (first_sweep)
 		{
-			const double* pr = &sh.P[tid * PM_KS];
-			double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 1
-			for (int k0 = 0; k0 < PM_K; k0 += 8)
+			const int kq = lane >> 4;
 #pragma unroll
-				for (int k = k0; k < k0 + 8; k += 4)
+			for (int si = 0; si < NE; si++)
+			{
+				const int strip = wave + (THREADS / 64) * si; // wave-uniform
+				if (strip < NT)
 				{
-					s0 = fma(pr[k], sh.ly[(k / 3) * 9 + 6 + k % 3], s0);
-					s1 = fma(pr[k + 1], sh.ly[((k + 1) / 3) * 9 + 6 + (k + 1) % 3], s1);
-					s2 = fma(pr[k + 2], sh.ly[((k + 2) / 3) * 9 + 6 + (k + 2) % 3], s2);
-					s3 = fma(pr[k + 3], sh.ly[((k + 3) / 3) * 9 + 6 + (k + 3) % 3], s3);
+					const double* pr = &sh.P[(16 * strip + (lane & 15)) * PM_KS + 12 * kq];
+					const double* yq = &sh.ly[kq * 36 + 6];
+					double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+					for (int k = 0; k < 12; k += 2)
+					{
+						s0 = fma(pr[k], yq[(k / 3) * 9 + k % 3], s0);
+						s1 = fma(pr[k + 1], yq[((k + 1) / 3) * 9 + (k + 1) % 3], s1);
+					}
+					double sum = s0 + s1;
+					sum += __shfl_xor(sum, 16, 64);
+					sum += __shfl_xor(sum, 32, 64);
+					eacc[si] -= sum;
 				}
-			eacc -= (s0 + s1) + (s2 + s3);
+			}
 		}
 		K9T(11);
 		// P P^T, four feature columns per MFMA: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15].
@@ -322,10 +337,16 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			}
 		}
 	}
-	if (tid < rows && eacc != 0.0) atomic_add_f64(E + (size_t)sh.pose_of[tid / 6] * 6 + tid % 6, eacc);
+	if (lane < 16)
+#pragma unroll
+		for (int si = 0; si < NE; si++)
+		{
+			const int row = 16 * (wave + (THREADS / 64) * si) + lane;
+			if (row < rows && eacc[si] != 0.0) atomic_add_f64(E + (size_t)sh.pose_of[row / 6] * 6 + row % 6, eacc[si]);
+		}
 	K9T(6);
 	K9T_FLUSH(1, 8);
-	K9T_FLUSH(11, 12);
+	K9T_FLUSH(11, 13);
 	K9T_COUNT(ns, T);
 }
 

@@ -167,10 +167,14 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			sh.ly[tid] = lyv; // zero for the features past the end of the tile
 			if (tid < nf * 9 && tid % 9 == 0 && !(lyv == lyv)) sh.bad = 1; // k_vinv: V^-1 of this feature has no Cholesky factor
 		}
-		if (tid < nf)
 		{
-			const int a = sh.fpt[pb + tid] - qb0, b = min(sh.fpt[pb + tid + 1] - qb0, PM_BF);
-			for (int e = a; e < b; e++) sh.bf[e] = (unsigned char)tid;
+			// block -> feature of the pass: 16 lanes per feature walk its run
+			const int ff = tid >> 4;
+			if (ff < nf)
+			{
+				const int a = sh.fpt[pb + ff] - qb0, b = min(sh.fpt[pb + ff + 1] - qb0, PM_BF);
+				for (int e = a + (tid & 15); e < b; e += 16) sh.bf[e] = (unsigned char)ff;
+			}
 		}
 		__syncthreads();
 		K9T(2);

@@ -9,7 +9,10 @@ A "step" = ONE full join tree over ONE resident set of local maps, whatever N is
 tree is sharded by sub-trees (linearsfm_amd/distributed.py: rank r joins block r of 2^k consecutive local maps, then
 log2(N) merge rounds in which packed sub-tree roots travel between the GPUs through RCCL send/recv) and `value` is the
 wall time of the whole tree.  Inputs are uploaded once and stay in HBM; no level writes its input, so every step reads
-them in place.  Prints ONE JSON line on rank 0.
+them in place.  Every timed step does the symbolic work of every join itself (pattern of S, ordering, symbolic
+factorisation), as the reference's timed region does; the repeat runs that reuse it are reported as `resolve_ms`.
+At N = 1 the line also carries the CPU baseline (the oracle on the host cores, three ways), the stand-alone streaming
+rate of the CG's SpMV kernel and one files-to-files run of the command line.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
@@ -27,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 # fp64 matrix peak: the guide lists FP32 matrix = FP32 vector = 157.3 TFLOP/s (64 FLOP/clk/SIMD); v_mfma_f64_16x16x4_f64 runs at half
 # that rate (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz) = 78.6 TFLOP/s, AMD's dense FP64 matrix figure for MI355X
 F64_MFMA_PEAK_TFLOPS = 78.6
-METRIC_NAMES = {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular", "rs90": "RS90-like monocular",
+METRIC_NAMES = {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular", "rs90": "RS90-like monocular", "aerial": "AP_Vaihingen-like aerial monocular",
                 "synth16k": "synthetic 16k monocular", "synth64k": "synthetic 64k stereo",
                 "spmv-stream": "CG SpMV stand-alone on a 1.4 GB Schur-like matrix"}
 
@@ -84,15 +87,50 @@ def spmv_stream(args, ctx, rank, world, torch, dist, synth_mod):
 
 
 def cpu_baseline(dicts, mono):
-    """Oracle (plain-C port of the reference path, single thread like the reference) on the same workload.
+    """Oracle (plain-C port of the reference path, single thread like the reference) on the same workload, three ways.
     Checker/baseline only -- never part of the measured product path."""
     from oracle import pyoracle as po
     po.build()
     out, timing, rc = po.divide_conquer(dicts, mono, match_hash=True)
+    # as the reference matches common features: std::find of every End label in Cur's labels, O(n1 n2) (Imp.cpp:2581-2599)
+    _, timing_find, _ = po.divide_conquer(dicts, mono, match_hash=False)
     # the "fair multi-core" figure: the independent joins of every level on many host threads (same result)
     threads = max(1, min(64, (os.cpu_count() or 1)))
     _, timing_mt, _ = po.divide_conquer(dicts, mono, match_hash=True, threads=threads)
-    return out, timing, rc, (timing_mt[0], threads)
+    return out, timing, rc, timing_find, (timing_mt[0], threads)
+
+
+def e2e_cli(maps, mono):
+    """Files -> files through the reference's command line (linearsfm_amd/LinearSFM: the drop-in for the reference's console
+    program): the set is written in the reference's localmap_k.txt format (setup, not timed), then ONE process reads it, uploads,
+    joins, downloads and writes the pose / feature files.  Returns wall seconds of that process and its own phase times."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from linearsfm_amd import api
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="lsfm_e2e_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max(1, min(32, os.cpu_count() or 1))) as ex:  # the C writer releases the GIL
+            list(ex.map(lambda km: api.write_localmap(os.path.join(d, f"localmap_{km[0] + 1}.txt"), km[1].__dict__, mono), enumerate(maps)))
+        write_s = time.perf_counter() - t0
+        nbytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+        exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+        cmd = [exe, "-path", d, "-num", str(len(maps)), "-type", "Monocular" if mono else "Stereo", "-p", os.path.join(d, "Pose.txt"),
+               "-f", os.path.join(d, "Feature.txt"), "-stats", "1"]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        wall = time.perf_counter() - t0
+        ph = re.search(r"lsfm_e2e: read ([\d.]+) s, context ([\d.]+) s, upload ([\d.]+) s, join tree ([\d.]+) s, download ([\d.]+) s, write ([\d.]+) s", p.stderr)
+        ok = p.returncode == 0 and os.path.getsize(os.path.join(d, "Pose.txt")) > 0
+        return {"e2e_cli_s": wall, "rc": p.returncode, "ok": ok, "input_MB": nbytes / 1e6, "setup_write_inputs_s": write_s,
+                "phases_s": dict(zip(("read", "context", "upload", "join_tree", "download", "write"), map(float, ph.groups()))) if ph else None,
+                "command": "linearsfm_amd/LinearSFM -path <dir> -num %d -type %s -p Pose.txt -f Feature.txt" % (len(maps), "Monocular" if mono else "Stereo")}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -110,7 +148,11 @@ def main():
     ap.add_argument("--cpu-max-maps", type=int, default=4096, help="sets larger than this time the oracle on their first maps only")
     ap.add_argument("--tol", type=float, default=1e-12, help="relative residual at which the refinement of a system stops (library default)")
     ap.add_argument("--mixed", action="store_true", help="Cholesky preconditioner kept and applied in fp32, fp64 residual correction (BASELINE configs[4])")
-    ap.add_argument("--no-plans", action="store_true", help="every step analyses from scratch (what a first run costs)")
+    ap.add_argument("--plans", action="store_true", help="time the repeat runs of the resident tree (structure analysed once) instead of "
+                                                         "runs that analyse every join like the reference does; the default reports both")
+    ap.add_argument("--no-plans", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--extras", type=int, default=1, help="1: also the stand-alone SpMV streaming leg and the files-to-files CLI run "
+                                                          "(N=1, default configuration sizes only); 0: skip")
     args = ap.parse_args()
 
     import torch
@@ -148,54 +190,67 @@ def main():
     lo, hi = bounds[rank]
     _, block = synth.make_config(args.config, n_maps, seed=0, new_per_frame=npf, vis=vis, only=(lo, hi))
     ctx = api.Context(local_rank)
-    ctx.set_pcg(args.tol, 4)
+    ctx.set_pcg(args.tol, 0)
     ctx.set_precision(args.mixed)
+    t0 = time.perf_counter()
     tree = ShardedTree(ctx, block, lo, n_maps, mono)   # PCIe copy, outside the timed region: inputs are resident from here on
-    if args.no_plans:
-        if tree.block_tree is not None:
-            ctx.tree_set_plans(tree.block_tree, False)
+    upload_ms = 1e3 * (time.perf_counter() - t0)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the first run analyses the structure of every level (sizes, pattern of S, symbolic factorisation) and leaves it with the
-    # resident tree; reported separately, never part of `value`
-    barrier()
-    t0 = time.perf_counter()
-    first_stats, _ = tree.run()
-    barrier()
-    first_ms = 1e3 * (time.perf_counter() - t0)
-    if args.no_plans:
-        for t in tree.merge_trees.values():
-            ctx.tree_set_plans(t, False)
+    def timed(steps):
+        """`steps` whole trees between two barrier + synchronize points: (seconds, summed stats, last stats, worst rc)"""
+        barrier()
+        t0 = time.perf_counter()
+        acc, last, worst = {}, None, 0
+        for _ in range(steps):
+            last, rc = tree.run()
+            worst = max(worst, rc)
+            for k, v in (last or {}).items():
+                if isinstance(v, (int, float)):
+                    acc[k] = acc.get(k, 0) + v
+        barrier()
+        return time.perf_counter() - t0, acc, last, worst
+
+    # ---- the timed region.  A step = one whole join tree that, like the reference's timed region (Imp.cpp:1929 -> 2068), also
+    # does the symbolic work of every join (pattern of S, ordering, symbolic factorisation: the reference's mask -> CRS and
+    # cholmod_analyze_p): lsfm_tree_set_plans(tree, 0).  The repeat runs of the resident tree that reuse that analysis are
+    # timed separately below (`resolve_ms`). ----
+    analysing = not args.plans
+    tree.set_plans(not analysing)
+    first_s, _, _, _ = timed(1)     # the very first run (code objects, arenas, rocPRIM temporaries come up here)
     for _ in range(max(0, args.warmup - 1)):
         tree.run()
-    barrier()
-    t0 = time.perf_counter()
-    stats = None
-    acc = {}
-    worst = 0
-    for _ in range(args.steps):
-        stats, rc = tree.run()
-        worst = max(worst, rc)
-        for k, v in (stats or {}).items():
-            if isinstance(v, (int, float)):
-                acc[k] = acc.get(k, 0) + v
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tm = torch.tensor([elapsed, first_ms], dtype=torch.float64, device="cuda")
+    elapsed, acc, stats, worst = timed(args.steps)
+    tm = torch.tensor([elapsed, first_s], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    elapsed, first_ms = float(tm[0].item()), float(tm[1].item())
+    elapsed, first_ms = float(tm[0].item()), 1e3 * float(tm[1].item())
     ms_per_step = 1e3 * elapsed / args.steps
+    # ---- the other mode, same steps: plans on (one analysing run leaves them, then the repeats) / off ----
+    tree.set_plans(analysing)
+    tree.run()
+    tree.run()
+    other_s, acc2, _, _ = timed(args.steps)
+    tm = torch.tensor([other_s], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    other_ms = 1e3 * float(tm[0].item()) / args.steps
+    analyse_ms, resolve_ms = (ms_per_step, other_ms) if analysing else (other_ms, ms_per_step)
+    # per-rank busy time of the timed steps (where a multi-GPU run loses its efficiency): device time of the trees the rank ran
+    busy = torch.zeros(world, dtype=torch.float64, device="cuda")
+    busy[rank] = acc.get("t_total_ms", 0.0) / args.steps
+    if world > 1:
+        dist.all_reduce(busy, op=dist.ReduceOp.SUM)
 
     if rank == 0:
         out = tree.download()
         # Per-kernel live measurements (HIP events on the library's stream around the launches, accumulated over the timed
-        # steps; at N > 1: of the trees rank 0 ran last, i.e. the top merge).  The roofline object describes whichever of the
-        # two instrumented HBM-streaming kernels took the most device time.
+        # steps; at N > 1: of the trees rank 0 ran, i.e. its block and the merges it took part in).  The roofline object
+        # describes whichever of the two instrumented kernels took the most device time.
         kern = {}
         for key, name in (("schur", "k_schur_panel (K9: Schur assembly S -= W V^-1 W^T, E -= W V^-1 eb; fp64 MFMA panels)"),
                           ("trf", "k_tr_entries (K3/K4: information transform I' = J^T I J, one lane per W block)"),
@@ -231,11 +286,21 @@ def main():
             "config": {"workload": f"{args.config} stand-in ({typ}): {n_maps} local maps, {npf} new features/frame visible in {vis} "
                                    f"frames, camera path {cpath}, {out['m']} poses / {out['n']} features in the final map",
                        "maps": n_maps, "sharding": f"{world} block(s) of {bounds[0][1] - bounds[0][0]} local maps, {max(0, world.bit_length() - 1)} merge round(s)",
-                       "pcg_rel_tol": args.tol, "plans": not args.no_plans,
-                       "value_definition": "wall ms of ONE whole join tree over all GPUs (barrier + synchronize on both sides, max over ranks)"},
+                       "pcg_rel_tol": args.tol, "plans": not analysing,
+                       "value_definition": "wall ms of ONE whole join tree over all GPUs (barrier + synchronize on both sides, max over ranks), inputs "
+                                           "resident in HBM; " + ("every step analyses every join (pattern of S, ordering, symbolic factorisation) "
+                                                                  "like the reference's timed region does" if analysing else
+                                                                  "repeat runs of the resident tree: structure analysed once, before the timed steps")},
+            "analysing_run_ms": analyse_ms,
+            "resolve_ms": resolve_ms,
+            "resolve_note": "resolve_ms: the same tree joined again with NEW work only (lsfm_tree_set_plans(tree, 1): container sizes, pattern of S, "
+                            "ordering and symbolic factorisation of every level kept from an earlier run, a level enqueued without host round trips); "
+                            "analysing_run_ms: every run does that analysis itself, as every run of the reference does (cholmod_analyze_p in every "
+                            "join).  `value` is " + ("analysing_run_ms" if analysing else "resolve_ms") + ".",
             "first_run_ms": first_ms,
-            "first_run_note": "the first run of a resident tree also analyses its structure (container sizes, block pattern of every Schur "
-                              "system, ordering + symbolic factorisation), which later runs of the same tree reuse; never part of value",
+            "upload_ms": upload_ms,
+            "upload_note": "lsfm_tree_upload of this rank's block from pageable host memory through the pinned ring (PCIe), before the timed region",
+            "per_rank_device_ms": [float(v) for v in busy.tolist()],
             "device_breakdown_ms": {k: acc.get(k, 0.0) / args.steps for k in
                                     ("t_total_ms", "t_transform_ms", "t_join_ms", "t_schur_ms", "t_pcg_ms", "t_backsub_ms")},
             "pcg_iterations_per_step": acc.get("pcg_iterations", 0) / args.steps,
@@ -265,22 +330,46 @@ def main():
                         "avg_launch_ms": kern["spmv"]["avg_ms"], "matrix_MB_top_level": (stats or {}).get("spmv_nnzb_upper_last", 0) * 288 / 1e6,
                         "note": "cache-resident on this configuration: the Schur matrix of a level is <= ~20 MB (L2 / Infinity Cache), the "
                                 "launch is latency-bound and -- with the exact factor as preconditioner -- runs ~5 times per level; the "
-                                "kernel's HBM-streaming rate is measured by tools/spmv_bench.py on matrices of 1 GB+"},
+                                "kernel's HBM-streaming rate is the cg_spmv_stream object of this line"},
             "kernels": {k: {"avg_launch_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"], "frac_of_hbm_peak": v["gbs"] / HBM_PEAK_GBS,
                             "ms_per_step": v["total_ms"], "launches_per_step": v["launches_per_step"],
                             **({"algorithmic_TFLOPs": v["tflops"], "frac_of_f64_mfma_peak": v["tflops"] / F64_MFMA_PEAK_TFLOPS} if k == "schur" else {})}
                         for k, v in kern.items()},
         }
+        extras = args.extras and world == 1
+        if extras:
+            # the CG's SpMV kernel where it streams: a Schur-like matrix far beyond the caches (same kernel, same entry point as
+            # `--config spmv-stream`, shorter: 65 536 poses, 0.35 GB of upper blocks)
+            m_s, band, hubs = 65536, 12, 12
+            rp32, colidx, val = synth.schur_like_matrix(m_s, band, hubs, seed=0)
+            xs = np.random.default_rng(1).normal(size=6 * m_s)
+            ctx.spmv_bench(rp32, colidx, val, xs, reps=3)
+            _, sms, sby = ctx.spmv_bench(rp32, colidx, val, xs, reps=20)
+            line["cg_spmv_stream"] = {"GBps": sby / (sms * 1e-3) / 1e9, "frac_of_hbm_peak": sby / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "avg_launch_ms": sms, "algorithmic_bytes_per_launch": sby, "launches": 20,
+                                      "matrix": f"{m_s} poses, band {band} + {hubs} hub rows, {len(colidx)} upper 6x6 blocks ({len(colidx) * 288 / 1e6:.0f} MB)",
+                                      "note": "k_spmv (K10a) stand-alone through lsfm_spmv_bench, HIP events around the timed launches; "
+                                              "algorithmic bytes nnzb*(288+4) + 4(m+1) + 96 m (SURVEY 8d)"}
+            del rp32, colidx, val
         if args.cpu_baseline and world == 1:  # the CPU leg runs at N=1 only, on the same set
             from oracle import pyoracle as po
             S = min(n_maps, args.cpu_max_maps)
             dicts = [po.localmap_to_dict(m) for m in block[:S]]
-            o_out, timing, orc, (mt_s, mt_threads) = cpu_baseline(dicts, mono)
+            o_out, timing, orc, timing_find, (mt_s, mt_threads) = cpu_baseline(dicts, mono)
             if S == n_maps:
-                g_out, g_ms = out, ms_per_step
+                g_out, g_analyse, g_resolve = out, analyse_ms, resolve_ms
             else:  # same prefix on the device, for a like-for-like ratio and a parity check of this very run
-                g_out, st2, _ = ctx.divide_conquer(dicts, mono)
-                g_ms = st2["t_total_ms"]
+                tp = ctx.tree_upload(dicts, mono)
+                ctx.tree_set_plans(tp, False)
+                ctx.tree_run(tp)
+                st2, _ = ctx.tree_run(tp)
+                g_analyse = st2["t_total_ms"]
+                g_out = ctx.tree_download(tp)
+                ctx.tree_set_plans(tp, True)
+                ctx.tree_run(tp)
+                st3, _ = ctx.tree_run(tp)
+                g_resolve = st3["t_total_ms"]
+                ctx.tree_free(tp)
             mask = o_out["stno"] <= 0
             perr = float(np.max(np.abs(g_out["stVal"][mask] - o_out["stVal"][mask]) / np.maximum(1.0, np.abs(o_out["stVal"][mask]))))
             ferr = float(np.max(np.abs(g_out["stVal"][~mask] - o_out["stVal"][~mask]) / np.maximum(1.0, np.abs(o_out["stVal"][~mask]))))
@@ -290,17 +379,30 @@ def main():
                                                 f"feature matching; host has {os.cpu_count()} cores",
                                     "oracle_breakdown_ms": {"transform": 1e3 * timing[1], "join_assembly": 1e3 * timing[2],
                                                             "schur_cholesky_backsub": 1e3 * timing[3]},
+                                    "as_reference_match": {"value": 1e3 * timing_find[0], "unit": "ms", "cores": 1,
+                                                           "join_assembly_ms": 1e3 * timing_find[2],
+                                                           "note": "the same port matching common features the way the reference does: std::find of "
+                                                                   "every End label over Cur's labels, O(n1 n2) (Imp.cpp:2581-2599); `value` above "
+                                                                   "uses a sort instead, so that the device is not credited for an algorithmic fix"},
                                     "multicore": {"value": 1e3 * mt_s, "unit": "ms", "cores": mt_threads,
                                                   "note": "same port, the independent joins of a level on OpenMP threads; the top "
                                                           "levels hold one join each, so this saturates at a few x"},
-                                    "gpu_same_sample_ms": g_ms,
+                                    "gpu_same_sample_ms": g_analyse,
+                                    "gpu_same_sample_resolve_ms": g_resolve,
+                                    "gpu_same_sample_note": "gpu_same_sample_ms: device runs that analyse every join, like the CPU figure does -- the like-for-like "
+                                                            "pair; gpu_same_sample_resolve_ms: repeat runs of the resident tree",
                                     "pose_param_max_rel_err_vs_oracle": perr,
                                     "feature_param_max_rel_err_vs_oracle": ferr,
                                     "parity_tolerance": 1e-6,
                                     "parity_note": "fixed tolerance; how far two fp64 evaluations of the reference path differ on this set, and both "
                                                    "against the long-double evaluation of the solves: profiles/r02_full_parity_*.json (tools/full_parity.py)"}
+        if extras and not args.maps:
+            tree.close()
+            tree = None
+            line["e2e_cli"] = e2e_cli(block, mono)
         print(json.dumps(line))
-    tree.close()
+    if tree is not None:
+        tree.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -68,14 +68,17 @@ typedef struct lsfm_stats {
 	double max_rel_residual;/* max over systems of ||E - S x|| / ||E|| at exit */
 	int levels, joins, transforms;
 	int not_converged;      /* number of systems that hit the iteration cap */
-	/* the two HBM-streaming kernels, each bracketed by HIP events on the context's stream (one launch per tree level):
-	 * K9 k_schur_w (Schur assembly) and K3/K4 k_tr_features (information transform).  bytes = algorithmic bytes of
-	 * those launches */
+	/* the two instrumented kernels, each bracketed by HIP events on the context's stream (one bracket per tree level):
+	 * K9 k_schur_panel (Schur assembly, all panel variants of a level + k_schur_w for the tiles none of them takes) and
+	 * K3/K4 k_tr_entries (information transform, one lane per W block).  bytes = algorithmic bytes of those launches
+	 *  */
 	long schur_launches, trf_launches;
 	double schur_ms, schur_bytes, trf_ms, trf_bytes;
 	/* algorithmic flops of the K9 launches: per feature with k W blocks, k (108 + 36) for W V^-1 and the right-hand side and
 	 * k (k + 1) / 2 * 216 for the pose pairs (Imp.cpp:2260-2328) -- at the top levels K9 is bound by the fp64 matrix rate */
 	double schur_flops;
+	/* wall ms lsfm_tree_upload took to bring the tree's N local maps into HBM (PCIe; never part of t_total_ms) */
+	double upload_ms;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -85,8 +88,9 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out);
 void lsfm_context_destroy(lsfm_context* ctx);
 /* Solver controls.  rel_tol: the refinement of a system stops when ||E - S x|| <= rel_tol * ||E|| (default 1e-12: the
  * residual level of a direct fp64 solve, which is what the reference computes) or when the true residual stops
- * shrinking; at most 50 refinement steps.  max_it_factor: accepted and ignored (the iteration cap is fixed). */
-int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor);
+ * shrinking.  max_steps: most refinement steps a system may take, 1 .. 50 (<= 0: the default, 50); a system that is
+ * still above 1e-9 relative when the cap is reached counts as not converged. */
+int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_steps);
 /* Precision of the preconditioner.  mode 0 (default): fp64 throughout, the reference's arithmetic.  mode 1, "mixed": the
  * Cholesky factor of every camera system is kept and applied in fp32 (half the bytes of the triangular solves; the
  * factorisation itself runs in fp64 and is rounded once -- an fp32 elimination breaks down on these matrices), while S,
@@ -138,6 +142,15 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
                     const int* feature, int m, int n, int nU, int nW, int Ref, int ScaP, int Fix, int Sign,
                     int FixBlk, const double* x0);
 
+/* Test / debug entry: the BLOCK PATTERN of the camera system S = U - W V^-1 W^T as the device builds it for a joint map
+ * given by its index arrays alone (hash set of the pose pairs that share a feature, plus U's pattern; sorted into block
+ * CSR).  It stands where the reference marks a dense m x m byte mask and scans it (Imp.cpp:2131-2205, sba_crsm_* 30-76)
+ * and where pba_constructAuxCSS{LM,GN} (Imp.cpp:2529-2549 / 7248-7280) lists the same pattern for cholmod_amd.
+ * Upper triangle, row by row, columns ascending, the diagonal block first: rowptr[m + 1], colidx[cap]; *nnzb receives the
+ * number of blocks (LSFM_ERR_ARG when cap is too small). */
+int lsfm_schur_pattern(lsfm_context* ctx, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
+                       int* rowptr, int* colidx, int cap, int* nnzb);
+
 /* ---- the scheduler itself ------------------------------------------------------------------------ */
 /* replaces lmj_PF3D_Divide_Conquer{Stereo,Mono} (Imp.h:205/220, Imp.cpp:1926-2063 / 6511-6630): hierarchical
  * join of maps[0..N) with the reference's binary-tree order; all joins of one tree level run as ONE batch on
@@ -167,21 +180,25 @@ int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* tree);
 /* ---- device-resident hand-off of a tree node (multi-GPU sub-tree sharding; no counterpart in the reference, whose
  * scheduler keeps every node in one process: m_LMsetS[i] = m_GMapS, Imp.cpp:2032) ---------------------------------
- * A finished tree's final map is PACKED into one contiguous device buffer (a 128-byte header of ints, then the arrays
+ * A finished tree's final map is PACKED into one contiguous device buffer (a 256-byte header, then the arrays
  * with map-local indices, each 256-byte aligned) that the caller owns and may move to another GPU by any means that
  * moves device bytes (RCCL send/recv, hipMemcpyPeer).  lsfm_tree_upload_dev builds the resident inputs of a new tree
  * from N such buffers on this context's device -- no host copy of the arrays, only the N headers are read back.
  *   lsfm_tree_export_size  bytes lsfm_tree_export_dev will write (0: tree not run / overwritten)
  *   lsfm_tree_export_dev   dst: device memory of >= cap bytes, accessible from the context's device
- *   lsfm_packed_size       total bytes of a packed map, from the first 128 bytes of it copied to the host (0: not a pack)
+ *   lsfm_packed_size       total bytes of a packed map, from its first LSFM_PACK_HEADER_BYTES (256) bytes copied to the
+ *                          host (0: not a pack -- magic, version, sizes or the array offsets stored in it do not fit)
  *   lsfm_tree_upload_dev   packed[k]: device pointer of packed map k (pose origins travel inside the pack) */
 size_t lsfm_tree_export_size(lsfm_context* ctx, lsfm_tree* tree);
 int lsfm_tree_export_dev(lsfm_context* ctx, lsfm_tree* tree, void* dst, size_t cap);
-size_t lsfm_packed_size(const void* host_header128);
+#define LSFM_PACK_HEADER_BYTES 256
+size_t lsfm_packed_size(const void* host_header256);
 int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, int mono, lsfm_tree** out);
-/* new VALUES for the resident inputs of a tree made by lsfm_tree_upload_dev: N packed maps with the same sizes (and, by
- * contract, the same labels and index arrays) as the ones it was built from -- the next step of a scheduler that joins
- * the same sub-tree roots again.  Keeps the tree's allocations and its plans (lsfm_tree_set_plans). */
+/* new VALUES for the resident inputs of a tree made by lsfm_tree_upload_dev: N packed maps with the same sizes as the ones
+ * it was built from -- the next step of a scheduler that joins the same sub-tree roots again.  Keeps the tree's
+ * allocations; its plans (lsfm_tree_set_plans) are kept when the labels and index arrays are the same too (a digest of
+ * them is taken on the device at upload and at reload) and dropped otherwise, so that a reload with another structure
+ * costs an analysing run instead of a wrong result. */
 int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* tree, const void* const* packed, int N);
 
 /* convenience: upload + run + download */

@@ -36,7 +36,7 @@ class LsfmStats(C.Structure):
                 ("max_rel_residual", C.c_double), ("levels", C.c_int), ("joins", C.c_int), ("transforms", C.c_int),
                 ("not_converged", C.c_int), ("schur_launches", C.c_long), ("trf_launches", C.c_long),
                 ("schur_ms", C.c_double), ("schur_bytes", C.c_double), ("trf_ms", C.c_double), ("trf_bytes", C.c_double),
-                ("schur_flops", C.c_double)]
+                ("schur_flops", C.c_double), ("upload_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -94,6 +94,7 @@ def lib():
         L.lsfm_read_localmaps.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P(LsfmMap), P(C.c_int)]
         L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
+        L.lsfm_schur_pattern.argtypes = [vp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, C.c_int, ip]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
         L.lsfm_wstream_bench.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, dp]
         _LIB = L
@@ -106,7 +107,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
-           "lsfm_spmv_bench", "lsfm_wstream_bench"]
+           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern"]
 
 
 def _c(a, dtype):
@@ -189,8 +190,9 @@ class Context:
             raise LsfmError(f"{what} failed (rc={rc}): {lib().lsfm_last_error(self._h).decode()}")
         return rc
 
-    def set_pcg(self, rel_tol=1e-10, max_it_factor=4):
-        self._check(lib().lsfm_set_pcg(self._h, float(rel_tol), int(max_it_factor)), "lsfm_set_pcg")
+    def set_pcg(self, rel_tol=1e-12, max_steps=0):
+        """Stopping rule of the refinement (relative residual) and the most steps a system may take (0: the default, 50)."""
+        self._check(lib().lsfm_set_pcg(self._h, float(rel_tol), int(max_steps)), "lsfm_set_pcg")
 
     def set_precision(self, mixed):
         """False: fp64 throughout.  True: the Cholesky preconditioner kept and applied in fp32, residual correction in fp64."""
@@ -302,6 +304,19 @@ class Context:
         finally:
             self.tree_free(t)
         return out, stats, rc
+
+    def schur_pattern(self, j):
+        """Upper block pattern (rowptr, colidx) of the camera system of a joint map dict, as the device builds it."""
+        m, n = int(j["m"]), int(j["n"])
+        Ui = _c(j["Ui"], np.int32); Uj = _c(j["Uj"], np.int32); ph = _c(j["photo"], np.int32); fe = _c(j["feature"], np.int32)
+        cap = m * (m + 1) // 2
+        rowptr = np.zeros(m + 1, np.int32)
+        colidx = np.zeros(max(cap, 1), np.int32)
+        nnzb = C.c_int(0)
+        self._check(lib().lsfm_schur_pattern(self._h, _ptr(Ui, C.c_int), _ptr(Uj, C.c_int), _ptr(ph, C.c_int), _ptr(fe, C.c_int), m, n,
+                                             len(Ui), len(ph), _ptr(rowptr, C.c_int), _ptr(colidx, C.c_int), cap, C.byref(nnzb)),
+                    "lsfm_schur_pattern")
+        return rowptr, colidx[:nnzb.value].copy()
 
     def spmv_bench(self, rowptr, colidx, val, x, reps=20):
         rowptr = _c(rowptr, np.int32); colidx = _c(colidx, np.int32); val = _c(val, np.float64); x = _c(x, np.float64)

@@ -96,15 +96,20 @@ void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, boo
 	h2d(ctx, o.Ui, Ui.data(), Ui.size() * sizeof(int)); h2d(ctx, o.Uj, Uj.data(), Uj.size() * sizeof(int));
 	h2d(ctx, o.photo, photo.data(), photo.size() * sizeof(int)); h2d(ctx, o.feature, feature.data(), feature.size() * sizeof(int));
 	h2d(ctx, o.fptr, fptr.data(), fptr.size() * sizeof(int));
-	// the big value arrays go map by map straight from the caller's buffers
-	for (int k = 0; k < N; k++)
+	// the big value arrays: every map's piece of an array, back to back, through the pinned ring -- one stream of large
+	// copies per array kind (N pageable copies per kind cost ~0.9 s for 3499 maps: 42 000 small transfers in all)
 	{
-		const lsfm_map& g = maps[k];
-		if (g.nU) LSFM_CHECK_HIP(hipMemcpyAsync(o.U + (size_t)o.u_off[k] * 36, g.U, (size_t)g.nU * 36 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-		if (g.nW) LSFM_CHECK_HIP(hipMemcpyAsync(o.W + (size_t)o.w_off[k] * 18, g.W, (size_t)g.nW * 18 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-		if (g.n) LSFM_CHECK_HIP(hipMemcpyAsync(o.V + (size_t)o.feat_off[k] * 9, g.V, (size_t)g.n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		std::vector<HostPiece> pu, pw, pv;
+		pu.reserve(N); pw.reserve(N); pv.reserve(N);
+		for (int k = 0; k < N; k++)
+		{
+			const lsfm_map& g = maps[k];
+			pu.push_back(HostPiece{ g.U, (size_t)g.nU * 36 * sizeof(double) });
+			pw.push_back(HostPiece{ g.W, (size_t)g.nW * 18 * sizeof(double) });
+			pv.push_back(HostPiece{ g.V, (size_t)g.n * 9 * sizeof(double) });
+		}
+		h2d_gather(ctx, o.U, pu); h2d_gather(ctx, o.W, pw); h2d_gather(ctx, o.V, pv);
 	}
-	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 	batch_set_offsets(ctx, ar, o);
 }
 
@@ -197,6 +202,41 @@ void batch_unpack_maps(lsfm_context* ctx, Arena& ar, const void* const* packed, 
 	if (o.NW) hipLaunchKernelGGL(k_fill_segment_ids, dim3((o.NW + 255) / 256), dim3(256), 0, s, o.fptr, o.NF, o.feature, o.NW);
 	LSFM_CHECK_HIP(hipGetLastError());
 	batch_set_offsets(ctx, ar, o);
+}
+
+// order-independent sum of position-dependent 64-bit hashes of an int array
+__global__ void k_digest_ints(const int* __restrict__ a, size_t n, unsigned long long salt, unsigned long long* __restrict__ out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long h = 0;
+	if (i < n)
+	{
+		unsigned long long x = (salt + i) * 0x9e3779b97f4a7c15ull ^ (unsigned long long)(unsigned)a[i];
+		x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+		h = x;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off, LSFM_WAVE);
+	if ((threadIdx.x & (LSFM_WAVE - 1)) == 0 && h) atomicAdd(out, h);
+}
+unsigned long long batch_structure_digest(lsfm_context* ctx, const DevBatch& b)
+{
+	unsigned long long* d = ctx->scratch.alloc<unsigned long long>(1);
+	dev_zero(ctx, d, sizeof *d);
+	const struct { const int* p; size_t n; } arr[] = { { b.pose_id, (size_t)b.M }, { b.pose_origin, (size_t)b.M }, { b.feat_id, (size_t)b.NF },
+		{ b.Ui, (size_t)b.NU }, { b.Uj, (size_t)b.NU }, { b.photo, (size_t)b.NW }, { b.fptr, (size_t)b.NF + 1 } };
+	unsigned long long salt = 1;
+	for (const auto& a : arr)
+	{
+		if (a.n) hipLaunchKernelGGL(k_digest_ints, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a.p, a.n, salt << 40, d);
+		salt++;
+	}
+	unsigned long long h = 0;
+	d2h(ctx, &h, d, sizeof h);
+	for (int k = 0; k < b.B; k++) // the host mirrors of the map records belong to the structure too
+		for (int v : { b.Ref[k], b.FRef[k], b.ScaP[k], b.Fix[k], b.FScaP[k], b.FFix[k], b.pose_off[k + 1], b.feat_off[k + 1], b.u_off[k + 1], b.w_off[k + 1] })
+			h = (h ^ (unsigned long long)(unsigned)v) * 0x100000001b3ull;
+	return h;
 }
 
 template <class T> static T* host_alloc(size_t n) { return static_cast<T*>(malloc((n ? n : 1) * sizeof(T))); }

@@ -22,6 +22,8 @@ struct lsfm_tree {
 	// level + one for the final re-anchoring transform
 	std::vector<LevelPlan> plans;
 	bool use_plans = true;
+	double upload_ms = 0; // wall time of lsfm_tree_upload (reported in lsfm_stats)
+	unsigned long long digest = 0; // of the resident inputs' labels and index arrays (trees built from packed maps: reload compares)
 };
 
 namespace {
@@ -161,8 +163,10 @@ int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, l
 		try
 		{
 			t->input_arena.init(input_bytes(maps, N));
+			const double t0 = now_ms();
 			batch_upload(ctx, t->input_arena, maps, N, t->mono, t->input);
 			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+			t->upload_ms = now_ms() - t0;
 		}
 		catch (...) { t->input_arena.destroy(); delete t; throw; }
 		*out = t;
@@ -233,7 +237,14 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
 				if (rs.chol_err)
 					LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
-				if (rs.not_converged && attempt == 0)
+				if (rs.plan_stale && attempt == 0)
+				{
+					// a plan met values it does not fit (LevelPlan::tr_sign): this run's result is void, repeat it analysing
+					t->plans.clear();
+					continue;
+				}
+				if (rs.plan_stale) LSFM_FAIL(LSFM_ERR_INTERNAL, "a level plan was reported stale in a run without plans");
+				if (rs.not_converged && attempt == 0 && t->use_plans)
 				{
 					// a planned run enqueues the refinement steps the first run needed; if a system asks for more this time,
 					// drop the plans and run the levels the slow way again (reads the state of every step back)
@@ -242,6 +253,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				}
 				st->not_converged += rs.not_converged;
 				st->max_rel_residual = std::max(st->max_rel_residual, rs.max_rel_residual);
+				st->upload_ms = t->upload_ms;
 				break;
 			}
 			ctx->flush_times();
@@ -297,14 +309,18 @@ int lsfm_tree_export_dev(lsfm_context* ctx, lsfm_tree* t, void* dst, size_t cap)
 	});
 }
 
+static_assert(sizeof(PackHeader) == LSFM_PACK_HEADER_BYTES, "include/lsfm.h documents the header size");
 size_t lsfm_packed_size(const void* host_header)
 {
 	if (!host_header) return 0;
 	PackHeader h;
 	memcpy(&h, host_header, sizeof h);
 	if (h.magic != LSFM_PACK_MAGIC || h.version != 1 || h.m < 0 || h.n < 0 || h.nU < 0 || h.nW < 0) return 0;
+	// the offsets an unpack follows are the ones the sizes imply, never just what the buffer says
 	PackHeader c = h;
-	return pack_layout(c) == h.total ? (size_t)h.total : 0;
+	if (pack_layout(c) != h.total) return 0;
+	for (int i = 0; i < 12; i++) if (c.off[i] != h.off[i]) return 0;
+	return (size_t)h.total;
 }
 
 int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, int mono, lsfm_tree** out)
@@ -335,6 +351,7 @@ int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, in
 		{
 			t->input_arena.init(bytes + (m + nf + nw) * 8 + (size_t)N * 4096 + ((size_t)1 << 20));
 			batch_unpack_maps(ctx, t->input_arena, packed, hdr.data(), N, t->mono, t->input);
+			t->digest = batch_structure_digest(ctx, t->input);
 			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 		}
 		catch (...) { t->input_arena.destroy(); delete t; throw; }
@@ -366,6 +383,14 @@ int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* t, const void* const* pac
 		t->done = false;
 		t->input_arena.reset(); // same sizes, same order: every array lands where it was
 		batch_unpack_maps(ctx, t->input_arena, packed, hdr.data(), N, t->mono, t->input);
+		ctx->scratch.reset();
+		const unsigned long long dg = batch_structure_digest(ctx, t->input);
+		if (dg != t->digest)
+		{
+			// same sizes, other labels / index arrays: everything the plans hold (S pattern, K9 slots, join offsets) is void
+			t->plans.clear();
+			t->digest = dg;
+		}
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 		return LSFM_OK;
 	});
@@ -391,6 +416,7 @@ int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono
 	lsfm_tree* t = nullptr;
 	int rc = lsfm_tree_upload(ctx, maps, N, mono, &t);
 	if (rc) return rc;
+	t->use_plans = false; // one run, then the tree is gone: nothing to record for a next one
 	int rrc = lsfm_tree_run(ctx, t, stats);
 	if (rrc < 0) { lsfm_tree_free(ctx, t); return rrc; }
 	rc = lsfm_tree_download(ctx, t, out);
@@ -533,6 +559,45 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
 	int rc = solve_raw(ctx, stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, x0, Ref, Fix);
 	if (rc >= 0) stVal[Fix] = Sign;
 	return rc;
+}
+
+int lsfm_schur_pattern(lsfm_context* ctx, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW, int* rowptr,
+                       int* colidx, int cap, int* nnzb)
+{
+	if (m <= 0 || n < 0 || nU < 0 || nW < 0 || !rowptr || !colidx || !nnzb || (nU && (!Ui || !Uj)) || (nW && (!photo || !feature))) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas(((size_t)nW * 64 + (size_t)nU * 64 + (size_t)m * 4096) * 2 + ((size_t)64 << 20));
+		ctx->arena[0].reset(); ctx->scratch.reset();
+		Arena& ar = ctx->arena[0];
+		std::vector<int> fptr(n + 1);
+		{
+			int j = 0;
+			for (int f = 0; f < n; f++)
+			{
+				fptr[f] = j;
+				while (j < nW && feature[j] == f) j++;
+			}
+			if (j != nW) LSFM_FAIL(LSFM_ERR_ARG, "W is not sorted by feature");
+			fptr[n] = nW;
+		}
+		for (int i = 0; i < nU; i++) if (Ui[i] < 0 || Uj[i] >= m || Ui[i] > Uj[i]) LSFM_FAIL(LSFM_ERR_ARG, "U block coordinates must satisfy 0 <= Ui <= Uj < m");
+		for (int j = 0; j < nW; j++) if (photo[j] < 0 || photo[j] >= m) LSFM_FAIL(LSFM_ERR_ARG, "photo index out of range");
+		int* dUi = ar.alloc<int>(nU); int* dUj = ar.alloc<int>(nU); int* dph = ar.alloc<int>(nW); int* dfp = ar.alloc<int>(n + 1);
+		h2d(ctx, dUi, Ui, nU * sizeof(int)); h2d(ctx, dUj, Uj, nU * sizeof(int)); h2d(ctx, dph, photo, nW * sizeof(int));
+		h2d(ctx, dfp, fptr.data(), (n + 1) * sizeof(int));
+		SolveIO io;
+		io.M = m; io.NF = n; io.NU = nU; io.NW = nW; io.nseg = 1;
+		io.Ui = dUi; io.Uj = dUj; io.photo = dph; io.fptr = dfp;
+		int cnt = 0;
+		const int* d_rowptr = nullptr;
+		const int* d_colidx = nullptr;
+		schur_pattern_only(ctx, io, &cnt, &d_rowptr, &d_colidx);
+		*nnzb = cnt;
+		if (cnt > cap) LSFM_FAIL(LSFM_ERR_ARG, "colidx too small for the pattern (" + std::to_string(cnt) + " blocks)");
+		d2h(ctx, rowptr, d_rowptr, (size_t)(m + 1) * sizeof(int));
+		d2h(ctx, colidx, d_colidx, (size_t)cnt * sizeof(int));
+		return LSFM_OK;
+	});
 }
 
 int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y,

@@ -3,7 +3,8 @@
 //   LinearSFM -path <dir> -num <N> -type Monocular|Stereo [-p <poses>] [-f <features>] [-st <state>] [-help]
 // Extra flags that do not collide with the reference's: -gpu <ordinal>, -tol <pcg rel tol>, -full <file> (final state
 // at %.17g), -info <file> (final map WITH its information matrix in the local-map format), -stats 1 (timing breakdown
-// on stderr).
+// on stderr: device stages of the join tree, then the wall seconds of every phase from files to files).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,8 @@ int main(int argc, char** argv)
 	if (type < 0) { printf("LinerSFM Error: Please Set Data Type:\n"); return 0; }
 	if (num <= 0) { fprintf(stderr, "LinearSFM: -num must be positive (got %d)\n", num); return 1; }
 
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double w0 = now();
 	std::vector<lsfm_map> maps(num);
 	{
 		// localmap_1.txt ... localmap_<num>.txt (Imp.cpp:125), parsed on all host cores
@@ -74,10 +77,11 @@ int main(int argc, char** argv)
 			return 1;
 		}
 	}
+	const double w1 = now();
 	lsfm_context* ctx = nullptr;
 	int rc = lsfm_context_create(gpu, 0, &ctx);
 	if (rc) { fprintf(stderr, "LinearSFM: no HIP device (rc=%d); this build has no CPU path\n", rc); return 2; }
-	if (tol > 0) lsfm_set_pcg(ctx, tol, 4);
+	if (tol > 0) lsfm_set_pcg(ctx, tol, 0);
 	// progress lines of the reference (Imp.cpp:1952, 1995)
 	{
 		int cnt = num, L = 0;
@@ -94,10 +98,25 @@ int main(int argc, char** argv)
 			L++;
 		}
 	}
+	// what lsfm_divide_conquer does, in its three steps so that each can be timed: maps to the device, the join tree (the
+	// region the reference times), the final map back
 	lsfm_map out;
 	lsfm_stats stats;
-	rc = lsfm_divide_conquer(ctx, maps.data(), num, type, &out, &stats);
+	lsfm_tree* tree = nullptr;
+	const double w2 = now();
+	rc = lsfm_tree_upload(ctx, maps.data(), num, type, &tree);
 	if (rc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
+	lsfm_tree_set_plans(tree, 0); // one run: nothing to keep for a next one
+	const double w3 = now();
+	rc = lsfm_tree_run(ctx, tree, &stats);
+	if (rc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
+	const double w4 = now();
+	{
+		const int drc = lsfm_tree_download(ctx, tree, &out);
+		if (drc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
+	}
+	lsfm_tree_free(ctx, tree);
+	const double w5 = now();
 	// the reference solves directly and cannot end half-way; a system the refinement left above its residual bound is
 	// reported and reflected in the exit code (the files are still written)
 	const bool partial = rc == LSFM_NOT_CONVERGED;
@@ -118,6 +137,9 @@ int main(int argc, char** argv)
 		if (f) { for (int i = 0; i < r; i++) fprintf(f, "%d %.17g\n", out.stno[i], out.stVal[i]); fclose(f); }
 	}
 	if (!info.empty() && lsfm_write_localmap(info.c_str(), type, &out)) fprintf(stderr, "LinearSFM: cannot write %s\n", info.c_str());
+	if (want_stats)
+		fprintf(stderr, "lsfm_e2e: read %.3f s, context %.3f s, upload %.3f s, join tree %.3f s, download %.3f s, write %.3f s\n", w1 - w0, w2 - w1, w3 - w2,
+		        w4 - w3, w5 - w4, now() - w5);
 	lsfm_map_release(&out);
 	for (auto& g : maps) lsfm_map_release(&g);
 	lsfm_context_destroy(ctx);

@@ -79,7 +79,7 @@ struct DevBatch {
 	const int* d_alias = nullptr;
 };
 
-struct PcgOptions { double rel_tol = 1e-12; int max_it_factor = 4; bool mixed = false; int spmv_variant = 0; };
+struct PcgOptions { double rel_tol = 1e-12; int max_steps = 50; bool mixed = false; int spmv_variant = 0; };
 
 // What the first run of a tree level leaves behind for the next runs of the SAME resident tree.  Everything here is
 // structure: it depends on the labels, the index arrays and the join tree of the uploaded local maps, which no run
@@ -91,7 +91,9 @@ struct PcgOptions { double rel_tol = 1e-12; int max_it_factor = 4; bool mixed = 
 struct LevelPlan {
 	bool valid = false;
 	std::vector<int> tr_cnt;     // transform: kept-block prefix values at the map boundaries (U then W)
-	std::vector<int> tr_sign;    // Mono: sign of the new scale of every transformed map
+	// Mono: sign of the new scale of every transformed map.  This one depends on VALUES (sign of a pose component): a
+	// planned level compares it with what the device computes from the current values and flags the run when they differ
+	std::vector<int> tr_sign;
 	std::vector<int> join_rb;    // join: ranks of the unmatched features at the map boundaries
 	std::vector<int> join_uo, join_wo; // Mono join: kept-U prefix at the map boundaries, W offsets of the joint maps
 	std::shared_ptr<void> solve; // pattern of S + symbolic factorisation + iteration count (lsfm_pcg.hip)
@@ -102,7 +104,7 @@ struct RunStatsDev {
 	int chol_err;          // 1 + block column of a non-positive pivot (first one wins)
 	int not_converged;     // systems left above the residual bound
 	int tr_err;            // 1 + map whose transform target was not found
-	int pad;
+	int plan_stale;        // a planned level met VALUES the plan does not fit (Mono: the sign of a new scale): the run is repeated without plans
 	double max_rel_residual;
 };
 
@@ -120,6 +122,7 @@ struct lsfm_context {
 	int* h_pinned = nullptr; // small pinned staging buffer for counters
 	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
 	size_t stage_size = 0, stage_off = 0;
+	hipEvent_t ev_half[2] = { nullptr, nullptr }; // h2d_gather: a half of the ring may be refilled once its copy has left
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	hipEvent_t evs[4] = { nullptr, nullptr, nullptr, nullptr }; // stage brackets of a solve (owned here: nothing to leak on an error path)
 	// Every entry point that resets or reallocates the arenas bumps this; a finished tree remembers the value it ended with,
@@ -154,6 +157,11 @@ void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, 
 int d2h_int(lsfm_context* ctx, const int* dptr);
 void d2h_ints(lsfm_context* ctx, const int* dptr, int* h, size_t n);
 void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes);
+// many host pieces -> ONE contiguous device range, in order, streamed through the two halves of the pinned ring (the host
+// fills one half while the other one is on the wire): a set of N local maps arrives as a dozen large copies instead of
+// ~3 N pageable ones.  Synchronises before and after.
+struct HostPiece { const void* p; size_t bytes; };
+void h2d_gather(lsfm_context* ctx, void* d, const std::vector<HostPiece>& pieces);
 void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes);
 void dev_zero(lsfm_context* ctx, void* d, size_t bytes);
 
@@ -174,6 +182,8 @@ static_assert(sizeof(PackHeader) == 256, "the header is the first 256 bytes of a
 size_t pack_layout(PackHeader& h); // fills off[] and total from the counts
 void batch_pack_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, void* dst, size_t cap);
 void batch_unpack_maps(lsfm_context* ctx, Arena& ar, const void* const* packed, const PackHeader* hdr, int N, bool mono, DevBatch& out);
+// digest of everything a tree's plans are derived from: labels, index arrays, pose origins (synchronises)
+unsigned long long batch_structure_digest(lsfm_context* ctx, const DevBatch& b);
 
 // ---- transform (lsfm_transform.hip): K1-K4 ------------------------------------------------------------------
 // target_ref[b] < 0 ... map b is passed through unchanged; otherwise the pose id the map is re-expressed in
@@ -220,6 +230,8 @@ struct SolveIO {
 	std::vector<int> seg_rows;         // host: block rows per segment
 };
 int solve_batch(lsfm_context* ctx, const SolveIO& io);
+// the block pattern of S alone (K8), from the index members of io: upper block CSR left in the scratch arena
+void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx);
 int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,
                   double* avg_ms, double* bytes);
 

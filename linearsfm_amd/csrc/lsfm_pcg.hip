@@ -1168,6 +1168,7 @@ struct SolvePlan {
 	CholDev ch;     // index members + host vectors (L, Dinv, Gd, d_err are per run)
 	int its = 1;    // refinement steps the first run needed ...
 	bool mixed = false; // ... with the preconditioner in this precision
+	double rel_tol = 0; // ... to this relative residual
 	char* mem = nullptr;
 	~SolvePlan() { if (mem) (void)hipFree(mem); }
 };
@@ -1186,7 +1187,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	}
 	struct Item { const void* src; size_t bytes; void** dst; };
 	SolvePlan& P = *sp;
-	P.sy = sy; P.ch = ch; P.its = its; P.mixed = ch.Lf != nullptr;
+	P.sy = sy; P.ch = ch; P.its = its; P.mixed = ch.Lf != nullptr; P.rel_tol = ctx->pcg.rel_tol;
 	P.sy.S = nullptr; P.sy.E = nullptr; P.sy.IV = nullptr;
 	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr; P.ch.Lf = nullptr; P.ch.Dinvf = nullptr;
 	std::vector<Item> items = {
@@ -1877,8 +1878,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	// preconditioner for the next step.  A first run reads the number of finished systems back after every step; a warm
 	// run enqueues the steps the first run needed -- the device-side tests still freeze what is done, and whether every
 	// system ended below its bound is read once at the end of the whole run.
-	const int maxit = 50;
-	const bool planned_run = warm && sp->mixed == mixed; // the step count was recorded with the preconditioner in this precision
+	const int maxit = std::max(1, std::min(50, ctx->pcg.max_steps));
+	// the step count was recorded with the preconditioner in this precision, for this tolerance, under this cap
+	const bool planned_run = warm && sp->mixed == mixed && sp->rel_tol == ctx->pcg.rel_tol && sp->its <= maxit;
 	int its = 0, ndone = planned_run ? 0 : d2h_int(ctx, d_misc + 1);
 	const int planned = planned_run ? sp->its : maxit;
 	while ((planned_run ? its < planned : (ndone < nseg && its < maxit)))
@@ -1935,7 +1937,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	}
 	if (warm)
 	{
-		if (!planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; } // the precision changed: the count was re-learnt
+		if (!planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt
 		hipLaunchKernelGGL(k_pcg_run_stats, dim3(nbs), dim3(128), 0, s, nseg, seg, ctx->d_run);
 		return 0; // the outcome is read at the end of the run (lsfm_tree_run)
 	}

@@ -97,6 +97,38 @@ void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes)
 	LSFM_CHECK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
 	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 }
+void h2d_gather(lsfm_context* ctx, void* d, const std::vector<HostPiece>& pieces)
+{
+	size_t total = 0;
+	for (const HostPiece& pc : pieces) total += pc.bytes;
+	if (!total) return;
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream)); // the ring is also the staging area of the small enqueued copies
+	ctx->stage_off = 0;
+	const size_t half = ctx->stage_size / 2;
+	for (auto& e : ctx->ev_half) if (!e) LSFM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	bool used[2] = { false, false };
+	size_t done = 0, ip = 0, ioff = 0;
+	int h = 0;
+	while (done < total)
+	{
+		if (used[h]) LSFM_CHECK_HIP(hipEventSynchronize(ctx->ev_half[h]));
+		char* buf = ctx->h_stage + (size_t)h * half;
+		size_t fill = 0;
+		while (fill < half && ip < pieces.size())
+		{
+			const size_t n = std::min(half - fill, pieces[ip].bytes - ioff);
+			if (n) memcpy(buf + fill, static_cast<const char*>(pieces[ip].p) + ioff, n);
+			fill += n; ioff += n;
+			if (ioff == pieces[ip].bytes) { ip++; ioff = 0; }
+		}
+		LSFM_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(d) + done, buf, fill, hipMemcpyHostToDevice, ctx->stream));
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_half[h], ctx->stream));
+		used[h] = true;
+		done += fill;
+		h ^= 1;
+	}
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+}
 void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes)
 {
 	if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -204,6 +236,7 @@ void lsfm_context_destroy(lsfm_context* c)
 	c->arena[0].destroy(); c->arena[1].destroy(); c->arena[2].destroy(); c->scratch.destroy();
 	if (c->h_pinned) (void)hipHostFree(c->h_pinned);
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
+	for (auto& e : c->ev_half) if (e) (void)hipEventDestroy(e);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -218,11 +251,11 @@ void lsfm_context_destroy(lsfm_context* c)
 	delete c;
 }
 
-int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_it_factor)
+int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_steps)
 {
-	if (!ctx || !(rel_tol > 0) || max_it_factor <= 0) return LSFM_ERR_ARG;
+	if (!ctx || !(rel_tol > 0) || max_steps > 50) return LSFM_ERR_ARG;
 	ctx->pcg.rel_tol = rel_tol;
-	ctx->pcg.max_it_factor = max_it_factor;
+	ctx->pcg.max_steps = max_steps <= 0 ? 50 : max_steps;
 	return LSFM_OK;
 }
 

@@ -695,6 +695,13 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 
+void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx)
+{
+	SchurSystem sy;
+	build_schur_pattern(ctx, io, sy);
+	*nnzb = sy.nnzb; *rowptr = sy.rowptr; *colidx = sy.colidx;
+}
+
 // Values of S and E: enqueued without a host synchronisation (the caller overlaps host work with K9); the K9 launch is
 // bracketed by the events ev2/ev3 of the context, read back by schur_values_stats() after the caller's next sync
 void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)

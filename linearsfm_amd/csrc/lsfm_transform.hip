@@ -228,30 +228,33 @@ k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map
 		{
 			double a22[9], adt[9], atmp[9], adtt[9];
 			mono_trans_jac(t, p, a22, adt, atmp, adtt);
-			double* q1 = (k == t.hub[0]) ? D : C1; // Imp.cpp:3495-3556
-			double* q2 = (k == t.hub[1]) ? D : C2; // Imp.cpp:3558-3581
+			// the old reference / scale pose collects its C term in D (Imp.cpp:3495-3556 / 3558-3581).  Written with selects on
+			// the values, not on the destination: a pointer chosen at run time puts all three blocks into scratch memory
+			const bool h0 = k == t.hub[0], h1 = k == t.hub[1];
+			double X1[36], X2[9];
+			zero<36>(X1);
 #pragma unroll
 			for (int r = 0; r < 3; r++)
 			{
 #pragma unroll
-				for (int c = 0; c < 3; c++) D[6 * r + c] += a22[3 * r + c];
+				for (int c = 0; c < 3; c++) { D[6 * r + c] += a22[3 * r + c]; X1[6 * r + c] = adt[3 * r + c]; X2[3 * r + c] = adtt[3 * r + c]; }
 				D[6 * (3 + r) + 3] += ddA2[r]; D[6 * (3 + r) + 4] += ddB2[r]; D[6 * (3 + r) + 5] += ddG2[r];
+				X1[6 * (3 + r) + 3] = ddA[r]; X1[6 * (3 + r) + 4] = ddB[r]; X1[6 * (3 + r) + 5] = ddG[r];
+				X1[6 * r + 3] = atmp[3 * r + 0]; X1[6 * r + 4] = atmp[3 * r + 1]; X1[6 * r + 5] = atmp[3 * r + 2];
 			}
 #pragma unroll
-			for (int r = 0; r < 3; r++)
-			{
-#pragma unroll
-				for (int c = 0; c < 3; c++) q1[6 * r + c] += adt[3 * r + c];
-				q1[6 * (3 + r) + 3] += ddA[r]; q1[6 * (3 + r) + 4] += ddB[r]; q1[6 * (3 + r) + 5] += ddG[r];
-				q1[6 * r + 3] += atmp[3 * r + 0]; q1[6 * r + 4] += atmp[3 * r + 1]; q1[6 * r + 5] += atmp[3 * r + 2];
-			}
+			for (int q = 0; q < 36; q++) { D[q] += h0 ? X1[q] : 0.0; C1[q] += h0 ? 0.0 : X1[q]; }
 #pragma unroll
 			for (int r = 0; r < 3; r++)
 #pragma unroll
-				for (int c = 0; c < 3; c++) q2[6 * r + c] += adtt[3 * r + c];
+				for (int c = 0; c < 3; c++) { D[6 * r + c] += h1 ? X2[3 * r + c] : 0.0; C2[6 * r + c] += h1 ? 0.0 : X2[3 * r + c]; }
 			if (k == t.nref) zero<36>(D);
-			if (k == t.nscap) for (int r = 0; r < 6; r++) D[6 * r + t.newFix] = 0.0;
-			if (t.c2fix) for (int r = 0; r < 6; r++) C1[6 * r + t.newFix] = 0.0;
+			const bool zD = k == t.nscap, zC = t.c2fix != 0;
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+#pragma unroll
+				for (int c = 0; c < 6; c++)
+					if (c == t.newFix) { if (zD) D[6 * r + c] = 0.0; if (zC) C1[6 * r + c] = 0.0; }
 			if (t.c3zero) zero<36>(C2);
 		}
 	}
@@ -389,7 +392,12 @@ k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_
 			for (int c = 0; c < 3; c++) { Cf[0][6 * r + c] = adt[3 * r + c]; Cf[NH - 1][6 * r + c] = adtt[3 * r + c]; Cf[NH - 1][6 * r + 3 + c] = 0.0; }
 			Cf[0][6 * r + 3] = atmp[3 * r]; Cf[0][6 * r + 4] = atmp[3 * r + 1]; Cf[0][6 * r + 5] = atmp[3 * r + 2];
 		}
-		if (t->c2fix) for (int r = 0; r < 3; r++) Cf[0][6 * r + t->newFix] = 0.0;
+		if (t->c2fix)
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int c = 0; c < 6; c++)
+					if (c == t->newFix) Cf[0][6 * r + c] = 0.0; // (a run-time index would put Cf into scratch memory)
 		if (t->c3zero) zero<18>(Cf[NH - 1]);
 	}
 	// V' = D_f^T V D_f
@@ -1025,6 +1033,13 @@ __global__ void k_tr_err_to_run(const int* err, RunStatsDev* run)
 {
 	if (*err && !run->tr_err) run->tr_err = *err;
 }
+// a planned Mono level took the signs of the new scales from the plan (the host mirrors of the map records need them
+// before the device has computed anything): they are values, not structure -- check them against what k_tr_params1 found
+__global__ void k_tr_sign_check(const TMap* __restrict__ tm, const int* __restrict__ planned, int B, RunStatsDev* run)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < B && tm[b].active > 0 && tm[b].sign1 != planned[b]) atomicExch(&run->plan_stale, 1);
+}
 
 void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std::vector<int>& target_ref,
                      const std::vector<int>& target_scap, const std::vector<int>& target_fix, bool mono, DevBatch& out,
@@ -1159,7 +1174,16 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	if (mono)
 	{
 		// Imp.cpp:3241-3244: the sign of the new scale is part of the map record the caller keeps
-		if (warm) { for (int b = 0; b < B; b++) if (tm[b].active) out.Sign[b] = plan->tr_sign[b]; }
+		if (warm)
+		{
+			for (int b = 0; b < B; b++) if (tm[b].active) out.Sign[b] = plan->tr_sign[b];
+			if (ctx->d_run)
+			{
+				int* d_sign = ctx->scratch.alloc<int>(B);
+				h2d(ctx, d_sign, plan->tr_sign.data(), sizeof(int) * B);
+				hipLaunchKernelGGL(k_tr_sign_check, dim3((B + 127) / 128), dim3(128), 0, s, d_tm, d_sign, B, ctx->d_run);
+			}
+		}
 		else
 		{
 			std::vector<TMap> dev(B);

@@ -140,7 +140,15 @@ class ShardedTree:
         self.out_bufs = {}      # round -> torch buffer the own node is packed into
         self.in_bufs = {}       # round -> torch buffer the partner's node arrives in
         self.result = None
+        self.plans = True
         self.gpu_direct = dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+    def set_plans(self, on):
+        """on = False: every run of every tree of this rank analyses its structure again (what the reference's timed region
+        contains: symbolic work in every join); True (default): later runs reuse what the first one recorded."""
+        self.plans = bool(on)
+        for t in list(self.merge_trees.values()) + ([self.block_tree] if self.block_tree is not None else []):
+            self.ctx.tree_set_plans(t, self.plans)
 
     # -- transport of one packed node -------------------------------------------------------------------------------
     def _send(self, buf, dst):
@@ -207,6 +215,7 @@ class ShardedTree:
             mt = self.merge_trees.get(j)
             if mt is None:
                 mt = self.merge_trees[j] = ctx.tree_upload_dev(ptrs, self.mono)
+                ctx.tree_set_plans(mt, self.plans)
             else:
                 ctx.tree_reload_dev(mt, ptrs)
             ctx.tree_set_final_reanchor(mt, reanchor)

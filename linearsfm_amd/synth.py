@@ -79,6 +79,17 @@ def rot_ypr(a, b, g):
                      [cg * sb * ca + sg * sa, cg * sb * sa - sg * ca, cg * cb]])
 
 
+def _rot_ypr_many(ang):
+    """rot_ypr for an [n,3] array of (a, b, g): [n,3,3], the same expressions element by element."""
+    a, b, g = ang[:, 0], ang[:, 1], ang[:, 2]
+    ca, sa, cb, sb, cg, sg = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(g), np.sin(g)
+    R = np.empty((ang.shape[0], 3, 3))
+    R[:, 0, 0] = cb * ca; R[:, 0, 1] = cb * sa; R[:, 0, 2] = -sb
+    R[:, 1, 0] = sg * sb * ca - cg * sa; R[:, 1, 1] = sg * sb * sa + cg * ca; R[:, 1, 2] = sg * cb
+    R[:, 2, 0] = cg * sb * ca + sg * sa; R[:, 2, 1] = cg * sb * sa - sg * ca; R[:, 2, 2] = cg * cb
+    return R
+
+
 def ypr_from_rot(R):
     """Inverse of rot_ypr away from cos(beta)=0 (LinearSFMImp.cpp:162-177)."""
     b = np.arctan2(-R[0, 2], np.hypot(R[0, 0], R[0, 1]))
@@ -105,7 +116,7 @@ def _drot(a, b, g):
 GOLDEN_ANGLE = 2.399963229728653
 
 
-def _world(n_frames, new_per_frame, vis, seed, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0), turn=GOLDEN_ANGLE):
+def _world(n_frames, new_per_frame, vis, seed, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0), turn=GOLDEN_ANGLE, strip=0, spacing=3.5, skip=0):
     """Camera path + points.  Camera moves in the x-y plane looking along +z, points in a slab above it.
 
     lap = 0: an open path that never returns (dead reckoning only; global coordinates of a long set are then so weakly
@@ -115,14 +126,28 @@ def _world(n_frames, new_per_frame, vis, seed, lap=0, home=10, revisit=0.4, dept
     (README.txt:58-60 names sets of up to 3499 local maps that the reference solved).  Points first seen within
     `home` frames of a lap boundary are re-observed, with probability `revisit`, by the frames at the same phase of the
     NEXT lap: the same feature id then appears in local maps that are a whole lap apart, and the join that brings the two
-    laps together closes the loop."""
+    laps together closes the loop.
+    skip = K > 0 (with lap): lap j also meets lap j + 2^r again for every r <= K with 2^r | j (a skip list over the laps: the
+    re-observed points of such a lap are dealt over its link lengths), so that every lap is O(log) links away from the
+    first one however long the set is -- a chain of laps linked to their neighbours only lets the dead-reckoning error of
+    a long set grow until two fp64 evaluations of the reference path disagree in the 5th digit (Mono, 2048 maps).
+    strip = L > 0 (instead of lap): an aerial block -- parallel flight strips of L frames, flown to and fro, `spacing` apart
+    (the points of a frame spread +-2.5 across the track: 3.5 leaves 30 % side overlap).  A point whose offset across the
+    track puts it inside the NEXT strip's footprint is seen again by the frames of that strip that pass the same place, so
+    every strip shares features with its neighbour along its whole length (a grid, not a chain with closures).  The
+    camera keeps its orientation on the way back (a nadir camera flown backwards): poses stay away from the +-pi yaw seam,
+    where two fp64 evaluations may legitimately print angles 2 pi apart."""
     rng1 = np.random.default_rng(seed + 1)
     rng2 = np.random.default_rng(seed + 2)
     i = np.arange(n_frames)
     step = 0.5
     heading = 0.6 * np.sin(2 * np.pi * i / 257.0) + 0.25 * np.sin(2 * np.pi * i / 61.0)
     pos = np.zeros((n_frames, 3))
-    if lap > 0:
+    if strip > 0:
+        js, ps = i // strip, i % strip
+        pos[:, 0] = step * np.where(js % 2 == 0, ps, strip - 1 - ps)
+        pos[:, 1] = spacing * js
+    elif lap > 0:
         R = step / (2.0 * np.sin(np.pi / lap))             # chord between consecutive frames = step
         psi = turn * (i // lap)
         phi = psi + np.pi + 2 * np.pi * (i % lap) / lap
@@ -138,7 +163,7 @@ def _world(n_frames, new_per_frame, vis, seed, lap=0, home=10, revisit=0.4, dept
 
     ph = rng1.uniform(0, 2 * np.pi, 3)
     ang = np.stack([heading * 0.4 + smooth(0.1, 143.0, ph[0]), smooth(0.15, 89.0, ph[1]), smooth(0.15, 113.0, ph[2])], 1)
-    Rw = np.stack([rot_ypr(*ang[k]) for k in range(n_frames)])        # world -> camera
+    Rw = _rot_ypr_many(ang)                                            # world -> camera
 
     # points: `new_per_frame` start at every frame s (also vis-1 frames before frame 0 so the first maps are full)
     starts = np.repeat(np.arange(-(vis - 1), n_frames), new_per_frame)
@@ -154,18 +179,54 @@ def _world(n_frames, new_per_frame, vis, seed, lap=0, home=10, revisit=0.4, dept
         ph_s = np.mod(starts, lap)
         near = (starts >= 0) & ((ph_s < home) | (ph_s >= lap - home))
         pick = near & (rng4.uniform(0, 1, npts) < revisit)
-        starts2[pick] = starts[pick] + lap
+        dist = np.ones(npts, np.int64)
+        if skip > 0:
+            jl = np.maximum(starts, 0) // lap
+            tz = np.zeros(npts, np.int64)                    # trailing zeros of the lap index, capped at `skip`
+            for r in range(1, skip + 1):
+                tz[(jl % (1 << r) == 0) & (jl > 0)] = r
+            rsel = (rng4.uniform(0, 1, npts) * (tz + 1)).astype(np.int64)
+            dist = 1 << np.minimum(rsel, tz)
+            dist[(jl + dist) * lap + lap > n_frames] = 1     # no such lap: the neighbour then
+        starts2[pick] = starts[pick] + lap * dist[pick]
+    if strip > 0:
+        # frame s = j L + p sees the point at the along-track places of its next vis frames; the next strip passes them in
+        # reverse order with its frames (j + 1) L + (L - p - vis) ...
+        js, ps = starts // strip, starts % strip
+        pick = (starts >= 0) & (ps + vis <= strip) & ((js + 1) * strip + strip <= n_frames) & (off[:, 1] >= spacing - 2.5)
+        starts2[pick] = (js[pick] + 1) * strip + strip - ps[pick] - vis
     return pos, Rw, starts, starts2, pts
 
 
 NEVER = -(1 << 40)
 
 
+class _Visibility:
+    """Which points every frame of a window [first, last] sees: `starts` is sorted (points are created frame by frame), and so
+    are the second windows of the re-observed points, so a query is two binary searches instead of a pass over all points
+    (the pass made the generation of a 65 536-map set quadratic: 17 minutes)."""
+
+    def __init__(self, starts, starts2, vis):
+        self.starts, self.vis = starts, vis
+        self.idx2 = np.nonzero(starts2 != NEVER)[0]
+        self.s2 = starts2[self.idx2]
+        if np.any(np.diff(self.s2) < 0):                    # (aerial strips: the second windows run against the first ones)
+            o = np.argsort(self.s2, kind="stable")
+            self.idx2, self.s2 = self.idx2[o], self.s2[o]
+        assert np.all(np.diff(starts) >= 0)
+
+    def __call__(self, first, last):
+        lo, hi = last - self.vis + 1, first                 # start <= first and start + vis - 1 >= last
+        a = np.arange(np.searchsorted(self.starts, lo, "left"), np.searchsorted(self.starts, hi, "right"))
+        b = self.idx2[np.searchsorted(self.s2, lo, "left"):np.searchsorted(self.s2, hi, "right")]
+        if b.size == 0:
+            return a
+        return np.union1d(a, b)                             # ascending point index, like a pass over all points
+
+
 def _visible(starts, starts2, vis, first, last):
-    """points seen by every frame of [first, last]"""
-    a = (starts <= first) & (starts + vis - 1 >= last)
-    b = (starts2 <= first) & (starts2 + vis - 1 >= last)
-    return np.nonzero(a | b)[0]
+    """points seen by every frame of [first, last] (one query; the generators keep a _Visibility)"""
+    return _Visibility(starts, starts2, vis)(first, last)
 
 
 def _rel_pose(pos, Rw, k, j):
@@ -179,18 +240,19 @@ def _rel_pose(pos, Rw, k, j):
 # Stereo
 # ----------------------------------------------------------------------------------------------
 def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_id=1, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0),
-                    turn=GOLDEN_ANGLE, only=None):
+                    turn=GOLDEN_ANGLE, only=None, strip=0, spacing=3.5, skip=0):
     """n_maps Stereo local maps over n_maps+1 frames (ids first_id..).  ~new_per_frame*(vis-1) features per map.
     lap/home/revisit: see _world (lap = 0: open path).  only = (lo, hi): just the maps lo..hi-1 of the set (each map draws
     its noise from its own generator, so a slice equals the corresponding part of the whole set)."""
     n_frames = n_maps + 1
-    pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn)
+    pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn, strip, spacing, skip)
     sinv = np.diag(1.0 / np.array([0.01, 0.01, 0.03]) ** 2)
+    seen = _Visibility(starts, starts2, vis)
     maps = []
     for k in range(*(only or (0, n_maps))):
         rng3 = np.random.default_rng([seed + 3, k])
         # points visible in frame k and k+1
-        sel = _visible(starts, starts2, vis, k, k + 1)
+        sel = seen(k, k + 1)
         n = sel.shape[0]
         t, R = _rel_pose(pos, Rw, k, k + 1)
         a, b, g = ypr_from_rot(R)
@@ -222,16 +284,17 @@ def make_stereo_set(n_maps, new_per_frame=130, vis=5, seed=0, noise=1e-3, first_
 # Mono
 # ----------------------------------------------------------------------------------------------
 def make_mono_set(n_maps, new_per_frame=300, vis=4, seed=0, noise=1e-3, first_id=1, lap=0, home=10, revisit=0.4, depth=(4.0, 12.0),
-                  turn=GOLDEN_ANGLE, only=None):
+                  turn=GOLDEN_ANGLE, only=None, strip=0, spacing=3.5, skip=0):
     """n_maps Mono local maps over n_maps+2 frames; map k = frames k,k+1,k+2 (Ref=k, ScaP=k+1).
     lap/home/revisit: see _world (lap = 0: open path); only = (lo, hi): just that slice of the set."""
     n_frames = n_maps + 2
-    pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn)
+    pos, Rw, starts, starts2, pts = _world(n_frames, new_per_frame, vis, seed, lap, home, revisit, depth, turn, strip, spacing, skip)
     w = 1.0 / (1e-3) ** 2
+    seen = _Visibility(starts, starts2, vis)
     maps = []
     for k in range(*(only or (0, n_maps))):
         rng3 = np.random.default_rng([seed + 3, k])
-        sel = _visible(starts, starts2, vis, k, k + 2)
+        sel = seen(k, k + 2)
         n = sel.shape[0]
         t1, R1 = _rel_pose(pos, Rw, k, k + 1)
         t2, R2 = _rel_pose(pos, Rw, k, k + 2)
@@ -355,10 +418,18 @@ def write_set(dirpath, maps):
 # coincide with the power-of-two blocks of the join tree.
 FLOWER = dict(lap=120, home=10, revisit=0.4)
 SPIRAL = dict(lap=40, home=20, revisit=0.5, turn=0.15)
+# AP_Vaihingen-like (BASELINE.json configs[4]; the real set is "Aerial Photogrammetric Vaihingen Monocular",
+# /root/reference/DataForC/AP_Vaihingen_C/...Dataset.txt:1, a link only): a monocular block of parallel strips with side overlap
+# -- 12 strips of 20 frames.  (The block is kept at a size whose global coordinates are well determined: with 30 % side overlap
+# the strips hang on each other through a third of their points only, and at 24 strips, or 40 frames a strip, two fp64
+# evaluations of the reference path already differ by 1e-5 on the far corner -- measured with the oracle and its
+# long-double twin; at this size by 5e-8.)
+AERIAL = dict(strip=20, spacing=3.5)
 CONFIGS = {
     "rs90":     ("Monocular", 88, 300, 4, SPIRAL),
     "rs468":    ("Monocular", 466, 300, 4, SPIRAL),
     "nc3500":   ("Stereo", 3499, 130, 5, FLOWER),
+    "aerial":   ("Monocular", 238, 150, 4, AERIAL),
     "synth16k": ("Monocular", 16384, 64, 4, SPIRAL),
     "synth64k": ("Stereo", 65536, 64, 5, FLOWER),
 }

@@ -283,3 +283,64 @@ def test_threaded_oracle_tree_is_identical(oracle, mono):
     assert rc1 == 0 and rc2 == 0
     for k in ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V"):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_oracle_whole_tree_from_fixture_inputs_to_fixture_result(oracle, name):
+    """orc_divide_conquer (the oracle's restatement of lmj_PF3D_Divide_Conquer*'s loop, Imp.cpp:1932-2063 / 6517-6630) on
+    the fixture's input maps against the fixture's final map: that one was produced join by join by make_golden.py, which
+    follows the reference's loop itself -- pairing, the unpaired carry (`NumLM == 1`, Imp.cpp:1940-1948), re-anchoring of the
+    odd outputs ((i + 1) % 2 == 0, Imp.cpp:1997) and of the final map (2039) -- and checks every transform and assembly on
+    the way against the real reference.  Same arithmetic in the same order: bit for bit."""
+    z = load_golden(name)
+    mono = str(z["type"]) == "Monocular"
+    maps = [get_map(z, f"in{k}") for k in range(int(z["N"]))]
+    exp = get_map(z, "result")
+    got, _, rc = oracle.divide_conquer(maps, mono, match_hash=False)
+    assert rc == 0
+    for k in ("Ref", "FRef", "m", "n"):
+        assert int(got[k]) == int(exp[k]), k
+    for k in ("stno", "Ui", "Uj", "photo", "feature", "FBlock"):
+        assert np.array_equal(np.asarray(got[k]).ravel(), np.asarray(exp[k]).ravel()), k
+    for k in ("stVal", "U", "W", "V"):
+        assert np.array_equal(np.asarray(got[k]).ravel(), np.asarray(exp[k]).ravel()), k
+    if mono:
+        for k in ("ScaP", "Fix", "Sign"):
+            assert int(got[k]) == int(exp[k]), k
+
+
+def test_generator_visibility_index_equals_a_pass_over_all_points():
+    """synth._Visibility (two binary searches per window) against the definition, on the three kinds of path: laps, laps with
+    skip links (second windows out of order), aerial strips (second windows run against the first ones)."""
+    for kw in (dict(lap=12, home=4, revisit=0.5), dict(lap=8, home=4, revisit=0.6, skip=3), dict(strip=10, spacing=3.5)):
+        pos, Rw, starts, starts2, pts = synth._world(70, 5, 4, 3, **kw)
+        seen = synth._Visibility(starts, starts2, 4)
+        assert np.any(starts2 != synth.NEVER)
+        for first in range(0, 66):
+            for last in (first + 1, first + 2):
+                a = (starts <= first) & (starts + 3 >= last)
+                b = (starts2 <= first) & (starts2 + 3 >= last)
+                assert np.array_equal(seen(first, last), np.nonzero(a | b)[0]), (kw, first, last)
+
+
+def test_aerial_block_structure():
+    """The AP_Vaihingen stand-in: parallel strips flown to and fro; a strip shares features with the NEXT strip along its whole
+    length (and with nothing further away), the first strip's maps look along +x, the second strip's along -x."""
+    typ, maps = synth.make_config("aerial")
+    assert typ == "Monocular" and len(maps) == 238
+    L = synth.AERIAL["strip"]
+    ids = [set(np.asarray(m.stno)[np.asarray(m.stno) > 0].tolist()) for m in maps]
+    for k in (2, 7, 13):                                  # map k of strip 0: frames k .. k+2
+        across = [len(ids[k] & ids[j]) for j in range(L, 2 * L - 2)]
+        assert max(across) > 30 and sum(1 for c in across if c) <= 8   # the few maps of strip 1 that pass the same place
+        assert all(len(ids[k] & ids[j]) == 0 for j in range(2 * L, 3 * L - 2))
+    assert maps[3].Sign == 1 and maps[L + 3].Sign == -1 and maps[3].Fix == maps[L + 3].Fix
+
+
+def test_generator_speed_of_the_large_sets():
+    """A 16 384-map set must build in well under a minute (the per-map visibility pass of round 2 made it quadratic)."""
+    import time
+    t0 = time.time()
+    typ, maps = synth.make_config("synth16k", 16384, only=(0, 1500))
+    dt = time.time() - t0
+    assert len(maps) == 1500 and dt < 10.0, dt

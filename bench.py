@@ -339,8 +339,8 @@ def main():
         extras = args.extras and world == 1
         if extras:
             # the CG's SpMV kernel where it streams: a Schur-like matrix far beyond the caches (same kernel, same entry point as
-            # `--config spmv-stream`, shorter: 65 536 poses, 0.35 GB of upper blocks)
-            m_s, band, hubs = 65536, 12, 12
+            # `--config spmv-stream`, a little shorter: 196 608 poses, 1.0 GB of upper blocks)
+            m_s, band, hubs = 196608, 12, 12
             rp32, colidx, val = synth.schur_like_matrix(m_s, band, hubs, seed=0)
             xs = np.random.default_rng(1).normal(size=6 * m_s)
             ctx.spmv_bench(rp32, colidx, val, xs, reps=3)

@@ -151,6 +151,17 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
 int lsfm_schur_pattern(lsfm_context* ctx, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
                        int* rowptr, int* colidx, int cap, int* nnzb);
 
+/* Test / measurement entry, NO device needed: the host half of the solver that stands where the reference calls cholmod_amd /
+ * cholmod_analyze_p (Imp.cpp:2413, 2440 / 7081, 7112) -- nested-dissection ordering along the join tree + symbolic block
+ * Cholesky factorisation of a camera system given by its upper block pattern (rowptr[m + 1], colidx: as lsfm_schur_pattern
+ * returns it; every diagonal block present) and, per pose, the index of the local map that brought it (origin[m]; NULL: its
+ * position).  Outputs (each optional): perm[m] (new -> old), colptr[m + 1] and rowidx[cap] = block CSC of L in the new
+ * numbering (rows ascending, diagonal first); info[8] = { blocks of L, height of the elimination tree, supernode groups, group
+ * levels, leaf tasks, poses in separators, 0, 0 }; *avg_ms = wall ms of one analysis, averaged over reps.  Returns LSFM_ERR_ARG
+ * when cap is too small (info[0] still holds the size needed). */
+int lsfm_symbolic_analyse(int m, const int* rowptr, const int* colidx, const int* origin, int reps, int* perm, int* colptr, int* rowidx,
+                          int cap, int* info, double* avg_ms);
+
 /* ---- the scheduler itself ------------------------------------------------------------------------ */
 /* replaces lmj_PF3D_Divide_Conquer{Stereo,Mono} (Imp.h:205/220, Imp.cpp:1926-2063 / 6511-6630): hierarchical
  * join of maps[0..N) with the reference's binary-tree order; all joins of one tree level run as ONE batch on

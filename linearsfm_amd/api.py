@@ -95,6 +95,7 @@ def lib():
         L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
         L.lsfm_schur_pattern.argtypes = [vp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, C.c_int, ip]
+        L.lsfm_symbolic_analyse.argtypes = [C.c_int, ip, ip, ip, C.c_int, ip, ip, ip, C.c_int, ip, dp]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
         L.lsfm_wstream_bench.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, dp]
         _LIB = L
@@ -107,7 +108,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
-           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern"]
+           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse"]
 
 
 def _c(a, dtype):
@@ -337,6 +338,25 @@ def _wstream(self, nblocks, mode, reps=10):
 
 
 Context.wstream_bench = _wstream
+
+
+def symbolic_analyse(rowptr, colidx, origin=None, reps=1):
+    """Host-only: ordering + symbolic block Cholesky of a camera system's upper block pattern (no device needed).
+    Returns dict(perm, colptr, rowidx, info, ms)."""
+    rowptr = _c(rowptr, np.int32); colidx = _c(colidx, np.int32)
+    m = len(rowptr) - 1
+    org = _c(origin, np.int32) if origin is not None else None
+    info = np.zeros(8, np.int32)
+    perm = np.zeros(m, np.int32); colptr = np.zeros(m + 1, np.int32)
+    ms = C.c_double()
+    lib().lsfm_symbolic_analyse(m, _ptr(rowptr, C.c_int), _ptr(colidx, C.c_int), _ptr(org, C.c_int) if org is not None else None, 1,
+                                _ptr(perm, C.c_int), _ptr(colptr, C.c_int), None, 0, _ptr(info, C.c_int), None)
+    rowidx = np.zeros(max(int(info[0]), 1), np.int32)
+    rc = lib().lsfm_symbolic_analyse(m, _ptr(rowptr, C.c_int), _ptr(colidx, C.c_int), _ptr(org, C.c_int) if org is not None else None, int(reps),
+                                     _ptr(perm, C.c_int), _ptr(colptr, C.c_int), _ptr(rowidx, C.c_int), len(rowidx), _ptr(info, C.c_int), C.byref(ms))
+    if rc:
+        raise LsfmError(f"lsfm_symbolic_analyse failed (rc={rc}): malformed pattern")
+    return dict(perm=perm, colptr=colptr, rowidx=rowidx[:int(info[0])], info=info, ms=ms.value)
 
 
 def read_localmap(path, mono):

@@ -25,6 +25,7 @@
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
 #include "lsfm_solve.hpp"
+#include "lsfm_symbolic.hpp"
 
 namespace lsfm {
 
@@ -618,7 +619,7 @@ __global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int
 //   k_sn_update  one lane per pair (a >= b) of common rows: block (r_a, r_b) -= sum_t X[a,t] X[b,t]^T, left through LDS
 //                as contiguous atomics (groups of one level share ancestors)
 // ---------------------------------------------------------------------------------------------------------------
-#define CHOL_GS 16
+/* CHOL_GS (most block columns of a group, 16): lsfm_symbolic.hpp */
 #define SN_RB 16                    /* block rows of the panel per work-group */
 #define SN_XS (6 * CHOL_GS + 1)     /* odd row stride of the panel rows in LDS */
 #define SN_THREADS 256               /* 96 lanes own rows; the rest is there to keep more loads in flight */
@@ -1131,8 +1132,6 @@ __global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double
 // ---------------------------------------------------------------------------------------------------------------
 // host: ordering + symbolic factorisation
 // ---------------------------------------------------------------------------------------------------------------
-static int bitlen(unsigned x) { int l = 0; while (x) { l++; x >>= 1; } return l; }
-
 struct CholHostIn {
 	std::vector<unsigned long long> keys; // sorted upper pattern of S
 	std::vector<int> origin;              // local map that brought each pose
@@ -1220,293 +1219,52 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	return sp;
 }
 
-static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHostIn& in, CholDev& ch)
+// symbolic analysis on the host (lsfm_symbolic.cpp), then every index array of it to the device in ONE copy
+static void chol_upload_symbolic(lsfm_context* ctx, const CholSymbolic& sym, CholDev& ch)
 {
-	const int M = sy.M, nnzb = sy.nnzb;
 	Arena& sc = ctx->scratch;
-	const std::vector<unsigned long long>& keys = in.keys;
-	const std::vector<int>& origin = in.origin;
-	// every index array of the analysis goes to the device in ONE copy (each copy is a host-device round trip)
-	std::vector<int> blob;
-	std::vector<std::pair<int**, size_t>> blob_dst;
-	auto pack = [&](int** dst, const std::vector<int>& v) { blob_dst.emplace_back(dst, blob.size()); blob.insert(blob.end(), v.begin(), v.end()); };
-	// Separators of the dissection: the edges that cross the cut of tree level l (the two poses come from different
-	// halves of a level-l node: bitlen(origin_p ^ origin_q) = l) must lose an endpoint to that level's separator.  From the
-	// top level down, over the edges no higher separator covers yet, a greedy vertex cover: the pose with the most
-	// uncovered crossing edges first (hub poses, then ONE side of a loop closure -- taking the higher-degree endpoint
-	// edge by edge, as round 1 did, put both sides of a closure in: 72 instead of 41 poses in the top separator of the
-	// NC3500-like set, elimination tree 330 instead of 227 columns high, 2.6 instead of 1.7 GFLOP).
-	std::vector<int> sep(M, 0);
+	ch.M = sym.M; ch.nnzL = sym.nnzL; ch.nlevels = sym.nlevels; ch.tail_begin = sym.tail_begin;
+	ch.level_ptr = sym.level_ptr;
+	ch.tlevel_ptr = sym.tlevel_ptr; ch.tlevel_maxsize = sym.tlevel_maxsize; ch.tlevel_col0 = sym.tlevel_col0; ch.tlevel_nsmall = sym.tlevel_nsmall;
+	ch.tlevel_small_lds = sym.tlevel_small_lds; ch.tlevel_outer = sym.tlevel_outer;
+	ch.ngroups = sym.ngroups; ch.glevel_ptr = sym.glevel_ptr; ch.glevel_maxnr = sym.glevel_maxnr;
+	const struct { int** dst; const std::vector<int>* v; } parts[] = {
+		{ &ch.grp_c0, &sym.grp_c0 }, { &ch.grp_s, &sym.grp_s }, { &ch.grp_nr, &sym.grp_nr }, { &ch.col_nin, &sym.col_nin }, { &ch.col_task, &sym.col_task },
+		{ &ch.col_lpos, &sym.col_lpos }, { &ch.task_cols, &sym.task_cols }, { &ch.task_ptr, &sym.task_ptr }, { &ch.colptr, &sym.colptr },
+		{ &ch.rowidx, &sym.rowidx }, { &ch.perm, &sym.perm }, { &ch.pinv, &sym.pinv }, { &ch.order, &sym.order } };
+	size_t total = 0;
+	for (const auto& pt : parts) total += pt.v->size();
+	static thread_local std::vector<int> blob;
+	blob.resize(total);
+	int* d_blob = sc.alloc<int>(total);
+	size_t off = 0;
+	for (const auto& pt : parts)
 	{
-		std::vector<std::vector<std::pair<int, int>>> lev_edges(34);
-		for (int e = 0; e < nnzb; e++)
-		{
-			const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-			if (p != q) lev_edges[bitlen((unsigned)(origin[p] ^ origin[q]))].emplace_back(p, q);
-		}
-		std::vector<int> cdeg(M, 0), start(M + 1, 0), adj;
-		std::vector<char> covered;
-		for (int l = 33; l >= 1; l--)
-		{
-			const auto& es = lev_edges[l];
-			if (es.empty()) continue;
-			// uncovered edges of the level, as a CSR adjacency with edge ids
-			std::vector<std::pair<int, int>> live;
-			for (const auto& pq : es) if (sep[pq.first] < l && sep[pq.second] < l) live.push_back(pq);
-			if (live.empty()) continue;
-			std::vector<int> verts;
-			for (const auto& pq : live) { if (!cdeg[pq.first]++) verts.push_back(pq.first); if (!cdeg[pq.second]++) verts.push_back(pq.second); }
-			std::sort(verts.begin(), verts.end());
-			int tot = 0;
-			for (int v : verts) { start[v] = tot; tot += cdeg[v]; }
-			adj.assign(tot, 0);
-			std::vector<int> fillv(verts.size(), 0);
-			auto vpos = [&](int v) { return (int)(std::lower_bound(verts.begin(), verts.end(), v) - verts.begin()); };
-			for (int e = 0; e < (int)live.size(); e++)
-			{
-				const int a = live[e].first, b = live[e].second;
-				adj[start[a] + fillv[vpos(a)]++] = e;
-				adj[start[b] + fillv[vpos(b)]++] = e;
-			}
-			covered.assign(live.size(), 0);
-			std::vector<int> cur(verts.size());
-			std::priority_queue<std::pair<int, int>> heap; // (uncovered crossing edges, pose): lazy deletion
-			for (size_t i = 0; i < verts.size(); i++) { cur[i] = cdeg[verts[i]]; heap.emplace(cur[i], verts[i]); }
-			while (!heap.empty())
-			{
-				const auto top = heap.top();
-				heap.pop();
-				const int v = top.second, iv = vpos(v);
-				if (top.first != cur[iv] || cur[iv] <= 0) continue; // stale entry
-				sep[v] = l;
-				for (int t = start[v]; t < start[v] + cdeg[v]; t++)
-				{
-					const int e = adj[t];
-					if (covered[e]) continue;
-					covered[e] = 1;
-					const int w = live[e].first == v ? live[e].second : live[e].first, iw = vpos(w);
-					if (--cur[iw] > 0) heap.emplace(cur[iw], w);
-				}
-				cur[iv] = 0;
-			}
-			for (int v : verts) cdeg[v] = 0;
-		}
+		if (!pt.v->empty()) memcpy(blob.data() + off, pt.v->data(), pt.v->size() * sizeof(int));
+		*pt.dst = d_blob + off;
+		off += pt.v->size();
 	}
-	std::vector<int> perm(M), pinv(M);
-	std::iota(perm.begin(), perm.end(), 0);
-	std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sep[a] < sep[b]; });
-	for (int i = 0; i < M; i++) pinv[perm[i]] = i;
-	// strict lower adjacency by row, new numbering
-	std::vector<int> rcnt(M + 1, 0);
-	for (int e = 0; e < nnzb; e++)
-	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p != q) rcnt[std::max(pinv[p], pinv[q]) + 1]++;
-	}
-	for (int i = 0; i < M; i++) rcnt[i + 1] += rcnt[i];
-	std::vector<int> radj(rcnt[M]), fill(M, 0);
-	for (int e = 0; e < nnzb; e++)
-	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p == q) continue;
-		const int a = std::min(pinv[p], pinv[q]), b = std::max(pinv[p], pinv[q]);
-		radj[rcnt[b] + fill[b]++] = a;
-	}
-	// elimination tree (ancestor path compression), column counts, column patterns by row sub-tree walks
-	std::vector<int> parent(M, -1), anc(M, -1);
-	for (int k = 0; k < M; k++)
-		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-		{
-			int i = radj[t];
-			while (i != -1 && i < k) { const int nx = anc[i]; anc[i] = k; if (nx == -1) parent[i] = k; i = nx; }
-		}
-	std::vector<int> mark(M, -1), ccount(M, 1);
-	for (int k = 0; k < M; k++)
-	{
-		mark[k] = k;
-		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-			for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
-	}
-	std::vector<int> colptr(M + 1, 0);
-	for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
-	const int nnzL = colptr[M];
-	std::vector<int> rowidx(nnzL), cfill(M, 1);
-	for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
-	std::fill(mark.begin(), mark.end(), -1);
-	for (int k = 0; k < M; k++)
-	{
-		mark[k] = k;
-		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-			for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + cfill[i]++] = k; mark[i] = k; }
-	}
-	// level sets (height above the leaves); the narrow top (<= 2 columns per level) becomes the tail
-	std::vector<int> lev(M, 0);
-	int nlev = 0;
-	for (int j = 0; j < M; j++)
-	{
-		if (parent[j] >= 0) lev[parent[j]] = std::max(lev[parent[j]], lev[j] + 1);
-		nlev = std::max(nlev, lev[j] + 1);
-	}
-	std::vector<int> lcount(nlev + 1, 0);
-	for (int j = 0; j < M; j++) lcount[lev[j] + 1]++;
-	int tail_level = nlev;
-	while (tail_level > 0 && lcount[tail_level] <= 2) tail_level--;
-	for (int l = 0; l < nlev; l++) lcount[l + 1] += lcount[l];
-	std::vector<int> order(M), lfill(nlev, 0);
-	for (int j = 0; j < M; j++) order[lcount[lev[j]] + lfill[lev[j]]++] = j; // ascending j inside a level
-	ch.M = M; ch.nnzL = nnzL; ch.nlevels = tail_level;
-	ch.level_ptr.assign(lcount.begin(), lcount.begin() + tail_level + 1);
-	ch.tail_begin = lcount[tail_level];
-	// tail columns must be walked in ascending index (= a topological order), not level order
-	std::sort(order.begin() + ch.tail_begin, order.end());
-	// ---- tasks.  Sub-trees of at most task_x blocks are walked by one work-group each (task level 0); above them
-	// every chain of the tree (a separator of the dissection: each column the only large child of the next) is one
-	// task, levelled by the chains below it.  Launches per triangular solve: ~ depth of the dissection, not the
-	// height of the elimination tree. ----
-	{
-		// "size" of a sub-tree = its blocks (pivot blocks included): a leaf task must fit LDS whole (small-task kernels)
-		static const int task_x = getenv("LSFM_TASK_X") ? atoi(getenv("LSFM_TASK_X")) : 90;
-		std::vector<int> size(M, 1), ntc(M, 0), topchild(M, -1), task(M, -1), tlev;
-		for (int j = 0; j < M; j++) size[j] = ccount[j];
-		for (int j = 0; j < M; j++) if (parent[j] >= 0) size[parent[j]] += size[j];
-		for (int j = 0; j < M; j++)
-			if (size[j] > task_x && parent[j] >= 0) { ntc[parent[j]]++; topchild[parent[j]] = j; }
-		int ntasks = 0;
-		// large columns, ascending: children first
-		for (int j = 0; j < M; j++)
-		{
-			if (size[j] <= task_x) continue;
-			if (ntc[j] == 1) { task[j] = task[topchild[j]]; continue; }
-			task[j] = ntasks++;
-			tlev.push_back(1);
-		}
-		// level of a chain = 1 + highest chain below it (ascending order sees the children first)
-		for (int j = 0; j < M; j++)
-		{
-			if (size[j] <= task_x) continue;
-			const int pj = parent[j];
-			if (pj >= 0 && task[pj] != task[j]) tlev[task[pj]] = std::max(tlev[task[pj]], tlev[task[j]] + 1);
-		}
-		// small sub-trees, descending: parents first
-		for (int j = M - 1; j >= 0; j--)
-		{
-			if (size[j] > task_x) continue;
-			const int pj = parent[j];
-			if (pj >= 0 && size[pj] <= task_x) task[j] = task[pj];
-			else { task[j] = ntasks++; tlev.push_back(0); }
-		}
-		int ntl = 0;
-		for (int t = 0; t < ntasks; t++) ntl = std::max(ntl, tlev[t] + 1);
-		// order tasks by level, columns by (task order, ascending index)
-		std::vector<int> tl_count(ntl + 1, 0), tpos(ntasks), tsize(ntasks, 0);
-		for (int t = 0; t < ntasks; t++) tl_count[tlev[t] + 1]++;
-		for (int l = 0; l < ntl; l++) tl_count[l + 1] += tl_count[l];
-		// tasks whose blocks fit LDS whole go first in their level (they take the small-task kernels)
-		std::vector<long> tblocks(ntasks, 0), tcolsn(ntasks, 0);
-		for (int j = 0; j < M; j++) { tblocks[task[j]] += ccount[j]; tcolsn[task[j]]++; }
-		auto task_lds = [&](int t) { return tblocks[t] * (288 + 4) + (5 * tcolsn[t] + 1) * 4 + 16; };
-		const long small_cap = 60 * 1024;
-		ch.tlevel_nsmall.assign(ntl, 0);
-		ch.tlevel_small_lds.assign(ntl, 0);
-		{
-			std::vector<int> f(ntl, 0);
-			for (int pass = 0; pass < 2; pass++)
-				for (int t = 0; t < ntasks; t++)
-				{
-					const bool small = task_lds(t) <= small_cap;
-					if (small != (pass == 0)) continue;
-					tpos[t] = tl_count[tlev[t]] + f[tlev[t]]++;
-					if (small) { ch.tlevel_nsmall[tlev[t]]++; ch.tlevel_small_lds[tlev[t]] = std::max(ch.tlevel_small_lds[tlev[t]], (int)task_lds(t)); }
-				}
-		}
-		for (int j = 0; j < M; j++) tsize[tpos[task[j]]]++;
-		std::vector<int> tptr(ntasks + 1, 0), tcols(M), tf(ntasks, 0);
-		for (int t = 0; t < ntasks; t++) tptr[t + 1] = tptr[t] + tsize[t];
-		for (int j = 0; j < M; j++) { const int t = tpos[task[j]]; tcols[tptr[t] + tf[t]++] = j; }
-		ch.tlevel_ptr = tl_count;
-		ch.tlevel_maxsize.assign(ntl, 0);
-		std::vector<int> ctask(M), clpos(M);
-		for (int t = 0; t < ntasks; t++)
-			for (int k = tptr[t]; k < tptr[t + 1]; k++) { ctask[tcols[k]] = t; clpos[tcols[k]] = k - tptr[t]; }
-		for (int l = 0; l < ntl; l++)
-			for (int t = tl_count[l]; t < tl_count[l + 1]; t++) ch.tlevel_maxsize[l] = std::max(ch.tlevel_maxsize[l], tsize[t]);
-		ch.tlevel_col0.assign(ntl + 1, 0);
-		for (int l = 0; l <= ntl; l++) ch.tlevel_col0[l] = tptr[tl_count[l]];
-		std::vector<int> nin(M, 0);
-		ch.tlevel_outer.assign(ntl, 0);
-		for (int j = 0; j < M; j++)
-		{
-			int m = 0;
-			while (colptr[j] + 1 + m < colptr[j + 1] && task[rowidx[colptr[j] + 1 + m]] == task[j]) m++;
-			nin[j] = m;
-			const int no = ccount[j] - 1 - m, l = tlev[task[j]];
-			ch.tlevel_outer[l] = std::max(ch.tlevel_outer[l], no * (no + 1) / 2);
-		}
-		// ---- supernode groups over the large columns (the factorisation above the leaf tasks) ----
-		{
-			std::vector<int> grp(M, -1), gc0, gs, glev;
-			for (int j = 0; j < M; j++)
-			{
-				if (size[j] <= task_x) continue;
-				const bool join = j > 0 && size[j - 1] > task_x && parent[j - 1] == j && ccount[j - 1] == ccount[j] + 1 && gs[grp[j - 1]] < CHOL_GS;
-				if (join) { grp[j] = grp[j - 1]; gs[grp[j]]++; }
-				else { grp[j] = (int)gc0.size(); gc0.push_back(j); gs.push_back(1); glev.push_back(0); }
-			}
-			const int ng = (int)gc0.size();
-			int ngl = 0;
-			for (int g = 0; g < ng; g++) // ascending first column: children before parents
-			{
-				const int pj = parent[gc0[g] + gs[g] - 1];
-				if (pj >= 0) glev[grp[pj]] = std::max(glev[grp[pj]], glev[g] + 1);
-				ngl = std::max(ngl, glev[g] + 1);
-			}
-			std::vector<int> gl_count(ngl + 1, 0), gfill(ngl, 0), o_c0(ng), o_s(ng), o_nr(ng);
-			for (int g = 0; g < ng; g++) gl_count[glev[g] + 1]++;
-			for (int l = 0; l < ngl; l++) gl_count[l + 1] += gl_count[l];
-			ch.glevel_maxnr.assign(ngl, 0);
-			for (int g = 0; g < ng; g++)
-			{
-				const int at = gl_count[glev[g]] + gfill[glev[g]]++;
-				o_c0[at] = gc0[g]; o_s[at] = gs[g]; o_nr[at] = ccount[gc0[g] + gs[g] - 1] - 1;
-				ch.glevel_maxnr[glev[g]] = std::max(ch.glevel_maxnr[glev[g]], o_nr[at]);
-			}
-			if (getenv("LSFM_DEBUG") && ng > 50)
-			{
-				// what relaxed amalgamation would buy: chains of groups (parent of a group's last column = first column of the next group)
-				int hist[CHOL_GS + 1] = { 0 };
-				for (int g = 0; g < ng; g++) hist[gs[g]]++;
-				fprintf(stderr, "[lsfm] groups %d, group levels %d, sizes:", ng, ngl);
-				for (int q = 1; q <= CHOL_GS; q++) fprintf(stderr, " %d", hist[q]);
-				long fills[6] = { 0 }; // boundaries j-1 | j inside a parent-child chain (parent[j-1] == j), by the fill a merge needs
-				for (int j = 1; j < M; j++)
-				{
-					if (size[j] <= task_x || size[j - 1] <= task_x || parent[j - 1] != j || grp[j] == grp[j - 1]) continue;
-					const int fill = ccount[j] + 1 - ccount[j - 1];
-					fills[fill <= 0 ? 0 : (fill <= 2 ? 1 : (fill <= 8 ? 2 : (fill <= 32 ? 3 : (fill <= 128 ? 4 : 5))))]++;
-				}
-				fprintf(stderr, " | chain boundaries by fill 0:%ld <=2:%ld <=8:%ld <=32:%ld <=128:%ld more:%ld\n", fills[0], fills[1], fills[2], fills[3], fills[4], fills[5]);
-				std::vector<int> per_level(ngl, 0);
-				for (int g = 0; g < ng; g++) per_level[glev[g]]++;
-				fprintf(stderr, "[lsfm] groups per level:");
-				for (int l = 0; l < ngl; l++) fprintf(stderr, " %d", per_level[l]);
-				fprintf(stderr, "\n");
-			}
-			ch.ngroups = ng;
-			ch.glevel_ptr = gl_count;
-			pack(&ch.grp_c0, o_c0); pack(&ch.grp_s, o_s); pack(&ch.grp_nr, o_nr);
-		}
-		pack(&ch.col_nin, nin); pack(&ch.col_task, ctask); pack(&ch.col_lpos, clpos); pack(&ch.task_cols, tcols); pack(&ch.task_ptr, tptr);
-	}
-	pack(&ch.colptr, colptr); pack(&ch.rowidx, rowidx); pack(&ch.perm, perm); pack(&ch.pinv, pinv); pack(&ch.order, order);
-	{
-		int* d_blob = sc.alloc<int>(blob.size());
-		h2d(ctx, d_blob, blob.data(), blob.size() * sizeof(int));
-		for (auto& pd : blob_dst) *pd.first = d_blob + pd.second;
-		ch.blob = d_blob; ch.blob_ints = blob.size();
-	}
+	h2d(ctx, d_blob, blob.data(), total * sizeof(int));
+	ch.blob = d_blob; ch.blob_ints = total;
 	chol_alloc_values(ctx, ch);
 	ch.d_err = sc.alloc<int>(1);
 	dev_zero(ctx, ch.d_err, sizeof(int));
+	if (getenv("LSFM_DEBUG") && sym.ngroups > 50)
+	{
+		int hist[CHOL_GS + 1] = { 0 };
+		for (int g = 0; g < sym.ngroups; g++) hist[sym.grp_s[g]]++;
+		fprintf(stderr, "[lsfm] groups %d, group levels %d, sizes:", sym.ngroups, (int)sym.glevel_ptr.size() - 1);
+		for (int q = 1; q <= CHOL_GS; q++) fprintf(stderr, " %d", hist[q]);
+		fprintf(stderr, " | groups per level:");
+		for (size_t l = 0; l + 1 < sym.glevel_ptr.size(); l++) fprintf(stderr, " %d", sym.glevel_ptr[l + 1] - sym.glevel_ptr[l]);
+		fprintf(stderr, "\n");
+	}
+}
+static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHostIn& in, CholDev& ch)
+{
+	static thread_local CholSymbolic sym;
+	chol_symbolic(in.keys.data(), sy.nnzb, in.origin.data(), sy.M, sym);
+	chol_upload_symbolic(ctx, sym, ch);
 }
 
 // the supernode-group path of the triangular solves applies (chol_apply): the forward substitution can ride on the factorisation

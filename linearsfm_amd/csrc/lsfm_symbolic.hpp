@@ -1,0 +1,31 @@
+// Host side of K10: ordering + symbolic factorisation of the camera system S of one tree level (all independent systems of
+// the level in one block matrix).  Stands where the reference calls cholmod_amd / cholmod_analyze_p in every join
+// (pba_solveCholmod{LM,GN}, Imp.cpp:2380-2449 / 7043-7121).  Plain C++ (no HIP): compiled by g++, callable without a
+// device -- lsfm_symbolic_analyse (include/lsfm.h) is the test / measurement entry.
+#pragma once
+#include <vector>
+
+namespace lsfm {
+
+#define CHOL_GS 16 /* most block columns of a supernode group (lsfm_pcg.hip: k_sn_panel keeps 6 * CHOL_GS dense scalar rows in LDS) */
+
+struct CholSymbolic {
+	int M = 0, nnzL = 0, nlevels = 0, tail_begin = 0;
+	// block CSC of L (row indices ascending inside a column, diagonal first), ordering
+	std::vector<int> colptr, rowidx, perm, pinv, order, level_ptr;
+	// tasks: connected pieces of the elimination tree that one work-group walks (leaf sub-trees; chains above them)
+	std::vector<int> task_cols, task_ptr, col_task, col_lpos, col_nin;
+	std::vector<int> tlevel_ptr, tlevel_maxsize, tlevel_col0, tlevel_nsmall, tlevel_small_lds, tlevel_outer;
+	// supernode groups over the columns above the leaf tasks, ordered by group level
+	int ngroups = 0;
+	std::vector<int> grp_c0, grp_s, grp_nr, glevel_ptr, glevel_maxnr;
+	// for the debug census
+	std::vector<int> parent, ccount;
+	int task_x = 0;
+};
+
+// keys[nnzb]: sorted (row << 32 | col) of the upper block pattern of S (every diagonal block present); origin[M]: index of
+// the local map that brought each pose (drives the nested dissection along the join tree).
+void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& out);
+
+} // namespace lsfm

@@ -221,6 +221,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		memset(&local, 0, sizeof local);
 		lsfm_stats* st = stats ? stats : &local;
 		ctx->stats = st;
+		struct InRun { lsfm_context* c; InRun(lsfm_context* x) : c(x) { c->in_tree_run = true; } ~InRun() { c->in_tree_run = false; } } in_run(ctx);
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 		try
 		{

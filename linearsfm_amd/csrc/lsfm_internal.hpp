@@ -19,6 +19,7 @@
 namespace lsfm {
 
 struct Error { int code; std::string msg; };
+struct DevBatch;
 
 #define LSFM_CHECK_HIP(expr)                                                                                   \
 	do {                                                                                                        \
@@ -77,6 +78,11 @@ struct DevBatch {
 	// such a map is W_alias[j + d_alias[map]] in the transform's INPUT (d_alias[map] == INT_MIN: materialised in W)
 	const double* W_alias = nullptr;
 	const int* d_alias = nullptr;
+	// Stereo tree levels that analyse: the sorted upper block pattern of the camera system this batch was solved with (null: not
+	// kept).  The next level's pattern contains it -- a joint feature is seen by everything its sources were seen by -- so it
+	// only adds the hub links and the pose pairs across the two maps of a pair (schur_pattern_early_issue)
+	const unsigned long long* s_keys = nullptr;
+	int s_nnzb = 0;
 };
 
 struct PcgOptions { double rel_tol = 1e-12; int max_steps = 50; bool mixed = false; int spmv_variant = 0; };
@@ -134,6 +140,18 @@ struct lsfm_context {
 	hipStream_t stream2 = nullptr;
 	hipEvent_t evA = nullptr, evB = nullptr;
 	bool pattern_dep = false;
+	// Early pattern of S (Stereo tree levels that analyse): the pose pairs of the JOINT map follow from the level's input index
+	// arrays, the feature matches and the hub pose of every transformed map, all known before the transform's heavy kernels
+	// run -- the pattern is put together on the side stream while those run, and the host's symbolic analysis no longer
+	// waits for them (lsfm_solve.hip: schur_pattern_early_*).  tr_in / tr_hub: set by transform_batch around its hook.
+	const lsfm::DevBatch* tr_in = nullptr;
+	const int* tr_hub = nullptr;        // [B] global pose index of the hub column of every transformed map, -1: passed through
+	std::shared_ptr<void> early;        // the build in flight (null: none)
+	hipStream_t stream3 = nullptr;      // its own stream: the side stream carries the transform's U stage, which waits for the block kernel
+	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)
+	int solved_nnzb = 0;
+	bool in_tree_run = false;           // lsfm_tree_run: errors of a level may be left in d_run and read at the end of the run
+	hipEvent_t evC = nullptr;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run
 	lsfm::LevelPlan* plan = nullptr; // plan of the tree level being run (null: stage-level calls, nothing is recorded or reused)
 	bool warm() const { return plan && plan->valid; }
@@ -230,6 +248,17 @@ struct SolveIO {
 	std::vector<int> seg_rows;         // host: block rows per segment
 };
 int solve_batch(lsfm_context* ctx, const SolveIO& io);
+// what the early pattern is made from: X = the level's input batch (index arrays only), per joint feature its source
+// features in X (srcE / srcC, -1: none), per map of X its hub pose
+struct EarlyPatternIn {
+	int M = 0, NFY = 0, NU = 0;
+	const int *Ui = nullptr, *Uj = nullptr, *pose_map = nullptr, *hub = nullptr;
+	const int *fptr = nullptr, *photo = nullptr, *feat_map = nullptr, *srcE = nullptr, *srcC = nullptr;
+	const unsigned long long* prev_keys = nullptr; // pattern of the level below (DevBatch::s_keys), null: none
+	int prev_nnzb = 0;
+};
+void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in); // enqueues on the side stream; the caller has recorded evC
+void schur_pattern_early_drop(lsfm_context* ctx);
 // the block pattern of S alone (K8), from the index members of io: upper block CSR left in the scratch arena
 void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx);
 int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,

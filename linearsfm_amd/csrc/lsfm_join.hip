@@ -242,6 +242,7 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	hipStream_t s = ctx->stream;
 	const int B = in.B, G = (B + 1) / 2;
 	st.smark = ctx->scratch.mark();
+	st.ar = &ar;
 
 	// ---- common features (K5) ----
 	int* match = ctx->scratch.alloc<int>(in.NF + 1);
@@ -317,12 +318,35 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	double* eF = st.eF = ctx->scratch.alloc<double>((size_t)NFY * 3);
 	zs.zero(s);
 	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
+	// a level that analyses, reached through the transform's hook: the sources of every joint feature, for the early pattern of S
+	static const bool early_on = !getenv("LSFM_NO_EARLY_PATTERN");
+	const bool early = early_on && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
+	int *srcE = nullptr, *srcC = nullptr;
+	if (early)
+	{
+		srcE = ctx->scratch.alloc<int>(NFY + 1); srcC = ctx->scratch.alloc<int>(NFY + 1);
+		LSFM_CHECK_HIP(hipMemsetAsync(srcE, 0xff, sizeof(int) * (size_t)(NFY + 1), s));
+		LSFM_CHECK_HIP(hipMemsetAsync(srcC, 0xff, sizeof(int) * (size_t)(NFY + 1), s));
+	}
 	if (in.NF)
 		for (int side = 0; side < 2; side++)
 			hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,
-			                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, (int*)nullptr, (int*)nullptr, side);
+			                   newf, lenE, lenC, out.V, eF, out.feat_id, out.feat, srcE, srcC, side);
+	if (early)
+	{
+		const DevBatch& X = *ctx->tr_in; // the level's input: its W runs and U blocks with the poses they had before the transform
+		EarlyPatternIn ei;
+		ei.M = in.M; ei.NFY = NFY; ei.NU = X.NU;
+		ei.Ui = X.Ui; ei.Uj = X.Uj; ei.pose_map = X.pose_map; ei.hub = ctx->tr_hub;
+		ei.fptr = X.fptr; ei.photo = X.photo; ei.feat_map = X.feat_map; ei.srcE = srcE; ei.srcC = srcC;
+		ei.prev_keys = X.s_keys; ei.prev_nnzb = X.s_nnzb;
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evC, s));
+		schur_pattern_early_issue(ctx, ei);
+	}
+	else schur_pattern_early_drop(ctx);
 	hipLaunchKernelGGL(k_add_lens, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY, lenE, lenC, lens);
 	dev_exclusive_scan(ctx, lens, out.fptr, NFY);
+	if (early) LSFM_CHECK_HIP(hipEventRecord(ctx->evC, s)); // the joint run pointers: the second half of the early pattern reads them
 	// where the run of every input feature starts in the joint map
 	st.wbase = ctx->scratch.alloc<int>(in.NF + 1);
 	if (in.NF) hipLaunchKernelGGL(k_join_wbase, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, newf, lenE, out.fptr, st.wbase);
@@ -345,8 +369,9 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
 		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
 	}
-	// everything the pattern of S needs is enqueued: the solve may build it beside the right-hand sides
-	if (!eP_out && !eF_out)
+	// everything the pattern of S needs is enqueued: the solve may build it beside the right-hand sides (unless it is under
+	// way already: schur_pattern_early_issue)
+	if (!eP_out && !eF_out && !ctx->early)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s));
 		ctx->pattern_dep = true;
@@ -371,8 +396,18 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	io.x_pose = out.pose; io.x_feat = out.feat;
 	io.seg_rows = seg_rows;
 	const bool warm = ctx->warm();
+	ctx->solved_keys = nullptr; ctx->solved_nnzb = 0;
 	int rc = solve_batch(ctx, io);
-	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s)); // a warm level is only enqueued: its scratch is reused in stream order
+	if (!warm && st.ar && ctx->in_tree_run && ctx->solved_keys && !getenv("LSFM_NO_EARLY_PATTERN"))
+	{
+		// the pattern of this level's system stays with its output for the level above (schur_pattern_early_issue)
+		unsigned long long* k = st.ar->alloc<unsigned long long>((size_t)ctx->solved_nnzb + 1);
+		LSFM_CHECK_HIP(hipMemcpyAsync(k, ctx->solved_keys, (size_t)ctx->solved_nnzb * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+		out.s_keys = k; out.s_nnzb = ctx->solved_nnzb;
+	}
+	// a level of a tree run is only enqueued (its scratch is reused in stream order, errors are read at the end of the run); a
+	// stage-level call stops here so that a failure surfaces at its stage
+	if (!warm && !ctx->in_tree_run) LSFM_CHECK_HIP(hipStreamSynchronize(s));
 	ctx->scratch.release(st.smark);
 	if (rc > 0 && ctx->stats) ctx->stats->not_converged += rc;
 	if (ctx->plan && !eP_out && !eF_out) ctx->plan->valid = true; // every stage of the level has left its structure behind

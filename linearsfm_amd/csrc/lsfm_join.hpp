@@ -13,6 +13,7 @@ struct JGroup {
 // state of a Stereo join between its two steps (lsfm_join.hip)
 struct JoinState {
 	size_t smark = 0;
+	Arena* ar = nullptr; // where the joint map lives
 	int *newf = nullptr, *lenE = nullptr, *srcf = nullptr, *wbase = nullptr;
 	double *eP = nullptr, *eF = nullptr;
 	std::vector<unsigned char> seg_active;

@@ -1555,7 +1555,40 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		// to them; the values wait for both.
 		static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
 		schur_vinv(ctx, io, sy);
-		if (side && ctx->pattern_dep)
+		bool have = false;
+		if (ctx->early)
+		{
+			// the pattern was put together on the side stream from the level's inputs while the transform ran (a Stereo level
+			// that analyses): its second half, and the copy of it for the host's analysis, stay there
+			ctx->pattern_dep = false;
+			LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evC, 0)); // (recorded again once the joint run pointers were enqueued)
+			std::swap(ctx->stream, ctx->stream3);
+			try
+			{
+				have = schur_pattern_early_finish(ctx, io, sy);
+				if (have)
+				{
+					if (getenv("LSFM_CHECK_EARLY_PATTERN"))
+					{
+						// debug / test: the pattern built from the finished joint map must be the same one
+						LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream3)); // (the main stream, swapped out: the joint map's index arrays)
+						SchurSystem ref;
+						build_schur_pattern(ctx, io, ref);
+						std::vector<unsigned long long> a(sy.nnzb), b(ref.nnzb);
+						d2h(ctx, a.data(), sy.upper_keys, a.size() * sizeof(unsigned long long));
+						d2h(ctx, b.data(), ref.upper_keys, b.size() * sizeof(unsigned long long));
+						if (a != b) LSFM_FAIL(LSFM_ERR_INTERNAL, "early pattern of S (" + std::to_string(a.size()) + " blocks) differs from the joint map's (" + std::to_string(b.size()) + ")");
+					}
+					chol_fetch(ctx, sy, io.d_pose_origin, hin);
+					LSFM_CHECK_HIP(hipEventRecord(ctx->evB, ctx->stream));
+				}
+			}
+			catch (...) { std::swap(ctx->stream, ctx->stream3); throw; }
+			std::swap(ctx->stream, ctx->stream3);
+			if (have) LSFM_CHECK_HIP(hipStreamWaitEvent(s, ctx->evB, 0));
+		}
+		if (have) {}
+		else if (side && ctx->pattern_dep)
 		{
 			ctx->pattern_dep = false;
 			LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evA, 0));
@@ -1625,12 +1658,16 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipLaunchKernelGGL(k_copy, dim3(nbe), dim3(256), 0, s, nscal, z, p);
 	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
 	dev_zero(ctx, Ap, nscal * sizeof(double));
-	if (warm) hipLaunchKernelGGL(k_chol_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run); // reported at the end of the run
-	else
-	{
-		int cerr = d2h_int(ctx, d_err);
+	// inside a tree run the outcome of a level (a non-positive pivot, systems left above their bound, the largest residual) is
+	// left in the run's device record and read once at the end of the run; a stage-level call, and a level whose structure is
+	// being recorded as a plan, reads it here
+	const bool deferred = warm || (ctx->in_tree_run && ctx->d_run && !lp);
+	ctx->solved_keys = sy.upper_keys; ctx->solved_nnzb = sy.nnzb;
+	auto check_factor = [&]() {
+		const int cerr = d2h_int(ctx, d_err);
 		if (cerr) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
-	}
+	};
+	if (deferred) hipLaunchKernelGGL(k_chol_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run); // reported at the end of the run
 
 	// One refinement step: x += alpha p, true residual, convergence test per system (converged systems freeze), then the
 	// preconditioner for the next step.  A first run reads the number of finished systems back after every step; a warm
@@ -1639,7 +1676,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	const int maxit = std::max(1, std::min(50, ctx->pcg.max_steps));
 	// the step count was recorded with the preconditioner in this precision, for this tolerance, under this cap
 	const bool planned_run = warm && sp->mixed == mixed && sp->rel_tol == ctx->pcg.rel_tol && sp->its <= maxit;
-	int its = 0, ndone = planned_run ? 0 : d2h_int(ctx, d_misc + 1);
+	// (a run that counts its steps does not stop to ask before the first one either: systems that start below their bound
+	// are frozen on the device, the step costs them nothing)
+	int its = 0, ndone = 0;
 	const int planned = planned_run ? sp->its : maxit;
 	while ((planned_run ? its < planned : (ndone < nseg && its < maxit)))
 	{
@@ -1655,6 +1694,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		else
 		{
 			ndone = d2h_int(ctx, d_misc + 1);
+			if (its == 1 && !deferred) check_factor(); // (the stream is drained: this costs no second wait)
 			if (ndone >= nseg) break;
 		}
 		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
@@ -1693,9 +1733,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		st->spmv_bytes += nsample * spmv_bytes(sy);
 		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
 	}
-	if (warm)
+	if (deferred)
 	{
-		if (!planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt
+		if (warm && !planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt
 		hipLaunchKernelGGL(k_pcg_run_stats, dim3(nbs), dim3(128), 0, s, nseg, seg, ctx->d_run);
 		return 0; // the outcome is read at the end of the run (lsfm_tree_run)
 	}

@@ -203,8 +203,10 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipSetDevice(device));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		c->stage_size = (size_t)64 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
@@ -246,8 +248,11 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->d_run) (void)hipFree(c->d_run);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	if (c->stream3) (void)hipStreamDestroy(c->stream3);
 	if (c->evA) (void)hipEventDestroy(c->evA);
 	if (c->evB) (void)hipEventDestroy(c->evB);
+	if (c->evC) (void)hipEventDestroy(c->evC);
+	c->early.reset();
 	delete c;
 }
 

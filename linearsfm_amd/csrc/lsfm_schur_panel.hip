@@ -35,8 +35,9 @@ namespace lsfm {
 #define PM_SMAX_MAX 64  /* the widest panel: the same 1024 threads take its 300 output tiles in two sweeps over the tile's passes */
 #define PM_HASH 64
 #define PM_THREADS 256
+#define PM_WIDE 512     /* threads of the 32 / 48 / 64-slot variants */
 #define PM_MAXE 3584 /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 per feature on average); later ones are added after the first blocks */
-#define PM_BF 352   /* >= rows held in registers per pass / 6 (4 x 256 or 2 x 1024) */
+#define PM_BF 352   /* >= rows held in registers per pass / 6 (4 x 256 or 3 x 512) */
 #define PM_DUP 0x80  /* eslot: a block whose (pose, feature) an earlier block of the tile already holds */
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -136,7 +137,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	// pointers, its L read from the staged copy.  (Measured before: staging with the global loads inside 4.5 of K9's 9.5 ms;
 	// the per-pass Cholesky of V^-1 behind a dependent load a quarter of a tile; 16 lanes per feature -- a feature seen by
 	// more than 10 poses went back to memory inside the staging -- a third of it.)
-	constexpr int PF = THREADS != 256 ? 2 : (T <= 9 ? 4 : (T <= 14 ? 3 : 2)); // rows per lane in flight: 4 x 256 rows = 10.6 poses per feature on average
+	constexpr int PF = THREADS != 256 ? (T <= 6 ? 3 : 2) : (T <= 9 ? 4 : (T <= 14 ? 3 : 2)); // rows per lane in flight: 4 x 256 rows = 10.6 poses per feature on average
 	double pw[PF][3];
 	double lyv = 0.0;
 	int qb0 = 0, R = 0;
@@ -375,27 +376,25 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		else if (tpw <= 3) PM_GO(3);
 		else PM_GO(6); // 96 rows: 21 tiles over 4 waves
 	}
-	else if constexpr (THREADS == 256)
+	else
 	{
+		// 32 / 48 / 64 slots: 512 threads -- eight waves, two to a SIMD, so that a wave may hold 256 registers: at most 13 output
+		// tiles (104 accumulator registers) per wave and sweep, nothing spills (the 1024-thread work-groups of round 2 capped a
+		// wave at 128 registers: 400-640 spilled registers in the 48 / 64-slot variants).  Wider panels take their output tiles
+		// in sweeps over the tile's passes: 32 slots 78 tiles = 10 per wave, 48 slots 171 tiles = 2 sweeps of 11, 64 slots
+		// 300 tiles = 3 sweeps of 13.
+		constexpr int TS = SMAX <= PM_SMAX ? 10 : (SMAX <= PM_SMAX_BIG ? 11 : 13);
 		if (tpw <= 1) PM_GO(1);
 		else if (tpw <= 3) PM_GO(3);
 		else if (tpw <= 6) PM_GO(6);
-		else if (tpw <= 9) PM_GO(9);
-		else if (tpw <= 14) PM_GO(14);
-		else PM_GO(20);
-	}
-	else
-	{
-		if (tpw <= 6) PM_GO(6);
-		else if (tpw <= 9) PM_GO(9);
-		else if (tpw <= 11 || SMAX <= PM_SMAX_BIG) PM_GO(11);
-		else if constexpr (SMAX > PM_SMAX_BIG)
+		else if (tpw <= TS) PM_GO(TS);
+		else
 		{
-			// 49 to 64 poses (Mono far up a deep tree: two hub blocks per feature and level): up to 300 output tiles, more
-			// accumulators than 16 waves hold -- two sweeps over the tile's passes, ten output tiles per wave each
-			pm_body<10, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, 0, true);
-			if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
-			pm_body<10, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, 10 * (THREADS / 64), false);
+			for (int q0 = 0; q0 < NW * tpw; q0 += NW * TS)
+			{
+				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, q0, q0 == 0);
+				if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
+			}
 		}
 	}
 #undef PM_GO
@@ -407,7 +406,10 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 // A tile is then all latency -- hashing, eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
 // work-groups share a CU instead of 2.
 template <int SMAX, int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : (SMAX <= 16 ? 3 : 2)))
+#ifndef LSFM_K9_OCC16
+#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
+#endif
+__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : LSFM_K9_OCC16))
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
               const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
               double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only, K9Cache kc)
@@ -560,11 +562,11 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	// the tiles it flags go to the 32-slot variant, what that one flags to the 48-slot one, the rest to k_schur_w
 	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 	                   (const unsigned char*)nullptr, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E,
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E,
 	                   fallback, (const unsigned char*)fallback, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE>), grid, dim3(PM_WIDE), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 	                   (const unsigned char*)fallback, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, 1024>), grid, dim3(1024), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
 	                   (const unsigned char*)fallback, kc);
 }
 

@@ -638,61 +638,231 @@ void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY);
 }
 
-// Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only
-void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+// ---- Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only ----
+// In three steps so that the pair insertion can come from the joint map (build_schur_pattern) or, earlier, from what the
+// joint map is made of (schur_pattern_early_issue): table set-up, [inserts], compaction (all enqueued); then -- after the
+// one read-back of the count -- sort, block CSR, SpMV index.
+struct PatternBuild {
+	unsigned long long *tab = nullptr, *list = nullptr, *d_k2 = nullptr;
+	int *hval = nullptr, *d_flags = nullptr; // [0] overflow, [1] count
+	size_t cap = 0;
+};
+static size_t pattern_capacity(size_t NU, size_t M)
+{
+	// S has little more than U's pattern (the W-induced pairs are mostly hub links that U already holds): 4x head room over
+	// NU + 8 M entries; a table that overflows is rebuilt larger
+	size_t cap = 1024;
+	while (cap < 4 * (NU + 8 * M + 64)) cap <<= 1;
+	return cap;
+}
+static void pattern_begin(lsfm_context* ctx, size_t cap, PatternBuild& pb)
+{
+	Arena& sc = ctx->scratch;
+	pb.cap = cap;
+	pb.tab = sc.alloc<unsigned long long>(cap);
+	pb.hval = sc.alloc<int>(cap);
+	pb.list = sc.alloc<unsigned long long>(cap);
+	pb.d_flags = sc.alloc<int>(4);
+	dev_zero(ctx, pb.d_flags, 4 * sizeof(int));
+	hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, pb.tab, cap, HEMPTY);
+}
+static void pattern_compact(lsfm_context* ctx, PatternBuild& pb)
+{
+	hipLaunchKernelGGL(k_pat_compact, dim3((unsigned)((pb.cap + 255) / 256)), dim3(256), 0, ctx->stream, pb.cap, pb.tab, pb.list, pb.d_flags + 1);
+}
+// reads the count back (synchronises ctx->stream); false: the table overflowed or is more than half full
+static bool pattern_count(lsfm_context* ctx, const PatternBuild& pb, int* cnt)
+{
+	int fl[2];
+	d2h_ints(ctx, pb.d_flags, fl, 2);
+	*cnt = fl[1];
+	return !fl[0] && (size_t)fl[1] * 2 <= pb.cap;
+}
+static void pattern_finish(lsfm_context* ctx, const SolveIO& io, const PatternBuild& pb, int cnt, SchurSystem& sy)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
 	const int M = io.M, NF = io.NF;
 	sy.M = M;
-	int* d_flags = sc.alloc<int>(4); // [0] overflow, [1] count, [2] mirrored count
+	sy.nnzb = cnt;
+	// sum over the features of (run length)^2: the pose pairs of K9, for its algorithmic flop count
 	unsigned long long* d_k2 = sc.alloc<unsigned long long>(1);
 	dev_zero(ctx, d_k2, sizeof(unsigned long long));
 	if (NF) hipLaunchKernelGGL(k_sum_run_squares, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, d_k2);
-	size_t cap = 1024;
-	// S has little more than U's pattern (the W-induced pairs are mostly hub links that U already holds): 4x head room over
-	// NU + 8 M entries; the loop below grows the table if a level needs more
-	while (cap < (size_t)4 * ((size_t)io.NU + 8 * (size_t)M + 64)) cap <<= 1;
-	unsigned long long *tab = nullptr, *list = nullptr;
-	int* hval = nullptr;
+	const unsigned long long mask = (unsigned long long)(pb.cap - 1);
+	int* dummy = sc.alloc<int>(cnt + 1);
+	dev_sort_pairs_u64(ctx, pb.list, dummy, cnt, 64);
+	sy.rowptr = sc.alloc<int>(M + 1);
+	sy.colidx = sc.alloc<int>(cnt + 1);
+	if (cnt) hipLaunchKernelGGL(k_pat_assign, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, pb.list, pb.tab, pb.hval, mask, sy.colidx);
+	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, cnt, pb.list, 32, sy.rowptr);
+	sy.tab = pb.tab; sy.hval = pb.hval; sy.mask = mask;
+	sy.upper_keys = pb.list;
+	build_spmv_index(ctx, sy, pb.list, pb.d_flags);
+	unsigned long long k2 = 0;
+	d2h(ctx, &k2, d_k2, sizeof k2);
+	sy.k9_flops = (double)io.NW * 144.0 + ((double)k2 + (double)io.NW) * 0.5 * 216.0;
+	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+{
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	const int M = io.M, NF = io.NF;
+	size_t cap = pattern_capacity(io.NU, M);
 	for (int attempt = 0;; attempt++)
 	{
-		size_t mk = sc.mark();
-		tab = sc.alloc<unsigned long long>(cap);
-		hval = sc.alloc<int>(cap);
-		list = sc.alloc<unsigned long long>(cap);
-		dev_zero(ctx, d_flags, 4 * sizeof(int));
-		hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, tab, cap, HEMPTY);
+		const size_t mk = sc.mark();
+		PatternBuild pb;
+		pattern_begin(ctx, cap, pb);
 		const int nu = std::max(io.NU, M);
-		if (nu) hipLaunchKernelGGL(k_pat_insert_u, dim3((nu + 255) / 256), dim3(256), 0, s, io.NU, M, io.Ui, io.Uj, tab, (unsigned long long)(cap - 1), d_flags);
-		if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, tab, (unsigned long long)(cap - 1), d_flags);
-		hipLaunchKernelGGL(k_pat_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, cap, tab, list, d_flags + 1);
-		int fl[2];
-		d2h_ints(ctx, d_flags, fl, 2);
-		if (!fl[0] && (size_t)fl[1] * 2 <= cap)
-		{
-			sy.nnzb = fl[1];
-			unsigned long long k2 = 0;
-			d2h(ctx, &k2, d_k2, sizeof k2);
-			sy.k9_flops = (double)io.NW * 144.0 + ((double)k2 + (double)io.NW) * 0.5 * 216.0;
-			break;
-		}
+		if (nu) hipLaunchKernelGGL(k_pat_insert_u, dim3((nu + 255) / 256), dim3(256), 0, s, io.NU, M, io.Ui, io.Uj, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
+		if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
+		pattern_compact(ctx, pb);
+		int cnt = 0;
+		if (pattern_count(ctx, pb, &cnt)) { pattern_finish(ctx, io, pb, cnt, sy); return; }
 		sc.release(mk);
 		cap <<= 2;
 		if (attempt > 10) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur pattern hash table kept overflowing");
 	}
-	const int cnt = sy.nnzb;
-	const unsigned long long mask = (unsigned long long)(cap - 1);
-	int* dummy = sc.alloc<int>(cnt + 1);
-	dev_sort_pairs_u64(ctx, list, dummy, cnt, 64);
-	sy.rowptr = sc.alloc<int>(M + 1);
-	sy.colidx = sc.alloc<int>(cnt + 1);
-	if (cnt) hipLaunchKernelGGL(k_pat_assign, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, list, tab, hval, mask, sy.colidx);
-	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, cnt, list, 32, sy.rowptr);
-	sy.tab = tab; sy.hval = hval; sy.mask = mask;
-	sy.upper_keys = list;
-	build_spmv_index(ctx, sy, list, d_flags);
-	LSFM_CHECK_HIP(hipGetLastError());
+}
+
+// ---- the same pattern, earlier ------------------------------------------------------------------------------------------
+// The joint map of a Stereo join is the two input maps side by side: a joint feature is seen by the poses of its End source,
+// the poses of its Cur source, and the hub pose of either map that is transformed on the way (the transform gives every feature
+// of the map a block to the hub pose, Imp.cpp:1303-1309, and folds old blocks to it into that one); U' holds U's pairs and
+// (k, hub) for every pose k of a transformed map (Imp.cpp:711-723).  All of that is known from the level's INPUT index arrays
+// once the features are matched -- before the transform's block kernels have run.
+__global__ void k_pat_insert_u_early(int NU, int M, const int* __restrict__ Ui, const int* __restrict__ Uj, const int* __restrict__ pose_map,
+                                     const int* __restrict__ hub, unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < NU) hash_insert(tab, mask, pair_key(Ui[i], Uj[i]), overflow);
+	if (i < M)
+	{
+		hash_insert(tab, mask, pair_key(i, i), overflow);
+		const int h = hub[pose_map[i]];
+		if (h >= 0) hash_insert(tab, mask, pair_key(i, h), overflow);
+	}
+}
+__global__ void __launch_bounds__(256)
+k_pat_insert_w_early(int NFY, const int* __restrict__ srcE, const int* __restrict__ srcC, const int* __restrict__ fptr, const int* __restrict__ photo,
+                     const int* __restrict__ feat_map, const int* __restrict__ hub, unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool inb = nf < NFY;
+	int jE = 0, lenE = 0, hE = -1, jC = 0, lenC = 0, hC = -1;
+	if (inb)
+	{
+		const int fe = srcE[nf], fc = srcC[nf];
+		if (fe >= 0) { jE = fptr[fe]; lenE = fptr[fe + 1] - jE; hE = hub[feat_map[fe]]; }
+		if (fc >= 0) { jC = fptr[fc]; lenC = fptr[fc + 1] - jC; hC = hub[feat_map[fc]]; }
+	}
+	const int nE = lenE + (hE >= 0 ? 1 : 0), len = nE + lenC + (hC >= 0 ? 1 : 0);
+	auto pose_at = [&](int i) -> int {
+		if (i < lenE) return photo[jE + i];
+		if (i < nE) return hE;
+		i -= nE;
+		return i < lenC ? photo[jC + i] : hC;
+	};
+	int maxlen = len;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, LSFM_WAVE));
+	const int lane = threadIdx.x & (LSFM_WAVE - 1);
+	for (int a = 0; a < maxlen; a++)
+	{
+		const int pa = (inb && a < len) ? pose_at(a) : -1;
+		for (int b = a + 1; b < maxlen; b++)
+		{
+			const bool v = inb && b < len;
+			unsigned long long key = v ? pair_key(pa, pose_at(b)) : 0ull;
+			unsigned long long m = __ballot(v);
+			if (m == 0ull) continue;
+			int leader = __ffsll((long long)m) - 1;
+			unsigned long long first = (unsigned long long)__shfl((long long)key, leader, LSFM_WAVE);
+			bool uniform = __ballot(v && key != first) == 0ull;
+			if (uniform) { if (lane == leader) hash_insert(tab, mask, key, overflow); }
+			else if (v) hash_insert(tab, mask, key, overflow);
+		}
+	}
+}
+
+// the pairs across the two sources of a matched joint feature (everything else of the level's pattern is in the pattern of the
+// level below or a hub link): (poses of End's run + End's hub) x (poses of Cur's run + Cur's hub)
+__global__ void __launch_bounds__(256)
+k_pat_insert_w_cross(int NFY, const int* __restrict__ srcE, const int* __restrict__ srcC, const int* __restrict__ fptr, const int* __restrict__ photo,
+                     const int* __restrict__ feat_map, const int* __restrict__ hub, unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+	if (nf >= NFY) return;
+	const int fe = srcE[nf], fc = srcC[nf];
+	if (fe < 0 || fc < 0) return;
+	const int jE = fptr[fe], lenE = fptr[fe + 1] - jE, hE = hub[feat_map[fe]];
+	const int jC = fptr[fc], lenC = fptr[fc + 1] - jC, hC = hub[feat_map[fc]];
+	for (int a = 0; a <= lenE; a++)
+	{
+		const int pa = a < lenE ? photo[jE + a] : hE;
+		if (pa < 0) continue;
+		for (int b = 0; b <= lenC; b++)
+		{
+			const int pb = b < lenC ? photo[jC + b] : hC;
+			if (pb >= 0) hash_insert(tab, mask, pair_key(pa, pb), overflow);
+		}
+	}
+}
+__global__ void k_pat_insert_keys(int n, const unsigned long long* __restrict__ keys, unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) hash_insert(tab, mask, keys[i], overflow);
+}
+
+struct EarlyPattern { PatternBuild pb; int M = 0; };
+
+void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in)
+{
+	ctx->early.reset();
+	auto ep = std::make_shared<EarlyPattern>();
+	ep->M = in.M;
+	// on the side stream, behind the point of the main stream where the matches and the hub poses are known (evC)
+	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evC, 0));
+	std::swap(ctx->stream, ctx->stream3);
+	try
+	{
+		hipStream_t s = ctx->stream;
+		const size_t cap = pattern_capacity(std::max((size_t)in.NU + in.M, (size_t)in.prev_nnzb + in.M), in.M);
+		pattern_begin(ctx, cap, ep->pb);
+		const int nu = std::max(in.NU, in.M);
+		const unsigned long long mask = (unsigned long long)(cap - 1);
+		if (nu) hipLaunchKernelGGL(k_pat_insert_u_early, dim3((nu + 255) / 256), dim3(256), 0, s, in.NU, in.M, in.Ui, in.Uj, in.pose_map, in.hub, ep->pb.tab, mask, ep->pb.d_flags);
+		if (in.prev_keys)
+		{
+			// the level below left its pattern: every pair inside one source map is in it; what is new are the pairs across
+			if (in.prev_nnzb) hipLaunchKernelGGL(k_pat_insert_keys, dim3((in.prev_nnzb + 255) / 256), dim3(256), 0, s, in.prev_nnzb, in.prev_keys, ep->pb.tab, mask, ep->pb.d_flags);
+			if (in.NFY) hipLaunchKernelGGL(k_pat_insert_w_cross, dim3((in.NFY + 255) / 256), dim3(256), 0, s, in.NFY, in.srcE, in.srcC, in.fptr, in.photo, in.feat_map, in.hub, ep->pb.tab, mask, ep->pb.d_flags);
+		}
+		else if (in.NFY) hipLaunchKernelGGL(k_pat_insert_w_early, dim3((in.NFY + 255) / 256), dim3(256), 0, s, in.NFY, in.srcE, in.srcC, in.fptr, in.photo, in.feat_map, in.hub, ep->pb.tab, mask, ep->pb.d_flags);
+		pattern_compact(ctx, ep->pb);
+		LSFM_CHECK_HIP(hipGetLastError());
+	}
+	catch (...) { std::swap(ctx->stream, ctx->stream3); throw; }
+	std::swap(ctx->stream, ctx->stream3);
+	ctx->early = ep;
+}
+void schur_pattern_early_drop(lsfm_context* ctx) { ctx->early.reset(); }
+
+// Second half, on the stream ctx->stream currently names (the caller has swapped the side stream in): count, sort, block CSR.
+// false: no early build in flight, or its table overflowed -- the caller builds the pattern from the joint map instead.
+bool schur_pattern_early_finish(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+{
+	std::shared_ptr<void> keep = ctx->early;
+	ctx->early.reset();
+	EarlyPattern* ep = static_cast<EarlyPattern*>(keep.get());
+	if (!ep || ep->M != io.M) return false;
+	int cnt = 0;
+	if (!pattern_count(ctx, ep->pb, &cnt)) return false;
+	pattern_finish(ctx, io, ep->pb, cnt, sy);
+	return true;
 }
 
 void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx)

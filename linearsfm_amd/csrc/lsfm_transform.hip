@@ -1029,6 +1029,12 @@ __global__ void k_tr_patch(TMap* tm, const int4* __restrict__ offs, int B)
 	const int4 o = offs[b];
 	tm[b].kU0 = o.x; tm[b].kW0 = o.y; tm[b].U0n = o.z; tm[b].W0n = o.w;
 }
+// hub pose of every map for the early pattern of S (lsfm_solve.hip): the dense column a transformed map gets, -1: passed through
+__global__ void k_tr_export_hubs(const TMap* __restrict__ tm, int B, int* __restrict__ hub)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < B) hub[b] = tm[b].active > 0 ? tm[b].hub[0] : -1;
+}
 __global__ void k_tr_err_to_run(const int* err, RunStatsDev* run)
 {
 	if (*err && !run->tr_err) run->tr_err = *err;
@@ -1094,6 +1100,14 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		hipLaunchKernelGGL(k_tr_params1, dim3((B + 127) / 128), dim3(128), 0, s, in.pose, d_tm, B, d_err);
 		hipLaunchKernelGGL(k_tr_new_poses, dim3((M + 255) / 256), dim3(256), 0, s, in.pose, in.pose_id, in.pose_map, M, d_tm, out.pose, out.pose_id);
 		hipLaunchKernelGGL(k_tr_params2, dim3((B + 127) / 128), dim3(128), 0, s, out.pose, d_tm, B);
+	}
+	ctx->tr_in = nullptr; ctx->tr_hub = nullptr;
+	if (hook && !mono && B)
+	{
+		// for the consumer laid out inside the hook (a Stereo join that analyses): what the early pattern of S is made from
+		int* d_hub = ctx->scratch.alloc<int>(B);
+		hipLaunchKernelGGL(k_tr_export_hubs, dim3((B + 127) / 128), dim3(128), 0, s, d_tm, B, d_hub);
+		ctx->tr_in = &in; ctx->tr_hub = d_hub;
 	}
 	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
 	// Stereo: + the 27 pose-dependent entries of (D_k, C_k) packed per pose, for k_tr_entries (after the one C section)
@@ -1207,9 +1221,12 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act, hook);
 	LSFM_CHECK_HIP(hipGetLastError());
 	(void)any;
+	ctx->tr_in = nullptr; ctx->tr_hub = nullptr;
 	// Scratch is released for the caller's next stage: everything that touches it is ordered on the main stream (the side
-	// stream's part rejoins it through evB above).  A first run also stops here so that a failure surfaces at its stage.
-	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	// stream's part rejoins it through evB above).  A first run also stops here so that a failure surfaces at its stage --
+	// unless its consumer was laid out inside the hook: that one goes on enqueuing (its solve stops for the device soon
+	// enough), so that the host's part of the solve's analysis runs beside these kernels, not after them.
+	if (!warm && !hook) LSFM_CHECK_HIP(hipStreamSynchronize(s));
 	if (!hook) ctx->scratch.release(smark); // with a hook its allocations outlive this call: the caller releases
 }
 

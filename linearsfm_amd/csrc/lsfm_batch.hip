@@ -15,14 +15,25 @@ __global__ void k_fill_segment_ids(const int* __restrict__ off, int B, int* __re
 	seg[i] = lo;
 }
 
-void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b)
+void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b, CopyBatch* cb)
 {
 	b.d_pose_off = ar.alloc<int>(b.B + 1);
 	b.d_feat_off = ar.alloc<int>(b.B + 1);
-	h2d(ctx, b.d_pose_off, b.pose_off.data(), (b.B + 1) * sizeof(int));
-	h2d(ctx, b.d_feat_off, b.feat_off.data(), (b.B + 1) * sizeof(int));
 	b.pose_map = ar.alloc<int>(b.M);
 	b.feat_map = ar.alloc<int>(b.NF);
+	if (cb)
+	{
+		// the caller's batch carries the two offset arrays; it calls batch_fill_maps once the batch is flushed
+		cb->h2d(b.d_pose_off, b.pose_off.data(), (b.B + 1) * sizeof(int));
+		cb->h2d(b.d_feat_off, b.feat_off.data(), (b.B + 1) * sizeof(int));
+		return;
+	}
+	h2d(ctx, b.d_pose_off, b.pose_off.data(), (b.B + 1) * sizeof(int));
+	h2d(ctx, b.d_feat_off, b.feat_off.data(), (b.B + 1) * sizeof(int));
+	batch_fill_maps(ctx, b);
+}
+void batch_fill_maps(lsfm_context* ctx, DevBatch& b)
+{
 	if (b.M) hipLaunchKernelGGL(k_fill_segment_ids, dim3((b.M + 255) / 256), dim3(256), 0, ctx->stream, b.d_pose_off, b.B, b.pose_map, b.M);
 	if (b.NF) hipLaunchKernelGGL(k_fill_segment_ids, dim3((b.NF + 255) / 256), dim3(256), 0, ctx->stream, b.d_feat_off, b.B, b.feat_map, b.NF);
 }

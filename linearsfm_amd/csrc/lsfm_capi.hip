@@ -2,6 +2,8 @@
 // (Imp.cpp:1926-2063 / 6511-6630): every level of the reference's binary join tree runs as ONE batch.
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #include "lsfm_internal.hpp"
 #include "lsfm_join.hpp"
@@ -23,6 +25,9 @@ struct lsfm_tree {
 	std::vector<LevelPlan> plans;
 	bool use_plans = true;
 	double upload_ms = 0; // wall time of lsfm_tree_upload (reported in lsfm_stats)
+	// per level: the refinement steps the level's systems needed in an earlier run (0: not known).  Not structure -- a guess about
+	// values that lets a run enqueue the steps of a level without stopping to ask; checked at the end of every run that uses it
+	std::vector<int> step_hint;
 	unsigned long long digest = 0; // of the resident inputs' labels and index arrays (trees built from packed maps: reload compares)
 };
 
@@ -80,6 +85,10 @@ int tree_levels(int N)
 void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 {
 	ctx->plan = (t->use_plans && level < (int)t->plans.size()) ? &t->plans[level] : nullptr;
+	ctx->mark("level");
+	if ((int)t->step_hint.size() <= level) t->step_hint.resize(level + 1, 0);
+	ctx->step_hint = t->step_hint[level];
+	ctx->steps_used = 0;
 	DevBatch& X = t->level;
 	const int B = X.B, npairs = B / 2;
 	std::vector<int> tref(B, -1), tscap(B, 0), tfix(B, 0);
@@ -126,9 +135,29 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); // (the join's layout kernels run inside)
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		js.smark = smark; // everything of this level goes at once
+		const bool analysing = !ctx->warm();
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
+		if (analysing && Y.B > 1)
+		{
+			// while the device solves this level: the next level's pattern and symbolic factorisation (lsfm_pcg.hip)
+			const int nb = Y.B;
+			std::vector<int> nref(nb, -1);
+			for (int i = 0; i < nb / 2; i++)
+			{
+				const int e2 = 2 * i, c2 = 2 * i + 1;
+				const bool re = Y.Ref[c2] > Y.FRef[c2];
+				const int cref = re ? Y.FRef[c2] : Y.Ref[c2];
+				if (re) nref[c2] = cref;
+				nref[e2] = cref;
+			}
+			for (int b = 0; b < nb; b++) if (nref[b] >= 0 && Y.Ref[b] == nref[b]) nref[b] = -1; // (same frame: passed through, Imp.cpp:352)
+			prefetch_next_level(ctx, Y, nref, level + 1);
+		}
+		else ctx->pre.reset();
 	}
 	LSFM_CHECK_HIP(hipEventRecord(e_t2, ctx->stream));
+	if (ctx->steps_used > 0) t->step_hint[level] = ctx->steps_used;
+	ctx->step_hint = 0;
 	ctx->plan = nullptr;
 	t->level = Y;
 	t->slot = sm;
@@ -183,6 +212,7 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	ctx->generation++;
 	ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
 	ctx->stage_off = 0; // the stream is idle: the staging ring starts over
+	ctx->pre.reset(); ctx->early.reset(); ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // nothing prepared by an earlier run
 	LSFM_CHECK_HIP(hipMemsetAsync(ctx->d_run, 0, sizeof(RunStatsDev), ctx->stream));
 	t->level = t->input;
 	const int nlev = tree_levels(t->N);
@@ -229,9 +259,26 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 			{
 				memset(st, 0, sizeof *st);
 				ctx->timed.clear(); ctx->ev_next = 0;
+				bool hinted = false;
+				for (int h : t->step_hint) hinted |= h > 0;
+				ctx->timeline_on = getenv("LSFM_TIMELINE") != nullptr;
+				ctx->timeline.clear();
 				const double t0 = now_ms();
+				ctx->mark("run");
 				tree_pass(ctx, t, st);
 				st->t_total_ms = now_ms() - t0;
+				ctx->mark("end");
+				if (ctx->timeline_on)
+				{
+					double prev = ctx->timeline.empty() ? 0 : ctx->timeline[0].second;
+					for (const auto& m : ctx->timeline)
+					{
+						if (!strcmp(m.first, "level")) fprintf(stderr, "\n[tl]");
+						fprintf(stderr, " %s+%.0f", m.first, 1e3 * (m.second - prev));
+						prev = m.second;
+					}
+					fprintf(stderr, "\n");
+				}
 				// what the warm levels left in the device accumulators instead of stopping for it
 				RunStatsDev rs;
 				LSFM_CHECK_HIP(hipMemcpy(&rs, ctx->d_run, sizeof rs, hipMemcpyDeviceToHost));
@@ -245,7 +292,13 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					continue;
 				}
 				if (rs.plan_stale) LSFM_FAIL(LSFM_ERR_INTERNAL, "a level plan was reported stale in a run without plans");
-				if (rs.not_converged && attempt == 0 && t->use_plans)
+				if ((rs.not_converged || rs.undone) && attempt == 0 && hinted)
+				{
+					// the steps of a level were enqueued by a count from an earlier run and did not suffice this time: forget the counts
+					t->step_hint.clear();
+					if (!t->use_plans) continue;
+				}
+				if ((rs.not_converged || rs.undone) && attempt == 0 && t->use_plans)
 				{
 					// a planned run enqueues the refinement steps the first run needed; if a system asks for more this time,
 					// drop the plans and run the levels the slow way again (reads the state of every step back)
@@ -255,6 +308,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				st->not_converged += rs.not_converged;
 				st->max_rel_residual = std::max(st->max_rel_residual, rs.max_rel_residual);
 				st->upload_ms = t->upload_ms;
+				st->schur_flops += 108.0 * (double)rs.k2;
 				break;
 			}
 			ctx->flush_times();

@@ -111,7 +111,10 @@ struct RunStatsDev {
 	int not_converged;     // systems left above the residual bound
 	int tr_err;            // 1 + map whose transform target was not found
 	int plan_stale;        // a planned level met VALUES the plan does not fit (Mono: the sign of a new scale): the run is repeated without plans
+	int undone;            // systems whose refinement was enqueued with a step count from an earlier run and had not met its stopping rule when the steps ran out
+	int pad;
 	double max_rel_residual;
+	unsigned long long k2;  // sum over the levels of sum over the features of (W run length)^2: K9's pose pairs, for its algorithmic flop count
 };
 
 } // namespace lsfm
@@ -148,9 +151,24 @@ struct lsfm_context {
 	const int* tr_hub = nullptr;        // [B] global pose index of the hub column of every transformed map, -1: passed through
 	std::shared_ptr<void> early;        // the build in flight (null: none)
 	hipStream_t stream3 = nullptr;      // its own stream: the side stream carries the transform's U stage, which waits for the block kernel
+	// One level ahead (Stereo tree runs that analyse): while the device factors and refines level L, the pattern of level
+	// L + 1's system is put together on stream3 from level L's joint maps (their index arrays are final long before the
+	// solve ends) and the host analyses it -- level L + 1 then finds its pattern and its symbolic factorisation waiting
+	// (lsfm_pcg.hip: prefetch_next_level).  Their arrays live in two small arenas used in turn.
+	lsfm::Arena sarena[2];
+	std::shared_ptr<void> pre;          // what was prepared for the level about to run (null: nothing)
+	hipEvent_t evY = nullptr, evP = nullptr; // joint index arrays of the level final (main stream) / prefetch complete (stream3)
 	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)
 	int solved_nnzb = 0;
-	bool in_tree_run = false;           // lsfm_tree_run: errors of a level may be left in d_run and read at the end of the run
+	// LSFM_TIMELINE=1: host wall-clock marks of a tree run (where the enqueuing thread is when), printed at the end of the run
+	std::vector<std::pair<const char*, double>> timeline;
+	bool timeline_on = false;
+	void mark(const char* what);
+	bool in_tree_run = false;
+	// refinement steps of the level being run: step_hint > 0 = what an earlier run of this tree needed here (the steps are then
+	// enqueued without asking the device after each one; whether they sufficed is read at the end of the run), steps_used = what
+	// a level that did ask needed
+	int step_hint = 0, steps_used = 0;           // lsfm_tree_run: errors of a level may be left in d_run and read at the end of the run
 	hipEvent_t evC = nullptr;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run
 	lsfm::LevelPlan* plan = nullptr; // plan of the tree level being run (null: stage-level calls, nothing is recorded or reused)
@@ -171,7 +189,8 @@ namespace lsfm {
 
 // ---- primitives (lsfm_prims.hip; rocPRIM scan / radix sort on the context stream) ------------------------
 void dev_exclusive_scan(lsfm_context* ctx, const int* in, int* out, size_t n); // out[n] = total (n+1 entries written)
-void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, size_t n, int end_bit);
+void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, size_t n, int end_bit, int begin_bit = 0); // stable, bits [begin, end)
+void dev_sort_keys_u64(lsfm_context* ctx, unsigned long long* keys, size_t n, int begin_bit, int end_bit);
 int d2h_int(lsfm_context* ctx, const int* dptr);
 void d2h_ints(lsfm_context* ctx, const int* dptr, int* h, size_t n);
 void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes);
@@ -180,13 +199,29 @@ void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes);
 // ~3 N pageable ones.  Synchronises before and after.
 struct HostPiece { const void* p; size_t bytes; };
 void h2d_gather(lsfm_context* ctx, void* d, const std::vector<HostPiece>& pieces);
+// Several small copies of a stage as ONE staged transfer + ONE kernel: a level makes ~20 of them (map records, offsets, copies
+// of label arrays), each a 10 us blit of its own when issued one by one -- 320 per tree, 3.4 ms of the NC3500-like tree's 41.
+// Host pieces are packed into the pinned ring behind a table of (destination, source, bytes), the whole goes to the device in
+// one copy, k_copy_many moves every piece (device-to-device pieces straight from their source).  Sizes are multiples of 4.
+struct CopyBatch {
+	lsfm_context* ctx;
+	struct Item { void* dst; const void* src; size_t bytes; bool host; };
+	std::vector<Item> items;
+	explicit CopyBatch(lsfm_context* c) : ctx(c) {}
+	void h2d(void* d, const void* h, size_t bytes) { if (bytes) items.push_back(Item{ d, h, bytes, true }); }
+	void d2d(void* d, const void* s, size_t bytes) { if (bytes) items.push_back(Item{ d, s, bytes, false }); }
+	void flush(); // enqueues on ctx->stream; the host sources may be freed afterwards
+};
 void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes);
 void dev_zero(lsfm_context* ctx, void* d, size_t bytes);
 
 // ---- batches (lsfm_batch.hip) -------------------------------------------------------------------------------
 void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, bool mono, DevBatch& out);
 void batch_download_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, lsfm_map* out);
-void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b); // uploads pose_off / feat_off, fills pose_map / feat_map
+struct CopyBatch;
+// uploads pose_off / feat_off, fills pose_map / feat_map (cb != null: the uploads join the caller's batch, which then calls batch_fill_maps)
+void batch_set_offsets(lsfm_context* ctx, Arena& ar, DevBatch& b, CopyBatch* cb = nullptr);
+void batch_fill_maps(lsfm_context* ctx, DevBatch& b);
 // A map packed into one contiguous device buffer for the hand-off between GPUs (include/lsfm.h): header, then the arrays
 // with map-local indices, each 256-byte aligned.
 struct PackHeader {
@@ -259,6 +294,8 @@ struct EarlyPatternIn {
 };
 void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in); // enqueues on the side stream; the caller has recorded evC
 void schur_pattern_early_drop(lsfm_context* ctx);
+// target_ref[b] of the NEXT level's transform for every map of `Y` (-1: passed through), as run_level will compute it
+void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int parity);
 // the block pattern of S alone (K8), from the index members of io: upper block CSR left in the scratch arena
 void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx);
 int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,

@@ -259,7 +259,9 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	if (ctx->warm()) rb = ctx->plan->join_rb; // known from an earlier run of the same tree
 	else
 	{
+		ctx->mark("jn_enq");
 		d2h_ints(ctx, d_rb, rb.data(), B + 1);
+		ctx->mark("jn_rb");
 		if (ctx->plan) ctx->plan->join_rb = rb;
 	}
 
@@ -292,22 +294,30 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	out.NF = out.feat_off[G];
 	const int NFY = out.NF;
 
+	CopyBatch cb(ctx); // group records, offsets, label arrays, activity flags: one transfer, one kernel
 	JGroup* d_grp = ctx->scratch.alloc<JGroup>(G);
-	h2d(ctx, d_grp, grp.data(), sizeof(JGroup) * G);
+	cb.h2d(d_grp, grp.data(), sizeof(JGroup) * G);
 
 	// ---- joint arrays (K6) ----
 	out.pose = ar.alloc<double>((size_t)in.M * 6);
 	out.pose_id = ar.alloc<int>(in.M);
 	out.pose_origin = ar.alloc<int>(in.M);
-	if (in.M) LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_origin, in.pose_origin, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
+	cb.d2d(out.pose_origin, in.pose_origin, (size_t)in.M * sizeof(int));
 	out.feat = ar.alloc<double>((size_t)NFY * 3);
 	out.feat_id = ar.alloc<int>(NFY);
 	out.U = ar.alloc<double>((size_t)in.NU * 36); out.Ui = ar.alloc<int>(in.NU); out.Uj = ar.alloc<int>(in.NU);
 	out.W = ar.alloc<double>((size_t)in.NW * 18); out.photo = ar.alloc<int>(in.NW); out.feature = ar.alloc<int>(in.NW);
 	out.fptr = ar.alloc<int>(NFY + 1);
 	out.V = ar.alloc<double>((size_t)NFY * 9);
-	batch_set_offsets(ctx, ar, out);
-	LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_id, in.pose_id, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
+	batch_set_offsets(ctx, ar, out, &cb);
+	cb.d2d(out.pose_id, in.pose_id, (size_t)in.M * sizeof(int));
+	// (the activity flags of the pairs, for the solve: 4-byte units)
+	st.d_act = reinterpret_cast<unsigned char*>(ctx->scratch.alloc<int>((G + 3) / 4 + 1));
+	st.act_padded.assign(((size_t)G + 3) / 4 * 4, 0);
+	std::copy(seg_active.begin(), seg_active.end(), st.act_padded.begin());
+	cb.h2d(st.d_act, st.act_padded.data(), st.act_padded.size());
+	cb.flush();
+	batch_fill_maps(ctx, out);
 	int* newf = st.newf = ctx->scratch.alloc<int>(in.NF + 1);
 	int* lens = ctx->scratch.alloc<int>(NFY + 2);
 	st.srcf = ctx->scratch.alloc<int>(in.NW + 1);
@@ -320,7 +330,7 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
 	// a level that analyses, reached through the transform's hook: the sources of every joint feature, for the early pattern of S
 	static const bool early_on = !getenv("LSFM_NO_EARLY_PATTERN");
-	const bool early = early_on && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
+	const bool early = early_on && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
 	int *srcE = nullptr, *srcC = nullptr;
 	if (early)
 	{
@@ -351,6 +361,7 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	st.wbase = ctx->scratch.alloc<int>(in.NF + 1);
 	if (in.NF) hipLaunchKernelGGL(k_join_wbase, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, newf, lenE, out.fptr, st.wbase);
 	LSFM_CHECK_HIP(hipGetLastError());
+	ctx->mark("jn_prep");
 }
 
 void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, JoinState& st, double* eP_out, double* eF_out)
@@ -365,10 +376,13 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	// (the transform's U stage) while the joint map was laid out
 	if (in.NU)
 	{
-		LSFM_CHECK_HIP(hipMemcpyAsync(out.U, in.U, (size_t)in.NU * 36 * sizeof(double), hipMemcpyDeviceToDevice, s));
-		LSFM_CHECK_HIP(hipMemcpyAsync(out.Ui, in.Ui, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
-		LSFM_CHECK_HIP(hipMemcpyAsync(out.Uj, in.Uj, (size_t)in.NU * sizeof(int), hipMemcpyDeviceToDevice, s));
+		CopyBatch cu(ctx);
+		cu.d2d(out.U, in.U, (size_t)in.NU * 36 * sizeof(double));
+		cu.d2d(out.Ui, in.Ui, (size_t)in.NU * sizeof(int));
+		cu.d2d(out.Uj, in.Uj, (size_t)in.NU * sizeof(int));
+		cu.flush();
 	}
+	LSFM_CHECK_HIP(hipEventRecord(ctx->evY, s)); // the joint maps' index arrays are final (prefetch_next_level reads them)
 	// everything the pattern of S needs is enqueued: the solve may build it beside the right-hand sides (unless it is under
 	// way already: schur_pattern_early_issue)
 	if (!eP_out && !eF_out && !ctx->early)
@@ -386,8 +400,7 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	if (eF_out) d2h(ctx, eF_out, eF, (size_t)NFY * 3 * sizeof(double));
 
 	// ---- solve (K7-K11) ----
-	unsigned char* d_act = ctx->scratch.alloc<unsigned char>(G);
-	h2d(ctx, d_act, seg_active.data(), G);
+	unsigned char* d_act = st.d_act;
 	SolveIO io;
 	io.M = in.M; io.NF = NFY; io.NU = in.NU; io.NW = in.NW; io.nseg = G;
 	io.d_pose_seg = out.pose_map; io.d_feat_seg = out.feat_map; io.d_seg_active = d_act;
@@ -398,7 +411,7 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	const bool warm = ctx->warm();
 	ctx->solved_keys = nullptr; ctx->solved_nnzb = 0;
 	int rc = solve_batch(ctx, io);
-	if (!warm && st.ar && ctx->in_tree_run && ctx->solved_keys && !getenv("LSFM_NO_EARLY_PATTERN"))
+	if (!warm && st.ar && ctx->in_tree_run && ctx->solved_keys && getenv("LSFM_NO_PREFETCH") && !getenv("LSFM_NO_EARLY_PATTERN"))
 	{
 		// the pattern of this level's system stays with its output for the level above (schur_pattern_early_issue)
 		unsigned long long* k = st.ar->alloc<unsigned long long>((size_t)ctx->solved_nnzb + 1);

@@ -16,7 +16,8 @@ struct JoinState {
 	Arena* ar = nullptr; // where the joint map lives
 	int *newf = nullptr, *lenE = nullptr, *srcf = nullptr, *wbase = nullptr;
 	double *eP = nullptr, *eF = nullptr;
-	std::vector<unsigned char> seg_active;
+	std::vector<unsigned char> seg_active, act_padded;
+	unsigned char* d_act = nullptr; // device copy of seg_active
 	std::vector<int> seg_rows;
 };
 void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, JoinState& st);

@@ -71,7 +71,8 @@ struct CholDev {
 	size_t blob_ints = 0;
 	float *Lf = nullptr, *Dinvf = nullptr; // mixed precision: the factor rounded to fp32 for the triangular solves (null: fp64)
 	double* wv = nullptr;   // [M*6] forward-solve results of the group columns (lsfm_pcg.hip k_sn_fwd / k_sn_bwd)
-	double* Gd = nullptr;   // parking area of the factored diagonal blocks of one group level: SN_GD doubles per group
+	double* Lg = nullptr;   // [nnzL*36] the factor of the supernode-group columns (same indexing as L; L keeps their unfactored blocks)
+	float* Lgf = nullptr;   // mixed precision: its fp32 copy
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
 	int* d_err = nullptr;
@@ -624,7 +625,6 @@ __global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int
 #define SN_XS (6 * CHOL_GS + 1)     /* odd row stride of the panel rows in LDS */
 #define SN_THREADS 256               /* 96 lanes own rows; the rest is there to keep more loads in flight */
 #define SN_LD 8                      /* loads in flight per lane in the copy loops (a dependent load costs ~1.5 us) */
-#define SN_GD (CHOL_GS * (CHOL_GS + 1) / 2 * 36) /* doubles per group in the parking area of the diagonal blocks */
 // 1 / sqrt(x) without the ~300-cycle IEEE sqrt + divide chains (they sat on the critical path of every column step):
 // hardware estimate + three Newton steps (full double precision up to an ulp or two -- the factor is a preconditioner
 // under iterative refinement)
@@ -650,9 +650,20 @@ __device__ __forceinline__ int sn_idx(int s, int u, int t) { return t * s - t * 
 // level, known before the factorisation starts): fv_g^T is one more panel row, so the recurrence leaves y_g = L_dd^-1 fv_g
 // in it, and every work-group takes X y_g off fv at its common rows -- what k_sn_fwd does in a launch of its own per
 // group level (25 of them at the top join).  y_g goes to fw for the backward substitution.
+// FUSED = false: grid (groups, chunks of SN_RB block rows of the panel); k_sn_update follows with the rank update.
+// FUSED = true:  grid (groups, pairs (ca >= cb) of chunks of SN_RB / 2 block rows): the work-group solves the panel rows of
+//                BOTH chunks and subtracts their product X_ca X_cb^T from the ancestors itself -- T = X X^T is a dense
+//                (48 x 6s) x (6s x 48) contraction on v_mfma_f64_16x16x4_f64, leaving as 36 contiguous atomics per block --
+//                so a group level is ONE launch.  The unfactored blocks are only read from L and the factor goes to a
+//                second array Lg (same indexing): no work-group overwrites what another one of the level still reads,
+//                nothing is parked.  (The solves of chunks shared by several pairs are redundant, like the diagonal part:
+//                latency, not work, is what a level costs.)  Used while a level's panels have few enough rows
+//                (chol_factor); beyond that the pairs would take more rounds of work-groups than the two launches.
+typedef double sn_v4d __attribute__((ext_vector_type(4)));
+template <bool FUSED>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
-                                                          const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Dinv, int* err,
-                                                          double* __restrict__ Gd, const int* __restrict__ rowidx, double* __restrict__ fv,
+                                                          const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Lg,
+                                                          double* __restrict__ Dinv, int* err, const int* __restrict__ rowidx, double* __restrict__ fv,
                                                           double* __restrict__ fw)
 {
 	// rows 0 .. 6 GS - 1: L_dd (dense scalar rows); rows 6 GS ..: the panel rows of this work-group.  Lanes 0..95 own the
@@ -661,15 +672,35 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	__shared__ double sD[36];
 	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
+	__shared__ int sRow[SN_RB];  // common row (position below the run) of every panel slot, -1: empty slot
+	__shared__ int spos[(SN_RB / 2) * (SN_RB / 2)]; // FUSED: block of L every (a, b) product goes to, -1: none
 	double* const Ls = Ms;
 	double* const Xs = Ms + 6 * CHOL_GS * SN_XS;
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
-	const int i0 = blockIdx.y * SN_RB;
-	if (blockIdx.y > 0 && i0 >= nr) return;
+	constexpr int HB = SN_RB / 2;
+	int ca = 0, cb = 0;
+	if constexpr (FUSED)
+	{
+		const int nch = (nr + HB - 1) / HB, p = blockIdx.y;
+		if (p > 0 && p >= nch * (nch + 1) / 2) return;
+		ca = (int)((sqrtf(8.0f * p + 1.0f) - 1.0f) * 0.5f);
+		while (ca * (ca + 1) / 2 > p) ca--;
+		while ((ca + 1) * (ca + 2) / 2 <= p) ca++;
+		cb = p - ca * (ca + 1) / 2;
+	}
+	else if (blockIdx.y > 0 && (int)blockIdx.y * SN_RB >= nr) return;
+	const bool diag_pair = !FUSED || ca == cb; // this work-group writes its (first) chunk's rows of the factor
 	const int tid = threadIdx.x, nt = blockDim.x;
 	const int nb = s * (s + 1) / 2, n6 = 6 * s;
 	// where every block of the run's diagonal part sits in the block storage / in the dense rows (one lane per block)
 	for (int t = tid; t < s; t += nt) sCol[t] = colptr[c0 + t];
+	if (tid < SN_RB)
+	{
+		int row;
+		if constexpr (FUSED) row = tid < HB ? ca * HB + tid : (ca == cb ? nr : cb * HB + (tid - HB));
+		else row = blockIdx.y * SN_RB + tid;
+		sRow[tid] = row < nr ? row : -1;
+	}
 	__syncthreads();
 	for (int e = tid; e < nb; e += nt)
 	{
@@ -679,10 +710,29 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		sSrc[e] = (sCol[t] + (u - t)) * 36;
 		sDst[e] = 6 * u * SN_XS + 6 * t;
 	}
+	const int rows0 = sCol[s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
+	if constexpr (FUSED)
+	{
+		// targets of the rank update, fetched now: the loads fly while the factorisation runs
+		if (tid < HB * HB)
+		{
+			const int a = tid / HB, b = tid - a * HB;
+			const int ia = sRow[a], ib = ca == cb ? sRow[b] : sRow[HB + b];
+			int pos = -1;
+			if (ia >= 0 && ib >= 0 && ia >= ib)
+			{
+				const int ra = rowidx[rows0 + ia], rb = rowidx[rows0 + ib];
+				// the rows of the run from rb on are a subset of column rb's rows; nested patterns put the target at the same offset
+				const int cbk = colptr[rb], nbk = colptr[rb + 1] - cbk;
+				pos = cbk + (ia - ib);
+				if (!(ia - ib < nbk && rowidx[pos] == ra)) pos = find_row(rowidx, cbk, cbk + nbk, ra);
+			}
+			spos[tid] = pos;
+		}
+	}
 	__syncthreads();
 	// blocks -> dense rows, two doubles per load, SN_LD loads in flight per lane (a dependent load costs ~1.5 us)
-	const int nrows = max(0, min(SN_RB, nr - i0));
-	const int nd2 = nb * 18, np2 = nrows * s * 18; // pairs of doubles: diagonal part, panel rows
+	const int nd2 = nb * 18, np2 = SN_RB * s * 18; // pairs of doubles: diagonal part, panel slots
 	for (int base = 0; base < nd2 + np2; base += nt * SN_LD)
 	{
 		double2 v[SN_LD];
@@ -693,8 +743,8 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const double2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
 			else if (q < nd2 + np2)
 			{
-				const int qq = q - nd2, blk = qq / 18, il = blk / s, t = blk - il * s;
-				v[i] = *reinterpret_cast<const double2*>(L + (size_t)(sCol[t] + (s - t) + i0 + il) * 36 + 2 * (qq - blk * 18));
+				const int qq = q - nd2, blk = qq / 18, il = blk / s, t = blk - il * s, row = sRow[il];
+				if (row >= 0) v[i] = *reinterpret_cast<const double2*>(L + (size_t)(sCol[t] + (s - t) + row) * 36 + 2 * (qq - blk * 18));
 			}
 		}
 #pragma unroll
@@ -705,17 +755,21 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			else if (q < nd2 + np2)
 			{
 				const int qq = q - nd2, blk = qq / 18, w = 2 * (qq - blk * 18), il = blk / s, t = blk - il * s;
-				double* d = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
-				d[0] = v[i].x; d[1] = v[i].y;
+				if (sRow[il] >= 0)
+				{
+					double* d = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+					d[0] = v[i].x; d[1] = v[i].y;
+				}
 			}
 		}
 	}
 	constexpr int XR = 6 * CHOL_GS + 6 * SN_RB; // row of the right-hand side, owned by lane 128 + 6 SN_RB
-	if (fv && tid < n6) Ms[XR * SN_XS + tid] = fv[(size_t)c0 * 6 + tid];
+	const bool with_fv = fv && diag_pair;
+	if (with_fv && tid < n6) Ms[XR * SN_XS + tid] = fv[(size_t)c0 * 6 + tid];
 	__syncthreads();
 	// row of Ms this lane owns (-1: none)
-	const int ri = tid < 6 * CHOL_GS ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? 6 * CHOL_GS + (tid - 128) : ((fv && tid == 128 + 6 * SN_RB) ? XR : -1));
-	const bool panel_lane = ri >= 6 * CHOL_GS && ((ri - 6 * CHOL_GS) < 6 * nrows || ri == XR);
+	const int ri = tid < 6 * CHOL_GS ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? 6 * CHOL_GS + (tid - 128) : ((with_fv && tid == 128 + 6 * SN_RB) ? XR : -1));
+	const bool panel_lane = ri >= 6 * CHOL_GS && (ri == XR || sRow[(ri - 6 * CHOL_GS) / 6] >= 0);
 	bool bad = false;
 	for (int t = 0; t < s; t++)
 	{
@@ -799,76 +853,102 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		__syncthreads();
 	}
 	if (bad && tid == 0) atomicExch(err, 1 + c0);
-	if (fv)
+	if (with_fv)
 	{
 		const double* yg = &Ms[XR * SN_XS];
 		if (blockIdx.y == 0 && tid < n6) fw[(size_t)c0 * 6 + tid] = yg[tid];
-		if (panel_lane && ri != XR)
+		const int slot = ri >= 6 * CHOL_GS && ri != XR ? (ri - 6 * CHOL_GS) / 6 : -1;
+		if (panel_lane && slot >= 0 && (!FUSED || slot < HB))
 		{
 			const double* xr = &Ms[ri * SN_XS];
 			double o0 = 0.0, o1 = 0.0;
 			for (int k = 0; k + 1 < n6; k += 2) { o0 = fma(xr[k], yg[k], o0); o1 = fma(xr[k + 1], yg[k + 1], o1); } // n6 is even
-			const int pr = ri - 6 * CHOL_GS, il = pr / 6, r = pr - 6 * il;
-			atomic_add_f64(fv + (size_t)rowidx[sCol[s - 1] + 1 + i0 + il] * 6 + r, -(o0 + o1));
+			const int r = (ri - 6 * CHOL_GS) - 6 * slot;
+			atomic_add_f64(fv + (size_t)rowidx[rows0 + sRow[slot]] * 6 + r, -(o0 + o1));
 		}
 	}
-	// inverse of every diagonal 6x6 factor (the triangular solves use it): lane (t, c) solves L_tt x = e_c
-	if (tid < n6)
-	{
-		const int t = tid / 6, c = tid - 6 * t;
-		const double* dg = &Ls[(6 * t) * SN_XS + 6 * t];
-		double x[6];
-#pragma unroll
-		for (int r = 0; r < 6; r++)
-		{
-			double v = r == c ? 1.0 : 0.0;
-#pragma unroll
-			for (int k = 0; k < r; k++) v = fma(-dg[r * SN_XS + k], x[k], v);
-			x[r] = v * sInvD[6 * t + r];
-		}
-#pragma unroll
-		for (int r = 0; r < 6; r++) Dinv[(size_t)(c0 + t) * 36 + r * 6 + c] = r >= c ? x[r] : 0.0; // every work-group writes the same values
-	}
-	// the factored diagonal blocks are parked (the other work-groups of the group may still be reading the unfactored
-	// ones from L); k_sn_update puts them in place
 	if (blockIdx.y == 0)
+	{
+		// inverse of every diagonal 6x6 factor (the triangular solves use it): lane (t, c) solves L_tt x = e_c
+		if (tid < n6)
+		{
+			const int t = tid / 6, c = tid - 6 * t;
+			const double* dg = &Ls[(6 * t) * SN_XS + 6 * t];
+			double x[6];
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+			{
+				double v = r == c ? 1.0 : 0.0;
+#pragma unroll
+				for (int k = 0; k < r; k++) v = fma(-dg[r * SN_XS + k], x[k], v);
+				x[r] = v * sInvD[6 * t + r];
+			}
+#pragma unroll
+			for (int r = 0; r < 6; r++) Dinv[(size_t)(c0 + t) * 36 + r * 6 + c] = r >= c ? x[r] : 0.0;
+		}
+		// the factored diagonal blocks, to the factor's own array (the other work-groups of the group read the unfactored ones from L)
 		for (int q = tid; q < nb * 36; q += nt)
 		{
 			const int e = q / 36, w = q - e * 36;
-			Gd[(size_t)g * SN_GD + q] = Ls[sDst[e] + (w / 6) * SN_XS + w % 6];
+			Lg[(size_t)sSrc[e] + w] = Ls[sDst[e] + (w / 6) * SN_XS + w % 6];
 		}
-	// the solved panel rows X = A L_dd^-T go back to their blocks
-	for (int q = tid; q < np2; q += nt)
+	}
+	// the solved panel rows X = A L_dd^-T of this work-group's own chunk
+	if (diag_pair)
+		for (int q = tid; q < (FUSED ? HB : SN_RB) * s * 18; q += nt)
+		{
+			const int blk = q / 18, w = 2 * (q - blk * 18), il = blk / s, t = blk - il * s, row = sRow[il];
+			if (row < 0) continue;
+			const double* x = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+			*reinterpret_cast<double2*>(Lg + (size_t)(sCol[t] + (s - t) + row) * 36 + w) = make_double2(x[0], x[1]);
+		}
+	if constexpr (FUSED)
 	{
-		const int blk = q / 18, w = 2 * (q - blk * 18), il = blk / s, t = blk - il * s;
-		const double* x = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
-		*reinterpret_cast<double2*>(L + (size_t)(sCol[t] + (s - t) + i0 + il) * 36 + w) = make_double2(x[0], x[1]);
+		if (nr == 0) return;
+		// ---- rank update of the ancestors: T = X_ca X_cb^T on the matrix cores.  Rows of X past 6 s are padded with zeros up to
+		// a multiple of 4 (the k step of the instruction); rows of empty slots hold stale numbers: their products are dropped ----
+		const int n6r = (n6 + 3) & ~3;
+		if (n6r > n6)
+			for (int q = tid; q < 6 * SN_RB * (n6r - n6); q += nt) Xs[(q / (n6r - n6)) * SN_XS + n6 + q % (n6r - n6)] = 0.0;
+		__syncthreads(); // (also: the diagonal rows in Ls are no longer read -- the products land there)
+		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+		const double* XB = ca == cb ? Xs : Xs + 6 * HB * SN_XS;
+		constexpr int NTL = (6 * HB) / 16; // 16-row tiles per side: 3
+		constexpr int TS = 6 * HB + 1;     // row stride of the products in LDS
+		double* sT = Ls;
+		for (int q = wave; q < NTL * NTL; q += SN_THREADS / 64)
+		{
+			const int ti = q / NTL, tj = q - ti * NTL;
+			const double* pa = &Xs[(16 * ti + (lane & 15)) * SN_XS + (lane >> 4)];
+			const double* pb = &XB[(16 * tj + (lane & 15)) * SN_XS + (lane >> 4)];
+			sn_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+			for (int ks = 0; ks < n6r; ks += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks], pb[ks], acc, 0, 0, 0);
+			// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+			for (int e = 0; e < 4; e++) sT[(16 * ti + (lane >> 4) + 4 * e) * TS + 16 * tj + (lane & 15)] = acc[e];
+		}
+		__syncthreads();
+		for (int idx = tid; idx < HB * HB * 36; idx += nt)
+		{
+			const int p = idx / 36, q = idx - p * 36, ps = spos[p];
+			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[(6 * (p / HB) + q / 6) * TS + 6 * (p % HB) + q % 6]);
+		}
 	}
 }
 
 #define SN_KS 4                      /* lanes per pair of rows in k_sn_update: each takes every 4th column of the run */
 #define SN_PAIRS (SN_THREADS / SN_KS)
+// the rank update of the levels whose panels are too tall for the fused kernel: X is read from the factor's array Lg, the
+// products are subtracted from the ancestors' (still unfactored) blocks in L
 __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                                           const double* __restrict__ Gd)
+                                                           const double* __restrict__ Lg)
 {
 	__shared__ double sT[SN_PAIRS * 37];
 	__shared__ int spos[SN_PAIRS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
 	const int npairs = nr * (nr + 1) / 2;
 	const int tid = threadIdx.x;
-	if (blockIdx.y == 0)
-	{
-		const int nb = s * (s + 1) / 2;
-		for (int q = tid; q < nb * 36; q += SN_THREADS)
-		{
-			const int e = q / 36;
-			int t = 0;
-			while (sn_idx(s, s - 1, t) < e) t++;
-			const int u = t + (e - sn_idx(s, t, t));
-			L[(size_t)(colptr[c0 + t] + (u - t)) * 36 + (q - e * 36)] = Gd[(size_t)g * SN_GD + q];
-		}
-	}
 	const int rows0 = colptr[c0 + s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
 	const int pl = tid / SN_KS, sub = tid - pl * SN_KS; // pair of this lane inside the round, its share of the columns
 	for (int base = blockIdx.y * SN_PAIRS; base < npairs; base += gridDim.y * SN_PAIRS)
@@ -889,8 +969,8 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 			{
 				const size_t cb = (size_t)colptr[c0 + t] + (s - t);
 				double La[36], Lb[36];
-				ld<36>(La, L + (cb + a) * 36);
-				ld<36>(Lb, L + (cb + b) * 36);
+				ld<36>(La, Lg + (cb + a) * 36);
+				ld<36>(Lb, Lg + (cb + b) * 36);
 				mmt<6, 6, 6, true>(La, Lb, T);
 			}
 			if (sub < s)
@@ -914,6 +994,14 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 		}
 		__syncthreads();
 	}
+}
+// the factor of the group columns back into L (only for the fall-back solves that read one array: chol_apply)
+__global__ void k_sn_merge(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ colptr, const double* __restrict__ Lg,
+                           double* __restrict__ L)
+{
+	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g];
+	const size_t b0 = (size_t)colptr[c0] * 36, b1 = (size_t)colptr[c0 + s] * 36;
+	for (size_t q = b0 + threadIdx.x; q < b1; q += blockDim.x) L[q] = Lg[q];
 }
 
 
@@ -1154,9 +1242,7 @@ static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
 	Arena& sc = ctx->scratch;
 	ch.L = sc.alloc<double>((size_t)ch.nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)ch.M * 36);
 	ch.wv = sc.alloc<double>((size_t)ch.M * 6);
-	int most = 1;
-	for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++) most = std::max(most, ch.glevel_ptr[l + 1] - ch.glevel_ptr[l]);
-	ch.Gd = sc.alloc<double>((size_t)most * (CHOL_GS * (CHOL_GS + 1) / 2 * 36));
+	ch.Lg = ch.ngroups ? sc.alloc<double>((size_t)ch.nnzL * 36) : nullptr; // (every block of a group column is written by the factorisation)
 	dev_zero(ctx, ch.L, (size_t)ch.nnzL * 36 * sizeof(double));
 }
 
@@ -1164,7 +1250,7 @@ static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
 // with its hash index and the whole symbolic factorisation, in one device allocation of their own.
 struct SolvePlan {
 	SchurSystem sy; // index members only (S, E, IV are per run)
-	CholDev ch;     // index members + host vectors (L, Dinv, Gd, d_err are per run)
+	CholDev ch;     // index members + host vectors (L, Lg, Dinv, d_err are per run)
 	int its = 1;    // refinement steps the first run needed ...
 	bool mixed = false; // ... with the preconditioner in this precision
 	double rel_tol = 0; // ... to this relative residual
@@ -1188,7 +1274,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	SolvePlan& P = *sp;
 	P.sy = sy; P.ch = ch; P.its = its; P.mixed = ch.Lf != nullptr; P.rel_tol = ctx->pcg.rel_tol;
 	P.sy.S = nullptr; P.sy.E = nullptr; P.sy.IV = nullptr;
-	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Gd = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr; P.ch.Lf = nullptr; P.ch.Dinvf = nullptr;
+	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Lg = nullptr; P.ch.Lgf = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr; P.ch.Lf = nullptr; P.ch.Dinvf = nullptr;
 	std::vector<Item> items = {
 		{ sy.rowptr, (M + 1) * 4, (void**)&P.sy.rowptr }, { sy.colidx, (nnzb + 1) * 4, (void**)&P.sy.colidx },
 		{ sy.upper_keys, nnzb * 8, (void**)&P.sy.upper_keys }, { sy.longrows, (M + 1) * 4, (void**)&P.sy.longrows },
@@ -1267,6 +1353,54 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 	chol_upload_symbolic(ctx, sym, ch);
 }
 
+// ---- one level ahead ---------------------------------------------------------------------------------------------------------
+// What a level that analyses needs from the host -- the pattern of its camera system and the symbolic factorisation --
+// depends on index arrays only, and the index arrays of level L + 1's joint maps follow from level L's: the joint map of
+// a pair is its two maps side by side (pose pairs inside a map: level L's pattern), plus the hub link of every pose of a
+// map the transform re-expresses, plus the pairs across the two maps from the features they share.  So while the device
+// factors and refines level L, stream3 puts level L + 1's pattern together from level L's joint maps and the host analyses
+// it; level L + 1 finds both waiting and enqueues its factorisation right behind its Schur assembly.
+struct PreLevel {
+	SchurSystem sy;
+	CholSymbolic sym;
+	int M = 0;
+};
+void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int parity)
+{
+	ctx->pre.reset();
+	static const bool on = !getenv("LSFM_NO_PREFETCH") && !getenv("LSFM_NO_EARLY_PATTERN");
+	if (!on || !ctx->solved_keys || !Y.M || Y.B < 2) return;
+	ctx->mark("pre_start");
+	auto pl = std::make_shared<PreLevel>();
+	pl->M = Y.M;
+	Arena& sa = ctx->sarena[parity & 1];
+	sa.reset();
+	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evY, 0)); // the joint maps' index arrays are final
+	CholHostIn hin;
+	bool ok = false;
+	std::swap(ctx->stream, ctx->stream3);
+	std::swap(ctx->scratch, sa);
+	try
+	{
+		int* d_tref = ctx->scratch.alloc<int>(Y.B);
+		h2d(ctx, d_tref, target_ref.data(), sizeof(int) * (size_t)Y.B);
+		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy);
+		if (ok)
+		{
+			chol_fetch(ctx, pl->sy, Y.pose_origin, hin);
+			LSFM_CHECK_HIP(hipEventRecord(ctx->evP, ctx->stream));
+		}
+	}
+	catch (...) { std::swap(ctx->scratch, sa); std::swap(ctx->stream, ctx->stream3); throw; }
+	std::swap(ctx->scratch, sa);
+	std::swap(ctx->stream, ctx->stream3);
+	ctx->mark("pre_pat");
+	if (!ok) return;
+	chol_symbolic(hin.keys.data(), pl->sy.nnzb, hin.origin.data(), pl->sy.M, pl->sym);
+	ctx->mark("pre_sym");
+	ctx->pre = pl;
+}
+
 // the supernode-group path of the triangular solves applies (chol_apply): the forward substitution can ride on the factorisation
 static bool chol_group_solve(const CholDev& ch)
 {
@@ -1303,16 +1437,31 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, (const double*)ch.L, (const double*)ch.Dinv, fwd_v);
 	}
 	if (groups)
+	{
+		// one launch per group level while the panels are short enough for the fused kernel (pairs of 8-row chunks: a panel of
+		// 160 rows is 210 work-groups per group); taller ones take the panel kernel + the rank-update kernel
+		static const int fuse_max = getenv("LSFM_SN_FUSE_MAX") ? atoi(getenv("LSFM_SN_FUSE_MAX")) : 160;
 		for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++)
 		{
 			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0, mnr = ch.glevel_maxnr[l];
 			if (!ng) continue;
-			hipLaunchKernelGGL(k_sn_panel, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-			                   ch.colptr, ch.L, ch.Dinv, ch.d_err, ch.Gd, ch.rowidx, fwd_v, ch.wv);
+			if (mnr <= fuse_max)
+			{
+				const int nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2);
+				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv);
+				continue;
+			}
+			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv);
 			const long np = (long)mnr * (mnr + 1) / 2;
 			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
-			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Gd);
+			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg);
 		}
+		// the solves that walk columns by task or by level read ONE array: give them the group columns there
+		if (ch.ngroups && !chol_group_solve(ch))
+			hipLaunchKernelGGL(k_sn_merge, dim3(ch.ngroups), dim3(256), 0, s, ch.grp_c0, ch.grp_s, ch.colptr, ch.Lg, ch.L);
+	}
 }
 
 // z = (L L^T)^-1 r in the original numbering, rz_dot[seg] += r . z
@@ -1338,23 +1487,24 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		const int n0 = ch.tlevel_ptr.size() > 1 ? ch.tlevel_ptr[1] - ch.tlevel_ptr[0] : 0;
 		const size_t lds0 = (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL + 8;
 		const int ngl = (int)ch.glevel_ptr.size() - 1;
-		auto sweep = [&](auto tag, const auto* Lx, const auto* Dx) {
+		// (Lx: the leaf columns' factor, in place in L; Gx: the group columns' factor, in its own array)
+		auto sweep = [&](auto tag, const auto* Lx, const auto* Gx, const auto* Dx) {
 			typedef decltype(tag) FT;
 			if (n0 && !fwd_done) hipLaunchKernelGGL(k_chol_fwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
 			for (int l = 0; l < ngl && !fwd_done; l++)
 			{
 				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
-				if (ng) hipLaunchKernelGGL(k_sn_fwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Lx, Dx, v, ch.wv);
+				if (ng) hipLaunchKernelGGL(k_sn_fwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Gx, Dx, v, ch.wv);
 			}
 			for (int l = ngl - 1; l >= 0; l--)
 			{
 				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
-				if (ng) hipLaunchKernelGGL(k_sn_bwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Lx, Dx, v, ch.wv);
+				if (ng) hipLaunchKernelGGL(k_sn_bwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Gx, Dx, v, ch.wv);
 			}
 			if (n0) hipLaunchKernelGGL(k_chol_bwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
 		};
-		if (ch.Lf) sweep(float(), (const float*)ch.Lf, (const float*)ch.Dinvf); // mixed precision: the factor applied in fp32
-		else sweep(double(), (const double*)ch.L, (const double*)ch.Dinv);
+		if (ch.Lf) sweep(float(), (const float*)ch.Lf, (const float*)ch.Lgf, (const float*)ch.Dinvf); // mixed precision: the factor applied in fp32
+		else sweep(double(), (const double*)ch.L, (const double*)ch.Lg, (const double*)ch.Dinv);
 		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
 		return;
 	}
@@ -1509,6 +1659,7 @@ __global__ void k_pcg_run_stats(int nseg, const PcgSeg* __restrict__ seg, RunSta
 	const PcgSeg& fin = seg[nseg + g];
 	const double rel = fin.ee > 0 ? sqrt(fin.rr / fin.ee) : 0.0;
 	if (!(rel < 1e-8) || (seg[g].done != 1 && !(rel < 1e-9))) atomicAdd(&run->not_converged, 1);
+	if (seg[g].done == 0) atomicAdd(&run->undone, 1);
 	// max of non-negative doubles = max of their bit patterns
 	atomicMax(reinterpret_cast<unsigned long long*>(&run->max_rel_residual), (unsigned long long)__double_as_longlong(rel == rel ? rel : 1e300));
 }
@@ -1556,16 +1707,46 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
 		schur_vinv(ctx, io, sy);
 		bool have = false;
-		if (ctx->early)
+		std::shared_ptr<void> pre_keep = ctx->pre;
+		ctx->pre.reset();
+		PreLevel* pre = static_cast<PreLevel*>(pre_keep.get());
+		if (pre && pre->M == M)
+		{
+			// prepared while the level below was being solved: pattern (device) and symbolic factorisation (host)
+			ctx->pattern_dep = false;
+			schur_pattern_early_drop(ctx);
+			{
+				SchurSystem prepared = pre->sy; // the index members; V^-1 and its factor are this level's (schur_vinv above)
+				prepared.IV = sy.IV; prepared.LY = sy.LY;
+				sy = prepared;
+			}
+			have = true;
+			LSFM_CHECK_HIP(hipStreamWaitEvent(s, ctx->evP, 0));
+			if (getenv("LSFM_CHECK_EARLY_PATTERN"))
+			{
+				LSFM_CHECK_HIP(hipStreamSynchronize(s));
+				SchurSystem ref;
+				build_schur_pattern(ctx, io, ref);
+				std::vector<unsigned long long> a(sy.nnzb), b(ref.nnzb);
+				d2h(ctx, a.data(), sy.upper_keys, a.size() * sizeof(unsigned long long));
+				d2h(ctx, b.data(), ref.upper_keys, b.size() * sizeof(unsigned long long));
+				if (a != b) LSFM_FAIL(LSFM_ERR_INTERNAL, "prefetched pattern of S (" + std::to_string(a.size()) + " blocks) differs from the joint map's (" + std::to_string(b.size()) + ")");
+			}
+		}
+		else pre = nullptr;
+		if (have) {}
+		else if (ctx->early)
 		{
 			// the pattern was put together on the side stream from the level's inputs while the transform ran (a Stereo level
 			// that analyses): its second half, and the copy of it for the host's analysis, stay there
 			ctx->pattern_dep = false;
 			LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evC, 0)); // (recorded again once the joint run pointers were enqueued)
 			std::swap(ctx->stream, ctx->stream3);
+			ctx->mark("sv_start");
 			try
 			{
 				have = schur_pattern_early_finish(ctx, io, sy);
+				ctx->mark("pat_fin");
 				if (have)
 				{
 					if (getenv("LSFM_CHECK_EARLY_PATTERN"))
@@ -1580,6 +1761,8 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 						if (a != b) LSFM_FAIL(LSFM_ERR_INTERNAL, "early pattern of S (" + std::to_string(a.size()) + " blocks) differs from the joint map's (" + std::to_string(b.size()) + ")");
 					}
 					chol_fetch(ctx, sy, io.d_pose_origin, hin);
+					ctx->mark("fetch");
+					schur_pattern_early_extras(ctx, io, sy);
 					LSFM_CHECK_HIP(hipEventRecord(ctx->evB, ctx->stream));
 				}
 			}
@@ -1612,7 +1795,10 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		build_schur_values(ctx, io, sy);
 		LSFM_CHECK_HIP(hipEventRecord(eb, s));
 		tw0 = wall();
-		chol_analyse(ctx, sy, hin, ch);
+		ctx->mark("k9_enq");
+		if (pre) chol_upload_symbolic(ctx, pre->sym, ch);
+		else chol_analyse(ctx, sy, hin, ch);
+		ctx->mark("analyse");
 		tw1 = wall();
 		d_err = ch.d_err;
 	}
@@ -1650,6 +1836,11 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		const size_t nl = (size_t)ch.nnzL * 36, nd = (size_t)ch.M * 36;
 		ch.Lf = sc.alloc<float>(nl); ch.Dinvf = sc.alloc<float>(nd);
 		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, nl, ch.L, ch.Lf);
+		if (ch.Lg)
+		{
+			ch.Lgf = sc.alloc<float>(nl);
+			hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, nl, ch.Lg, ch.Lgf);
+		}
 		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, nd, ch.Dinv, ch.Dinvf);
 	}
 	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
@@ -1675,11 +1866,14 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	// system ended below its bound is read once at the end of the whole run.
 	const int maxit = std::max(1, std::min(50, ctx->pcg.max_steps));
 	// the step count was recorded with the preconditioner in this precision, for this tolerance, under this cap
-	const bool planned_run = warm && sp->mixed == mixed && sp->rel_tol == ctx->pcg.rel_tol && sp->its <= maxit;
+	// ... or, in a run that analyses, what an earlier run of the same tree needed at this level (a guess about values, checked at
+	// the end of the run like a plan's count)
+	const bool hinted = !warm && deferred && ctx->step_hint > 0 && ctx->step_hint <= maxit;
+	const bool planned_run = hinted || (warm && sp->mixed == mixed && sp->rel_tol == ctx->pcg.rel_tol && sp->its <= maxit);
 	// (a run that counts its steps does not stop to ask before the first one either: systems that start below their bound
 	// are frozen on the device, the step costs them nothing)
 	int its = 0, ndone = 0;
-	const int planned = planned_run ? sp->its : maxit;
+	const int planned = hinted ? ctx->step_hint : (planned_run ? sp->its : maxit);
 	while ((planned_run ? its < planned : (ndone < nseg && its < maxit)))
 	{
 		const int cur = its & 1;
@@ -1693,7 +1887,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		if (planned_run) { if (its >= planned) break; }
 		else
 		{
+			ctx->mark("cg_enq");
 			ndone = d2h_int(ctx, d_misc + 1);
+			ctx->mark("cg_sync");
 			if (its == 1 && !deferred) check_factor(); // (the stream is drained: this costs no second wait)
 			if (ndone >= nseg) break;
 		}
@@ -1733,6 +1929,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		st->spmv_bytes += nsample * spmv_bytes(sy);
 		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
 	}
+	ctx->steps_used = planned_run ? 0 : std::max(its, 1);
 	if (deferred)
 	{
 		if (warm && !planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt

@@ -1,5 +1,6 @@
 // Context, arenas and the two library primitives used off the hot path (prefix sum, radix sort: rocPRIM).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -47,16 +48,29 @@ void dev_exclusive_scan(lsfm_context* ctx, const int* in, int* out, size_t n)
 	ctx->scratch.release(mk);
 }
 
-void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, size_t n, int end_bit)
+void dev_sort_keys_u64(lsfm_context* ctx, unsigned long long* keys, size_t n, int begin_bit, int end_bit)
 {
-	if (n == 0) return;
+	if (n == 0 || end_bit <= begin_bit) return;
+	size_t mk = ctx->scratch.mark();
+	unsigned long long* k2 = ctx->scratch.alloc<unsigned long long>(n);
+	size_t tb = 0;
+	LSFM_CHECK_HIP(rocprim::radix_sort_keys(nullptr, tb, keys, k2, n, begin_bit, end_bit, ctx->stream));
+	void* tmp = ctx->scratch.alloc_bytes(tb);
+	LSFM_CHECK_HIP(rocprim::radix_sort_keys(tmp, tb, keys, k2, n, begin_bit, end_bit, ctx->stream));
+	LSFM_CHECK_HIP(hipMemcpyAsync(keys, k2, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+	ctx->scratch.release(mk);
+}
+
+void dev_sort_pairs_u64(lsfm_context* ctx, unsigned long long* keys, int* vals, size_t n, int end_bit, int begin_bit)
+{
+	if (n == 0 || end_bit <= begin_bit) return;
 	size_t mk = ctx->scratch.mark();
 	unsigned long long* k2 = ctx->scratch.alloc<unsigned long long>(n);
 	int* v2 = ctx->scratch.alloc<int>(n);
 	size_t tb = 0;
-	LSFM_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, k2, vals, v2, n, 0, end_bit, ctx->stream));
+	LSFM_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, k2, vals, v2, n, begin_bit, end_bit, ctx->stream));
 	void* tmp = ctx->scratch.alloc_bytes(tb);
-	LSFM_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, k2, vals, v2, n, 0, end_bit, ctx->stream));
+	LSFM_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, keys, k2, vals, v2, n, begin_bit, end_bit, ctx->stream));
 	LSFM_CHECK_HIP(hipMemcpyAsync(keys, k2, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
 	LSFM_CHECK_HIP(hipMemcpyAsync(vals, v2, n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
 	ctx->scratch.release(mk);
@@ -85,7 +99,7 @@ void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes)
 		const size_t need = (bytes + 63) & ~(size_t)63;
 		if (ctx->stage_off + need > ctx->stage_size)
 		{
-			LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+			LSFM_CHECK_HIP(hipDeviceSynchronize()); // (every stream of the context may have copies from the ring in flight)
 			ctx->stage_off = 0;
 		}
 		char* slot = ctx->h_stage + ctx->stage_off;
@@ -129,6 +143,81 @@ void h2d_gather(lsfm_context* ctx, void* d, const std::vector<HostPiece>& pieces
 	}
 	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 }
+struct CopyDesc { unsigned long long dst, src, bytes, pad; };
+__global__ void __launch_bounds__(256) k_copy_many(const CopyDesc* __restrict__ descs)
+{
+	const CopyDesc d = descs[blockIdx.x];
+	const size_t first = (size_t)blockIdx.y * blockDim.x + threadIdx.x, stride = (size_t)gridDim.y * blockDim.x;
+	if (((d.dst | d.src | d.bytes) & 15ull) == 0)
+	{
+		uint4* o = reinterpret_cast<uint4*>(d.dst);
+		const uint4* i = reinterpret_cast<const uint4*>(d.src);
+		for (size_t q = first; q < d.bytes / 16; q += stride) o[q] = i[q];
+	}
+	else
+	{
+		unsigned* o = reinterpret_cast<unsigned*>(d.dst);
+		const unsigned* i = reinterpret_cast<const unsigned*>(d.src);
+		for (size_t q = first; q < d.bytes / 4; q += stride) o[q] = i[q];
+	}
+}
+void CopyBatch::flush()
+{
+	if (items.empty()) return;
+	if (items.size() == 1)
+	{
+		const Item& it = items[0];
+		if (it.host) lsfm::h2d(ctx, it.dst, it.src, it.bytes);
+		else LSFM_CHECK_HIP(hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+		items.clear();
+		return;
+	}
+	size_t table = items.size() * sizeof(CopyDesc), host_bytes = 0, most = 0;
+	for (const Item& it : items)
+	{
+		if (it.bytes % 4) LSFM_FAIL(LSFM_ERR_INTERNAL, "CopyBatch: sizes must be multiples of 4 bytes");
+		if (it.host) host_bytes += (it.bytes + 15) & ~(size_t)15;
+		most = std::max(most, it.bytes);
+	}
+	const size_t total = table + host_bytes;
+	if (!ctx->h_stage || total > ctx->stage_size / 4)
+	{
+		// too large to stage in one piece: one by one
+		for (const Item& it : items)
+		{
+			if (it.host) lsfm::h2d(ctx, it.dst, it.src, it.bytes);
+			else LSFM_CHECK_HIP(hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+		}
+		items.clear();
+		return;
+	}
+	if (ctx->stage_off + total + 64 > ctx->stage_size)
+	{
+		LSFM_CHECK_HIP(hipDeviceSynchronize());
+		ctx->stage_off = 0;
+	}
+	char* slot = ctx->h_stage + ctx->stage_off;
+	ctx->stage_off += (total + 63) & ~(size_t)63;
+	char* dev = static_cast<char*>(ctx->scratch.alloc_bytes(total)); // (256-byte aligned: the 16-byte path applies to aligned pieces)
+	CopyDesc* desc = reinterpret_cast<CopyDesc*>(slot);
+	size_t off = table;
+	for (size_t i = 0; i < items.size(); i++)
+	{
+		const Item& it = items[i];
+		desc[i].dst = (unsigned long long)(size_t)it.dst; desc[i].bytes = it.bytes; desc[i].pad = 0;
+		if (it.host)
+		{
+			memcpy(slot + off, it.src, it.bytes);
+			desc[i].src = (unsigned long long)(size_t)(dev + off);
+			off += (it.bytes + 15) & ~(size_t)15;
+		}
+		else desc[i].src = (unsigned long long)(size_t)it.src;
+	}
+	LSFM_CHECK_HIP(hipMemcpyAsync(dev, slot, total, hipMemcpyHostToDevice, ctx->stream));
+	const unsigned ny = (unsigned)std::min<size_t>(256, std::max<size_t>(1, most / (64 * 1024)));
+	hipLaunchKernelGGL(k_copy_many, dim3((unsigned)items.size(), ny), dim3(256), 0, ctx->stream, reinterpret_cast<const CopyDesc*>(dev));
+	items.clear();
+}
 void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes)
 {
 	if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -141,6 +230,11 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 
 } // namespace lsfm
 
+void lsfm_context::mark(const char* what)
+{
+	if (!timeline_on) return;
+	timeline.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
 hipEvent_t lsfm_context::pool_event()
 {
 	if (ev_next == ev_pool.size())
@@ -172,7 +266,8 @@ void lsfm_context::ensure_arenas(size_t bytes_each)
 	// the estimate is an upper bound that ignores the merging of common features (an order of magnitude at depth): never
 	// ask for more than a share of what the device has free; a tree that really needs more fails with LSFM_ERR_OOM at
 	// the allocation that overflows its arena
-	arena[0].destroy(); arena[1].destroy(); arena[2].destroy(); scratch.destroy();
+	arena[0].destroy(); arena[1].destroy(); arena[2].destroy(); scratch.destroy(); sarena[0].destroy(); sarena[1].destroy();
+	pre.reset();
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)4 << 30))
 		bytes_each = std::min(bytes_each, (free_b - ((size_t)2 << 30)) / 5);
@@ -180,6 +275,8 @@ void lsfm_context::ensure_arenas(size_t bytes_each)
 	arena[1].init(bytes_each);
 	arena[2].init(bytes_each);
 	scratch.init(bytes_each);
+	sarena[0].init(std::max<size_t>((size_t)96 << 20, bytes_each / 6));
+	sarena[1].init(std::max<size_t>((size_t)96 << 20, bytes_each / 6));
 	arena_bytes = bytes_each;
 	arena_req = requested;
 }
@@ -203,10 +300,17 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipSetDevice(device));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+		{
+			// the early pattern's stream: its small kernels must not queue behind the work-groups of the transform's block kernels
+			int least = 0, greatest = 0;
+			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+			LSFM_CHECK_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest));
+		}
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evY, hipEventDisableTiming));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		c->stage_size = (size_t)64 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
@@ -252,6 +356,10 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->evA) (void)hipEventDestroy(c->evA);
 	if (c->evB) (void)hipEventDestroy(c->evB);
 	if (c->evC) (void)hipEventDestroy(c->evC);
+	if (c->evY) (void)hipEventDestroy(c->evY);
+	if (c->evP) (void)hipEventDestroy(c->evP);
+	c->pre.reset();
+	c->sarena[0].destroy(); c->sarena[1].destroy();
 	c->early.reset();
 	delete c;
 }

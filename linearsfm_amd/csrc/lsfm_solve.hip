@@ -16,6 +16,7 @@
 
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
+#include "lsfm_join.hpp"
 #include "lsfm_solve.hpp"
 
 namespace lsfm {
@@ -138,14 +139,21 @@ k_pat_insert_w(int NF, const int* __restrict__ fptr, const int* __restrict__ pho
 }
 
 // sum over the features of (run length)^2: the pose pairs of K9 (for its algorithmic flop count)
-__global__ void k_sum_run_squares(int NF, const int* __restrict__ fptr, unsigned long long* out)
+__global__ void __launch_bounds__(256) k_sum_run_squares(int NF, const int* __restrict__ fptr, unsigned long long* out)
 {
-	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	// a few hundred work-groups striding over the features, ONE atomic each (one per wave on a single address took 120 us)
+	__shared__ unsigned long long part[4];
 	unsigned long long v = 0;
-	if (f < NF) { const unsigned long long k = (unsigned long long)(fptr[f + 1] - fptr[f]); v = k * k; }
+	for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < NF; f += gridDim.x * blockDim.x)
+	{
+		const unsigned long long k = (unsigned long long)(fptr[f + 1] - fptr[f]);
+		v += k * k;
+	}
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, LSFM_WAVE);
-	if ((threadIdx.x & (LSFM_WAVE - 1)) == 0 && v) atomicAdd(out, v);
+	if ((threadIdx.x & (LSFM_WAVE - 1)) == 0) part[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) { v = part[0] + part[1] + part[2] + part[3]; if (v) atomicAdd(out, v); }
 }
 
 __global__ void k_pat_compact(size_t cap, const unsigned long long* __restrict__ tab, unsigned long long* __restrict__ list, int* __restrict__ count)
@@ -625,7 +633,11 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 		unsigned long long* ent = sc.alloc<unsigned long long>((size_t)2 * cnt);
 		int* oth = sc.alloc<int>((size_t)2 * cnt);
 		hipLaunchKernelGGL(k_spmv_gather_keys, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, sorted_upper, ent, oth);
-		dev_sort_pairs_u64(ctx, ent, oth, (size_t)2 * cnt, 64);
+		// by target row only (the high word; the sort is stable and the product is a segmented sum over rows: the order inside a
+		// row is free); the holes (all bits set) end up last
+		int rb = 1;
+		while ((1 << rb) <= M) rb++;
+		dev_sort_pairs_u64(ctx, ent, oth, (size_t)2 * cnt, 32 + rb, 32);
 		sy.gent = ent; sy.goth = oth;
 	}
 }
@@ -678,30 +690,27 @@ static bool pattern_count(lsfm_context* ctx, const PatternBuild& pb, int* cnt)
 	*cnt = fl[1];
 	return !fl[0] && (size_t)fl[1] * 2 <= pb.cap;
 }
+// sorted key list + block CSR: all that the host's symbolic analysis and K9 wait for (enqueued, nothing read back)
 static void pattern_finish(lsfm_context* ctx, const SolveIO& io, const PatternBuild& pb, int cnt, SchurSystem& sy)
 {
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
-	const int M = io.M, NF = io.NF;
+	const int M = io.M;
 	sy.M = M;
 	sy.nnzb = cnt;
-	// sum over the features of (run length)^2: the pose pairs of K9, for its algorithmic flop count
-	unsigned long long* d_k2 = sc.alloc<unsigned long long>(1);
-	dev_zero(ctx, d_k2, sizeof(unsigned long long));
-	if (NF) hipLaunchKernelGGL(k_sum_run_squares, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, d_k2);
 	const unsigned long long mask = (unsigned long long)(pb.cap - 1);
-	int* dummy = sc.alloc<int>(cnt + 1);
-	dev_sort_pairs_u64(ctx, pb.list, dummy, cnt, 64);
+	// keys are (row << 32 | column) with both below M: two stable sorts over the bits in use (columns, then rows) instead of
+	// one over all 64 -- a third of the passes
+	int rb = 1;
+	while ((1 << rb) <= M) rb++;
+	dev_sort_keys_u64(ctx, pb.list, cnt, 0, rb);
+	dev_sort_keys_u64(ctx, pb.list, cnt, 32, 32 + rb);
 	sy.rowptr = sc.alloc<int>(M + 1);
 	sy.colidx = sc.alloc<int>(cnt + 1);
 	if (cnt) hipLaunchKernelGGL(k_pat_assign, dim3((cnt + 255) / 256), dim3(256), 0, s, cnt, pb.list, pb.tab, pb.hval, mask, sy.colidx);
 	hipLaunchKernelGGL(k_rowptr_from_keys, dim3((M + 1 + 255) / 256), dim3(256), 0, s, M, cnt, pb.list, 32, sy.rowptr);
 	sy.tab = pb.tab; sy.hval = pb.hval; sy.mask = mask;
 	sy.upper_keys = pb.list;
-	build_spmv_index(ctx, sy, pb.list, pb.d_flags);
-	unsigned long long k2 = 0;
-	d2h(ctx, &k2, d_k2, sizeof k2);
-	sy.k9_flops = (double)io.NW * 144.0 + ((double)k2 + (double)io.NW) * 0.5 * 216.0;
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 
@@ -721,7 +730,12 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
 		pattern_compact(ctx, pb);
 		int cnt = 0;
-		if (pattern_count(ctx, pb, &cnt)) { pattern_finish(ctx, io, pb, cnt, sy); return; }
+		if (pattern_count(ctx, pb, &cnt))
+		{
+			pattern_finish(ctx, io, pb, cnt, sy);
+			build_spmv_index(ctx, sy, pb.list, pb.d_flags);
+			return;
+		}
 		sc.release(mk);
 		cap <<= 2;
 		if (attempt > 10) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur pattern hash table kept overflowing");
@@ -817,6 +831,91 @@ __global__ void k_pat_insert_keys(int n, const unsigned long long* __restrict__ 
 	if (i < n) hash_insert(tab, mask, keys[i], overflow);
 }
 
+// ---- the pattern of the NEXT level's system, from this level's joint maps (prefetch_next_level, lsfm_pcg.hip) -------------
+// hub pose of every map of the batch in the next level's transform: the pose whose id is the map's target reference
+__global__ void k_pre_hubs(int M, const int* __restrict__ pose_id, const int* __restrict__ pose_map, const int* __restrict__ tref, int* __restrict__ hub)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= M) return;
+	const int b = pose_map[k];
+	if (tref[b] >= 0 && pose_id[k] == tref[b]) hub[b] = k;
+}
+// pairs across the two maps of a pair, one lane per feature of the second map that has a match in the first
+__global__ void __launch_bounds__(256)
+k_pat_insert_w_cross_match(int NF, const int* __restrict__ feat_map, const int* __restrict__ match, const int* __restrict__ fptr,
+                           const int* __restrict__ photo, const int* __restrict__ hub, unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	const int fc = blockIdx.x * blockDim.x + threadIdx.x;
+	if (fc >= NF || !(feat_map[fc] & 1)) return;
+	const int fe = match[fc];
+	if (fe < 0) return;
+	const int jE = fptr[fe], lenE = fptr[fe + 1] - jE, hE = hub[feat_map[fe]];
+	const int jC = fptr[fc], lenC = fptr[fc + 1] - jC, hC = hub[feat_map[fc]];
+	for (int a = 0; a <= lenE; a++)
+	{
+		const int pa = a < lenE ? photo[jE + a] : hE;
+		if (pa < 0) continue;
+		for (int b = 0; b <= lenC; b++)
+		{
+			const int pb = b < lenC ? photo[jC + b] : hC;
+			if (pb >= 0) hash_insert(tab, mask, pair_key(pa, pb), overflow);
+		}
+	}
+}
+// ctx->stream / ctx->scratch name the stream and the arena the caller wants this on.  prev_keys: the pattern of the level that
+// produced Y (every pair inside one of Y's maps).  false: nothing to build from.
+bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy)
+{
+	if (!prev_keys || !Y.M) return false;
+	hipStream_t s = ctx->stream;
+	Arena& sc = ctx->scratch;
+	static const bool dbg = getenv("LSFM_DEBUG_SYNC") != nullptr;
+	auto chk = [&](const char* what) {
+		if (!dbg) return;
+		hipError_t e = hipDeviceSynchronize();
+		fprintf(stderr, "[prefetch] %s: %s\n", what, hipGetErrorString(e));
+	};
+	chk("before");
+	int* hub = sc.alloc<int>(Y.B);
+	LSFM_CHECK_HIP(hipMemsetAsync(hub, 0xff, sizeof(int) * (size_t)Y.B, s));
+	hipLaunchKernelGGL(k_pre_hubs, dim3((Y.M + 255) / 256), dim3(256), 0, s, Y.M, Y.pose_id, Y.pose_map, d_tref, hub);
+	chk("hubs");
+	int* match = sc.alloc<int>(Y.NF + 1);
+	int* unm = sc.alloc<int>(Y.NF + 2);
+	if (Y.NF) join_match_features(ctx, Y, match, unm);
+	chk("match");
+	size_t cap = pattern_capacity(std::max((size_t)Y.NU + Y.M, (size_t)prev_nnzb + Y.M), Y.M);
+	SolveIO io;
+	io.M = Y.M;
+	for (int attempt = 0;; attempt++)
+	{
+		const size_t mk = sc.mark();
+		PatternBuild pb;
+		pattern_begin(ctx, cap, pb);
+		const unsigned long long mask = (unsigned long long)(cap - 1);
+		const int nu = std::max(Y.NU, Y.M);
+		chk("begin");
+		hipLaunchKernelGGL(k_pat_insert_u_early, dim3((nu + 255) / 256), dim3(256), 0, s, Y.NU, Y.M, Y.Ui, Y.Uj, Y.pose_map, hub, pb.tab, mask, pb.d_flags);
+		chk("insert_u");
+		if (prev_nnzb) hipLaunchKernelGGL(k_pat_insert_keys, dim3((prev_nnzb + 255) / 256), dim3(256), 0, s, prev_nnzb, prev_keys, pb.tab, mask, pb.d_flags);
+		chk("insert_keys");
+		if (Y.NF) hipLaunchKernelGGL(k_pat_insert_w_cross_match, dim3((Y.NF + 255) / 256), dim3(256), 0, s, Y.NF, Y.feat_map, match, Y.fptr, Y.photo, hub, pb.tab, mask, pb.d_flags);
+		chk("insert_cross");
+		pattern_compact(ctx, pb);
+		chk("compact");
+		int cnt = 0;
+		if (pattern_count(ctx, pb, &cnt))
+		{
+			pattern_finish(ctx, io, pb, cnt, sy);
+			build_spmv_index(ctx, sy, pb.list, pb.d_flags);
+			return true;
+		}
+		sc.release(mk);
+		cap <<= 2;
+		if (attempt > 10) return false;
+	}
+}
+
 struct EarlyPattern { PatternBuild pb; int M = 0; };
 
 void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in)
@@ -863,6 +962,12 @@ bool schur_pattern_early_finish(lsfm_context* ctx, const SolveIO& io, SchurSyste
 	if (!pattern_count(ctx, ep->pb, &cnt)) return false;
 	pattern_finish(ctx, io, ep->pb, cnt, sy);
 	return true;
+}
+// after the keys have gone to the host: -- enqueued only -- the SpMV index, which nothing needs before the first product of the CG
+void schur_pattern_early_extras(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
+{
+	(void)io;
+	build_spmv_index(ctx, sy, sy.upper_keys, nullptr);
 }
 
 void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx)
@@ -917,7 +1022,11 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			ctx->stats->schur_launches++;
 			// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)
 			ctx->stats->schur_bytes += (double)io.NW * (144 + 4) + (double)io.NF * (72 + 24 + 4) + (double)sy.nnzb * 288 + (double)io.M * 48;
-			ctx->stats->schur_flops += sy.k9_flops;
+			// algorithmic flops of K9 = 144 NW + 108 (sum of squared run lengths + NW): the sum is taken on the device and read with
+			// the run's record at the end of a tree run (lsfm_tree_run adds 108 x that)
+			ctx->stats->schur_flops += (double)io.NW * (144.0 + 108.0);
+			if (ctx->in_tree_run && ctx->d_run)
+				hipLaunchKernelGGL(k_sum_run_squares, dim3(std::min((NF + 255) / 256, 512)), dim3(256), 0, s, NF, io.fptr, &ctx->d_run->k2);
 		}
 	}
 	LSFM_CHECK_HIP(hipGetLastError());

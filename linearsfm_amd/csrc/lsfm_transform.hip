@@ -1075,23 +1075,30 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	TMap* d_tm = ctx->scratch.alloc<TMap>(B);
 	int* d_err = ctx->scratch.alloc<int>(1);
 	dev_zero(ctx, d_err, sizeof(int));
-	h2d(ctx, d_tm, tm.data(), sizeof(TMap) * B);
+	CopyBatch cb(ctx); // the small copies of the prologue: map records, offsets, label arrays -- one transfer, one kernel
+	cb.h2d(d_tm, tm.data(), sizeof(TMap) * B);
 
 	out = DevBatch();
 	out.B = B; out.M = in.M; out.NF = in.NF;
 	out.pose_off = in.pose_off; out.feat_off = in.feat_off;
 	out.Ref = in.Ref; out.FRef = in.FRef; out.ScaP = in.ScaP; out.Fix = in.Fix; out.Sign = in.Sign; out.FScaP = in.FScaP; out.FFix = in.FFix;
 	// nothing of `out` may alias `in`: the two live in different arenas with different lifetimes
-	batch_set_offsets(ctx, ar, out);
+	batch_set_offsets(ctx, ar, out, &cb);
 	out.feat_id = ar.alloc<int>(in.NF);
-	if (in.NF) LSFM_CHECK_HIP(hipMemcpyAsync(out.feat_id, in.feat_id, (size_t)in.NF * sizeof(int), hipMemcpyDeviceToDevice, s));
+	cb.d2d(out.feat_id, in.feat_id, (size_t)in.NF * sizeof(int));
 	out.pose = ar.alloc<double>((size_t)in.M * 6);
 	out.pose_id = ar.alloc<int>(in.M);
 	out.pose_origin = ar.alloc<int>(in.M);
-	if (in.M) LSFM_CHECK_HIP(hipMemcpyAsync(out.pose_origin, in.pose_origin, (size_t)in.M * sizeof(int), hipMemcpyDeviceToDevice, s));
+	cb.d2d(out.pose_origin, in.pose_origin, (size_t)in.M * sizeof(int));
 	out.feat = ar.alloc<double>((size_t)in.NF * 3);
 	out.V = ar.alloc<double>((size_t)in.NF * 9);
 	out.fptr = ar.alloc<int>(in.NF + 1);
+	int* d_uoff = ctx->scratch.alloc<int>(B + 1);
+	int* d_woff = ctx->scratch.alloc<int>(B + 1);
+	cb.h2d(d_uoff, in.u_off.data(), (B + 1) * sizeof(int));
+	cb.h2d(d_woff, in.w_off.data(), (B + 1) * sizeof(int));
+	cb.flush();
+	batch_fill_maps(ctx, out);
 
 	const int M = in.M;
 	if (M)
@@ -1132,11 +1139,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	}
 	dev_exclusive_scan(ctx, keepU, KU, in.NU);
 	dev_exclusive_scan(ctx, keepW, KW, in.NW);
-	int* d_uoff = ctx->scratch.alloc<int>(B + 1);
-	int* d_woff = ctx->scratch.alloc<int>(B + 1);
 	int* d_cnt = ctx->scratch.alloc<int>(2 * (B + 1));
-	h2d(ctx, d_uoff, in.u_off.data(), (B + 1) * sizeof(int));
-	h2d(ctx, d_woff, in.w_off.data(), (B + 1) * sizeof(int));
 	LevelPlan* plan = ctx->plan;
 	const bool warm = ctx->warm();
 	std::vector<int> cnt(2 * (B + 1));
@@ -1144,8 +1147,10 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	else
 	{
 		hipLaunchKernelGGL(k_tr_gather_counts, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, d_uoff, d_woff, B, d_cnt);
+		ctx->mark("tr_enq");
 		d2h_ints(ctx, d_cnt, cnt.data(), cnt.size());
 		int err = d2h_int(ctx, d_err);
+		ctx->mark("tr_cnt");
 		if (err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(err - 1));
 		if (plan) plan->tr_cnt = cnt;
 	}
@@ -1219,6 +1224,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		}
 	if (mono) launch_stage<2>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act, hook);
 	else launch_stage<1>(ctx, in, out, d_tm, KU, KW, Dp, Cp, Gpose, PP, nw_act_in, nw_act_out, nf_act, hook);
+	ctx->mark("tr_done");
 	LSFM_CHECK_HIP(hipGetLastError());
 	(void)any;
 	ctx->tr_in = nullptr; ctx->tr_hub = nullptr;

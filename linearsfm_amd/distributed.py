@@ -139,6 +139,8 @@ class ShardedTree:
         self.merge_trees = {}   # round -> tree built from packed buffers
         self.out_bufs = {}      # round -> torch buffer the own node is packed into
         self.in_bufs = {}       # round -> torch buffer the partner's node arrives in
+        self.in_host = {}       # round -> pinned host landing buffer (gloo: the payload is staged through the host)
+        self.pending = {}       # round -> receives posted at the start of a run
         self.result = None
         self.plans = True
         self.gpu_direct = dist.is_initialized() and dist.get_backend(group) == "nccl"
@@ -159,7 +161,30 @@ class ShardedTree:
             # the next run() packs into the same buffer on the library's own stream, which knows nothing of RCCL's: wait here
             torch.cuda.current_stream(self.device).synchronize()
 
+    def _post_recv(self, src, slot):
+        """Posts the receives of the node `src` will send in round `slot` NOW, into the buffer of the last run (same structure,
+        same size: a resident tree is joined again and again), so that the transfer runs while this rank is still busy with
+        its own block or its export.  First run of a slot: nothing is known yet, _recv does it all."""
+        buf = self.in_bufs.get(slot)
+        if buf is None:
+            return
+        size = torch.zeros(1, dtype=torch.int64, device=self.device if self.gpu_direct else "cpu")
+        land = buf if self.gpu_direct else self.in_host.setdefault(slot, torch.empty(buf.numel(), dtype=torch.uint8).pin_memory())
+        self.pending[slot] = (size, land, dist.irecv(size, src=src, group=self.group), dist.irecv(land, src=src, group=self.group))
+
     def _recv(self, src, slot):
+        posted = self.pending.pop(slot, None)
+        if posted is not None:
+            size, land, w0, w1 = posted
+            w0.wait()
+            w1.wait()
+            buf = self.in_bufs[slot]
+            if int(size.item()) != buf.numel():
+                raise RuntimeError("a sub-tree root changed its size between two runs of a resident tree")
+            if not self.gpu_direct:
+                buf.copy_(land, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()  # the library reads the buffer on its own stream next
+            return buf
         size = torch.zeros(1, dtype=torch.int64, device=self.device if self.gpu_direct else "cpu")
         dist.recv(size, src=src, group=self.group)
         n = int(size.item())
@@ -191,6 +216,10 @@ class ShardedTree:
         """Returns (stats of the last tree run on this rank or None, worst return code on this rank)."""
         ctx = self.ctx
         cur, stats, worst = None, None, 0
+        # the partners' nodes may start travelling as soon as they exist: post every receive of this run whose buffer is known
+        for act in merge_schedule(self.rank, self.world, self.nonempty):
+            if act[0] == "merge" and act[1] is not None:
+                self._post_recv(act[1], act[2])
         if self.block_tree is not None:
             stats, rc = ctx.tree_run(self.block_tree)
             worst = max(worst, rc)

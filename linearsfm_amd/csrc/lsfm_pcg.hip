@@ -34,6 +34,7 @@ struct PcgSeg {
 	double pAp;
 	double rr, ee, thresh, rr_prev;
 	int done, its, row0, active;
+	int slow, pad; // steps in a row that shrank the true residual by less than half
 };
 static_assert(sizeof(PcgSeg) % sizeof(double) == 0, "PcgSeg is strided in doubles by the fused dot products");
 #define SEG_STRIDE ((int)(sizeof(PcgSeg) / sizeof(double)))
@@ -67,6 +68,7 @@ struct CholDev {
 	int *grp_c0 = nullptr, *grp_s = nullptr, *grp_nr = nullptr; // [ngroups] first column, columns, rows below the run
 	std::vector<int> glevel_ptr;    // host: groups of level l = [glevel_ptr[l], glevel_ptr[l+1])
 	std::vector<int> glevel_maxnr;  // host: most rows below a run of the level
+	std::vector<int> glevel_maxs;   // host: most block columns of a run of the level (LDS of k_sn_panel)
 	int* blob = nullptr;    // all index arrays above are slices of this one allocation
 	size_t blob_ints = 0;
 	float *Lf = nullptr, *Dinvf = nullptr; // mixed precision: the factor rounded to fp32 for the triangular solves (null: fp64)
@@ -664,18 +666,22 @@ template <bool FUSED>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Lg,
                                                           double* __restrict__ Dinv, int* err, const int* __restrict__ rowidx, double* __restrict__ fv,
-                                                          double* __restrict__ fw)
+                                                          double* __restrict__ fw, int smax)
 {
+	// LDS by the widest run of the LEVEL (smax block columns), not by CHOL_GS: most levels of most systems hold runs of 1-6
+	// columns, and at 150 KB a work-group had a CU to itself -- a level of 2 000 small work-groups took 8 rounds
+	extern __shared__ double Ms[];
+	const int LD = 6 * smax;                       // dense scalar rows of the diagonal part
+	const int xs = ((LD + 3) & ~3) + 1;            // odd row stride, with room for the zero padding of the MFMA k step
 	// rows 0 .. 6 GS - 1: L_dd (dense scalar rows); rows 6 GS ..: the panel rows of this work-group.  Lanes 0..95 own the
 	// diagonal rows, lanes 128..223 (two other waves, other SIMDs) the panel rows: the same recurrence, in step
-	__shared__ double Ms[(6 * CHOL_GS + 6 * SN_RB + 1) * SN_XS]; // + the row of the right-hand side
 	__shared__ double sD[36];
 	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
 	__shared__ int sRow[SN_RB];  // common row (position below the run) of every panel slot, -1: empty slot
 	__shared__ int spos[(SN_RB / 2) * (SN_RB / 2)]; // FUSED: block of L every (a, b) product goes to, -1: none
 	double* const Ls = Ms;
-	double* const Xs = Ms + 6 * CHOL_GS * SN_XS;
+	double* const Xs = Ms + LD * xs;
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
 	constexpr int HB = SN_RB / 2;
 	int ca = 0, cb = 0;
@@ -708,7 +714,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		while (sn_idx(s, s - 1, t) < e) t++; // column of packed block e (s <= 16: a short scan)
 		const int u = t + (e - sn_idx(s, t, t));
 		sSrc[e] = (sCol[t] + (u - t)) * 36;
-		sDst[e] = 6 * u * SN_XS + 6 * t;
+		sDst[e] = 6 * u * xs + 6 * t;
 	}
 	const int rows0 = sCol[s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
 	if constexpr (FUSED)
@@ -751,25 +757,25 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		for (int i = 0; i < SN_LD; i++)
 		{
 			const int q = base + i * nt + tid;
-			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * SN_XS + w % 6]; d[0] = v[i].x; d[1] = v[i].y; }
+			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * xs + w % 6]; d[0] = v[i].x; d[1] = v[i].y; }
 			else if (q < nd2 + np2)
 			{
 				const int qq = q - nd2, blk = qq / 18, w = 2 * (qq - blk * 18), il = blk / s, t = blk - il * s;
 				if (sRow[il] >= 0)
 				{
-					double* d = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+					double* d = &Xs[(6 * il + w / 6) * xs + 6 * t + w % 6];
 					d[0] = v[i].x; d[1] = v[i].y;
 				}
 			}
 		}
 	}
-	constexpr int XR = 6 * CHOL_GS + 6 * SN_RB; // row of the right-hand side, owned by lane 128 + 6 SN_RB
+	const int XR = LD + 6 * SN_RB; // row of the right-hand side, owned by lane 128 + 6 SN_RB
 	const bool with_fv = fv && diag_pair;
-	if (with_fv && tid < n6) Ms[XR * SN_XS + tid] = fv[(size_t)c0 * 6 + tid];
+	if (with_fv && tid < n6) Ms[XR * xs + tid] = fv[(size_t)c0 * 6 + tid];
 	__syncthreads();
 	// row of Ms this lane owns (-1: none)
-	const int ri = tid < 6 * CHOL_GS ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? 6 * CHOL_GS + (tid - 128) : ((with_fv && tid == 128 + 6 * SN_RB) ? XR : -1));
-	const bool panel_lane = ri >= 6 * CHOL_GS && (ri == XR || sRow[(ri - 6 * CHOL_GS) / 6] >= 0);
+	const int ri = tid < LD ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? LD + (tid - 128) : ((with_fv && tid == 128 + 6 * SN_RB) ? XR : -1));
+	const bool panel_lane = ri >= LD && (ri == XR || sRow[(ri - LD) / 6] >= 0);
 	bool bad = false;
 	for (int t = 0; t < s; t++)
 	{
@@ -778,7 +784,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		const bool mine = panel_lane || (ri >= k0 && ri < n6);
 		if (mine)
 		{
-			const double* xi = &Ms[ri * SN_XS];
+			const double* xi = &Ms[ri * xs];
 #pragma unroll
 			for (int c = 0; c < 6; c++) a[c] = xi[k0 + c];
 			for (int v = 0; v < t; v++) // block by block: 42 LDS reads in flight, then 36 multiply-adds
@@ -789,7 +795,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 #pragma unroll
 				for (int c = 0; c < 6; c++)
 				{
-					const double* lr = &Ls[(k0 + c) * SN_XS + 6 * v];
+					const double* lr = &Ls[(k0 + c) * xs + 6 * v];
 #pragma unroll
 					for (int k = 0; k < 6; k++) a[c] = fma(-xv[k], lr[k], a[c]);
 				}
@@ -821,7 +827,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 #pragma unroll
 					for (int c = k + 1; c <= r; c++) d[r * (r + 1) / 2 + c] -= d[r * (r + 1) / 2 + k] * d[c * (c + 1) / 2 + k];
 			}
-			double* xo = &Ms[ri * SN_XS + k0];
+			double* xo = &Ms[ri * xs + k0];
 			if (ri < k0 + 6)
 			{
 				// a row of the diagonal block itself: row (ri - k0) of the factor, zeros above the diagonal
@@ -855,15 +861,15 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	if (bad && tid == 0) atomicExch(err, 1 + c0);
 	if (with_fv)
 	{
-		const double* yg = &Ms[XR * SN_XS];
+		const double* yg = &Ms[XR * xs];
 		if (blockIdx.y == 0 && tid < n6) fw[(size_t)c0 * 6 + tid] = yg[tid];
-		const int slot = ri >= 6 * CHOL_GS && ri != XR ? (ri - 6 * CHOL_GS) / 6 : -1;
+		const int slot = ri >= LD && ri != XR ? (ri - LD) / 6 : -1;
 		if (panel_lane && slot >= 0 && (!FUSED || slot < HB))
 		{
-			const double* xr = &Ms[ri * SN_XS];
+			const double* xr = &Ms[ri * xs];
 			double o0 = 0.0, o1 = 0.0;
 			for (int k = 0; k + 1 < n6; k += 2) { o0 = fma(xr[k], yg[k], o0); o1 = fma(xr[k + 1], yg[k + 1], o1); } // n6 is even
-			const int r = (ri - 6 * CHOL_GS) - 6 * slot;
+			const int r = (ri - LD) - 6 * slot;
 			atomic_add_f64(fv + (size_t)rowidx[rows0 + sRow[slot]] * 6 + r, -(o0 + o1));
 		}
 	}
@@ -873,14 +879,14 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		if (tid < n6)
 		{
 			const int t = tid / 6, c = tid - 6 * t;
-			const double* dg = &Ls[(6 * t) * SN_XS + 6 * t];
+			const double* dg = &Ls[(6 * t) * xs + 6 * t];
 			double x[6];
 #pragma unroll
 			for (int r = 0; r < 6; r++)
 			{
 				double v = r == c ? 1.0 : 0.0;
 #pragma unroll
-				for (int k = 0; k < r; k++) v = fma(-dg[r * SN_XS + k], x[k], v);
+				for (int k = 0; k < r; k++) v = fma(-dg[r * xs + k], x[k], v);
 				x[r] = v * sInvD[6 * t + r];
 			}
 #pragma unroll
@@ -890,7 +896,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		for (int q = tid; q < nb * 36; q += nt)
 		{
 			const int e = q / 36, w = q - e * 36;
-			Lg[(size_t)sSrc[e] + w] = Ls[sDst[e] + (w / 6) * SN_XS + w % 6];
+			Lg[(size_t)sSrc[e] + w] = Ls[sDst[e] + (w / 6) * xs + w % 6];
 		}
 	}
 	// the solved panel rows X = A L_dd^-T of this work-group's own chunk
@@ -899,7 +905,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		{
 			const int blk = q / 18, w = 2 * (q - blk * 18), il = blk / s, t = blk - il * s, row = sRow[il];
 			if (row < 0) continue;
-			const double* x = &Xs[(6 * il + w / 6) * SN_XS + 6 * t + w % 6];
+			const double* x = &Xs[(6 * il + w / 6) * xs + 6 * t + w % 6];
 			*reinterpret_cast<double2*>(Lg + (size_t)(sCol[t] + (s - t) + row) * 36 + w) = make_double2(x[0], x[1]);
 		}
 	if constexpr (FUSED)
@@ -909,23 +915,40 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		// a multiple of 4 (the k step of the instruction); rows of empty slots hold stale numbers: their products are dropped ----
 		const int n6r = (n6 + 3) & ~3;
 		if (n6r > n6)
-			for (int q = tid; q < 6 * SN_RB * (n6r - n6); q += nt) Xs[(q / (n6r - n6)) * SN_XS + n6 + q % (n6r - n6)] = 0.0;
+			for (int q = tid; q < 6 * SN_RB * (n6r - n6); q += nt) Xs[(q / (n6r - n6)) * xs + n6 + q % (n6r - n6)] = 0.0;
 		__syncthreads(); // (also: the diagonal rows in Ls are no longer read -- the products land there)
 		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-		const double* XB = ca == cb ? Xs : Xs + 6 * HB * SN_XS;
+		const double* XB = ca == cb ? Xs : Xs + 6 * HB * xs;
 		constexpr int NTL = (6 * HB) / 16; // 16-row tiles per side: 3
 		constexpr int TS = 6 * HB + 1;     // row stride of the products in LDS
-		double* sT = Ls;
-		for (int q = wave; q < NTL * NTL; q += SN_THREADS / 64)
-		{
-			const int ti = q / NTL, tj = q - ti * NTL;
-			const double* pa = &Xs[(16 * ti + (lane & 15)) * SN_XS + (lane >> 4)];
-			const double* pb = &XB[(16 * tj + (lane & 15)) * SN_XS + (lane >> 4)];
-			sn_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-			for (int ks = 0; ks < n6r; ks += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks], pb[ks], acc, 0, 0, 0);
-			// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+		double* sT = Ms; // (over the diagonal rows, and into the X rows when the diagonal part is small: hence the barrier below)
+		constexpr int TPW = (NTL * NTL + SN_THREADS / 64 - 1) / (SN_THREADS / 64);
+		sn_v4d acc[TPW];
 #pragma unroll
-			for (int e = 0; e < 4; e++) sT[(16 * ti + (lane >> 4) + 4 * e) * TS + 16 * tj + (lane & 15)] = acc[e];
+		for (int i = 0; i < TPW; i++)
+		{
+			acc[i] = (sn_v4d){ 0.0, 0.0, 0.0, 0.0 };
+			const int q = wave + (SN_THREADS / 64) * i;
+			if (q < NTL * NTL)
+			{
+				const int ti = q / NTL, tj = q - ti * NTL;
+				const double* pa = &Xs[(16 * ti + (lane & 15)) * xs + (lane >> 4)];
+				const double* pb = &XB[(16 * tj + (lane & 15)) * xs + (lane >> 4)];
+				for (int ks = 0; ks < n6r; ks += 4) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks], pb[ks], acc[i], 0, 0, 0);
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < TPW; i++)
+		{
+			const int q = wave + (SN_THREADS / 64) * i;
+			if (q < NTL * NTL)
+			{
+				const int ti = q / NTL, tj = q - ti * NTL;
+				// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+				for (int e = 0; e < 4; e++) sT[(16 * ti + (lane >> 4) + 4 * e) * TS + 16 * tj + (lane & 15)] = acc[i][e];
+			}
 		}
 		__syncthreads();
 		for (int idx = tid; idx < HB * HB * 36; idx += nt)
@@ -994,6 +1017,13 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 		}
 		__syncthreads();
 	}
+}
+// dynamic LDS of k_sn_panel for a level whose widest run has smax block columns (the products of the rank update are staged over
+// the same memory: at least 48 x 49 doubles)
+static size_t sn_panel_lds(int smax)
+{
+	const size_t LD = 6 * (size_t)smax, xs = ((LD + 3) & ~(size_t)3) + 1;
+	return std::max((LD + 6 * SN_RB + 1) * xs, (size_t)(6 * SN_RB / 2) * (6 * SN_RB / 2 + 1)) * sizeof(double);
 }
 // the factor of the group columns back into L (only for the fall-back solves that read one array: chol_apply)
 __global__ void k_sn_merge(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ colptr, const double* __restrict__ Lg,
@@ -1313,7 +1343,7 @@ static void chol_upload_symbolic(lsfm_context* ctx, const CholSymbolic& sym, Cho
 	ch.level_ptr = sym.level_ptr;
 	ch.tlevel_ptr = sym.tlevel_ptr; ch.tlevel_maxsize = sym.tlevel_maxsize; ch.tlevel_col0 = sym.tlevel_col0; ch.tlevel_nsmall = sym.tlevel_nsmall;
 	ch.tlevel_small_lds = sym.tlevel_small_lds; ch.tlevel_outer = sym.tlevel_outer;
-	ch.ngroups = sym.ngroups; ch.glevel_ptr = sym.glevel_ptr; ch.glevel_maxnr = sym.glevel_maxnr;
+	ch.ngroups = sym.ngroups; ch.glevel_ptr = sym.glevel_ptr; ch.glevel_maxnr = sym.glevel_maxnr; ch.glevel_maxs = sym.glevel_maxs;
 	const struct { int** dst; const std::vector<int>* v; } parts[] = {
 		{ &ch.grp_c0, &sym.grp_c0 }, { &ch.grp_s, &sym.grp_s }, { &ch.grp_nr, &sym.grp_nr }, { &ch.col_nin, &sym.col_nin }, { &ch.col_task, &sym.col_task },
 		{ &ch.col_lpos, &sym.col_lpos }, { &ch.task_cols, &sym.task_cols }, { &ch.task_ptr, &sym.task_ptr }, { &ch.colptr, &sym.colptr },
@@ -1439,21 +1469,31 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	if (groups)
 	{
 		// one launch per group level while the panels are short enough for the fused kernel (pairs of 8-row chunks: a panel of
-		// 160 rows is 210 work-groups per group); taller ones take the panel kernel + the rank-update kernel
-		static const int fuse_max = getenv("LSFM_SN_FUSE_MAX") ? atoi(getenv("LSFM_SN_FUSE_MAX")) : 160;
+		// 64 rows is 36 work-groups per group, each repeating the solve of its two chunks); taller ones take the panel kernel +
+		// the rank-update kernel (a synth-16k Mono tree, whose upper levels have panels of 100-300 rows: 684 ms against 826
+		// with everything fused)
+		static const int fuse_max = getenv("LSFM_SN_FUSE_MAX") ? atoi(getenv("LSFM_SN_FUSE_MAX")) : 64;
+		static const bool lds_set = []() {
+			// (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sn_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_panel_lds(CHOL_GS));
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sn_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_panel_lds(CHOL_GS));
+			return true;
+		}();
+		(void)lds_set;
 		for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++)
 		{
 			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0, mnr = ch.glevel_maxnr[l];
 			if (!ng) continue;
+			const int smax = l < ch.glevel_maxs.size() ? ch.glevel_maxs[l] : CHOL_GS;
 			if (mnr <= fuse_max)
 			{
 				const int nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2);
-				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv);
+				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax);
 				continue;
 			}
-			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv);
+			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax);
 			const long np = (long)mnr * (mnr + 1) / 2;
 			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
 			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg);
@@ -1637,8 +1677,13 @@ __global__ void k_pcg_check(int nseg, PcgSeg* seg, int* ndone)
 	if (g.done) return;
 	const double rr = g.rr;
 	g.its++;
-	// converged, or the true residual stopped shrinking (attainable accuracy reached)
-	if (!(rr > g.thresh) || !(rr < 0.25 * g.rr_prev) || !(rr == rr)) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
+	// converged; or the true residual stopped shrinking where a direct solve would leave it too (relative 1e-8: attainable
+	// accuracy reached); or -- far above that -- three steps in a row that hardly moved it (a system this badly conditioned is
+	// reported: the final check counts it as not converged).  One slow step alone does not end the refinement: the camera
+	// systems of a deep monocular tree now and then take a step that gains little and go on to 1e-12 with the next.
+	const bool slow = !(rr < 0.25 * g.rr_prev);
+	g.slow = slow ? g.slow + 1 : 0;
+	if (!(rr > g.thresh) || !(rr == rr) || (slow && (!(rr > 1e-16 * g.ee) || g.slow >= 3))) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
 	g.rr_prev = rr;
 }
 // after update2 (separate launch: update2 reads the scalars of its system from every row): reset the accumulators
@@ -1659,7 +1704,9 @@ __global__ void k_pcg_run_stats(int nseg, const PcgSeg* __restrict__ seg, RunSta
 	const PcgSeg& fin = seg[nseg + g];
 	const double rel = fin.ee > 0 ? sqrt(fin.rr / fin.ee) : 0.0;
 	if (!(rel < 1e-8) || (seg[g].done != 1 && !(rel < 1e-9))) atomicAdd(&run->not_converged, 1);
-	if (seg[g].done == 0) atomicAdd(&run->undone, 1);
+	// (steps enqueued by a count from an earlier run: a system that had not met its stopping rule when they ran out and is not
+	// within two orders of the target either -- the run is repeated asking after every step)
+	if (seg[g].done == 0 && !(rel < 1e-10)) atomicAdd(&run->undone, 1);
 	// max of non-negative doubles = max of their bit patterns
 	atomicMax(reinterpret_cast<unsigned long long*>(&run->max_rel_residual), (unsigned long long)__double_as_longlong(rel == rel ? rel : 1e300));
 }

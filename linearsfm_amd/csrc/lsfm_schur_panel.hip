@@ -137,7 +137,12 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	// pointers, its L read from the staged copy.  (Measured before: staging with the global loads inside 4.5 of K9's 9.5 ms;
 	// the per-pass Cholesky of V^-1 behind a dependent load a quarter of a tile; 16 lanes per feature -- a feature seen by
 	// more than 10 poses went back to memory inside the staging -- a third of it.)
-	constexpr int PF = THREADS != 256 ? (T <= 6 ? 3 : 2) : (T <= 9 ? 4 : (T <= 14 ? 3 : 2)); // rows per lane in flight: 4 x 256 rows = 10.6 poses per feature on average
+#ifndef LSFM_K9_PF6
+#define LSFM_K9_PF6 3
+#endif
+	// rows per lane in flight: 4 x 256 rows = 10.6 poses per feature on average (LSFM_K9_PF6 = 3: the 16-slot variant fits its 170
+	// registers without spilling, with 8 poses per feature prefetched)
+	constexpr int PF = THREADS != 256 ? (T <= 6 ? 3 : 2) : (T <= 3 ? 4 : (T <= 6 ? LSFM_K9_PF6 : (T <= 14 ? 3 : 2)));
 	double pw[PF][3];
 	double lyv = 0.0;
 	int qb0 = 0, R = 0;

@@ -334,11 +334,13 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		for (int g = 0; g < ng; g++) gl_count[glev[g] + 1]++;
 		for (int l = 0; l < ngl; l++) gl_count[l + 1] += gl_count[l];
 		ch.glevel_maxnr.assign(ngl, 0);
+		ch.glevel_maxs.assign(ngl, 1);
 		for (int g = 0; g < ng; g++)
 		{
 			const int at = gl_count[glev[g]] + gfill[glev[g]]++;
 			ch.grp_c0[at] = gc0[g]; ch.grp_s[at] = gs[g]; ch.grp_nr[at] = ccount[gc0[g] + gs[g] - 1] - 1;
 			ch.glevel_maxnr[glev[g]] = std::max(ch.glevel_maxnr[glev[g]], ch.grp_nr[at]);
+			ch.glevel_maxs[glev[g]] = std::max(ch.glevel_maxs[glev[g]], gs[g]);
 		}
 		ch.ngroups = ng;
 		ch.glevel_ptr = gl_count;

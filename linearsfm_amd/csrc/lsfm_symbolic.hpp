@@ -18,7 +18,7 @@ struct CholSymbolic {
 	std::vector<int> tlevel_ptr, tlevel_maxsize, tlevel_col0, tlevel_nsmall, tlevel_small_lds, tlevel_outer;
 	// supernode groups over the columns above the leaf tasks, ordered by group level
 	int ngroups = 0;
-	std::vector<int> grp_c0, grp_s, grp_nr, glevel_ptr, glevel_maxnr;
+	std::vector<int> grp_c0, grp_s, grp_nr, glevel_ptr, glevel_maxnr, glevel_maxs;
 	// for the debug census
 	std::vector<int> parent, ccount;
 	int task_x = 0;

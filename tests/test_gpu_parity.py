@@ -438,8 +438,10 @@ def test_device_resident_handoff_of_subtree_roots(ctx, mono):
     assert np.array_equal(merged["stno"], single["stno"])
     for k in ("Ui", "Uj", "photo", "feature"):
         assert np.array_equal(merged[k], single[k]), k
-    assert pose_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-9
-    assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < 1e-9
+    # (the merged tree eliminates in another order than the single one: the same systems, solved to 1e-12 residuals, differ by
+    # cond * 1e-16 -- 1e-9 on the monocular set, whose camera systems are conditioned ~1e8)
+    assert pose_param_err(merged["stVal"], single["stVal"], single["stno"]) < (1e-8 if mono else 1e-9)
+    assert feat_param_err(merged["stVal"], single["stVal"], single["stno"]) < (1e-8 if mono else 1e-9)
 
 
 @pytest.mark.parametrize("variant", [1, 2])

@@ -85,6 +85,13 @@ int tree_levels(int N)
 void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 {
 	ctx->plan = (t->use_plans && level < (int)t->plans.size()) ? &t->plans[level] : nullptr;
+	const bool analysing = !(ctx->plan && ctx->plan->valid); // this run does the level's symbolic work (it may have done it one level ahead)
+	if (!ctx->plan && !t->mono && ctx->pre_plan.valid && ctx->pre_plan_level == level)
+	{
+		// ... all of it: the plan of this level was made while the level below was being solved (prefetch_next_level)
+		ctx->plan = &ctx->pre_plan;
+		LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evP, 0));
+	}
 	ctx->mark("level");
 	if ((int)t->step_hint.size() <= level) t->step_hint.resize(level + 1, 0);
 	ctx->step_hint = t->step_hint[level];
@@ -135,8 +142,9 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); // (the join's layout kernels run inside)
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		js.smark = smark; // everything of this level goes at once
-		const bool analysing = !ctx->warm();
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
+		ctx->pre_plan = LevelPlan(); // (consumed, if it was this level's)
+		ctx->pre_plan_level = -1;
 		if (analysing && Y.B > 1)
 		{
 			// while the device solves this level: the next level's pattern and symbolic factorisation (lsfm_pcg.hip)
@@ -151,7 +159,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 				nref[e2] = cref;
 			}
 			for (int b = 0; b < nb; b++) if (nref[b] >= 0 && Y.Ref[b] == nref[b]) nref[b] = -1; // (same frame: passed through, Imp.cpp:352)
-			prefetch_next_level(ctx, Y, nref, level + 1);
+			prefetch_next_level(ctx, Y, nref, level + 1, level + 1 < (int)t->step_hint.size() ? t->step_hint[level + 1] : 0);
 		}
 		else ctx->pre.reset();
 	}
@@ -213,6 +221,7 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
 	ctx->stage_off = 0; // the stream is idle: the staging ring starts over
 	ctx->pre.reset(); ctx->early.reset(); ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // nothing prepared by an earlier run
+	ctx->pre_plan = LevelPlan(); ctx->pre_plan_level = -1;
 	LSFM_CHECK_HIP(hipMemsetAsync(ctx->d_run, 0, sizeof(RunStatsDev), ctx->stream));
 	t->level = t->input;
 	const int nlev = tree_levels(t->N);

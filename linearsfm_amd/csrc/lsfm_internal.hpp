@@ -157,6 +157,11 @@ struct lsfm_context {
 	// (lsfm_pcg.hip: prefetch_next_level).  Their arrays live in two small arenas used in turn.
 	lsfm::Arena sarena[2];
 	std::shared_ptr<void> pre;          // what was prepared for the level about to run (null: nothing)
+	// ... and, when an earlier run of the tree has left the refinement step count of that level, everything else the level
+	// would stop for (kept-block counts of its transform, unmatched-feature ranks of its join): a plan of the level made
+	// one level ahead -- the level then runs like a planned one, without a single host <-> device round trip
+	lsfm::LevelPlan pre_plan;
+	int pre_plan_level = -1;
 	hipEvent_t evY = nullptr, evP = nullptr; // joint index arrays of the level final (main stream) / prefetch complete (stream3)
 	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)
 	int solved_nnzb = 0;
@@ -295,7 +300,7 @@ struct EarlyPatternIn {
 void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in); // enqueues on the side stream; the caller has recorded evC
 void schur_pattern_early_drop(lsfm_context* ctx);
 // target_ref[b] of the NEXT level's transform for every map of `Y` (-1: passed through), as run_level will compute it
-void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int parity);
+void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int next_level, int step_hint);
 // the block pattern of S alone (K8), from the index members of io: upper block CSR left in the scratch arena
 void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx);
 int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,

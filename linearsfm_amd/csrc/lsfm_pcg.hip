@@ -1336,7 +1336,9 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 }
 
 // symbolic analysis on the host (lsfm_symbolic.cpp), then every index array of it to the device in ONE copy
-static void chol_upload_symbolic(lsfm_context* ctx, const CholSymbolic& sym, CholDev& ch)
+// index arrays of a symbolic factorisation to the device (ctx->scratch / ctx->stream as the caller has set them), host vectors
+// copied: what a plan keeps
+static void chol_upload_index(lsfm_context* ctx, const CholSymbolic& sym, CholDev& ch)
 {
 	Arena& sc = ctx->scratch;
 	ch.M = sym.M; ch.nnzL = sym.nnzL; ch.nlevels = sym.nlevels; ch.tail_begin = sym.tail_begin;
@@ -1362,6 +1364,11 @@ static void chol_upload_symbolic(lsfm_context* ctx, const CholSymbolic& sym, Cho
 	}
 	h2d(ctx, d_blob, blob.data(), total * sizeof(int));
 	ch.blob = d_blob; ch.blob_ints = total;
+}
+static void chol_upload_symbolic(lsfm_context* ctx, const CholSymbolic& sym, CholDev& ch)
+{
+	Arena& sc = ctx->scratch;
+	chol_upload_index(ctx, sym, ch);
 	chol_alloc_values(ctx, ch);
 	ch.d_err = sc.alloc<int>(1);
 	dev_zero(ctx, ch.d_err, sizeof(int));
@@ -1395,40 +1402,68 @@ struct PreLevel {
 	CholSymbolic sym;
 	int M = 0;
 };
-void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int parity)
+void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int next_level, int step_hint)
 {
 	ctx->pre.reset();
+	ctx->pre_plan = LevelPlan();
+	ctx->pre_plan_level = -1;
 	static const bool on = !getenv("LSFM_NO_PREFETCH") && !getenv("LSFM_NO_EARLY_PATTERN");
 	if (!on || !ctx->solved_keys || !Y.M || Y.B < 2) return;
+	// with the step count an earlier run left for that level, the level can run like a planned one (no round trip at all): then
+	// its counts are prepared too.  (LSFM_CHECK_EARLY_PATTERN keeps to the path that compares the pattern.)
+	static const bool plan_on = !getenv("LSFM_NO_PREPLAN");
+	const bool whole = plan_on && step_hint > 0 && !getenv("LSFM_CHECK_EARLY_PATTERN");
 	ctx->mark("pre_start");
 	auto pl = std::make_shared<PreLevel>();
 	pl->M = Y.M;
-	Arena& sa = ctx->sarena[parity & 1];
+	Arena& sa = ctx->sarena[next_level & 1];
 	sa.reset();
 	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evY, 0)); // the joint maps' index arrays are final
+	if (ctx->timeline_on) { (void)hipEventSynchronize(ctx->evY); ctx->mark("pre_evY"); }
 	CholHostIn hin;
+	std::vector<int> counts;
 	bool ok = false;
-	std::swap(ctx->stream, ctx->stream3);
-	std::swap(ctx->scratch, sa);
-	try
+	struct Swap { // this stretch runs on stream3 and allocates from the small arena of the level's parity
+		lsfm_context* c; Arena& a;
+		Swap(lsfm_context* x, Arena& y) : c(x), a(y) { std::swap(c->stream, c->stream3); std::swap(c->scratch, a); }
+		~Swap() { std::swap(c->scratch, a); std::swap(c->stream, c->stream3); }
+	};
 	{
+		Swap sw(ctx, sa);
 		int* d_tref = ctx->scratch.alloc<int>(Y.B);
 		h2d(ctx, d_tref, target_ref.data(), sizeof(int) * (size_t)Y.B);
-		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy);
+		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy, whole ? &counts : nullptr);
 		if (ok)
 		{
-			chol_fetch(ctx, pl->sy, Y.pose_origin, hin);
+			chol_fetch(ctx, pl->sy, Y.pose_origin, hin); // (synchronises stream3: the counts have arrived too)
 			LSFM_CHECK_HIP(hipEventRecord(ctx->evP, ctx->stream));
 		}
 	}
-	catch (...) { std::swap(ctx->scratch, sa); std::swap(ctx->stream, ctx->stream3); throw; }
-	std::swap(ctx->scratch, sa);
-	std::swap(ctx->stream, ctx->stream3);
 	ctx->mark("pre_pat");
 	if (!ok) return;
 	chol_symbolic(hin.keys.data(), pl->sy.nnzb, hin.origin.data(), pl->sy.M, pl->sym);
 	ctx->mark("pre_sym");
-	ctx->pre = pl;
+	if (!whole)
+	{
+		ctx->pre = pl;
+		return;
+	}
+	// the whole plan of the level: index arrays of the factorisation to the device now (stream3 again), counts as the host read them
+	auto sp = std::make_shared<SolvePlan>();
+	sp->sy = pl->sy;
+	sp->its = step_hint; sp->mixed = ctx->pcg.mixed; sp->rel_tol = ctx->pcg.rel_tol;
+	{
+		Swap sw(ctx, sa);
+		chol_upload_index(ctx, pl->sym, sp->ch);
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evP, ctx->stream));
+	}
+	const int B = Y.B;
+	ctx->pre_plan.tr_cnt.assign(counts.begin(), counts.begin() + 2 * (B + 1));
+	ctx->pre_plan.join_rb.assign(counts.begin() + 2 * (B + 1), counts.end());
+	ctx->pre_plan.solve = sp;
+	ctx->pre_plan.valid = true;
+	ctx->pre_plan_level = next_level;
+	ctx->mark("pre_plan");
 }
 
 // the supernode-group path of the triangular solves applies (chol_apply): the forward substitution can ride on the factorisation

@@ -862,9 +862,31 @@ k_pat_insert_w_cross_match(int NF, const int* __restrict__ feat_map, const int* 
 		}
 	}
 }
+// which blocks of the batch survive the next level's transform as they are (k_tr_flags of lsfm_transform.hip, from the hubs alone)
+__global__ void k_pre_flags(const int* __restrict__ Ui, const int* __restrict__ Uj, int NU, const int* __restrict__ photo, int NW,
+                            const int* __restrict__ pose_map, const int* __restrict__ hub, int* __restrict__ keepU, int* __restrict__ keepW)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < NU) { const int a = Ui[i], b = Uj[i], h = hub[pose_map[a]]; keepU[i] = (h < 0 || (a != h && b != h)) ? 1 : 0; }
+	if (i < NW) { const int k = photo[i], h = hub[pose_map[k]]; keepW[i] = (h < 0 || k != h) ? 1 : 0; }
+	if (i == 0) { keepU[NU] = 0; keepW[NW] = 0; }
+}
+__global__ void k_pre_gather(const int* __restrict__ KU, const int* __restrict__ KW, const int* __restrict__ R, const int* __restrict__ uoff,
+                             const int* __restrict__ woff, const int* __restrict__ foff, int B, int* __restrict__ out)
+{
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > B) return;
+	out[b] = KU[uoff[b]];
+	out[B + 1 + b] = KW[woff[b]];
+	out[2 * (B + 1) + b] = R[foff[b]];
+}
 // ctx->stream / ctx->scratch name the stream and the arena the caller wants this on.  prev_keys: the pattern of the level that
-// produced Y (every pair inside one of Y's maps).  false: nothing to build from.
-bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy)
+// produced Y (every pair inside one of Y's maps).  false: nothing to build from.  counts (optional): what the next level's
+// transform and join read back from the device -- kept-block prefixes at the map boundaries (U, then W: transform_batch's
+// `cnt`) and the ranks of the unmatched features there (join_stereo_prepare's `rb`), 3 (B + 1) ints, valid after the
+// caller's next synchronisation of the stream.
+bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy,
+                            std::vector<int>* counts)
 {
 	if (!prev_keys || !Y.M) return false;
 	hipStream_t s = ctx->stream;
@@ -883,7 +905,26 @@ bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_t
 	int* match = sc.alloc<int>(Y.NF + 1);
 	int* unm = sc.alloc<int>(Y.NF + 2);
 	if (Y.NF) join_match_features(ctx, Y, match, unm);
+	else dev_zero(ctx, unm, 2 * sizeof(int));
 	chk("match");
+	if (counts)
+	{
+		const int B = Y.B;
+		int* keepU = sc.alloc<int>(Y.NU + 1); int* keepW = sc.alloc<int>(Y.NW + 1);
+		int* KU = sc.alloc<int>(Y.NU + 2); int* KW = sc.alloc<int>(Y.NW + 2); int* R = sc.alloc<int>(Y.NF + 2);
+		const int nmax = std::max(std::max(Y.NU, Y.NW), 1);
+		hipLaunchKernelGGL(k_pre_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, Y.Ui, Y.Uj, Y.NU, Y.photo, Y.NW, Y.pose_map, hub, keepU, keepW);
+		dev_exclusive_scan(ctx, keepU, KU, Y.NU);
+		dev_exclusive_scan(ctx, keepW, KW, Y.NW);
+		dev_exclusive_scan(ctx, unm, R, Y.NF);
+		int* d_off = sc.alloc<int>(2 * (B + 1));
+		h2d(ctx, d_off, Y.u_off.data(), (B + 1) * sizeof(int));
+		h2d(ctx, d_off + B + 1, Y.w_off.data(), (B + 1) * sizeof(int));
+		int* d_cnt = sc.alloc<int>(3 * (B + 1));
+		hipLaunchKernelGGL(k_pre_gather, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, R, d_off, d_off + B + 1, Y.d_feat_off, B, d_cnt);
+		counts->resize(3 * (size_t)(B + 1));
+		LSFM_CHECK_HIP(hipMemcpyAsync(counts->data(), d_cnt, counts->size() * sizeof(int), hipMemcpyDeviceToHost, s));
+	}
 	size_t cap = pattern_capacity(std::max((size_t)Y.NU + Y.M, (size_t)prev_nnzb + Y.M), Y.M);
 	SolveIO io;
 	io.M = Y.M;
@@ -1004,7 +1045,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		int most = 0;
 		for (int r : io.seg_rows) most = std::max(most, r);
 		// the per-tile slots of the panel kernel: from the plan of the level, or recorded now when this run leaves one
-		if (!sy.k9.ns && ctx->plan)
+		if (!sy.k9.ns && ctx->plan && ctx->plan != &ctx->pre_plan) // (a plan made one level ahead lives for one level: nothing to record for)
 		{
 			sy.k9.ns = sc.alloc<int>(ntiles + 1);
 			sy.k9.pose = sc.alloc<int>((size_t)ntiles * 64 + 1);

@@ -188,6 +188,9 @@ int lsfm_tree_set_final_reanchor(lsfm_tree* tree, int on);
  * analyses from scratch (what a first run costs; lsfm_stats.t_total_ms of the first run reports it too). */
 int lsfm_tree_set_plans(lsfm_tree* tree, int on);
 int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
+/* the state vector of the final map alone (no information blocks): *m poses, *n features; stno / stVal (each optional, caller's
+ * arrays of cap >= 6 m + 3 n entries) in the layout of lsfm_map -- both NULL: sizes only */
+int lsfm_tree_download_state(lsfm_context* ctx, lsfm_tree* tree, int* m, int* n, int* stno, double* stVal, size_t cap);
 void lsfm_tree_free(lsfm_context* ctx, lsfm_tree* tree);
 /* ---- device-resident hand-off of a tree node (multi-GPU sub-tree sharding; no counterpart in the reference, whose
  * scheduler keeps every node in one process: m_LMsetS[i] = m_GMapS, Imp.cpp:2032) ---------------------------------
@@ -211,6 +214,32 @@ int lsfm_tree_upload_dev(lsfm_context* ctx, const void* const* packed, int N, in
  * them is taken on the device at upload and at reload) and dropped otherwise, so that a reload with another structure
  * costs an analysing run instead of a wrong result. */
 int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* tree, const void* const* packed, int N);
+
+/* ---- feature-sharded joins: the top of the tree over several GPUs (no counterpart in the reference; SURVEY 8e "P2") --------
+ * The Schur loop (Imp.cpp:2244-2332), the back-substitution (2980-3020) and the feature part of the information transform
+ * (1270-1917) are sums over features.  G processes (one per GPU) each hold a SLICE of every map -- all poses and U blocks,
+ * the features f with feat_id % G == slice together with their V and W blocks (the same feature of two maps lands in the
+ * same slice, so common features still meet in a join) -- and run the SAME tree; three sums per level cross the GPUs:
+ *   transform   the pose rows of I C and the hub-hub block (sum over the features of W C_f, C_f^T (I C)_f)
+ *   join        S = U - sum_f W V^-1 W^T and E = eP - sum_f W V^-1 eF (U's part is taken by rank 0 alone); in a run that
+ *               analyses also the union of the ranks' pose-pair patterns
+ *   solve       the pose solution of rank 0 replaces everyone's (the replicated factorisations may differ in the last bit)
+ * The library does not link a collective library: the caller hands over device memory `dev_buf` that the reduced arrays
+ * live in and a function that sums `count` elements at `offset_bytes` of that buffer over all ranks, in place, ordered after
+ * the work already enqueued on `hip_stream` and before the work enqueued on it afterwards (RCCL: ncclAllReduce on that stream;
+ * torch.distributed: all_reduce under torch.cuda.ExternalStream(hip_stream)).  Returns 0 on success.  Every rank must call
+ * lsfm_tree_run on its slice tree at the same time; the number and sizes of the calls are the same on every rank. */
+#define LSFM_DTYPE_F64 0
+#define LSFM_DTYPE_I64 1
+typedef int (*lsfm_allreduce_fn)(void* user, size_t offset_bytes, size_t count, int dtype, void* hip_stream);
+/* fn == NULL: off (the default).  world == 1 is allowed (every sum is then this rank's own: a way to exercise the caller's function) */
+int lsfm_tree_set_comm(lsfm_tree* tree, int rank, int world, lsfm_allreduce_fn fn, void* user, void* dev_buf, size_t dev_bytes);
+/* The final map of a finished tree cut into `nslices` packs (same format as lsfm_tree_export_dev: every pack holds ALL poses
+ * and U blocks, and the features with feat_id % nslices == slice in their order, with their V and W blocks).
+ *   lsfm_tree_export_slice_sizes  bytes of every slice pack, sizes[nslices]
+ *   lsfm_tree_export_slice_dev    writes pack `slice` to dst (device memory of >= cap bytes) */
+int lsfm_tree_export_slice_sizes(lsfm_context* ctx, lsfm_tree* tree, int nslices, size_t* sizes);
+int lsfm_tree_export_slice_dev(lsfm_context* ctx, lsfm_tree* tree, int nslices, int slice, void* dst, size_t cap);
 
 /* convenience: upload + run + download */
 int lsfm_divide_conquer(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, lsfm_map* out, lsfm_stats* stats);

@@ -46,6 +46,11 @@ class LsfmError(RuntimeError):
     pass
 
 
+# include/lsfm.h lsfm_allreduce_fn: (user, offset_bytes, count, dtype, hip_stream) -> 0 on success
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p)
+LSFM_DTYPE_F64, LSFM_DTYPE_I64 = 0, 1
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -85,7 +90,11 @@ def lib():
         L.lsfm_packed_size.restype = C.c_size_t
         L.lsfm_tree_upload_dev.argtypes = [vp, P(vp), C.c_int, C.c_int, P(vp)]
         L.lsfm_tree_reload_dev.argtypes = [vp, vp, P(vp), C.c_int]
+        L.lsfm_tree_set_comm.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp, vp, C.c_size_t]
+        L.lsfm_tree_export_slice_sizes.argtypes = [vp, vp, C.c_int, P(C.c_size_t)]
+        L.lsfm_tree_export_slice_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t]
         L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
+        L.lsfm_tree_download_state.argtypes = [vp, vp, ip, ip, ip, dp, C.c_size_t]
         L.lsfm_tree_free.argtypes = [vp, vp]
         L.lsfm_tree_free.restype = None
         L.lsfm_divide_conquer.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(LsfmMap), P(LsfmStats)]
@@ -105,8 +114,8 @@ def lib():
 EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_set_precision", "lsfm_set_spmv_variant", "lsfm_last_error", "lsfm_stream",
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
-           "lsfm_tree_download", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
-           "lsfm_tree_upload_dev", "lsfm_tree_reload_dev",
+           "lsfm_tree_download", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
+           "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse"]
 
@@ -271,6 +280,16 @@ class Context:
         self._check(lib().lsfm_tree_download(self._h, tree, C.byref(out)), "lsfm_tree_download")
         return map_to_dict(out)
 
+    def tree_download_state(self, tree):
+        """(m, n, stno, stVal) of the final map: the state vector without the information blocks."""
+        m, n = C.c_int(0), C.c_int(0)
+        self._check(lib().lsfm_tree_download_state(self._h, tree, C.byref(m), C.byref(n), None, None, 0), "lsfm_tree_download_state")
+        r = 6 * m.value + 3 * n.value
+        stno = np.zeros(r, np.int32); stVal = np.zeros(r)
+        self._check(lib().lsfm_tree_download_state(self._h, tree, C.byref(m), C.byref(n), _ptr(stno, C.c_int), _ptr(stVal, C.c_double), r),
+                    "lsfm_tree_download_state")
+        return m.value, n.value, stno, stVal
+
     def tree_free(self, tree):
         lib().lsfm_tree_free(self._h, tree)
 
@@ -294,6 +313,23 @@ class Context:
         t = C.c_void_p()
         self._check(lib().lsfm_tree_upload_dev(self._h, arr, len(dev_ptrs), int(mono), C.byref(t)), "lsfm_tree_upload_dev")
         return t
+
+    # ---- feature-sharded joins (the top of the tree over several GPUs) -----------------------------------
+    def tree_export_slice_sizes(self, tree, nslices):
+        sizes = (C.c_size_t * nslices)()
+        self._check(lib().lsfm_tree_export_slice_sizes(self._h, tree, int(nslices), sizes), "lsfm_tree_export_slice_sizes")
+        return [int(v) for v in sizes]
+
+    def tree_export_slice_dev(self, tree, nslices, slice_, dev_ptr, cap):
+        """Pack `slice_` (features with feat_id % nslices == slice_, all poses and U blocks) of a finished tree's final map."""
+        self._check(lib().lsfm_tree_export_slice_dev(self._h, tree, int(nslices), int(slice_), C.c_void_p(int(dev_ptr)), int(cap)),
+                    "lsfm_tree_export_slice_dev")
+
+    def tree_set_comm(self, tree, rank, world, fn, dev_ptr, dev_bytes):
+        """fn: an ALLREDUCE_FN instance (the caller keeps it alive as long as the tree runs); None / world <= 1: off."""
+        cb = fn if fn is not None else C.cast(None, ALLREDUCE_FN)
+        self._check(lib().lsfm_tree_set_comm(tree, int(rank), int(world), cb, None, C.c_void_p(int(dev_ptr) if dev_ptr else None),
+                                             int(dev_bytes)), "lsfm_tree_set_comm")
 
     def divide_conquer(self, maps, mono, final_reanchor=True):
         t = self.tree_upload(maps, mono)

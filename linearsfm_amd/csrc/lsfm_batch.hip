@@ -169,6 +169,104 @@ void batch_pack_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, void
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 
+// ---- slices of a map by feature label (feature-sharded joins: lsfm_tree_export_slice_*) ------------------------------------
+__device__ __forceinline__ int slice_of(int id, int G) { const int r = id % G; return r < 0 ? r + G : r; }
+__global__ void k_slice_count(int NF, const int* __restrict__ feat_id, const int* __restrict__ fptr, int G, int* __restrict__ cnt)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= NF) return;
+	const int g = slice_of(feat_id[f], G);
+	atomicAdd(&cnt[g], 1);
+	atomicAdd(&cnt[G + g], fptr[f + 1] - fptr[f]);
+}
+__global__ void k_slice_flags(int NF, const int* __restrict__ feat_id, const int* __restrict__ fptr, int G, int g, int* __restrict__ flag, int* __restrict__ wlen)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f > NF) return;
+	const bool in = f < NF && slice_of(feat_id[f], G) == g;
+	flag[f] = in ? 1 : 0;
+	wlen[f] = in ? fptr[f + 1] - fptr[f] : 0;
+}
+__global__ void k_slice_features(int NF, const int* __restrict__ flag, const int* __restrict__ pos, const int* __restrict__ wpos, const double* __restrict__ feat,
+                                 const double* __restrict__ V, const int* __restrict__ feat_id, double* __restrict__ ofeat, double* __restrict__ oV,
+                                 int* __restrict__ oid, int* __restrict__ ofptr)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f > NF) return;
+	if (f == NF) { ofptr[pos[NF]] = wpos[NF]; return; }
+	if (!flag[f]) return;
+	const int p = pos[f];
+	for (int c = 0; c < 3; c++) ofeat[(size_t)p * 3 + c] = feat[(size_t)f * 3 + c];
+	for (int c = 0; c < 9; c++) oV[(size_t)p * 9 + c] = V[(size_t)f * 9 + c];
+	oid[p] = feat_id[f];
+	ofptr[p] = wpos[f];
+}
+__global__ void __launch_bounds__(256)
+k_slice_w(int NW, const int* __restrict__ feature, const int* __restrict__ fptr, const int* __restrict__ flag, const int* __restrict__ wpos,
+          const double* __restrict__ W, const int* __restrict__ photo, double* __restrict__ oW, int* __restrict__ ophoto)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NW) return;
+	const int f = feature[j];
+	if (!flag[f]) return;
+	const int d = wpos[f] + (j - fptr[f]);
+	double w[18];
+	ld<18>(w, W + (size_t)j * 18);
+	st<18>(oW + (size_t)d * 18, w);
+	ophoto[d] = photo[j];
+}
+
+void batch_slice_counts(lsfm_context* ctx, const DevBatch& b, int G, std::vector<int>& nf, std::vector<int>& nw)
+{
+	if (b.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "slices are cut from a single map");
+	const size_t mk = ctx->scratch.mark();
+	int* cnt = ctx->scratch.alloc<int>(2 * (size_t)G);
+	dev_zero(ctx, cnt, sizeof(int) * 2 * (size_t)G);
+	if (b.NF) hipLaunchKernelGGL(k_slice_count, dim3((b.NF + 255) / 256), dim3(256), 0, ctx->stream, b.NF, b.feat_id, b.fptr, G, cnt);
+	std::vector<int> h(2 * (size_t)G);
+	d2h_ints(ctx, cnt, h.data(), h.size());
+	nf.assign(h.begin(), h.begin() + G);
+	nw.assign(h.begin() + G, h.end());
+	ctx->scratch.release(mk);
+}
+
+// pack `slice` of the batch's single map: all poses and U blocks, the slice's features in their order with V and their W runs
+void batch_pack_slice(lsfm_context* ctx, const DevBatch& b, bool mono, int G, int g, int nf, int nw, void* dst, size_t cap)
+{
+	hipStream_t s = ctx->stream;
+	if (b.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "slices are cut from a single map");
+	if (b.W_alias) LSFM_FAIL(LSFM_ERR_INTERNAL, "cannot pack a batch whose W blocks are aliased");
+	PackHeader h;
+	memset(&h, 0, sizeof h);
+	h.magic = LSFM_PACK_MAGIC; h.version = 1; h.mono = mono;
+	h.m = b.M; h.n = nf; h.nU = b.NU; h.nW = nw;
+	h.Ref = b.Ref[0]; h.FRef = b.FRef[0]; h.ScaP = b.ScaP[0]; h.Fix = b.Fix[0]; h.Sign = b.Sign[0]; h.FScaP = b.FScaP[0]; h.FFix = b.FFix[0];
+	if (pack_layout(h) > cap) LSFM_FAIL(LSFM_ERR_ARG, "export buffer too small");
+	char* d = static_cast<char*>(dst);
+	h2d(ctx, d, &h, sizeof h);
+	auto cp = [&](int slot, const void* src, size_t bytes) {
+		if (bytes) LSFM_CHECK_HIP(hipMemcpyAsync(d + h.off[slot], src, bytes, hipMemcpyDeviceToDevice, s));
+	};
+	// (a single map: its indices are local already)
+	cp(0, b.pose, (size_t)h.m * 48); cp(2, b.U, (size_t)h.nU * 288); cp(5, b.pose_id, (size_t)h.m * 4); cp(6, b.pose_origin, (size_t)h.m * 4);
+	cp(8, b.Ui, (size_t)h.nU * 4); cp(9, b.Uj, (size_t)h.nU * 4);
+	const int NF = b.NF;
+	int* flag = ctx->scratch.alloc<int>((size_t)NF + 2);
+	int* wlen = ctx->scratch.alloc<int>((size_t)NF + 2);
+	int* pos = ctx->scratch.alloc<int>((size_t)NF + 2);
+	int* wpos = ctx->scratch.alloc<int>((size_t)NF + 2);
+	hipLaunchKernelGGL(k_slice_flags, dim3((NF + 256) / 256), dim3(256), 0, s, NF, b.feat_id, b.fptr, G, g, flag, wlen);
+	dev_exclusive_scan(ctx, flag, pos, NF);
+	dev_exclusive_scan(ctx, wlen, wpos, NF);
+	hipLaunchKernelGGL(k_slice_features, dim3((NF + 256) / 256), dim3(256), 0, s, NF, flag, pos, wpos, b.feat, b.V, b.feat_id,
+	                   reinterpret_cast<double*>(d + h.off[1]), reinterpret_cast<double*>(d + h.off[4]), reinterpret_cast<int*>(d + h.off[7]),
+	                   reinterpret_cast<int*>(d + h.off[11]));
+	if (b.NW)
+		hipLaunchKernelGGL(k_slice_w, dim3((b.NW + 255) / 256), dim3(256), 0, s, b.NW, b.feature, b.fptr, flag, wpos, b.W, b.photo,
+		                   reinterpret_cast<double*>(d + h.off[3]), reinterpret_cast<int*>(d + h.off[10]));
+	LSFM_CHECK_HIP(hipGetLastError());
+}
+
 // N packed maps (device) -> one batch with global indices in `ar`
 void batch_unpack_maps(lsfm_context* ctx, Arena& ar, const void* const* packed, const PackHeader* hdr, int N, bool mono, DevBatch& o)
 {

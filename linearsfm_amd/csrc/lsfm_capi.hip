@@ -29,6 +29,11 @@ struct lsfm_tree {
 	// values that lets a run enqueue the steps of a level without stopping to ask; checked at the end of every run that uses it
 	std::vector<int> step_hint;
 	unsigned long long digest = 0; // of the resident inputs' labels and index arrays (trees built from packed maps: reload compares)
+	// feature-sharded tree (lsfm_tree_set_comm): this process holds one slice of every map; comm.fn == null: off
+	Comm comm;
+	// sizes of the slice packs of the final map (lsfm_tree_export_slice_*): structure, learnt at the first export
+	int slice_n = 0;
+	std::vector<int> slice_nf, slice_nw;
 };
 
 namespace {
@@ -145,7 +150,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
 		ctx->pre_plan = LevelPlan(); // (consumed, if it was this level's)
 		ctx->pre_plan_level = -1;
-		if (analysing && Y.B > 1)
+		if (analysing && Y.B > 1 && !ctx->comm)
 		{
 			// while the device solves this level: the next level's pattern and symbolic factorisation (lsfm_pcg.hip)
 			const int nb = Y.B;
@@ -260,7 +265,8 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		memset(&local, 0, sizeof local);
 		lsfm_stats* st = stats ? stats : &local;
 		ctx->stats = st;
-		struct InRun { lsfm_context* c; InRun(lsfm_context* x) : c(x) { c->in_tree_run = true; } ~InRun() { c->in_tree_run = false; } } in_run(ctx);
+		struct InRun { lsfm_context* c; InRun(lsfm_context* x, Comm* cm) : c(x) { c->in_tree_run = true; c->comm = cm; } ~InRun() { c->in_tree_run = false; c->comm = nullptr; } }
+			in_run(ctx, t->comm.fn ? &t->comm : nullptr);
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 		try
 		{
@@ -291,6 +297,25 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				// what the warm levels left in the device accumulators instead of stopping for it
 				RunStatsDev rs;
 				LSFM_CHECK_HIP(hipMemcpy(&rs, ctx->d_run, sizeof rs, hipMemcpyDeviceToHost));
+				if (ctx->comm)
+				{
+					// feature-sharded run: whether the run is repeated (below) must be decided alike on every rank -- a rank that
+					// went on alone would wait for sums nobody else takes part in
+					Comm& cm = *ctx->comm;
+					cm.restart();
+					long long* d_fl = cm.alloc<long long>(8);
+					long long fl[8] = { rs.tr_err != 0, rs.chol_err != 0, rs.plan_stale != 0, rs.not_converged, rs.undone, 0, 0, 0 };
+					LSFM_CHECK_HIP(hipMemcpyAsync(d_fl, fl, sizeof fl, hipMemcpyHostToDevice, ctx->stream));
+					LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+					cm.allreduce(ctx->stream, d_fl, 8, LSFM_DTYPE_I64);
+					LSFM_CHECK_HIP(hipMemcpyAsync(fl, d_fl, sizeof fl, hipMemcpyDeviceToHost, ctx->stream));
+					LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+					if (fl[0] && !rs.tr_err) rs.tr_err = 1;
+					if (fl[1] && !rs.chol_err) rs.chol_err = 1;
+					rs.plan_stale = fl[2] != 0;
+					rs.not_converged = (int)((fl[3] + cm.world - 1) / cm.world); // (every rank solves every system: the count, not its multiple)
+					rs.undone = (int)((fl[4] + cm.world - 1) / cm.world);
+				}
 				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
 				if (rs.chol_err)
 					LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
@@ -347,6 +372,34 @@ int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* t, lsfm_map* out)
 			LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context (it lives in the context's arenas): "
 			                        "download a tree before the context is used for anything else, or run it again");
 		batch_download_map(ctx, t->level, 0, t->mono, out);
+		return LSFM_OK;
+	});
+}
+
+int lsfm_tree_download_state(lsfm_context* ctx, lsfm_tree* t, int* m, int* n, int* stno, double* stVal, size_t cap)
+{
+	if (!t || !m || !n) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		if (!t->done || t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (t->generation != ctx->generation) LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context");
+		const DevBatch& b = t->level;
+		*m = b.M; *n = b.NF;
+		if (!stno && !stVal) return LSFM_OK;
+		const size_t r = (size_t)6 * b.M + (size_t)3 * b.NF;
+		if (cap < r) LSFM_FAIL(LSFM_ERR_ARG, "state arrays too small");
+		if (stVal)
+		{
+			d2h(ctx, stVal, b.pose, (size_t)b.M * 6 * sizeof(double));
+			d2h(ctx, stVal + (size_t)6 * b.M, b.feat, (size_t)b.NF * 3 * sizeof(double));
+		}
+		if (stno)
+		{
+			std::vector<int> pid(b.M), fid(b.NF);
+			d2h(ctx, pid.data(), b.pose_id, (size_t)b.M * sizeof(int));
+			d2h(ctx, fid.data(), b.feat_id, (size_t)b.NF * sizeof(int));
+			for (int i = 0; i < b.M; i++) for (int c = 0; c < 6; c++) stno[6 * (size_t)i + c] = -pid[i];
+			for (int i = 0; i < b.NF; i++) for (int c = 0; c < 3; c++) stno[6 * (size_t)b.M + 3 * (size_t)i + c] = fid[i];
+		}
 		return LSFM_OK;
 	});
 }
@@ -456,6 +509,55 @@ int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* t, const void* const* pac
 			t->digest = dg;
 		}
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+		return LSFM_OK;
+	});
+}
+
+int lsfm_tree_set_comm(lsfm_tree* t, int rank, int world, lsfm_allreduce_fn fn, void* user, void* dev_buf, size_t dev_bytes)
+{
+	if (!t) return LSFM_ERR_ARG;
+	if (!fn) { t->comm = Comm(); return LSFM_OK; }
+	if (world < 1 || rank < 0 || rank >= world || !dev_buf || dev_bytes < 4096) return LSFM_ERR_ARG;
+	t->comm.rank = rank; t->comm.world = world; t->comm.fn = fn; t->comm.user = user;
+	t->comm.buf = static_cast<char*>(dev_buf); t->comm.cap = dev_bytes; t->comm.off = 0;
+	return LSFM_OK;
+}
+
+int lsfm_tree_export_slice_sizes(lsfm_context* ctx, lsfm_tree* t, int nslices, size_t* sizes)
+{
+	if (!t || !sizes || nslices <= 0) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		if (!t->done || t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (t->generation != ctx->generation) LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context");
+		if (t->slice_n != nslices)
+		{
+			// how many features and W blocks every slice holds: structure -- counted once, kept for the later runs of the tree
+			batch_slice_counts(ctx, t->level, nslices, t->slice_nf, t->slice_nw);
+			t->slice_n = nslices;
+		}
+		const DevBatch& b = t->level;
+		for (int g = 0; g < nslices; g++)
+		{
+			PackHeader h;
+			memset(&h, 0, sizeof h);
+			h.m = b.M; h.n = t->slice_nf[g]; h.nU = b.NU; h.nW = t->slice_nw[g];
+			sizes[g] = pack_layout(h);
+		}
+		return LSFM_OK;
+	});
+}
+
+int lsfm_tree_export_slice_dev(lsfm_context* ctx, lsfm_tree* t, int nslices, int slice, void* dst, size_t cap)
+{
+	if (!t || !dst || nslices <= 0 || slice < 0 || slice >= nslices) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		if (!t->done || t->level.B != 1) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (t->generation != ctx->generation) LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context");
+		if (t->slice_n != nslices) LSFM_FAIL(LSFM_ERR_ARG, "call lsfm_tree_export_slice_sizes with the same number of slices first");
+		const size_t mk = ctx->scratch.mark();
+		batch_pack_slice(ctx, t->level, t->mono, nslices, slice, t->slice_nf[slice], t->slice_nw[slice], dst, cap);
+		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream)); // the caller hands dst to another library / stream next
+		ctx->scratch.release(mk);
 		return LSFM_OK;
 	});
 }

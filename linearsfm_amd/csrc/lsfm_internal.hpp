@@ -117,6 +117,34 @@ struct RunStatsDev {
 	unsigned long long k2;  // sum over the levels of sum over the features of (W run length)^2: K9's pose pairs, for its algorithmic flop count
 };
 
+// Feature-sharded joins (include/lsfm.h, lsfm_tree_set_comm): the sums that cross the GPUs.  The arrays to be reduced are
+// carved out of the caller's buffer (bump allocation, restarted by every stage: a stage's arrays are consumed in stream order
+// before the next stage zeroes its own), the caller's function sums them over the ranks in place.
+struct Comm {
+	int rank = 0, world = 1;
+	lsfm_allreduce_fn fn = nullptr;
+	void* user = nullptr;
+	char* buf = nullptr;
+	size_t cap = 0, off = 0;
+	void restart() { off = 0; }
+	void* alloc_bytes(size_t bytes)
+	{
+		const size_t a = (off + 255) & ~size_t(255);
+		if (a + bytes > cap)
+			throw Error{ LSFM_ERR_ARG, "the buffer handed to lsfm_tree_set_comm is too small (" + std::to_string(a + bytes) + " bytes needed, " + std::to_string(cap) + " given)" };
+		off = a + bytes;
+		return buf + a;
+	}
+	template <class T> T* alloc(size_t n) { return static_cast<T*>(alloc_bytes(n * sizeof(T))); }
+	// p: inside the buffer; count elements of 8 bytes
+	void allreduce(hipStream_t s, void* p, size_t count, int dtype) const
+	{
+		if (!count) return;
+		const int rc = fn(user, (size_t)(static_cast<char*>(p) - buf), count, dtype, (void*)s);
+		if (rc) throw Error{ LSFM_ERR_INTERNAL, "the caller's all-reduce failed with code " + std::to_string(rc) };
+	}
+};
+
 } // namespace lsfm
 
 struct lsfm_context {
@@ -179,6 +207,7 @@ struct lsfm_context {
 	lsfm::LevelPlan* plan = nullptr; // plan of the tree level being run (null: stage-level calls, nothing is recorded or reused)
 	bool warm() const { return plan && plan->valid; }
 	lsfm::RunStatsDev* d_run = nullptr; // device accumulators of the current run
+	lsfm::Comm* comm = nullptr;         // feature-sharded tree run (set for the duration of lsfm_tree_run): sums cross the GPUs
 	// timing of stages without stopping for them: events from a pool, elapsed times added to their sinks by flush_times()
 	std::vector<hipEvent_t> ev_pool;
 	size_t ev_next = 0;
@@ -239,6 +268,10 @@ static_assert(sizeof(PackHeader) == 256, "the header is the first 256 bytes of a
 #define LSFM_PACK_MAGIC 0x4d46534c
 size_t pack_layout(PackHeader& h); // fills off[] and total from the counts
 void batch_pack_map(lsfm_context* ctx, const DevBatch& b, int k, bool mono, void* dst, size_t cap);
+// the single map of `b` cut by feature label: slice g holds the features with feat_id % nslices == g (order kept) with their V
+// and W blocks, and ALL poses and U blocks.  batch_slice_counts: features / W blocks of every slice (synchronises).
+void batch_slice_counts(lsfm_context* ctx, const DevBatch& b, int nslices, std::vector<int>& nf, std::vector<int>& nw);
+void batch_pack_slice(lsfm_context* ctx, const DevBatch& b, bool mono, int nslices, int slice, int nf, int nw, void* dst, size_t cap);
 void batch_unpack_maps(lsfm_context* ctx, Arena& ar, const void* const* packed, const PackHeader* hdr, int N, bool mono, DevBatch& out);
 // digest of everything a tree's plans are derived from: labels, index arrays, pose origins (synchronises)
 unsigned long long batch_structure_digest(lsfm_context* ctx, const DevBatch& b);

@@ -330,7 +330,7 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
 	// a level that analyses, reached through the transform's hook: the sources of every joint feature, for the early pattern of S
 	static const bool early_on = !getenv("LSFM_NO_EARLY_PATTERN");
-	const bool early = early_on && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
+	const bool early = early_on && !ctx->comm && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
 	int *srcE = nullptr, *srcC = nullptr;
 	if (early)
 	{
@@ -385,7 +385,7 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	LSFM_CHECK_HIP(hipEventRecord(ctx->evY, s)); // the joint maps' index arrays are final (prefetch_next_level reads them)
 	// everything the pattern of S needs is enqueued: the solve may build it beside the right-hand sides (unless it is under
 	// way already: schur_pattern_early_issue)
-	if (!eP_out && !eF_out && !ctx->early)
+	if (!eP_out && !eF_out && !ctx->early && !ctx->comm)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s));
 		ctx->pattern_dep = true;
@@ -393,7 +393,7 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	// ---- right-hand sides ----
 	if (NFY)
 		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);
-	if (in.NU)
+	if (in.NU && (!ctx->comm || ctx->comm->rank == 0)) // (feature-sharded run: U is replicated, its part of the sum is rank 0's)
 		hipLaunchKernelGGL(k_join_rhs_u, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, in.U, in.Ui, in.Uj, in.pose, eP);
 	LSFM_CHECK_HIP(hipGetLastError());
 	if (eP_out) d2h(ctx, eP_out, eP, (size_t)in.M * 6 * sizeof(double));

@@ -113,7 +113,7 @@ __global__ void k_mono_u_flags(int NU, const int* __restrict__ Ui, const int* __
 __global__ void k_mono_u_fill(int NU, const double* __restrict__ U, const int* __restrict__ Ui, const int* __restrict__ Uj,
                               const int* __restrict__ pose_map, const MGroup* __restrict__ grp, const int* __restrict__ keep,
                               const int* __restrict__ KU, const int* __restrict__ pnew, const double* __restrict__ prior,
-                              double* __restrict__ Uy, int* __restrict__ Uiy, int* __restrict__ Ujy, double* __restrict__ eP)
+                              double* __restrict__ Uy, int* __restrict__ Uiy, int* __restrict__ Ujy, double* __restrict__ eP, int add_rhs)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= NU) return;
@@ -137,6 +137,7 @@ __global__ void k_mono_u_fill(int NU, const double* __restrict__ U, const int* _
 		double* d = Uy + (size_t)KU[g.flU] * 36; // summed into End's (P2,P2) block
 		for (int q = 0; q < 36; q++) atomic_add_f64(d + q, u[q]);
 	}
+	if (!add_rhs) return; // feature-sharded run: U is replicated, its part of the right-hand side is rank 0's
 	const double* xb = prior + (size_t)b * 6;
 	for (int r = 0; r < 6; r++)
 	{
@@ -511,7 +512,7 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	dev_zero(ctx, out.U, (size_t)out.NU * 36 * sizeof(double));
 	if (in.NU)
 		hipLaunchKernelGGL(k_mono_u_fill, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, in.U, in.Ui, in.Uj, in.pose_map, d_mg, keepU, KU, pnew,
-		                   prior, out.U, out.Ui, out.Uj, eP);
+		                   prior, out.U, out.Ui, out.Uj, eP, (!ctx->comm || ctx->comm->rank == 0) ? 1 : 0);
 
 	// ---- features: V, run lengths, W ----
 	int* newf = sc.alloc<int>(in.NF + 1);

@@ -1792,7 +1792,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		std::shared_ptr<void> pre_keep = ctx->pre;
 		ctx->pre.reset();
 		PreLevel* pre = static_cast<PreLevel*>(pre_keep.get());
-		if (pre && pre->M == M)
+		if (pre && pre->M == M && !ctx->comm)
 		{
 			// prepared while the level below was being solved: pattern (device) and symbolic factorisation (host)
 			ctx->pattern_dep = false;
@@ -1817,7 +1817,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		}
 		else pre = nullptr;
 		if (have) {}
-		else if (ctx->early)
+		else if (ctx->early && !ctx->comm)
 		{
 			// the pattern was put together on the side stream from the level's inputs while the transform ran (a Stereo level
 			// that analyses): its second half, and the copy of it for the host's analysis, stay there
@@ -1853,7 +1853,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			if (have) LSFM_CHECK_HIP(hipStreamWaitEvent(s, ctx->evB, 0));
 		}
 		if (have) {}
-		else if (side && ctx->pattern_dep)
+		else if (side && ctx->pattern_dep && !ctx->comm)
 		{
 			ctx->pattern_dep = false;
 			LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evA, 0));
@@ -1984,6 +1984,18 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		LSFM_CHECK_HIP(hipStreamSynchronize(s));
 		fprintf(stderr, "[lsfm] solve M=%d nseg=%d nnzb=%d nnzL=%d etree levels=%d tail=%d task levels=%d group levels=%d %s| analyse %.2f ms, factor %.2f ms, cg(%d its) %.2f ms\n", M, nseg,
 		        sy.nnzb, ch.nnzL, ch.nlevels, ch.M - ch.tail_begin, (int)ch.tlevel_ptr.size() - 1, (int)ch.glevel_ptr.size() - 1, warm ? "(plan) " : "", tw1 - tw0, tw2 - tw1, its, wall() - tw2);
+	}
+	if (ctx->comm)
+	{
+		// feature-sharded run: every rank solved the same system, but the factorisations add their updates in whatever order the
+		// atomics land -- the solutions may differ in the last bit.  Rank 0's replaces everyone's, so that the replicated state
+		// (and every decision taken from it) stays the same on all ranks.
+		Comm& cm = *ctx->comm;
+		double* xb = cm.alloc<double>(nscal);
+		if (cm.rank == 0) LSFM_CHECK_HIP(hipMemcpyAsync(xb, x, nscal * sizeof(double), hipMemcpyDeviceToDevice, s));
+		else LSFM_CHECK_HIP(hipMemsetAsync(xb, 0, nscal * sizeof(double), s));
+		cm.allreduce(s, xb, nscal, LSFM_DTYPE_F64);
+		LSFM_CHECK_HIP(hipMemcpyAsync(x, xb, nscal * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
 	// ---- true residual, statistics; one SpMV launch timed with HIP events on this stream.  Nothing here waits for
 	// the device before the back-substitution is enqueued ----

@@ -714,6 +714,7 @@ static void pattern_finish(lsfm_context* ctx, const SolveIO& io, const PatternBu
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 
+__global__ void k_pat_insert_keys(int n, const unsigned long long* __restrict__ keys, unsigned long long* tab, unsigned long long mask, int* overflow);
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
 	hipStream_t s = ctx->stream;
@@ -730,7 +731,42 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
 		pattern_compact(ctx, pb);
 		int cnt = 0;
-		if (pattern_count(ctx, pb, &cnt))
+		bool ok = pattern_count(ctx, pb, &cnt);
+		if (ctx->comm)
+		{
+			// feature-sharded run: the pattern of S is the UNION of what the ranks' slices induce.  Every rank learns every rank's
+			// count (a vector with one slot per rank, summed), then every rank's keys (each writes its list at its offset of a
+			// zeroed array, summed as integers), inserts them all and compacts again.  A rank whose table overflowed says so in
+			// the count exchange and all of them start over with a larger table together.
+			Comm& cm = *ctx->comm;
+			cm.restart();
+			long long* d_counts = cm.alloc<long long>(cm.world + 1);
+			std::vector<long long> hc(cm.world + 1, 0);
+			hc[cm.rank] = ok ? cnt : 0;
+			hc[cm.world] = ok ? 0 : 1;
+			h2d(ctx, d_counts, hc.data(), sizeof(long long) * hc.size());
+			cm.allreduce(s, d_counts, hc.size(), LSFM_DTYPE_I64);
+			d2h(ctx, hc.data(), d_counts, sizeof(long long) * hc.size());
+			ok = hc[cm.world] == 0;
+			if (ok)
+			{
+				long long total = 0, mine = 0;
+				for (int r = 0; r < cm.world; r++) { if (r == cm.rank) mine = total; total += hc[r]; }
+				if ((size_t)total * 2 > cap) ok = false; // (the same answer on every rank)
+				else
+				{
+					unsigned long long* all = cm.alloc<unsigned long long>((size_t)total + 1);
+					LSFM_CHECK_HIP(hipMemsetAsync(all, 0, sizeof(unsigned long long) * (size_t)total, s));
+					if (cnt) LSFM_CHECK_HIP(hipMemcpyAsync(all + mine, pb.list, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
+					cm.allreduce(s, all, (size_t)total, LSFM_DTYPE_I64);
+					if (total) hipLaunchKernelGGL(k_pat_insert_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (int)total, all, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
+					dev_zero(ctx, pb.d_flags + 1, sizeof(int));
+					pattern_compact(ctx, pb);
+					ok = pattern_count(ctx, pb, &cnt); // replicated from here on: the same table contents on every rank
+				}
+			}
+		}
+		if (ok)
 		{
 			pattern_finish(ctx, io, pb, cnt, sy);
 			build_spmv_index(ctx, sy, pb.list, pb.d_flags);
@@ -1029,13 +1065,29 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	const int* hval = sy.hval;
 	const unsigned long long mask = sy.mask;
 	const int ntiles = (NF + SCHUR_TILE - 1) / SCHUR_TILE;
-	ZeroSpan zs(sc);
-	sy.S = sc.alloc<double>((size_t)cnt * 36);
-	unsigned char* fb = sc.alloc<unsigned char>(ntiles + 1); // tiles the panel kernel hands to the per-feature kernel
-	zs.zero(s);
-	sy.E = sc.alloc<double>((size_t)M * 6);
+	unsigned char* fb;
+	if (ctx->comm)
+	{
+		// feature-sharded run: S and E back to back in the caller's buffer; this rank's features subtract their part (rank 0
+		// starts from U and the pose part of the right-hand side, the others from zero), then the sum over the ranks
+		ctx->comm->restart();
+		sy.S = ctx->comm->alloc<double>((size_t)cnt * 36 + (size_t)M * 6);
+		sy.E = sy.S + (size_t)cnt * 36;
+		LSFM_CHECK_HIP(hipMemsetAsync(sy.S, 0, (size_t)cnt * 36 * sizeof(double), s));
+		fb = sc.alloc<unsigned char>(ntiles + 1);
+		LSFM_CHECK_HIP(hipMemsetAsync(fb, 0, ntiles + 1, s));
+	}
+	else
+	{
+		ZeroSpan zs(sc);
+		sy.S = sc.alloc<double>((size_t)cnt * 36);
+		fb = sc.alloc<unsigned char>(ntiles + 1); // tiles the panel kernel hands to the per-feature kernel
+		zs.zero(s);
+		sy.E = sc.alloc<double>((size_t)M * 6);
+	}
 	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
-	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
+	if (io.NU && (!ctx->comm || ctx->comm->rank == 0))
+		hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
@@ -1070,6 +1122,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 				hipLaunchKernelGGL(k_sum_run_squares, dim3(std::min((NF + 255) / 256, 512)), dim3(256), 0, s, NF, io.fptr, &ctx->d_run->k2);
 		}
 	}
+	if (ctx->comm) ctx->comm->allreduce(s, sy.S, (size_t)cnt * 36 + (size_t)M * 6, LSFM_DTYPE_F64);
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 

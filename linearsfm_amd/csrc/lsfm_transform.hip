@@ -1003,7 +1003,10 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 	// U stage: needs the pose rows of G (complete after k_tr_entries) but nothing of the feature epilogue, which runs
 	// on the main stream meanwhile; k_tr_diag needs both
 	static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
-	hipStream_t su = (side && ev_entries) ? ctx->stream2 : s;
+	// feature-sharded run: what the features of this rank's slice added to the pose rows of G (k_tr_entries) and to the hub-hub
+	// blocks (k_tr_feat_post) becomes the sum over all slices before the pose kernels read and extend it
+	if (ctx->comm) ctx->comm->allreduce(s, Gpose, (size_t)M * 36 * NH + (size_t)in.B * 3 * 36, LSFM_DTYPE_F64);
+	hipStream_t su = (side && ev_entries && !ctx->comm) ? ctx->stream2 : s;
 	if (su != s) LSFM_CHECK_HIP(hipStreamWaitEvent(su, ctx->evA, 0));
 	if (in.NU)
 		hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, su, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
@@ -1119,10 +1122,23 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
 	// Stereo: + the 27 pose-dependent entries of (D_k, C_k) packed per pose, for k_tr_entries (after the one C section)
 	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh + (nh == 1 ? (size_t)M * 27 : (size_t)M * 63));
-	ZeroSpan zs(ctx->scratch);
-	double* Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
-	double* PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);
-	zs.zero(s);
+	double *Gpose, *PP;
+	if (ctx->comm)
+	{
+		// feature-sharded run: the two accumulators the features add to live back to back in the caller's buffer and are summed
+		// over the ranks between the feature kernels and the pose kernels (launch_stage)
+		ctx->comm->restart();
+		Gpose = ctx->comm->alloc<double>((size_t)M * 36 * nh + (size_t)B * 3 * 36);
+		PP = Gpose + (size_t)M * 36 * nh;
+		LSFM_CHECK_HIP(hipMemsetAsync(Gpose, 0, ((size_t)M * 36 * nh + (size_t)B * 3 * 36) * sizeof(double), s));
+	}
+	else
+	{
+		ZeroSpan zs(ctx->scratch);
+		Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
+		PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);
+		zs.zero(s);
+	}
 	if (M)
 	{
 		if (mono) hipLaunchKernelGGL(k_tr_pose_jac<2>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);

@@ -16,6 +16,15 @@ join, exactly as the reference's loop treats an intermediate node ((i+1)%2 == 0,
 map goes back to the first frame of the whole set (2039-2063).  The tree shape -- and therefore every transform and
 join -- is identical to the single-process order.
 
+That is sub-tree sharding ("P1"); its merge rounds leave half of the remaining GPUs idle each.  `top="shard"` (the default of
+ShardedTree with more than one rank) replaces them by FEATURE-SHARDED top levels ("P2"): after its block, every rank cuts its
+sub-tree root into G slices by feature label (feat_id % G; all poses and U blocks in every slice), slice g of every block goes
+to rank g (one all-to-all of packed device buffers), and ALL ranks run the top log2(G) levels together, each on its slice of
+the features -- the Schur loop (Imp.cpp:2244-2332), the feature part of the transform (1270-1917) and the back-substitution
+(2980-3020) are sums over features.  Three all-reduces per level cross the GPUs (RCCL over xGMI with the nccl backend): the
+pose rows of the transform's I C, the camera system (S, E) before it is factored, and the pose solution of rank 0 (the
+replicated factorisations may differ in the last bit); see include/lsfm.h, lsfm_tree_set_comm.
+
 `merge_schedule` is the schedule itself (pure Python, shared by both back ends); `ShardedTree` drives the HIP library;
 `sharded_divide_conquer` runs the same schedule with a caller-supplied CPU back end (the tests pass the oracle) so that
 the scheduling is covered by world-size-2/3/4 gloo tests without a GPU.
@@ -111,6 +120,94 @@ def hip_run_tree(ctx):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# feature-sharded top levels: what both back ends share
+# ---------------------------------------------------------------------------------------------------------------
+def joint_feature_order(id_lists):
+    """Feature labels of the map the reference's tree makes of maps with the given label lists, in its order: a join keeps
+    End's features in their order and appends Cur's unmatched ones in theirs (Imp.cpp:2601-2660); an unpaired trailing map
+    is carried."""
+    level = [np.asarray(a, np.int64) for a in id_lists]
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level) - 1, 2):
+            E, Cu = level[i], level[i + 1]
+            nxt.append(np.concatenate([E, Cu[~np.isin(Cu, E)]]))
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0]
+
+
+def slice_map(d, nslices, g):
+    """Slice g of a map dict: all poses and U blocks, the features with label % nslices == g in their order with V and W."""
+    m, n = int(d["m"]), int(d["n"])
+    stno, stVal = np.asarray(d["stno"]), np.asarray(d["stVal"])
+    fid = stno[6 * m::3]
+    keep = np.nonzero(fid % nslices == g)[0]
+    newidx = np.full(n, -1, np.int64)
+    newidx[keep] = np.arange(len(keep))
+    feature = np.asarray(d["feature"])
+    wsel = np.nonzero(newidx[feature] >= 0)[0] if len(feature) else np.zeros(0, np.int64)
+    out = dict(d)
+    out["n"] = len(keep)
+    sel = (6 * m + 3 * keep[:, None] + np.arange(3)[None, :]).reshape(-1)
+    out["stno"] = np.concatenate([stno[:6 * m], stno[sel]]).astype(np.int32)
+    out["stVal"] = np.concatenate([stVal[:6 * m], stVal[sel]])
+    out["V"] = np.asarray(d["V"]).reshape(-1, 9)[keep]
+    out["W"] = np.asarray(d["W"]).reshape(-1, 18)[wsel]
+    out["photo"] = np.asarray(d["photo"])[wsel].astype(np.int32)
+    out["feature"] = newidx[feature[wsel]].astype(np.int32)
+    out["nW"] = len(wsel)
+    fb = np.zeros(len(keep), np.int32)
+    if len(wsel):
+        cnt = np.bincount(out["feature"], minlength=len(keep))
+        fb = (np.cumsum(cnt) - cnt).astype(np.int32)
+    out["FBlock"] = fb
+    return out
+
+
+def merge_slices(slices, order):
+    """The whole map from its feature slices (map dicts; slices[0] supplies poses and U) with the features in `order` (labels)."""
+    base = slices[0]
+    m = int(base["m"])
+    order = np.asarray(order, np.int64)
+    n = len(order)
+    srt = np.argsort(order, kind="stable")
+    out = {k: base[k] for k in base}
+    stno = np.concatenate([np.asarray(base["stno"])[:6 * m], np.repeat(order, 3)]).astype(np.int32)
+    stVal = np.concatenate([np.asarray(base["stVal"])[:6 * m], np.zeros(3 * n)])
+    V = np.zeros((n, 9))
+    lens = np.zeros(n, np.int64)
+    gpos_all = []
+    for sl in slices:
+        ids = np.asarray(sl["stno"])[6 * m::3].astype(np.int64)
+        gp = srt[np.searchsorted(order[srt], ids)] if len(ids) else np.zeros(0, np.int64)
+        assert np.array_equal(order[gp], ids), "a slice holds a feature the joint order does not know"
+        gpos_all.append(gp)
+        stVal[6 * m:].reshape(n, 3)[gp] = np.asarray(sl["stVal"])[6 * m:].reshape(-1, 3)
+        V[gp] = np.asarray(sl["V"]).reshape(-1, 9)
+        fe = np.asarray(sl["feature"])
+        if len(fe):
+            lens[gp] += np.bincount(fe, minlength=len(ids))
+    assert sum(len(g) for g in gpos_all) == n, "the slices do not add up to the joint map"
+    FB = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nW = int(FB[-1])
+    W = np.zeros((nW, 18)); photo = np.zeros(nW, np.int32); feature = np.zeros(nW, np.int32)
+    for sl, gp in zip(slices, gpos_all):
+        fe = np.asarray(sl["feature"])
+        k = len(fe)
+        if not k:
+            continue
+        fb = np.asarray(sl["FBlock"]).astype(np.int64)
+        dest = FB[gp[fe]] + (np.arange(k) - fb[fe])
+        W[dest] = np.asarray(sl["W"]).reshape(-1, 18)
+        photo[dest] = np.asarray(sl["photo"])
+        feature[dest] = gp[fe]
+    out.update(n=n, stno=stno, stVal=stVal, V=V, W=W, photo=photo, feature=feature, nW=nW, FBlock=FB[:-1].astype(np.int32))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # HIP back end: nodes stay on the devices
 # ---------------------------------------------------------------------------------------------------------------
 class ShardedTree:
@@ -118,7 +215,12 @@ class ShardedTree:
     run() joins the whole tree and leaves the final map on rank 0 (download()).  run() can be repeated: the block trees
     and the merge trees keep their allocations and their plans, the packed buffers are reused."""
 
-    def __init__(self, ctx, maps_block, lo, n_total, mono, group=None, device=None):
+    def __init__(self, ctx, maps_block, lo, n_total, mono, group=None, device=None, top="shard", comm_bytes=0, shard_single=False):
+        """top: "shard" -- the levels above the blocks run feature-sharded on ALL ranks (all-reduces per level); "merge" --
+        pairwise merge rounds on half of the remaining ranks each (no collective in the data path).  comm_bytes: size of the
+        device buffer the all-reduced arrays live in (0: 512 MiB; it must hold the largest camera system, 288 bytes per block).
+        shard_single: take the feature-sharded path with ONE rank too (tests: the whole collective path on one GPU)."""
+        assert top in ("shard", "merge")
         self.ctx, self.mono, self.group = ctx, bool(mono), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -135,7 +237,18 @@ class ShardedTree:
                 d.setdefault("pose_origin", np.full(int(d["m"]), lo + k, np.int32))
                 block.append(d)
             self.block_tree = ctx.tree_upload(block, self.mono)
-            ctx.tree_set_final_reanchor(self.block_tree, first_reanchor(self.rank, self.world))
+        self.top = top if (self.world > 1 or shard_single) else "merge"
+        if self.block_tree is not None:
+            # (feature-sharded top: an odd-indexed root goes back to its first frame inside the top tree's first level, on all ranks)
+            ctx.tree_set_final_reanchor(self.block_tree, first_reanchor(self.rank, self.world) if self.top == "merge" else False)
+        self.comm_bytes = int(comm_bytes) or (512 << 20)
+        self.comm_buf = None    # device memory the all-reduced arrays live in (feature-sharded top)
+        self.comm_cb = None     # keeps the ctypes callback alive
+        self.comm_error = None
+        self.top_tree = None
+        self.slice_out, self.slice_in, self.slice_sizes = {}, {}, None
+        self.block_ids = None   # feature labels of this rank's sub-tree root, in its order (for the order of the final map)
+        self.order = None
         self.merge_trees = {}   # round -> tree built from packed buffers
         self.out_bufs = {}      # round -> torch buffer the own node is packed into
         self.in_bufs = {}       # round -> torch buffer the partner's node arrives in
@@ -149,7 +262,7 @@ class ShardedTree:
         """on = False: every run of every tree of this rank analyses its structure again (what the reference's timed region
         contains: symbolic work in every join); True (default): later runs reuse what the first one recorded."""
         self.plans = bool(on)
-        for t in list(self.merge_trees.values()) + ([self.block_tree] if self.block_tree is not None else []):
+        for t in list(self.merge_trees.values()) + [t for t in (self.block_tree, self.top_tree) if t is not None]:
             self.ctx.tree_set_plans(t, self.plans)
 
     # -- transport of one packed node -------------------------------------------------------------------------------
@@ -211,9 +324,142 @@ class ShardedTree:
         self.ctx.tree_export_dev(tree, buf.data_ptr(), n)  # synchronises the library's stream
         return buf
 
+    # -- feature-sharded top levels -----------------------------------------------------------------------------------
+    def _allreduce_callback(self):
+        """The function the library calls for every sum that crosses the GPUs (include/lsfm.h lsfm_allreduce_fn): `count`
+        8-byte elements at `offset` of self.comm_buf, in place.  nccl: torch's all_reduce under the library's own stream
+        (ExternalStream) -- ordered on the device, the host does not wait.  gloo (tests: several ranks on one GPU): staged
+        through the host."""
+        from . import api
+        ext = torch.cuda.ExternalStream(int(self.ctx.stream() or 0), device=self.device)
+        f64, i64 = self.comm_buf.view(torch.float64), self.comm_buf.view(torch.int64)
+
+        def cb(user, offset, count, dtype, stream):
+            try:
+                v = (i64 if dtype == api.LSFM_DTYPE_I64 else f64)[offset // 8: offset // 8 + count]
+                if self.gpu_direct:
+                    with torch.cuda.stream(ext):
+                        dist.all_reduce(v, group=self.group)
+                elif not dist.is_initialized():
+                    pass
+                else:
+                    ext.synchronize()
+                    h = v.cpu()
+                    dist.all_reduce(h, group=self.group)
+                    v.copy_(h)
+                    torch.cuda.synchronize(self.device)
+                return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                self.comm_error = e
+                return 1
+        return api.ALLREDUCE_FN(cb)
+
+    def _exchange_slices(self, sizes):
+        """Slice g of this rank's root goes to rank g; slice `rank` of every other block arrives.  sizes[src][dst] bytes."""
+        G, me = self.world, self.rank
+        reqs, staged = [], []
+        for b in range(G):
+            if b == me or not self.nonempty[b]:
+                continue
+            n = int(sizes[b][me])
+            buf = self.slice_in.get(b)
+            if buf is None or buf.numel() != n:
+                buf = self.slice_in[b] = torch.empty(n, dtype=torch.uint8, device=self.device)
+            if self.gpu_direct:
+                reqs.append(dist.P2POp(dist.irecv, buf, b, self.group))
+            else:
+                host = torch.empty(n, dtype=torch.uint8).pin_memory()
+                staged.append((buf, host))
+                reqs.append(dist.P2POp(dist.irecv, host, b, self.group))
+        if self.block_tree is not None:
+            for g in range(G):
+                if g != me:
+                    reqs.append(dist.P2POp(dist.isend, self.slice_out[g] if self.gpu_direct else self.slice_out[g].cpu(), g, self.group))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        for buf, host in staged:
+            buf.copy_(host, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()  # the library reads the buffers on its own stream next
+
+    def _run_shard(self):
+        ctx, G, me = self.ctx, self.world, self.rank
+        stats, worst = None, 0
+        if self.block_tree is not None:
+            stats, rc = ctx.tree_run(self.block_tree)
+            worst = max(worst, rc)
+            if self.block_ids is None:  # structure: fetched once
+                m, n, stno, _ = ctx.tree_download_state(self.block_tree)
+                self.block_ids = stno[6 * m::3].copy()
+            mine = ctx.tree_export_slice_sizes(self.block_tree, G)
+            for g in range(G):
+                buf = self.slice_out.get(g)
+                if buf is None or buf.numel() != mine[g]:
+                    buf = self.slice_out[g] = torch.empty(mine[g], dtype=torch.uint8, device=self.device)
+                ctx.tree_export_slice_dev(self.block_tree, G, g, buf.data_ptr(), mine[g])  # synchronises the library's stream
+        else:
+            mine = [0] * G
+        if self.slice_sizes is None:  # structure: exchanged once
+            t = torch.tensor(mine, dtype=torch.int64, device=self.device if self.gpu_direct else "cpu")
+            allt = [torch.zeros_like(t) for _ in range(G)]
+            if dist.is_initialized():
+                dist.all_gather(allt, t, group=self.group)
+            else:
+                allt = [t]
+            self.slice_sizes = [[int(v) for v in a.tolist()] for a in allt]
+        self._exchange_slices(self.slice_sizes)
+        parts = [(self.slice_out[me] if b == me else self.slice_in[b]) for b in range(G) if self.nonempty[b]]
+        ptrs = [b.data_ptr() for b in parts]
+        if self.top_tree is None:
+            self.top_tree = ctx.tree_upload_dev(ptrs, self.mono)
+            ctx.tree_set_plans(self.top_tree, self.plans)
+            self.comm_buf = torch.zeros(self.comm_bytes, dtype=torch.uint8, device=self.device)
+            self.comm_cb = self._allreduce_callback()
+            ctx.tree_set_comm(self.top_tree, me, G, self.comm_cb, self.comm_buf.data_ptr(), self.comm_bytes)
+        else:
+            ctx.tree_reload_dev(self.top_tree, ptrs)
+        self.comm_error = None
+        try:
+            stats, rc = ctx.tree_run(self.top_tree)
+        except Exception:
+            if self.comm_error is not None:
+                raise self.comm_error
+            raise
+        worst = max(worst, rc)
+        self.result = self.top_tree
+        return stats, worst
+
+    def _download_shard(self, full):
+        """Rank 0: the final map put together from the ranks' feature slices, in the order the single tree leaves it in
+        (full=False: state vector only -- stno, stVal, m, n).  Collective: every rank calls it."""
+        ctx, G = self.ctx, self.world
+        if self.order is None:
+            ids = [None] * G
+            if dist.is_initialized():
+                dist.all_gather_object(ids, self.block_ids, group=self.group)
+            else:
+                ids = [self.block_ids]
+            self.order = joint_feature_order([a for a, ne in zip(ids, self.nonempty) if ne])
+        if full:
+            piece = ctx.tree_download(self.top_tree)
+        else:
+            m, n, stno, stVal = ctx.tree_download_state(self.top_tree)
+            piece = dict(m=m, n=n, stno=stno, stVal=stVal, V=np.zeros((n, 9)), W=np.zeros((0, 18)), photo=np.zeros(0, np.int32),
+                         feature=np.zeros(0, np.int32), FBlock=np.zeros(n, np.int32))
+        pieces = [None] * G if self.rank == 0 else None
+        if dist.is_initialized():
+            dist.gather_object(piece, pieces, dst=0, group=self.group)
+        else:
+            pieces = [piece]
+        if self.rank != 0:
+            return None
+        return merge_slices(pieces, self.order)
+
     # -- one whole tree ---------------------------------------------------------------------------------------------
     def run(self):
         """Returns (stats of the last tree run on this rank or None, worst return code on this rank)."""
+        if self.top == "shard":
+            return self._run_shard()
         ctx = self.ctx
         cur, stats, worst = None, None, 0
         # the partners' nodes may start travelling as soon as they exist: post every receive of this run whose buffer is known
@@ -255,13 +501,17 @@ class ShardedTree:
             self.result = cur
         return stats, worst
 
-    def download(self):
-        """The final map (rank 0, after run())."""
+    def download(self, full=True):
+        """The final map (rank 0, after run()).  With the feature-sharded top every rank holds a slice of the features: the call
+        is then collective (every rank makes it, rank 0 gets the map, the others None); full=False gathers the state vector only."""
+        if self.top == "shard":
+            return self._download_shard(full)
         if self.result is None:
             raise RuntimeError("no result on this rank (rank 0 holds it after run())")
         return self.ctx.tree_download(self.result)
 
     def close(self):
-        for t in list(self.merge_trees.values()) + ([self.block_tree] if self.block_tree is not None else []):
+        for t in list(self.merge_trees.values()) + [t for t in (self.block_tree, self.top_tree) if t is not None]:
             self.ctx.tree_free(t)
-        self.merge_trees, self.block_tree, self.result = {}, None, None
+        self.merge_trees, self.block_tree, self.top_tree, self.result = {}, None, None, None
+        self.comm_cb = None

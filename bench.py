@@ -6,9 +6,11 @@ binary tree, the region the reference itself times: LinearSFMImp.cpp:1929 -> 206
     python bench.py --gpus N --steps K --warmup W
 
 A "step" = ONE full join tree over ONE resident set of local maps, whatever N is ("scaling": "strong"): with N > 1 the
-tree is sharded by sub-trees (linearsfm_amd/distributed.py: rank r joins block r of 2^k consecutive local maps, then
-log2(N) merge rounds in which packed sub-tree roots travel between the GPUs through RCCL send/recv) and `value` is the
-wall time of the whole tree.  Inputs are uploaded once and stay in HBM; no level writes its input, so every step reads
+tree is sharded twice (linearsfm_amd/distributed.py): rank r joins block r of 2^k consecutive local maps on its own (the
+independent joins of the lower levels), then the sub-tree roots are cut by feature label, slice g of every root goes to rank g
+(all-to-all of packed device buffers), and ALL ranks run the top log2(N) levels on their slice of the features with RCCL
+all-reduces of the sums that cross features (`--top merge`: pairwise merge rounds instead).  `value` is the wall time of
+the whole tree.  Inputs are uploaded once and stay in HBM; no level writes its input, so every step reads
 them in place.  Every timed step does the symbolic work of every join itself (pattern of S, ordering, symbolic
 factorisation), as the reference's timed region does; the repeat runs that reuse it are reported as `resolve_ms`.
 At N = 1 the line also carries the CPU baseline (the oracle on the host cores, three ways), the stand-alone streaming
@@ -151,6 +153,10 @@ def main():
     ap.add_argument("--plans", action="store_true", help="time the repeat runs of the resident tree (structure analysed once) instead of "
                                                          "runs that analyse every join like the reference does; the default reports both")
     ap.add_argument("--no-plans", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--top", default="shard", choices=("shard", "merge"),
+                    help="N > 1: how the levels above the ranks' blocks run -- shard: feature-sharded on ALL ranks, RCCL all-reduces of the "
+                         "transform's pose rows, the camera system and the pose solution per level; merge: pairwise merge rounds of packed "
+                         "sub-tree roots on half of the remaining ranks each")
     ap.add_argument("--extras", type=int, default=1, help="1: also the stand-alone SpMV streaming leg and the files-to-files CLI run "
                                                           "(N=1, default configuration sizes only); 0: skip")
     args = ap.parse_args()
@@ -163,8 +169,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("LSFM_BENCH_ONE_GPU"):
+            # development aid: all ranks on cuda:0 with gloo (two ranks of one RCCL communicator cannot share a device); checks the
+            # multi-rank logic of this script on a one-GPU box -- the numbers it prints are not a scaling measurement
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -193,7 +206,7 @@ def main():
     ctx.set_pcg(args.tol, 0)
     ctx.set_precision(args.mixed)
     t0 = time.perf_counter()
-    tree = ShardedTree(ctx, block, lo, n_maps, mono)   # PCIe copy, outside the timed region: inputs are resident from here on
+    tree = ShardedTree(ctx, block, lo, n_maps, mono, top=args.top)   # PCIe copy, outside the timed region: inputs are resident from here on
     upload_ms = 1e3 * (time.perf_counter() - t0)
 
     def barrier():
@@ -225,7 +238,8 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         tree.run()
     elapsed, acc, stats, worst = timed(args.steps)
-    tm = torch.tensor([elapsed, first_s], dtype=torch.float64, device="cuda")
+    rdev = "cpu" if os.environ.get("LSFM_BENCH_ONE_GPU") else "cuda"
+    tm = torch.tensor([elapsed, first_s], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed, first_ms = float(tm[0].item()), 1e3 * float(tm[1].item())
@@ -235,19 +249,20 @@ def main():
     tree.run()
     tree.run()
     other_s, acc2, _, _ = timed(args.steps)
-    tm = torch.tensor([other_s], dtype=torch.float64, device="cuda")
+    tm = torch.tensor([other_s], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     other_ms = 1e3 * float(tm[0].item()) / args.steps
     analyse_ms, resolve_ms = (ms_per_step, other_ms) if analysing else (other_ms, ms_per_step)
     # per-rank busy time of the timed steps (where a multi-GPU run loses its efficiency): device time of the trees the rank ran
-    busy = torch.zeros(world, dtype=torch.float64, device="cuda")
+    busy = torch.zeros(world, dtype=torch.float64, device=rdev)
     busy[rank] = acc.get("t_total_ms", 0.0) / args.steps
     if world > 1:
         dist.all_reduce(busy, op=dist.ReduceOp.SUM)
 
+    # (feature-sharded top: every rank holds a slice of the final map's features -- the download is collective)
+    out = tree.download(full=False) if (world > 1 and args.top == "shard") else (tree.download() if rank == 0 else None)
     if rank == 0:
-        out = tree.download()
         # Per-kernel live measurements (HIP events on the library's stream around the launches, accumulated over the timed
         # steps; at N > 1: of the trees rank 0 ran, i.e. its block and the merges it took part in).  The roofline object
         # describes whichever of the two instrumented kernels took the most device time.
@@ -285,7 +300,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config} stand-in ({typ}): {n_maps} local maps, {npf} new features/frame visible in {vis} "
                                    f"frames, camera path {cpath}, {out['m']} poses / {out['n']} features in the final map",
-                       "maps": n_maps, "sharding": f"{world} block(s) of {bounds[0][1] - bounds[0][0]} local maps, {max(0, world.bit_length() - 1)} merge round(s)",
+                       "maps": n_maps, "sharding": (f"{world} block(s) of {bounds[0][1] - bounds[0][0]} local maps, " +
+                                    (f"{max(0, world.bit_length() - 1)} merge round(s)" if (world == 1 or args.top == "merge") else
+                                     f"then the top {max(0, (world - 1).bit_length())} level(s) feature-sharded over all {world} ranks "
+                                     "(features by label mod N; RCCL all-reduce of the transform's pose rows, of S and E, and of the pose solution, per level)")),
                        "pcg_rel_tol": args.tol, "plans": not analysing,
                        "value_definition": "wall ms of ONE whole join tree over all GPUs (barrier + synchronize on both sides, max over ranks), inputs "
                                            "resident in HBM; " + ("every step analyses every join (pattern of S, ordering, symbolic factorisation) "
@@ -301,6 +319,8 @@ def main():
             "upload_ms": upload_ms,
             "upload_note": "lsfm_tree_upload of this rank's block from pageable host memory through the pinned ring (PCIe), before the timed region",
             "per_rank_device_ms": [float(v) for v in busy.tolist()],
+            "rank0_phases_ms": ({k: acc.get(k, 0.0) / args.steps for k in ("phase_block_ms", "phase_exchange_ms", "phase_top_ms")}
+                                if "phase_top_ms" in acc else None),
             "device_breakdown_ms": {k: acc.get(k, 0.0) / args.steps for k in
                                     ("t_total_ms", "t_transform_ms", "t_join_ms", "t_schur_ms", "t_pcg_ms", "t_backsub_ms")},
             "pcg_iterations_per_step": acc.get("pcg_iterations", 0) / args.steps,

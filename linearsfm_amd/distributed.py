@@ -107,6 +107,37 @@ def sharded_divide_conquer(maps, mono, run_tree, group=None):
     return node if rank == 0 else None
 
 
+def sharded_divide_conquer_top(maps, mono, run_tree, run_slices, group=None):
+    """The same tree with FEATURE-SHARDED top levels, on a caller-supplied CPU back end (the tests pass the oracle): rank r joins
+    block r (run_tree), cuts the root into `world` slices by feature label, takes slice `rank` of every block and evaluates the
+    top levels on them together with the other ranks -- run_slices(list of slice dicts, mono, rank, world) -> slice dict of the
+    final map, with the sums over features taken across the ranks inside.  Returns the final map on rank 0, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    _, bounds = shard_bounds(len(maps), world)
+    nonempty = [hi > lo for lo, hi in bounds]
+    lo, hi = bounds[rank]
+    slices, ids = None, None
+    if hi > lo:
+        block = []
+        for k, m in enumerate(maps[lo:hi]):
+            d = dict(m if isinstance(m, dict) else m.__dict__)
+            d.setdefault("pose_origin", np.full(int(d["m"]), lo + k, np.int32))
+            block.append(d)
+        node = run_tree(block, mono, first_reanchor(rank, world))
+        ids = np.asarray(node["stno"])[6 * int(node["m"])::3].copy()
+        slices = [slice_map(node, world, g) for g in range(world)]
+    everything = [None] * world
+    dist.all_gather_object(everything, (slices, ids), group=group)  # (a test-sized all-to-all: every rank picks its column)
+    mine = [everything[b][0][rank] for b in range(world) if nonempty[b]]
+    piece = run_slices(mine, mono, rank, world)
+    pieces = [None] * world if rank == 0 else None
+    dist.gather_object(piece, pieces, dst=0, group=group)
+    if rank != 0:
+        return None
+    return merge_slices(pieces, joint_feature_order([everything[b][1] for b in range(world) if nonempty[b]]))
+
+
 def hip_run_tree(ctx):
     """`run_tree` back end over the HIP library for sharded_divide_conquer (host hand-off; ShardedTree is the device-resident
     scheduler): raises on a failure, refuses a result whose systems did not all converge."""
@@ -382,9 +413,22 @@ class ShardedTree:
             buf.copy_(host, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()  # the library reads the buffers on its own stream next
 
+    @staticmethod
+    def _add_stats(a, b):
+        """Stats of two tree runs of one step as one record: times and counts add up, the residual is the larger one."""
+        if a is None or b is None:
+            return dict(b or a or {})
+        out = {}
+        for k in set(a) | set(b):
+            x, y = a.get(k, 0), b.get(k, 0)
+            out[k] = max(x, y) if k in ("max_rel_residual", "spmv_nnzb_upper_last", "spmv_rows_last", "upload_ms") else x + y
+        return out
+
     def _run_shard(self):
+        import time
         ctx, G, me = self.ctx, self.world, self.rank
         stats, worst = None, 0
+        t0 = time.perf_counter()
         if self.block_tree is not None:
             stats, rc = ctx.tree_run(self.block_tree)
             worst = max(worst, rc)
@@ -399,6 +443,7 @@ class ShardedTree:
                 ctx.tree_export_slice_dev(self.block_tree, G, g, buf.data_ptr(), mine[g])  # synchronises the library's stream
         else:
             mine = [0] * G
+        t1 = time.perf_counter()
         if self.slice_sizes is None:  # structure: exchanged once
             t = torch.tensor(mine, dtype=torch.int64, device=self.device if self.gpu_direct else "cpu")
             allt = [torch.zeros_like(t) for _ in range(G)]
@@ -419,14 +464,20 @@ class ShardedTree:
         else:
             ctx.tree_reload_dev(self.top_tree, ptrs)
         self.comm_error = None
+        t2 = time.perf_counter()
         try:
-            stats, rc = ctx.tree_run(self.top_tree)
+            top_stats, rc = ctx.tree_run(self.top_tree)
         except Exception:
             if self.comm_error is not None:
                 raise self.comm_error
             raise
+        t3 = time.perf_counter()
         worst = max(worst, rc)
         self.result = self.top_tree
+        stats = self._add_stats(stats, top_stats)
+        # host wall clock of the step's phases on this rank: own block (+ cutting its root into slices), all-to-all of the slices
+        # (+ unpacking them), the feature-sharded top levels
+        stats["phase_block_ms"], stats["phase_exchange_ms"], stats["phase_top_ms"] = 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)
         return stats, worst
 
     def _download_shard(self, full):

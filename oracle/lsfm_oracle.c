@@ -22,6 +22,29 @@ void orc_set_final_reanchor(int on) { g_final_reanchor = on; }
 static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
 static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: out of memory\n"); exit(1); } return p; }
 
+/* Feature-sharded evaluation of the same tree (checker of linearsfm_amd's multi-GPU top levels; no counterpart in the
+ * reference): every process holds a slice of the features of every map (all poses and U blocks) and the sums over features that
+ * enter pose-side quantities -- the hub rows of the transformed U (Imp.cpp:1270-1917), S and E (2244-2332), the pattern of S --
+ * are summed over the processes by the caller's function: count elements of 8 bytes at buf, in place (dtype 0: double, 1: 64-bit
+ * integer).  U's own part of S and of the right-hand side is rank 0's. */
+static orc_reduce_fn g_reduce = NULL;
+static int g_rank = 0, g_world = 1;
+void orc_set_comm(int rank, int world, orc_reduce_fn fn) { g_rank = rank; g_world = world; g_reduce = world > 1 ? fn : NULL; }
+static int comm_on(void) { return g_reduce != NULL; }
+static int comm_owns_u(void) { return g_reduce == NULL || g_rank == 0; }
+/* the hub slots [0, nslots) of newU that the feature loop of a transform adds to: a buffer of their own while the features are
+ * walked (so that the U loop's values, which every process has, are not summed twice), then the sum over the processes */
+static double* hub_begin(double* newU, int nslots) { return comm_on() ? xcalloc((size_t)nslots * 36, sizeof(double)) : newU; }
+static void hub_end(double* newU, double* hub, int nslots)
+{
+	size_t i;
+	if (!comm_on()) return;
+	g_reduce(hub, (long)nslots * 36, 0);
+	for (i = 0; i < (size_t)nslots * 36; i++) newU[i] += hub[i];
+	free(hub);
+}
+
+
 static double now_s(void)
 {
 	struct timespec ts;
@@ -373,7 +396,7 @@ void orc_transform_stereo(const orc_map* in, int Ref, orc_map* out)
 	int pos, i, j, N, m = in->m, n = in->n, posID, n_newU, n_newW, a, b;
 	double t[3], Alpha, Beta, Gamma, R[9], R2[9], R3[9], dRA[9], dRB[9], dRG[9], dA[3], dB[3], dG[3];
 	const double* ptr1 = in->stVal;
-	double *ptr2, *J1, *J2, *newU, *newW, *newV;
+	double *ptr2, *J1, *J2, *newU, *newW, *newV, *hubU;
 	const int* stno = in->stno;
 
 	if (in->Ref == Ref) { orc_map_copy(out, in); return; } /* Imp.cpp:352-355 (shallow alias there) */
@@ -532,6 +555,7 @@ void orc_transform_stereo(const orc_map* in, int Ref, orc_map* out)
 	out->feature = xmalloc((in->nW + n) * sizeof(int));
 	out->photo = xmalloc((in->nW + n) * sizeof(int));
 	n_newW = 0; j = 0;
+	hubU = hub_begin(newU, m);
 	for (i = 0; i < n; i++)
 	{
 		double* ptrPID = newW + (size_t)n_newW * 18;
@@ -542,7 +566,7 @@ void orc_transform_stereo(const orc_map* in, int Ref, orc_map* out)
 		out->FBlock[i] = n_newW;
 		out->feature[n_newW] = i; out->photo[n_newW] = posID; n_newW++;
 		/* the feature's own V block (diagonal source): Line 4 -> (posID,posID), Line 5 -> W(posID,i), Line 3 -> V' */
-		jt_b_j(J2f, 3, 6, Vb, 3, J2f, 6, T); place_pp(newU, posID, T, posID, posID, 0);
+		jt_b_j(J2f, 3, 6, Vb, 3, J2f, 6, T); place_pp(hubU, posID, T, posID, posID, 0);
 		jt_b_j(J2f, 3, 6, Vb, 3, J1f, 3, T); add_blk(ptrPID, T, 6, 3, 0);
 		jt_b_j(J1f, 3, 3, Vb, 3, J1f, 3, T); add_blk(newV + (size_t)i * 9, T, 3, 3, 0);
 		while (j < in->nW && in->feature[j] == i)
@@ -553,7 +577,7 @@ void orc_transform_stereo(const orc_map* in, int Ref, orc_map* out)
 			const double* J2p = J2 + (size_t)k * 36;
 			double* dst;
 			/* Line 4: J2p^T W J2f -> (posID,posID), both orientations (source is off-diagonal) */
-			jt_b_j(J2p, 6, 6, Wb, 3, J2f, 6, T); place_pp(newU, posID, T, posID, posID, 1);
+			jt_b_j(J2p, 6, 6, Wb, 3, J2f, 6, T); place_pp(hubU, posID, T, posID, posID, 1);
 			/* Line 5: J2p^T W J1f -> W'(posID,i) */
 			jt_b_j(J2p, 6, 6, Wb, 3, J1f, 3, T); add_blk(ptrPID, T, 6, 3, 0);
 			/* Line 3: J1p^T W J1f -> W'(k,i)   (Imp.cpp:1759-1769) */
@@ -561,11 +585,12 @@ void orc_transform_stereo(const orc_map* in, int Ref, orc_map* out)
 			else { dst = newW + (size_t)n_newW * 18; out->feature[n_newW] = i; out->photo[n_newW] = k; n_newW++; }
 			jt_b_j(J1p, 6, 6, Wb, 3, J1f, 3, T); add_blk(dst, T, 6, 3, 0);
 			/* Line 6: J1p^T W J2f -> pair (k,posID) */
-			jt_b_j(J1p, 6, 6, Wb, 3, J2f, 6, T); place_pp(newU, k, T, k, posID, 1);
+			jt_b_j(J1p, 6, 6, Wb, 3, J2f, 6, T); place_pp(hubU, k, T, k, posID, 1);
 			j++;
 		}
 	}
 	out->nW = n_newW;
+	hub_end(newU, hubU, m);
 	free(J1); free(J2);
 }
 
@@ -578,7 +603,7 @@ void orc_transform_mono(const orc_map* in, int Ref, int ScaP, int Fix, orc_map* 
 	double t[3], t2[3], ts[3], d[3], Scale, Scale2, Sign, Alpha, Beta, Gamma, R[9], R2[9], R3[9], dRA[9], dRB[9], dRG[9];
 	double dA[3], dB[3], dG[3], dSdt[9], dSdA[3], dSdB[3], dSdG[3], dSdtt[9];
 	const double* ptr1 = in->stVal;
-	double *ptr2, *J1, *J2, *J3, *newU, *newW, *newV;
+	double *ptr2, *J1, *J2, *J3, *newU, *newW, *newV, *hubU;
 	const int* stno = in->stno;
 	size_t size1, size2;
 
@@ -772,6 +797,7 @@ void orc_transform_mono(const orc_map* in, int Ref, int ScaP, int Fix, orc_map* 
 	out->feature = xmalloc((in->nW + 2 * n) * sizeof(int));
 	out->photo = xmalloc((in->nW + 2 * n) * sizeof(int));
 	n_newW = 0; j = 0;
+	hubU = hub_begin(newU, 2 * m);
 	for (i = 0; i < n; i++)
 	{
 		double *ptrPID, *ptrPID2;
@@ -790,10 +816,10 @@ void orc_transform_mono(const orc_map* in, int Ref, int ScaP, int Fix, orc_map* 
 		jt_b_j(Jf[0], 3, 3, Vb, 3, Jf[0], 3, T); add_blk(newV + (size_t)i * 9, T, 3, 3, 0);     /* 5323-5349 */
 		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[0], 3, T); add_blk(ptrPID, T, 6, 3, 0);                   /* 5149-5175 */
 		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[0], 3, T); add_blk(ptrPID2, T, 6, 3, 0);                  /* 5470-5496 */
-		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[1], 6, T); place_pp(newU, posID, T, posID, posID, 0);     /* 5041-5110 */
-		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[2], 6, T); place_pp(newU, m + posID2, T, posID2, posID2, 0); /* 5362-5431 */
-		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[2], 6, T); place_pp(newU, posID2, T, posID, posID2, 0);   /* 5197-5320 */
-		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[1], 6, T); place_pp(newU, posID2, T, posID2, posID, 0);
+		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[1], 6, T); place_pp(hubU, posID, T, posID, posID, 0);     /* 5041-5110 */
+		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[2], 6, T); place_pp(hubU, m + posID2, T, posID2, posID2, 0); /* 5362-5431 */
+		jt_b_j(Jf[1], 3, 6, Vb, 3, Jf[2], 6, T); place_pp(hubU, posID2, T, posID, posID2, 0);   /* 5197-5320 */
+		jt_b_j(Jf[2], 3, 6, Vb, 3, Jf[1], 6, T); place_pp(hubU, posID2, T, posID2, posID, 0);
 		while (j < in->nW && in->feature[j] == i)
 		{
 			const double* Wb = in->W + (size_t)j * 18;
@@ -821,13 +847,14 @@ void orc_transform_mono(const orc_map* in, int Ref, int ScaP, int Fix, orc_map* 
 						else if (al == 1 && be == 1) slot = posID;               /* 5598 */
 						else if (al == 2 && be == 2) slot = m + posID2;          /* 6248 */
 						else slot = posID2;                                      /* 5718, 6366 */
-						place_pp(newU, slot, T, rr, cc, 1);
+						place_pp(hubU, slot, T, rr, cc, 1);
 					}
 				}
 			j++;
 		}
 	}
 	out->nW = n_newW;
+	hub_end(newU, hubU, 2 * m);
 	free(J1); free(J2); free(J3);
 }
 
@@ -940,8 +967,8 @@ void orc_join_assemble_stereo(const orc_map* End, const orc_map* Cur, orc_map* J
 		const double* u = End->U + (size_t)i * 36;
 		memcpy(J->U + (size_t)i * 36, u, 36 * sizeof(double));
 		J->Ui[i] = End->Ui[i]; J->Uj[i] = End->Uj[i];
-		mv66(u, End->stVal + End->Uj[i] * 6, eP + J->Ui[i] * 6, 0);
-		if (End->Ui[i] != End->Uj[i]) mv66(u, End->stVal + End->Ui[i] * 6, eP + J->Uj[i] * 6, 1);
+		if (comm_owns_u()) mv66(u, End->stVal + End->Uj[i] * 6, eP + J->Ui[i] * 6, 0);
+		if (comm_owns_u() && End->Ui[i] != End->Uj[i]) mv66(u, End->stVal + End->Ui[i] * 6, eP + J->Uj[i] * 6, 1);
 	}
 	for (i = 0; i < Cur->nU; i++)
 	{
@@ -949,8 +976,8 @@ void orc_join_assemble_stereo(const orc_map* End, const orc_map* Cur, orc_map* J
 		int o = End->nU + i;
 		memcpy(J->U + (size_t)o * 36, u, 36 * sizeof(double));
 		J->Ui[o] = Cur->Ui[i] + m1; J->Uj[o] = Cur->Uj[i] + m1;
-		mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + J->Ui[o] * 6, 0);
-		if (Cur->Ui[i] != Cur->Uj[i]) mv66(u, Cur->stVal + Cur->Ui[i] * 6, eP + J->Uj[o] * 6, 1);
+		if (comm_owns_u()) mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + J->Ui[o] * 6, 0);
+		if (comm_owns_u() && Cur->Ui[i] != Cur->Uj[i]) mv66(u, Cur->stVal + Cur->Ui[i] * 6, eP + J->Uj[o] * 6, 1);
 	}
 
 	/* features of End (with the matching Cur run appended), Imp.cpp:2747-2860 */
@@ -1112,8 +1139,8 @@ void orc_join_assemble_mono(orc_map* End, orc_map* Cur, orc_map* J, double** ePo
 			if (End->Ui[i] == posID2 && End->Uj[i] == posID2) { Fl = 1; FlA = ptr2; }
 			memcpy(ptr2, u, 36 * sizeof(double));
 			J->Ui[ul] = End->Ui[i]; J->Uj[ul] = End->Uj[i];
-			mv66(u, End->stVal + End->Uj[i] * 6, eP + J->Ui[ul] * 6, 0);
-			if (End->Ui[i] != End->Uj[i]) mv66(u, End->stVal + End->Ui[i] * 6, eP + J->Uj[ul] * 6, 1);
+			if (comm_owns_u()) mv66(u, End->stVal + End->Uj[i] * 6, eP + J->Ui[ul] * 6, 0);
+			if (comm_owns_u() && End->Ui[i] != End->Uj[i]) mv66(u, End->stVal + End->Ui[i] * 6, eP + J->Uj[ul] * 6, 1);
 			ptr2 += 36; ul++;
 		}
 	}
@@ -1126,14 +1153,14 @@ void orc_join_assemble_mono(orc_map* End, orc_map* Cur, orc_map* J, double** ePo
 			if (ci == posID2 && cj == posID2 && Fl == 1)
 			{
 				for (k = 0; k < 36; k++) FlA[k] += u[k];
-				mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + posID2 * 6, 0);
+				if (comm_owns_u()) mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + posID2 * 6, 0);
 			}
 			else
 			{
 				memcpy(ptr2, u, 36 * sizeof(double));
 				J->Ui[ul] = ci; J->Uj[ul] = cj;
-				mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + ci * 6, 0);
-				if (Cur->Ui[i] != Cur->Uj[i]) mv66(u, Cur->stVal + Cur->Ui[i] * 6, eP + cj * 6, 1);
+				if (comm_owns_u()) mv66(u, Cur->stVal + Cur->Uj[i] * 6, eP + ci * 6, 0);
+				if (comm_owns_u() && Cur->Ui[i] != Cur->Uj[i]) mv66(u, Cur->stVal + Cur->Ui[i] * 6, eP + cj * 6, 1);
 				ptr2 += 36; ul++;
 			}
 		}
@@ -1282,6 +1309,34 @@ void orc_set_extended(int on) { g_extended = on; }
 /* run length of each feature in feature[] (mapPhoto, Imp.cpp:2134-2153) and the block pattern of S (upper): pose pairs
  * sharing a feature + U pattern.  The reference sets a dense m x m byte mask (Imp.cpp:2131-2205) and scans it into a CRS
  * index (sba_crsm, Imp.cpp:2190-2205); the same set is built here row by row from a pose->entries index. */
+static int cmp_ll(const void* a, const void* b) { long long x = *(const long long*)a, y = *(const long long*)b; return x < y ? -1 : x > y; }
+/* feature-sharded evaluation: the pattern of S is the union of what the processes' feature slices induce (U's pattern is in all
+ * of them).  Every process learns every process's count, then every process's (row, column) keys: each writes its list at its
+ * offset of a zeroed array that is summed as integers. */
+static void pattern_union(int m, int** rowptr_io, int** colidx_io)
+{
+	int *rowptr = *rowptr_io, *colidx = *colidx_io, r, p;
+	long total = 0, mine = 0, i, nu = 0;
+	long long* counts = xcalloc(g_world, sizeof(long long));
+	long long* keys;
+	counts[g_rank] = rowptr[m];
+	g_reduce(counts, g_world, 1);
+	for (r = 0; r < g_world; r++) { if (r == g_rank) mine = total; total += (long)counts[r]; }
+	keys = xcalloc(total ? total : 1, sizeof(long long));
+	for (p = 0; p < m; p++)
+		for (i = rowptr[p]; i < rowptr[p + 1]; i++) keys[mine + i] = (long long)p * m + colidx[i];
+	g_reduce(keys, total, 1);
+	qsort(keys, total, sizeof(long long), cmp_ll);
+	for (i = 0; i < total; i++) if (i == 0 || keys[i] != keys[i - 1]) keys[nu++] = keys[i];
+	free(rowptr); free(colidx);
+	rowptr = xcalloc(m + 1, sizeof(int));
+	colidx = xmalloc((nu + 1) * sizeof(int));
+	for (i = 0; i < nu; i++) { rowptr[keys[i] / m + 1]++; colidx[i] = (int)(keys[i] % m); }
+	for (p = 0; p < m; p++) rowptr[p + 1] += rowptr[p];
+	free(counts); free(keys);
+	*rowptr_io = rowptr; *colidx_io = colidx;
+}
+
 static void schur_pattern(const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW,
                           int** mapPhoto_o, int** rowptr_o, int** colidx_o)
 {
@@ -1360,6 +1415,7 @@ static void schur_pattern(const int* Ui, const int* Uj, const int* photo, const 
 		free(ucnt); free(uptr); free(ulist); free(tmpcols); free(mark);
 	}
 	free(pcnt); free(pptr); free(plist); free(fstart);
+	if (comm_on()) pattern_union(m, &rowptr, &colidx);
 	*mapPhoto_o = mapPhoto; *rowptr_o = rowptr; *colidx_o = colidx;
 }
 

@@ -117,6 +117,11 @@ void orc_set_match_hash(int on);
 /* on = 0: orc_divide_conquer leaves the final map in the frame of its last join (a subtree root, Imp.cpp:2032),
  * instead of taking it back to its first frame (Imp.cpp:2039-2063) */
 void orc_set_final_reanchor(int on);
+/* Feature-sharded evaluation (checker of the multi-GPU top levels): this process holds slice `rank` of `world` of the features
+ * of every map; fn sums `count` 8-byte elements at buf over the processes, in place (dtype 0: double, 1: 64-bit integer).
+ * world <= 1 or fn == NULL: off. */
+typedef void (*orc_reduce_fn)(void* buf, long count, int dtype);
+void orc_set_comm(int rank, int world, orc_reduce_fn fn);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ def lib():
         L.orc_set_match_hash.argtypes = [C.c_int]
         L.orc_set_final_reanchor.argtypes = [C.c_int]
         L.orc_set_extended.argtypes = [C.c_int]
+        L.orc_set_comm.argtypes = [C.c_int, C.c_int, REDUCE_FN]
         L.orc_schur_csc.argtypes = [dp, ip, ip, C.c_int, C.c_int, C.c_int, P(ip), P(ip), P(dp)]
         L.orc_schur_csc.restype = C.c_int
         L.orc_solve_features.argtypes = [dp, dp, dp, dp, dp, C.c_int, ip, ip, C.c_int]
@@ -68,6 +69,23 @@ def lib():
 
 
 _KEEP = {}
+
+# orc_reduce_fn (lsfm_oracle.h): sums `count` 8-byte elements at buf over the processes, in place (dtype 0: double, 1: int64)
+REDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_int)
+
+
+def torch_reduce_fn(group=None):
+    """An orc_reduce_fn over torch.distributed (gloo on CPU): the feature-sharded evaluation of a tree by several processes."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(buf, count, dtype):
+        if count <= 0:
+            return
+        a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int64 if dtype == 1 else C.c_double)), shape=(count,))
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, group=group)  # in place: t shares the C buffer
+    return REDUCE_FN(fn)
 
 
 def _arr(ptr, n, dtype):
@@ -250,11 +268,17 @@ def schur_csc(S, rowptr, colidx, m, skipblk=-1, skipfix=-1):
     return out
 
 
-def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True, threads=0, extended=False):
+def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=True, threads=0, extended=False, comm=None):
     """Full hierarchical join of a list of map dicts; returns (final map dict, timing[4], rc).
     threads > 0: the independent joins of a level on that many host threads (same result, timing[0] only).
-    extended: every solve of the tree in long double (transform and assembly stay fp64: they are pinned to the reference)."""
+    extended: every solve of the tree in long double (transform and assembly stay fp64: they are pinned to the reference).
+    comm = (rank, world, REDUCE_FN): feature-sharded evaluation -- `dicts` are this process's slices of the maps (orc_set_comm)."""
     L = lib()
+    if comm is not None:
+        assert threads == 0 and not extended
+        L.orc_set_comm(int(comm[0]), int(comm[1]), comm[2])
+    else:
+        L.orc_set_comm(0, 1, C.cast(None, REDUCE_FN))
     L.orc_set_extended(int(extended))
     L.orc_set_match_hash(int(match_hash))
     L.orc_set_final_reanchor(int(final_reanchor))
@@ -268,6 +292,8 @@ def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=T
         rc = L.orc_divide_conquer_omp(arr, N, int(mono), C.byref(out), int(threads), timing)
     else:
         rc = L.orc_divide_conquer(arr, N, int(mono), C.byref(out), int(verbose), timing)
+    if comm is not None:
+        L.orc_set_comm(0, 1, C.cast(None, REDUCE_FN))
     res = map_to_dict(out)
     L.orc_map_free(C.byref(out))
     return res, list(timing), rc

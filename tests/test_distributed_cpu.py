@@ -92,3 +92,71 @@ def test_merge_schedule_is_a_binary_tree():
             for r, acts in merges.items():
                 for _, peer, j, reanchor in acts[:-1] if r == 0 else acts:
                     assert reanchor == ((r >> (j + 1)) % 2 == 1)
+
+
+# ---- feature-sharded top levels (linearsfm_amd.distributed "P2") with the oracle as back end --------------------------------
+def _oracle_run_slices(slices, mono, rank, world):
+    from oracle import pyoracle as po
+    fn = po.torch_reduce_fn()
+    out, _, rc = po.divide_conquer(slices, mono, final_reanchor=True, comm=(rank, world, fn))
+    assert rc == 0
+    return out
+
+
+def _worker_top(rank, world, port, n_maps, mono, q):
+    from linearsfm_amd.distributed import sharded_divide_conquer_top
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = sharded_divide_conquer_top(_make(n_maps, mono), mono, _oracle_run_tree, _oracle_run_slices)
+    if rank == 0:
+        q.put({k: out[k] for k in ("stno", "stVal", "Ui", "Uj", "photo", "feature", "Ref", "FRef", "U", "W", "V")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_maps,mono", [(2, 8, False), (2, 7, False), (3, 11, False), (2, 6, True), (4, 13, False), (4, 16, True),
+                                               (4, 5, False)])
+def test_feature_sharded_top_levels_equal_serial_tree(oracle, world, n_maps, mono):
+    """Every rank joins its block, then ALL ranks evaluate the levels above on their slice of the features (label mod world); the
+    sums over features that enter pose-side quantities (hub rows of the transformed U, S and E, the pattern of S) cross the
+    ranks through gloo all-reduces inside the oracle.  Same structure as the serial tree; values equal up to the order of those
+    sums."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_top, args=(r, world, port, n_maps, mono, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = _oracle_run_tree(_make(n_maps, mono), mono, True)
+    for k in ("stno", "Ui", "Uj", "photo", "feature"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert got["Ref"] == exp["Ref"] and got["FRef"] == exp["FRef"]
+    scale = np.maximum(1.0, np.abs(exp["stVal"]))
+    assert np.max(np.abs(got["stVal"] - exp["stVal"]) / scale) < 1e-9
+    for k in ("U", "W", "V"):  # the information matrix of the final map, put together from the slices
+        a, b = np.asarray(got[k]).reshape(-1), np.asarray(exp[k]).reshape(-1)
+        assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(b))), k
+
+
+def test_slices_of_a_map_add_up_to_the_map():
+    from linearsfm_amd.distributed import joint_feature_order, merge_slices, slice_map
+    from oracle import pyoracle as po
+    maps = [po.localmap_to_dict(m) for m in _make(6, False)]
+    node = _oracle_run_tree(maps[:4], False, True)
+    order = np.asarray(node["stno"])[6 * node["m"]::3]
+    for G in (1, 2, 3, 5):
+        parts = [slice_map(node, G, g) for g in range(G)]
+        assert sum(p["n"] for p in parts) == node["n"]
+        back = merge_slices(parts, order)
+        for k in ("stno", "stVal", "V", "W", "photo", "feature", "FBlock"):
+            assert np.array_equal(np.asarray(back[k]).reshape(-1), np.asarray(node[k]).reshape(-1)), (G, k)
+    # the order of a joint map's features: End's, then Cur's unmatched ones
+    a = np.asarray(maps[0]["stno"])[6 * maps[0]["m"]::3]
+    b = np.asarray(maps[1]["stno"])[6 * maps[1]["m"]::3]
+    j = _oracle_run_tree(maps[:2], False, False)
+    assert np.array_equal(joint_feature_order([a, b]), np.asarray(j["stno"])[6 * j["m"]::3])

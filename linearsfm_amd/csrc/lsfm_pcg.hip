@@ -1018,6 +1018,130 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 		__syncthreads();
 	}
 }
+// The same rank update on the matrix cores, for the panels too tall for the fused kernel (a synth-16k Mono tree: 100-300 common
+// rows per group at its upper levels -- k_sn_update, one scalar 6x6 product chain per PAIR of rows, was 11 % of that tree's
+// device time and loaded every block of X once per partner row).  One work-group per pair (ca >= cb) of 8-block-row chunks of a
+// group's solved panel X (read from Lg): both chunks go to LDS as dense scalar rows once, T = X_ca X_cb^T is a (48 x 6s) x (6s x
+// 48) contraction on v_mfma_f64_16x16x4_f64 (nine 16x16 tiles over the four waves), and the 64 products leave as 36 contiguous
+// atomics each -- the tail of k_sn_panel<true> without its redundant solves.  grid (groups, pairs of chunks of the level's
+// tallest panel, capped: a work-group walks pairs gridDim.y apart).
+__global__ void __launch_bounds__(SN_THREADS) k_sn_syrk(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
+                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
+                                                         const double* __restrict__ Lg, int smax)
+{
+	extern __shared__ double Ms[];
+	constexpr int HB = SN_RB / 2, NTL = (6 * HB) / 16, TS = 6 * HB + 1, TPW = (NTL * NTL + SN_THREADS / 64 - 1) / (SN_THREADS / 64);
+	__shared__ int spos[HB * HB];
+	__shared__ int sCol[CHOL_GS];
+	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	if (nr == 0) return;
+	const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int n6 = 6 * s, n6r = (n6 + 3) & ~3;
+	const int xs = ((6 * smax + 3) & ~3) + 1; // odd row stride, room for the zero padding of the MFMA k step
+	double* const XA = Ms;
+	double* const XBs = Ms + 6 * HB * xs;
+	const int nch = (nr + HB - 1) / HB, npairs = nch * (nch + 1) / 2;
+	for (int t = tid; t < s; t += nt) sCol[t] = colptr[c0 + t];
+	__syncthreads();
+	const int rows0 = sCol[s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
+	for (int p = blockIdx.y; p < npairs; p += gridDim.y)
+	{
+		int ca = (int)((sqrtf(8.0f * p + 1.0f) - 1.0f) * 0.5f);
+		while (ca * (ca + 1) / 2 > p) ca--;
+		while ((ca + 1) * (ca + 2) / 2 <= p) ca++;
+		const int cb = p - ca * (ca + 1) / 2;
+		const bool two = ca != cb;
+		// targets of the 64 products (fetched first: the loads fly while the panel rows arrive)
+		if (tid < HB * HB)
+		{
+			const int a = tid / HB, b = tid - a * HB;
+			const int ia = ca * HB + a, ib = cb * HB + b;
+			int pos = -1;
+			if (ia < nr && ib < nr && ia >= ib)
+			{
+				const int ra = rowidx[rows0 + ia], rb = rowidx[rows0 + ib];
+				const int cbk = colptr[rb], nbk = colptr[rb + 1] - cbk;
+				pos = cbk + (ia - ib);
+				if (!(ia - ib < nbk && rowidx[pos] == ra)) pos = find_row(rowidx, cbk, cbk + nbk, ra);
+			}
+			spos[tid] = pos;
+		}
+		// the two chunks of X as dense scalar rows: 2 x HB x s blocks, two doubles per load, SN_LD loads in flight per lane;
+		// rows past the panel's end and the padding columns are zero
+		const int np2 = (two ? 2 : 1) * HB * s * 18;
+		for (int base = 0; base < np2; base += nt * SN_LD)
+		{
+			double2 v[SN_LD];
+#pragma unroll
+			for (int i = 0; i < SN_LD; i++)
+			{
+				const int q = base + i * nt + tid;
+				v[i] = make_double2(0.0, 0.0);
+				if (q < np2)
+				{
+					const int blk = q / 18, il = blk / s, t = blk - il * s;
+					const int row = (il < HB ? ca * HB + il : cb * HB + (il - HB));
+					if (row < nr) v[i] = *reinterpret_cast<const double2*>(Lg + (size_t)(sCol[t] + (s - t) + row) * 36 + 2 * (q - blk * 18));
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < SN_LD; i++)
+			{
+				const int q = base + i * nt + tid;
+				if (q < np2)
+				{
+					const int blk = q / 18, w = 2 * (q - blk * 18), il = blk / s, t = blk - il * s;
+					double* d = &Ms[(6 * il + w / 6) * xs + 6 * t + w % 6];
+					d[0] = v[i].x; d[1] = v[i].y;
+				}
+			}
+		}
+		if (n6r > n6)
+			for (int q = tid; q < (two ? 2 : 1) * 6 * HB * (n6r - n6); q += nt) Ms[(q / (n6r - n6)) * xs + n6 + q % (n6r - n6)] = 0.0;
+		__syncthreads();
+		const double* XB = two ? XBs : XA;
+		sn_v4d acc[TPW];
+#pragma unroll
+		for (int i = 0; i < TPW; i++)
+		{
+			acc[i] = (sn_v4d){ 0.0, 0.0, 0.0, 0.0 };
+			const int q = wave + (SN_THREADS / 64) * i;
+			if (q < NTL * NTL)
+			{
+				const int ti = q / NTL, tj = q - ti * NTL;
+				const double* pa = &XA[(16 * ti + (lane & 15)) * xs + (lane >> 4)];
+				const double* pb = &XB[(16 * tj + (lane & 15)) * xs + (lane >> 4)];
+				for (int ks = 0; ks < n6r; ks += 4) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks], pb[ks], acc[i], 0, 0, 0);
+			}
+		}
+		__syncthreads(); // the products are staged over the panel rows
+		double* sT = Ms;
+#pragma unroll
+		for (int i = 0; i < TPW; i++)
+		{
+			const int q = wave + (SN_THREADS / 64) * i;
+			if (q < NTL * NTL)
+			{
+				const int ti = q / NTL, tj = q - ti * NTL;
+				// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+				for (int e = 0; e < 4; e++) sT[(16 * ti + (lane >> 4) + 4 * e) * TS + 16 * tj + (lane & 15)] = acc[i][e];
+			}
+		}
+		__syncthreads();
+		for (int idx = tid; idx < HB * HB * 36; idx += nt)
+		{
+			const int pp = idx / 36, q = idx - pp * 36, ps = spos[pp];
+			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[(6 * (pp / HB) + q / 6) * TS + 6 * (pp % HB) + q % 6]);
+		}
+		__syncthreads(); // spos and the staged products are overwritten by the next pair
+	}
+}
+static size_t sn_syrk_lds(int smax)
+{
+	const size_t xs = ((6 * (size_t)smax + 3) & ~(size_t)3) + 1;
+	return std::max((size_t)(6 * SN_RB) * xs, (size_t)(6 * SN_RB / 2) * (6 * SN_RB / 2 + 1)) * sizeof(double);
+}
 // dynamic LDS of k_sn_panel for a level whose widest run has smax block columns (the products of the rank update are staged over
 // the same memory: at least 48 x 49 doubles)
 static size_t sn_panel_lds(int smax)
@@ -1512,6 +1636,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			// (dynamic LDS beyond 64 KB has to be asked for once per kernel)
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sn_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_panel_lds(CHOL_GS));
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sn_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_panel_lds(CHOL_GS));
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sn_syrk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_syrk_lds(CHOL_GS));
 			return true;
 		}();
 		(void)lds_set;
@@ -1529,9 +1654,19 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			}
 			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
 			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax);
-			const long np = (long)mnr * (mnr + 1) / 2;
-			hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
-			                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg);
+			static const bool scalar_update = getenv("LSFM_SN_SCALAR_UPDATE") != nullptr; // the round-2 kernel, kept for comparison
+			if (scalar_update)
+			{
+				const long np = (long)mnr * (mnr + 1) / 2;
+				hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
+				                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg);
+			}
+			else
+			{
+				const long nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2), npair = nch * (nch + 1) / 2;
+				hipLaunchKernelGGL(k_sn_syrk, dim3(ng, (unsigned)std::max<long>(1, std::min<long>(npair, 8192))), dim3(SN_THREADS), sn_syrk_lds(smax), s,
+				                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg, smax);
+			}
 		}
 		// the solves that walk columns by task or by level read ONE array: give them the group columns there
 		if (ch.ngroups && !chol_group_solve(ch))

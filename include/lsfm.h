@@ -79,6 +79,9 @@ typedef struct lsfm_stats {
 	double schur_flops;
 	/* wall ms lsfm_tree_upload took to bring the tree's N local maps into HBM (PCIe; never part of t_total_ms) */
 	double upload_ms;
+	/* how many times the tree was joined by this call: 1, or more when a run was repeated (a plan or step count of an earlier run
+	 * that did not fit the values, a system left above its bound by an unlucky rounding of its factorisation) */
+	int attempts;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */

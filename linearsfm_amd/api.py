@@ -36,7 +36,7 @@ class LsfmStats(C.Structure):
                 ("max_rel_residual", C.c_double), ("levels", C.c_int), ("joins", C.c_int), ("transforms", C.c_int),
                 ("not_converged", C.c_int), ("schur_launches", C.c_long), ("trf_launches", C.c_long),
                 ("schur_ms", C.c_double), ("schur_bytes", C.c_double), ("trf_ms", C.c_double), ("trf_bytes", C.c_double),
-                ("schur_flops", C.c_double), ("upload_ms", C.c_double)]
+                ("schur_flops", C.c_double), ("upload_ms", C.c_double), ("attempts", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -228,6 +228,13 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	ctx->pre.reset(); ctx->early.reset(); ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // nothing prepared by an earlier run
 	ctx->pre_plan = LevelPlan(); ctx->pre_plan_level = -1;
 	LSFM_CHECK_HIP(hipMemsetAsync(ctx->d_run, 0, sizeof(RunStatsDev), ctx->stream));
+	static const bool poison = getenv("LSFM_POISON") != nullptr; // debug: every byte a run has not written itself reads as NaN / -1
+	if (poison)
+	{
+		for (int i = 0; i < 3; i++) LSFM_CHECK_HIP(hipMemsetAsync(ctx->arena[i].base, 0xFF, ctx->arena[i].cap, ctx->stream));
+		LSFM_CHECK_HIP(hipMemsetAsync(ctx->scratch.base, 0xFF, ctx->scratch.cap, ctx->stream));
+		for (int i = 0; i < 2; i++) if (ctx->sarena[i].base) LSFM_CHECK_HIP(hipMemsetAsync(ctx->sarena[i].base, 0xFF, ctx->sarena[i].cap, ctx->stream));
+	}
 	t->level = t->input;
 	const int nlev = tree_levels(t->N);
 	if ((int)t->plans.size() != nlev + 1) t->plans.assign(nlev + 1, LevelPlan());
@@ -270,10 +277,14 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 		try
 		{
+			const double t_begin = now_ms();
 			for (int attempt = 0;; attempt++)
 			{
 				memset(st, 0, sizeof *st);
+				st->attempts = attempt + 1;
 				ctx->timed.clear(); ctx->ev_next = 0;
+				static const bool no_hints = getenv("LSFM_NO_STEP_HINTS") != nullptr; // debug: every run asks after every refinement step
+				if (no_hints) t->step_hint.clear();
 				bool hinted = false;
 				for (int h : t->step_hint) hinted |= h > 0;
 				ctx->timeline_on = getenv("LSFM_TIMELINE") != nullptr;
@@ -281,7 +292,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				const double t0 = now_ms();
 				ctx->mark("run");
 				tree_pass(ctx, t, st);
-				st->t_total_ms = now_ms() - t0;
+				st->t_total_ms = now_ms() - t_begin; // (repeated attempts included; the stage times below are the last attempt's)
 				ctx->mark("end");
 				if (ctx->timeline_on)
 				{
@@ -316,6 +327,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					rs.not_converged = (int)((fl[3] + cm.world - 1) / cm.world); // (every rank solves every system: the count, not its multiple)
 					rs.undone = (int)((fl[4] + cm.world - 1) / cm.world);
 				}
+				if (rs.floored && getenv("LSFM_DEBUG_CONV")) fprintf(stderr, "[lsfm conv] %d pivot(s) of the separators held at their lower bound in this run\n", rs.floored);
 				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
 				if (rs.chol_err)
 					LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
@@ -337,6 +349,15 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					// a planned run enqueues the refinement steps the first run needed; if a system asks for more this time,
 					// drop the plans and run the levels the slow way again (reads the state of every step back)
 					t->plans.clear();
+					continue;
+				}
+				if (rs.not_converged && attempt < 2)
+				{
+					// A system was left above its bound although every level asked after every step.  Seen in one synth-16k Mono tree
+					// out of fifteen: the last 6x6 block of the root's top separator -- what is left of 1e6..1e8-sized entries after
+					// 16 000 columns of updates whose atomic sums land in another order every run -- came out slightly indefinite and
+					// its factor, taken by magnitude (k_sn_panel), was too poor a preconditioner.  The tree is joined again (at most
+					// twice): the rounding falls differently.  What is still not converged then is reported (LSFM_NOT_CONVERGED).
 					continue;
 				}
 				st->not_converged += rs.not_converged;

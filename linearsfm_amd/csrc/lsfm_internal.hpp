@@ -112,7 +112,7 @@ struct RunStatsDev {
 	int tr_err;            // 1 + map whose transform target was not found
 	int plan_stale;        // a planned level met VALUES the plan does not fit (Mono: the sign of a new scale): the run is repeated without plans
 	int undone;            // systems whose refinement was enqueued with a step count from an earlier run and had not met its stopping rule when the steps ran out
-	int pad;
+	int floored;           // pivots of the separators replaced by their lower bound (static pivoting, lsfm_pcg.hip k_sn_panel)
 	double max_rel_residual;
 	unsigned long long k2;  // sum over the levels of sum over the features of (W run length)^2: K9's pose pairs, for its algorithmic flop count
 };

@@ -77,6 +77,7 @@ struct CholDev {
 	float* Lgf = nullptr;   // mixed precision: its fp32 copy
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
+	double* diag0 = nullptr; // [M*6] diagonal of S as it was scattered (new numbering): the scale a pivot of the separators is held against
 	int* d_err = nullptr;
 };
 
@@ -89,7 +90,7 @@ __device__ __forceinline__ int find_row(const int* __restrict__ rowidx, int lo, 
 // A (upper blocks of S, old numbering) -> lower blocks of P S P^T in L's storage
 __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ keys, const double* __restrict__ S, const int* __restrict__ pinv,
                                const int* __restrict__ colptr, const int* __restrict__ rowidx, const unsigned char* __restrict__ fixed,
-                               double* __restrict__ L)
+                               double* __restrict__ L, double* __restrict__ diag0)
 {
 	int e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= nnzb) return;
@@ -108,6 +109,7 @@ __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ 
 			double v = tr ? s[c * 6 + r] : s[r * 6 + c];
 			if (fixed && (fixed[(size_t)rowp * 6 + r] || fixed[(size_t)colp * 6 + c])) v = (rowp == colp && r == c) ? 1.0 : 0.0;
 			d[r * 6 + c] = v;
+			if (i == j && r == c) diag0[(size_t)j * 6 + r] = v;
 		}
 }
 
@@ -666,7 +668,7 @@ template <bool FUSED>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Lg,
                                                           double* __restrict__ Dinv, int* err, const int* __restrict__ rowidx, double* __restrict__ fv,
-                                                          double* __restrict__ fw, int smax)
+                                                          double* __restrict__ fw, int smax, const double* __restrict__ diag0, double piv_floor, int* nfloor)
 {
 	// LDS by the widest run of the LEVEL (smax block columns), not by CHOL_GS: most levels of most systems hold runs of 1-6
 	// columns, and at 150 KB a work-group had a CU to itself -- a level of 2 000 small work-groups took 8 rounds
@@ -780,7 +782,9 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	for (int t = 0; t < s; t++)
 	{
 		const int k0 = 6 * t;
-		double a[6];
+		double a[6], flr[6]; // (the pivot bounds of the column: fetched here, used after the barrier -- not on the critical path)
+#pragma unroll
+		for (int k = 0; k < 6; k++) flr[k] = diag0[(size_t)(c0 + t) * 6 + k];
 		const bool mine = panel_lane || (ri >= k0 && ri < n6);
 		if (mine)
 		{
@@ -817,7 +821,26 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			for (int k = 0; k < 6; k++)
 			{
 				double pv = d[k * (k + 1) / 2 + k];
-				if (!(pv > 0)) { bad = true; pv = 1.0; }
+				// Modified Cholesky for the separators.  What is left of the last diagonal blocks of a top separator after everything
+				// below them has been eliminated is, for the weakly observable directions of a long monocular chain (scale drift),
+				// the difference of numbers a thousand to 1e13 times larger, with off-diagonal noise that depends on the order the
+				// atomic sums landed in: one synth-16k root system in fifteen found the last 6x6 block slightly indefinite
+				// (a pivot of -1e-3 x the entry S had there).  Forcing such a pivot to 1 -- what this code did -- put 1e3..1e7-sized
+				// columns into the factor, the next pivots went to -1e15, -1e31, and the preconditioner returned numbers of size
+				// 1e80: the refinement ended at the residual it started with.  Now a pivot is taken by its magnitude, bounded
+				// below by piv_floor x the entry S had: the factor is the exact factor of S plus a small perturbation in those one
+				// or two directions, which the CG around it removes in a few steps.  Only a pivot that is negative on the scale
+				// of S itself (or not a number) means the system is not positive definite.
+				const double fl = piv_floor * flr[k], neg = piv_floor > 0 ? -0.01 * flr[k] : 0.0; // (piv_floor = 0: any non-positive pivot is an error)
+				if (!(pv > fl))
+				{
+					if (!(pv == pv) || !(pv > neg) || !(fl > 0)) { bad = true; pv = 1.0; }
+					else { pv = fmax(fabs(pv), fl); if (nfloor && ri == k0 + k) atomicAdd(nfloor, 1); }
+				}
+#ifdef LSFM_DEBUG_PIVOT
+				if (ri == k0 + k && blockIdx.y == 0 && c0 + t >= 16380)
+					printf("[piv] col %d k %d pv %.6e fl %.3e raw %.6e sD %.6e\n", c0 + t, k, pv, fl, d[k * (k + 1) / 2 + k], sD[k * 6 + k]);
+#endif
 				di[k] = fast_rsqrt(pv);
 				d[k * (k + 1) / 2 + k] = pv * di[k];
 #pragma unroll
@@ -1396,6 +1419,7 @@ static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
 	Arena& sc = ctx->scratch;
 	ch.L = sc.alloc<double>((size_t)ch.nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)ch.M * 36);
 	ch.wv = sc.alloc<double>((size_t)ch.M * 6);
+	ch.diag0 = sc.alloc<double>((size_t)ch.M * 6);
 	ch.Lg = ch.ngroups ? sc.alloc<double>((size_t)ch.nnzL * 36) : nullptr; // (every block of a group column is written by the factorisation)
 	dev_zero(ctx, ch.L, (size_t)ch.nnzL * 36 * sizeof(double));
 }
@@ -1604,7 +1628,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 	hipStream_t s = ctx->stream;
 	if (sy.nnzb)
 		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, s, sy.nnzb, sy.upper_keys, sy.S, ch.pinv, ch.colptr, ch.rowidx,
-		                   fixed, ch.L);
+		                   fixed, ch.L, ch.diag0);
 	static const bool groups = !getenv("LSFM_NO_GROUPS");
 	for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
 	{
@@ -1632,6 +1656,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		// the rank-update kernel (a synth-16k Mono tree, whose upper levels have panels of 100-300 rows: 684 ms against 826
 		// with everything fused)
 		static const int fuse_max = getenv("LSFM_SN_FUSE_MAX") ? atoi(getenv("LSFM_SN_FUSE_MAX")) : 64;
+		static const double piv_floor = getenv("LSFM_PIVOT_FLOOR") ? atof(getenv("LSFM_PIVOT_FLOOR")) : 1e-13; // (0: none)
 		static const bool lds_set = []() {
 			// (dynamic LDS beyond 64 KB has to be asked for once per kernel)
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sn_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_panel_lds(CHOL_GS));
@@ -1649,11 +1674,11 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			{
 				const int nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2);
 				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax);
+				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr);
 				continue;
 			}
 			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax);
+			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr);
 			static const bool scalar_update = getenv("LSFM_SN_SCALAR_UPDATE") != nullptr; // the round-2 kernel, kept for comparison
 			if (scalar_update)
 			{
@@ -1851,9 +1876,13 @@ __global__ void k_pcg_check(int nseg, PcgSeg* seg, int* ndone)
 	// accuracy reached); or -- far above that -- three steps in a row that hardly moved it (a system this badly conditioned is
 	// reported: the final check counts it as not converged).  One slow step alone does not end the refinement: the camera
 	// systems of a deep monocular tree now and then take a step that gains little and go on to 1e-12 with the next.
+	// (ten such steps, not three: the residuals of a CG are not monotone, and the top systems of a 16 384-map monocular tree --
+	// conditioned ~1e10, factored with sums whose order changes from run to run -- were given up at 3e-8 in one run out of a
+	// dozen where a few more steps take them to 1e-11; a system that ends above 1e-8 is a failure anyway, patience costs the
+	// others nothing)
 	const bool slow = !(rr < 0.25 * g.rr_prev);
 	g.slow = slow ? g.slow + 1 : 0;
-	if (!(rr > g.thresh) || !(rr == rr) || (slow && (!(rr > 1e-16 * g.ee) || g.slow >= 3))) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
+	if (!(rr > g.thresh) || !(rr == rr) || (slow && (!(rr > 1e-16 * g.ee) || g.slow >= 10))) { g.done = (rr == rr) ? 1 : 2; atomicAdd(ndone, 1); }
 	g.rr_prev = rr;
 }
 // after update2 (separate launch: update2 reads the scalars of its system from every row): reset the accumulators
@@ -1879,6 +1908,42 @@ __global__ void k_pcg_run_stats(int nseg, const PcgSeg* __restrict__ seg, RunSta
 	if (seg[g].done == 0 && !(rel < 1e-10)) atomicAdd(&run->undone, 1);
 	// max of non-negative doubles = max of their bit patterns
 	atomicMax(reinterpret_cast<unsigned long long*>(&run->max_rel_residual), (unsigned long long)__double_as_longlong(rel == rel ? rel : 1e300));
+}
+// LSFM_DEBUG_CONV=1: sum and maximum of |a[i]| (what went into a large system and what its factorisation left)
+__global__ void k_dbg_absstats(size_t n, const double* __restrict__ a, double* __restrict__ out)
+{
+	double s = 0.0, m = 0.0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const double v = fabs(a[i]);
+		s += v; if (v > m || !(v == v)) m = v == v ? v : 1e300;
+	}
+	atomic_add_f64(out, s);
+	atomicMax(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)__double_as_longlong(m));
+}
+// LSFM_DEBUG_CONV=1: the columns whose diagonal factor has an inverse beyond 1e3
+__global__ void k_dbg_dinv(int M, const double* __restrict__ Dinv, const double* __restrict__ diag0, const int* __restrict__ colptr, int first_group_col)
+{
+	int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= M) return;
+	double m = 0.0;
+	for (int q = 0; q < 36; q++) m = fmax(m, fabs(Dinv[(size_t)j * 36 + q]));
+	if (m > 1e3 || !(m == m))
+		printf("[lsfm conv] column %d (%s, %d blocks): max |Dinv| %.3e, Dinv diag %.3e %.3e %.3e %.3e %.3e %.3e, diag0 %.3e %.3e %.3e %.3e %.3e %.3e\n", j,
+		       j >= first_group_col ? "group" : "leaf", colptr[j + 1] - colptr[j], m, Dinv[(size_t)j * 36], Dinv[(size_t)j * 36 + 7], Dinv[(size_t)j * 36 + 14],
+		       Dinv[(size_t)j * 36 + 21], Dinv[(size_t)j * 36 + 28], Dinv[(size_t)j * 36 + 35], diag0[j * 6], diag0[j * 6 + 1], diag0[j * 6 + 2], diag0[j * 6 + 3],
+		       diag0[j * 6 + 4], diag0[j * 6 + 5]);
+}
+// LSFM_DEBUG_CONV=1: the systems a level leaves above 1e-9, with the state of their refinement
+__global__ void k_pcg_debug(int nseg, int M, const PcgSeg* __restrict__ seg)
+{
+	int g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= nseg || !seg[g].active) return;
+	const PcgSeg& fin = seg[nseg + g];
+	const double rel = fin.ee > 0 ? sqrt(fin.rr / fin.ee) : 0.0;
+	if (!(rel < 1e-9))
+		printf("[lsfm conv] M=%d nseg=%d system %d: rel %.3e its %d done %d slow %d rr_prev/ee %.3e thresh/ee %.3e ee %.3e pAp %.3e rz %.3e %.3e\n", M, nseg, g, rel, seg[g].its,
+		       seg[g].done, seg[g].slow, seg[g].rr_prev / fin.ee, seg[g].thresh / fin.ee, fin.ee, seg[g].pAp, seg[g].rz[0], seg[g].rz[1]);
 }
 __global__ void k_chol_err_to_run(const int* err, RunStatsDev* run)
 {
@@ -2162,6 +2227,21 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	if (deferred)
 	{
 		if (warm && !planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt
+		static const bool dbg_conv = getenv("LSFM_DEBUG_CONV") != nullptr;
+		if (dbg_conv) hipLaunchKernelGGL(k_pcg_debug, dim3(nbs), dim3(128), 0, s, nseg, M, seg);
+		if (dbg_conv && M > 10000 && nseg == 1)
+		{
+			double* d = sc.alloc<double>(12);
+			dev_zero(ctx, d, 12 * sizeof(double));
+			auto st = [&](const double* a, size_t n, int k) { if (a && n) hipLaunchKernelGGL(k_dbg_absstats, dim3(512), dim3(256), 0, s, n, a, d + 2 * k); };
+			st(sy.S, (size_t)sy.nnzb * 36, 0); st(sy.E, (size_t)M * 6, 1); st(ch.L, (size_t)ch.nnzL * 36, 2); st(ch.Lg, (size_t)ch.nnzL * 36, 3);
+			st(ch.Dinv, (size_t)ch.M * 36, 4); st(x, nscal, 5);
+			hipLaunchKernelGGL(k_dbg_dinv, dim3((ch.M + 255) / 256), dim3(256), 0, s, ch.M, ch.Dinv, ch.diag0, ch.colptr, 0);
+			double h[12];
+			d2h(ctx, h, d, sizeof h);
+			fprintf(stderr, "[lsfm conv] root M=%d: |S| sum %.15e max %.6e  |E| sum %.15e  |L| sum %.12e max %.3e  |Lg| sum %.12e max %.3e  |Dinv| sum %.6e max %.3e  |x| sum %.12e max %.3e\n",
+			        M, h[0], h[1], h[2], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+		}
 		hipLaunchKernelGGL(k_pcg_run_stats, dim3(nbs), dim3(128), 0, s, nseg, seg, ctx->d_run);
 		return 0; // the outcome is read at the end of the run (lsfm_tree_run)
 	}

@@ -439,7 +439,11 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
              int* __restrict__ nfeature, double* __restrict__ Gsum, double* __restrict__ Gpose, int* __restrict__ hubJ, int alias_passthrough,
              const int* __restrict__ wbase, const int* __restrict__ newf, int* __restrict__ srcf)
 {
-	constexpr int GCAP = 32, TW = 18 * NH; // LDS: 9 (18) KB pose table + 36 KB block rows -> three work-groups per CU
+	// LDS: pose table + 36 KB block rows.  Stereo: 32 poses, 9 KB -> three work-groups per CU.  Mono: two hub columns, and far up
+	// a deep tree a tile of 128 features is seen by 33-64 poses (two hub blocks per feature and level) -- with a 32-entry table
+	// most of a top level's blocks fell through to 72 global atomics each on rows the neighbouring tiles also add to (a synth-16k
+	// root transform: 35 ms); 64 entries, 37 KB: still the two work-groups per CU its registers allow
+	constexpr int GCAP = NH == 1 ? 32 : 64, TW = 18 * NH;
 	__shared__ int gkeys[GCAP];
 	__shared__ double gvals[NH * GCAP * 36];
 	__shared__ double sT[TRE_ROUND * 18];

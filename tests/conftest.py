@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The HIP runtime of THIS process comes up before any test starts a child process that uses the GPU (tests/test_gpu_cli.py
+    runs the command-line program): a parent that initialises HIP just as such a child is being torn down has been seen to find
+    no device (hipGetDeviceCount -> 0), depending on which tests were selected.  No GPU: nothing happens."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def _has_gpu():
     try:
         import torch

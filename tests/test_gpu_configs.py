@@ -96,9 +96,25 @@ def test_synth16k_mono_full_size_properties(ctx):
     i.e. the Mono transform at 16k poses / two hub columns inverts itself."""
     typ, maps = synth.make_config("synth16k")
     assert typ == "Monocular" and len(maps) == 16384
-    out, stats, rc = ctx.divide_conquer(maps, True)
+    t = ctx.tree_upload([m.__dict__ for m in maps], True)
     del maps
-    assert rc == 0 and stats["not_converged"] == 0, stats
+    try:
+        ctx.tree_set_plans(t, False)
+        # Every run analyses, and every one must end with all systems converged.  The root system of this tree is at the edge of
+        # fp64: in one run out of fifteen the last 6x6 block of its top separator comes out slightly indefinite (the atomic sums
+        # of 16 000 columns of updates land in another order every run); the factorisation then takes the pivot by its
+        # magnitude, and a tree whose refinement still stalls is joined again (stats["attempts"] > 1) -- never reported as
+        # converged when it is not.
+        attempts = []
+        for _ in range(10):
+            stats, rc = ctx.tree_run(t)
+            assert rc == 0 and stats["not_converged"] == 0 and stats["max_rel_residual"] < 1e-8, stats
+            attempts.append(stats["attempts"])
+        print("attempts per run:", attempts)
+        assert max(attempts) <= 3
+        out = ctx.tree_download(t)
+    finally:
+        ctx.tree_free(t)
     print(f"synth16k: {out['m']} poses / {out['n']} features / {out['nW']} W blocks, {stats['levels']} levels, {stats['t_total_ms']:.0f} ms, "
           f"max rel residual {stats['max_rel_residual']:.2e}")
     # (most systems end at 1e-12 .. 1e-14; the camera systems of a monocular chain this deep are conditioned ~1e10 and one or

@@ -106,7 +106,7 @@ def test_synth16k_mono_full_size_properties(ctx):
         # magnitude, and a tree whose refinement still stalls is joined again (stats["attempts"] > 1) -- never reported as
         # converged when it is not.
         attempts = []
-        for _ in range(10):
+        for _ in range(4):
             stats, rc = ctx.tree_run(t)
             assert rc == 0 and stats["not_converged"] == 0 and stats["max_rel_residual"] < 1e-8, stats
             attempts.append(stats["attempts"])

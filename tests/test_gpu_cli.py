@@ -92,3 +92,19 @@ def test_cli_forward_substitution_inside_and_outside_the_factorisation(tmp_path)
         out[tag] = _table(s)
     assert np.array_equal(out["fused"][:, 0], out["apart"][:, 0])
     assert np.max(np.abs(out["fused"][:, 1] - out["apart"][:, 1]) / np.maximum(1.0, np.abs(out["apart"][:, 1]))) < 1e-9
+
+
+@pytest.mark.parametrize("typ,n", [("Stereo", 13), ("Monocular", 9)])
+def test_rccl_allreduce_hook_from_cpp(tmp_path, typ, n):
+    """liblsfm_rccl.so (RCCL behind lsfm_allreduce_fn, for C / C++ hosts) on one GPU: linearsfm_amd/lsfm_rccl_selftest joins the set
+    as one tree and as two blocks + a top tree whose sums all go through ncclAllReduce on the library's stream (a communicator
+    of one rank), and compares."""
+    mono = typ == "Monocular"
+    maps = synth.make_mono_set(n, 8, 4, seed=43, **synth.SPIRAL) if mono else synth.make_stereo_set(n, 8, 5, seed=43, lap=30, home=5)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "lsfm_rccl_selftest")
+    assert os.path.exists(exe), "build() must have produced the self-test"
+    r = subprocess.run([exe, "-path", str(d), "-num", str(n), "-type", typ], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all-reduces" in r.stdout

@@ -49,3 +49,19 @@ def test_product_never_imports_oracle():
                     if re.search(r"(from|import)\s+oracle|oracle/|lsfm_oracle|pyoracle", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_rccl_hook_library_exports_its_header():
+    """liblsfm_rccl.so (RCCL behind lsfm_allreduce_fn for C / C++ hosts) loads and exports what include/lsfm_rccl.h declares."""
+    import ctypes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "linearsfm_amd", "liblsfm_rccl.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+        g.build()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "lsfm_rccl.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(lsfm_rccl_[a-z_0-9]+)\s*\(", txt)))
+    assert len(syms) >= 6
+    L = ctypes.CDLL(path)
+    for s in syms:
+        assert hasattr(L, s), s

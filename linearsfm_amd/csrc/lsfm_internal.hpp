@@ -191,6 +191,7 @@ struct lsfm_context {
 	lsfm::LevelPlan pre_plan;
 	int pre_plan_level = -1;
 	hipEvent_t evY = nullptr, evP = nullptr; // joint index arrays of the level final (main stream) / prefetch complete (stream3)
+	hipEvent_t evK = nullptr;                // the level's Schur assembly (K9) has left the main stream: the chain of the factorisation starts
 	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)
 	int solved_nnzb = 0;
 	// LSFM_TIMELINE=1: host wall-clock marks of a tree run (where the enqueuing thread is when), printed at the end of the run

@@ -1566,7 +1566,12 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 	pl->M = Y.M;
 	Arena& sa = ctx->sarena[next_level & 1];
 	sa.reset();
-	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evY, 0)); // the joint maps' index arrays are final
+	// The joint maps' index arrays are final at evY: the pattern kernels start there, beside the level's right-hand-side kernels and
+	// K9.  Measured alternative (LSFM_PREFETCH_LATE=1): start them once K9 has left the main stream (evK), beside the
+	// factorisation's chain of small launches -- K9 then runs undisturbed (0.66 -> 0.58 ms per level) but the host gets its
+	// pattern 0.6 ms later at every level and the next level is enqueued late: 54.5 instead of 50.4 ms per tree.
+	static const bool late_start = getenv("LSFM_PREFETCH_LATE") != nullptr;
+	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, late_start ? ctx->evK : ctx->evY, 0));
 	if (ctx->timeline_on) { (void)hipEventSynchronize(ctx->evY); ctx->mark("pre_evY"); }
 	CholHostIn hin;
 	std::vector<int> counts;
@@ -1975,6 +1980,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		schur_vinv(ctx, io, sy);
 		build_schur_values(ctx, io, sy);
 		LSFM_CHECK_HIP(hipEventRecord(eb, s));
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		chol_alloc_values(ctx, ch);
 		d_err = ch.d_err = sc.alloc<int>(1);
 		dev_zero(ctx, d_err, sizeof(int));
@@ -2076,6 +2082,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		}
 		build_schur_values(ctx, io, sy);
 		LSFM_CHECK_HIP(hipEventRecord(eb, s));
+		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		tw0 = wall();
 		ctx->mark("k9_enq");
 		if (pre) chol_upload_symbolic(ctx, pre->sym, ch);

@@ -148,6 +148,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		js.smark = smark; // everything of this level goes at once
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
+		if (ctx->pre_pending) ctx->drop_prepared(); // (a plan the level's solve did not take up)
 		ctx->pre_plan = LevelPlan(); // (consumed, if it was this level's)
 		ctx->pre_plan_level = -1;
 		if (analysing && Y.B > 1 && !ctx->comm)
@@ -166,7 +167,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 			for (int b = 0; b < nb; b++) if (nref[b] >= 0 && Y.Ref[b] == nref[b]) nref[b] = -1; // (same frame: passed through, Imp.cpp:352)
 			prefetch_next_level(ctx, Y, nref, level + 1, level + 1 < (int)t->step_hint.size() ? t->step_hint[level + 1] : 0);
 		}
-		else ctx->pre.reset();
+		else ctx->drop_prepared();
 	}
 	LSFM_CHECK_HIP(hipEventRecord(e_t2, ctx->stream));
 	if (ctx->steps_used > 0) t->step_hint[level] = ctx->steps_used;
@@ -225,8 +226,7 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	ctx->generation++;
 	ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
 	ctx->stage_off = 0; // the stream is idle: the staging ring starts over
-	ctx->pre.reset(); ctx->early.reset(); ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // nothing prepared by an earlier run
-	ctx->pre_plan = LevelPlan(); ctx->pre_plan_level = -1;
+	ctx->drop_prepared(); ctx->early.reset(); ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // nothing prepared by an earlier run
 	LSFM_CHECK_HIP(hipMemsetAsync(ctx->d_run, 0, sizeof(RunStatsDev), ctx->stream));
 	static const bool poison = getenv("LSFM_POISON") != nullptr; // debug: every byte a run has not written itself reads as NaN / -1
 	if (poison)

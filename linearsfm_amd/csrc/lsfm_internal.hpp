@@ -8,9 +8,13 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -145,6 +149,55 @@ struct Comm {
 	}
 };
 
+// One helper thread per context for host work that the enqueuing thread need not wait for at once (the symbolic factorisation
+// of the next level: lsfm_pcg.hip prefetch_next_level).  One job at a time; wait() returns when it is done and rethrows what
+// it threw.  The thread lives as long as the context, so that what it keeps per thread (the symbolic analysis' workspace)
+// is kept between jobs.
+struct HostWorker {
+	std::thread th;
+	std::mutex m;
+	std::condition_variable cv;
+	std::function<void()> job;
+	std::exception_ptr err;
+	bool busy = false, quit = false;
+	~HostWorker()
+	{
+		{ std::lock_guard<std::mutex> l(m); quit = true; }
+		cv.notify_all();
+		if (th.joinable()) th.join();
+	}
+	void run(std::function<void()> f)
+	{
+		std::unique_lock<std::mutex> l(m);
+		cv.wait(l, [&] { return !busy; });
+		job = std::move(f); busy = true; err = nullptr;
+		if (!th.joinable())
+			th = std::thread([this] {
+				std::unique_lock<std::mutex> lk(m);
+				for (;;)
+				{
+					cv.wait(lk, [&] { return quit || (busy && job); });
+					if (quit) return;
+					std::function<void()> j = std::move(job);
+					job = nullptr;
+					lk.unlock();
+					std::exception_ptr e;
+					try { j(); } catch (...) { e = std::current_exception(); }
+					lk.lock();
+					err = e; busy = false;
+					cv.notify_all();
+				}
+			});
+		cv.notify_all();
+	}
+	void wait()
+	{
+		std::unique_lock<std::mutex> l(m);
+		cv.wait(l, [&] { return !busy; });
+		if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); }
+	}
+};
+
 } // namespace lsfm
 
 struct lsfm_context {
@@ -190,6 +243,16 @@ struct lsfm_context {
 	// one level ahead -- the level then runs like a planned one, without a single host <-> device round trip
 	lsfm::LevelPlan pre_plan;
 	int pre_plan_level = -1;
+	// ... whose solve part (symbolic factorisation: host work) may still be under way on the helper thread when the level starts:
+	// its transform, join and Schur assembly are enqueued meanwhile, solve_batch completes the plan (lsfm_pcg.hip)
+	std::shared_ptr<void> pre_pending;
+	std::unique_ptr<lsfm::HostWorker> worker;
+	// nothing the helper thread still reads may be dropped: wait for it, then forget what was prepared
+	void drop_prepared()
+	{
+		if (worker) { try { worker->wait(); } catch (...) {} }
+		pre.reset(); pre_pending.reset(); pre_plan = lsfm::LevelPlan(); pre_plan_level = -1;
+	}
 	hipEvent_t evY = nullptr, evP = nullptr; // joint index arrays of the level final (main stream) / prefetch complete (stream3)
 	hipEvent_t evK = nullptr;                // the level's Schur assembly (K9) has left the main stream: the chain of the factorisation starts
 	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)

@@ -1548,13 +1548,20 @@ static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHos
 struct PreLevel {
 	SchurSystem sy;
 	CholSymbolic sym;
+	CholHostIn hin;          // what the symbolic analysis reads (kept here: it may run on the helper thread)
 	int M = 0;
+	bool on_worker = false;  // sym is being made by ctx->worker: wait() before it is read
+	// the level's whole plan (counts in ctx->pre_plan already): what completes its solve part
+	bool whole = false;
+	int level = -1, its = 0;
 };
+static void pre_wait(lsfm_context* ctx, PreLevel* pl)
+{
+	if (pl && pl->on_worker) { ctx->worker->wait(); pl->on_worker = false; }
+}
 void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int next_level, int step_hint)
 {
-	ctx->pre.reset();
-	ctx->pre_plan = LevelPlan();
-	ctx->pre_plan_level = -1;
+	ctx->drop_prepared();
 	static const bool on = !getenv("LSFM_NO_PREFETCH") && !getenv("LSFM_NO_EARLY_PATTERN");
 	if (!on || !ctx->solved_keys || !Y.M || Y.B < 2) return;
 	// with the step count an earlier run left for that level, the level can run like a planned one (no round trip at all): then
@@ -1573,7 +1580,7 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 	static const bool late_start = getenv("LSFM_PREFETCH_LATE") != nullptr;
 	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, late_start ? ctx->evK : ctx->evY, 0));
 	if (ctx->timeline_on) { (void)hipEventSynchronize(ctx->evY); ctx->mark("pre_evY"); }
-	CholHostIn hin;
+	CholHostIn& hin = pl->hin;
 	std::vector<int> counts;
 	bool ok = false;
 	struct Swap { // this stretch runs on stream3 and allocates from the small arena of the level's parity
@@ -1594,29 +1601,57 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 	}
 	ctx->mark("pre_pat");
 	if (!ok) return;
-	chol_symbolic(hin.keys.data(), pl->sy.nnzb, hin.origin.data(), pl->sy.M, pl->sym);
+	// The symbolic factorisation is host work that only the level's FACTORISATION needs: it goes to the helper thread, and the
+	// caller enqueues the next level's transform, join and Schur assembly meanwhile -- they need the counts only, which arrived
+	// with the pattern.  (Done here, on this thread, the device sat idle 1-3 ms at every level boundary waiting for the next
+	// level to be enqueued: 9 of an analysing run's 50 ms.)  LSFM_NO_WORKER=1: on this thread, as before.
+	static const bool use_worker = !getenv("LSFM_NO_WORKER");
+	if (use_worker)
+	{
+		if (!ctx->worker) ctx->worker.reset(new HostWorker());
+		PreLevel* raw = pl.get(); // (kept alive by ctx->pre / ctx->pre_pending until pre_wait has returned)
+		pl->on_worker = true;
+		ctx->worker->run([raw]() { chol_symbolic(raw->hin.keys.data(), raw->sy.nnzb, raw->hin.origin.data(), raw->sy.M, raw->sym); });
+	}
+	else chol_symbolic(hin.keys.data(), pl->sy.nnzb, hin.origin.data(), pl->sy.M, pl->sym);
 	ctx->mark("pre_sym");
 	if (!whole)
 	{
 		ctx->pre = pl;
 		return;
 	}
-	// the whole plan of the level: index arrays of the factorisation to the device now (stream3 again), counts as the host read them
-	auto sp = std::make_shared<SolvePlan>();
-	sp->sy = pl->sy;
-	sp->its = step_hint; sp->mixed = ctx->pcg.mixed; sp->rel_tol = ctx->pcg.rel_tol;
-	{
-		Swap sw(ctx, sa);
-		chol_upload_index(ctx, pl->sym, sp->ch);
-		LSFM_CHECK_HIP(hipEventRecord(ctx->evP, ctx->stream));
-	}
+	// the whole plan of the level: the counts as the host read them now; its solve part (index arrays of the factorisation to the
+	// device) is completed by the level's solve_batch -> pre_plan_complete
+	pl->whole = true; pl->level = next_level; pl->its = step_hint;
 	const int B = Y.B;
 	ctx->pre_plan.tr_cnt.assign(counts.begin(), counts.begin() + 2 * (B + 1));
 	ctx->pre_plan.join_rb.assign(counts.begin() + 2 * (B + 1), counts.end());
-	ctx->pre_plan.solve = sp;
+	ctx->pre_plan.solve.reset();
 	ctx->pre_plan.valid = true;
 	ctx->pre_plan_level = next_level;
+	ctx->pre_pending = pl;
 	ctx->mark("pre_plan");
+}
+// the solve part of a plan made one level ahead: waits for the symbolic factorisation, sends its index arrays to the device (stream3,
+// the small arena of the level's parity) and makes the main stream wait for them
+static std::shared_ptr<void> pre_plan_complete(lsfm_context* ctx)
+{
+	std::shared_ptr<void> keep = ctx->pre_pending;
+	ctx->pre_pending.reset();
+	PreLevel* pl = static_cast<PreLevel*>(keep.get());
+	pre_wait(ctx, pl);
+	auto sp = std::make_shared<SolvePlan>();
+	sp->sy = pl->sy;
+	sp->its = pl->its; sp->mixed = ctx->pcg.mixed; sp->rel_tol = ctx->pcg.rel_tol;
+	Arena& sa = ctx->sarena[pl->level & 1];
+	{
+		std::swap(ctx->stream, ctx->stream3); std::swap(ctx->scratch, sa);
+		try { chol_upload_index(ctx, pl->sym, sp->ch); LSFM_CHECK_HIP(hipEventRecord(ctx->evP, ctx->stream)); }
+		catch (...) { std::swap(ctx->scratch, sa); std::swap(ctx->stream, ctx->stream3); throw; }
+		std::swap(ctx->scratch, sa); std::swap(ctx->stream, ctx->stream3);
+	}
+	LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evP, 0));
+	return sp;
 }
 
 // the supernode-group path of the triangular solves applies (chol_apply): the forward substitution can ride on the factorisation
@@ -1961,8 +1996,12 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	Arena& sc = ctx->scratch;
 	const int M = io.M, nseg = io.nseg;
 	LevelPlan* lp = ctx->plan;
+	// a plan made one level ahead whose symbolic factorisation may still be under way on the helper thread: the Schur assembly
+	// needs the pattern only, so it is enqueued first
+	PreLevel* pending = (lp && lp == &ctx->pre_plan && !lp->solve && ctx->pre_pending) ? static_cast<PreLevel*>(ctx->pre_pending.get()) : nullptr;
+	if (!pending && ctx->pre_pending) { pre_wait(ctx, static_cast<PreLevel*>(ctx->pre_pending.get())); ctx->pre_pending.reset(); } // (not this level's: dropped)
 	SolvePlan* sp = lp ? static_cast<SolvePlan*>(lp->solve.get()) : nullptr;
-	const bool warm = sp != nullptr; // pattern + symbolic factorisation known from an earlier run of the same tree level
+	const bool warm = sp != nullptr || pending != nullptr; // pattern + symbolic factorisation known from an earlier run of the same tree level (or made one level ahead)
 	hipEvent_t ea = ctx->pool_event(), eb = ctx->pool_event(), ec = ctx->pool_event(), ed = ctx->pool_event();
 	LSFM_CHECK_HIP(hipEventRecord(ea, s));
 	SchurSystem sy;
@@ -1975,12 +2014,19 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	if (warm)
 	{
 		ctx->pattern_dep = false;
-		sy = sp->sy;
-		ch = sp->ch;
+		sy = pending ? pending->sy : sp->sy;
 		schur_vinv(ctx, io, sy);
 		build_schur_values(ctx, io, sy);
 		LSFM_CHECK_HIP(hipEventRecord(eb, s));
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
+		if (pending)
+		{
+			ctx->mark("k9_enq");
+			lp->solve = pre_plan_complete(ctx);
+			sp = static_cast<SolvePlan*>(lp->solve.get());
+			ctx->mark("sym_wait");
+		}
+		ch = sp->ch;
 		chol_alloc_values(ctx, ch);
 		d_err = ch.d_err = sc.alloc<int>(1);
 		dev_zero(ctx, d_err, sizeof(int));
@@ -1998,6 +2044,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		std::shared_ptr<void> pre_keep = ctx->pre;
 		ctx->pre.reset();
 		PreLevel* pre = static_cast<PreLevel*>(pre_keep.get());
+		if (pre && !(pre->M == M && !ctx->comm)) pre_wait(ctx, pre); // (not used: nothing of it may go while the helper thread reads it)
 		if (pre && pre->M == M && !ctx->comm)
 		{
 			// prepared while the level below was being solved: pattern (device) and symbolic factorisation (host)
@@ -2085,7 +2132,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		tw0 = wall();
 		ctx->mark("k9_enq");
-		if (pre) chol_upload_symbolic(ctx, pre->sym, ch);
+		if (pre) { pre_wait(ctx, pre); chol_upload_symbolic(ctx, pre->sym, ch); }
 		else chol_analyse(ctx, sy, hin, ch);
 		ctx->mark("analyse");
 		tw1 = wall();

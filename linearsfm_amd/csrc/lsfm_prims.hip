@@ -338,6 +338,8 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 void lsfm_context_destroy(lsfm_context* c)
 {
 	if (!c) return;
+	c->drop_prepared();
+	c->worker.reset(); // (joins the helper thread)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->arena[0].destroy(); c->arena[1].destroy(); c->arena[2].destroy(); c->scratch.destroy();

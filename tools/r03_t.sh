@@ -1,7 +1,8 @@
 ulimit -c 0
-D=gpurun_out/r03i; mkdir -p $D
-for mode in late early; do
-  if [ $mode = early ]; then export LSFM_PREFETCH_EARLY=1; else unset LSFM_PREFETCH_EARLY; fi
+D=gpurun_out/r03k; mkdir -p $D
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_sharded.py -x -q -m gpu 2>&1 | tail -3
+for mode in worker noworker; do
+  if [ $mode = noworker ]; then export LSFM_NO_WORKER=1; else unset LSFM_NO_WORKER; fi
   for rep in 1 2; do
   timeout 300 python bench.py --steps 10 --warmup 2 --cpu-baseline 0 --extras 0 > $D/bnc_$mode$rep.log 2>/dev/null
   python - <<PY
@@ -11,3 +12,6 @@ d=json.loads(l[0]); print("$mode", round(d["value"],2), round(d["resolve_ms"],2)
 PY
   done
 done
+unset LSFM_NO_WORKER
+LSFM_TIMELINE=1 timeout 300 python bench.py --steps 2 --warmup 2 --cpu-baseline 0 --extras 0 > $D/bench_tl.json 2> $D/timeline.txt
+grep -n "^\[tl\]" $D/timeline.txt | sed -n 44,52p | cut -c1-300

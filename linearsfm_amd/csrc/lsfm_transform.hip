@@ -714,21 +714,11 @@ k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict
 	{
 		const double* fd = FD + (size_t)f * (9 + TW);
 		ld<9>(Df, fd);
-		double V[9];
-		ld<9>(V, Vold + (size_t)f * 9);
 		const int base = wbase[f];
 		const int hubs[2] = { t->hub[0], NH == 2 ? t->hub[1] : -1 };
 		double hubW[NH][18];
 #pragma unroll
-		for (int s = 0; s < NH; s++)
-		{
-			ld<18>(Cf[s], fd + 9 + 18 * s);
-			double Gs[18];
-			ld<18>(Gs, Gsum + (size_t)f * TW + 18 * s);
-			mm<3, 3, 6, false>(V, Cf[s], G[s]); // G_s,f = V C_s,f + sum_k W_kf^T C_s,k
-			for (int i = 0; i < 18; i++) G[s][i] += Gs[i];
-			zero<18>(hubW[s]);
-		}
+		for (int s = 0; s < NH; s++) zero<18>(hubW[s]);
 		// old blocks of the feature to the hub pose(s): their D_k^T W D_f joins the new hub block.  The entry kernel
 		// left the block's index; only duplicates make the lane walk its run
 		bool walk = false;
@@ -758,6 +748,21 @@ k_tr_feat_post(int NF, int M, const TMap* __restrict__ tm, const int* __restrict
 				mm<6, 3, 3, false>(T1, Df, Wn);
 				for (int i = 0; i < 18; i++) hubW[s == 0 ? 0 : NH - 1][i] += Wn[i];
 			}
+		// G_s,f = V C_s,f + sum_k W_kf^T C_s,k  (after the hub blocks above: C_f, V and the sums are not alive while a 6x6 pose
+		// Jacobian and a block are -- the Stereo kernel spilled 16 registers with everything loaded up front)
+		{
+			double V[9];
+			ld<9>(V, Vold + (size_t)f * 9);
+#pragma unroll
+			for (int s = 0; s < NH; s++)
+			{
+				ld<18>(Cf[s], fd + 9 + 18 * s);
+				double Gs[18];
+				ld<18>(Gs, Gsum + (size_t)f * TW + 18 * s);
+				mm<3, 3, 6, false>(V, Cf[s], G[s]);
+				for (int i = 0; i < 18; i++) G[s][i] += Gs[i];
+			}
+		}
 		// leading hub block(s) of the feature: W'(h_s, f) = hubW_s + G_s^T D_f
 #pragma unroll
 		for (int s = 0; s < NH; s++)

@@ -321,7 +321,9 @@ def main():
                             "join).  `value` is " + ("analysing_run_ms" if analysing else "resolve_ms") + ".",
             "first_run_ms": first_ms,
             "upload_ms": upload_ms,
-            "upload_note": "lsfm_tree_upload of this rank's block from pageable host memory through the pinned ring (PCIe), before the timed region",
+            "upload_c_abi_ms": (stats or {}).get("upload_ms"),
+            "upload_note": "upload_ms: building the lsfm_map views of this rank's block in Python + lsfm_tree_upload (pageable host memory -> "
+                           "pinned ring -> HBM), before the timed region; upload_c_abi_ms: lsfm_tree_upload alone (lsfm_stats.upload_ms)",
             "per_rank_device_ms": [float(v) for v in busy.tolist()],
             "rank0_phases_ms": ({k: acc.get(k, 0.0) / args.steps for k in ("phase_block_ms", "phase_exchange_ms", "phase_top_ms")}
                                 if "phase_top_ms" in acc else None),

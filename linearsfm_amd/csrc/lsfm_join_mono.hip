@@ -420,13 +420,6 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	hipLaunchKernelGGL(k_mono_wrap, dim3((G + 127) / 128), dim3(128), 0, s, G, d_mg, prior);
 	LevelPlan* plan = ctx->plan;
 	const bool warm = ctx->warm(); // the structure of this level is known from an earlier run of the same tree: no round trips
-	if (!warm)
-	{
-		d2h(ctx, mg.data(), d_mg, sizeof(MGroup) * G);
-		for (int g = 0; g < G; g++)
-			if (mg[g].pair && (mg[g].P1 < 0 || mg[g].P2 < 0 || mg[g].C1 < 0 || mg[g].C2 < 0))
-				LSFM_FAIL(LSFM_ERR_ARG, "Mono join: shared reference / scale pose missing in pair " + std::to_string(g));
-	}
 	const int MY = M - 2 * npair;
 
 	// ---- common features (K5), same as Stereo ----
@@ -439,12 +432,38 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	dev_exclusive_scan(ctx, unm, RF, in.NF);
 	int* d_rb = sc.alloc<int>(B + 1);
 	hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, RF, in.d_feat_off, B + 1, d_rb);
-	std::vector<int> rb(B + 1);
-	if (warm) rb = plan->join_rb;
+	// ---- U: which blocks survive (index work, needed on the host for the container sizes like the unmatched ranks) ----
+	int* keepU = sc.alloc<int>(in.NU + 1);
+	int* KU = sc.alloc<int>(in.NU + 2);
+	if (in.NU) hipLaunchKernelGGL(k_mono_u_fl, dim3((in.NU + 255) / 256), dim3(256), 0, s, in.NU, in.Ui, in.Uj, in.pose_map, d_mg);
+	hipLaunchKernelGGL(k_mono_u_flags, dim3((in.NU + 256) / 256), dim3(256), 0, s, in.NU, in.Ui, in.Uj, in.pose_map, d_mg, keepU);
+	dev_exclusive_scan(ctx, keepU, KU, in.NU);
+	std::vector<int> rb(B + 1), uo(B + 1);
+	if (warm) { rb = plan->join_rb; uo = plan->join_uo; }
 	else
 	{
-		d2h_ints(ctx, d_rb, rb.data(), B + 1);
-		if (plan) plan->join_rb = rb;
+		// ONE read-back for everything the host needs of this level's structure: the pair records (are the shared poses there?), the
+		// ranks of the unmatched features and the kept-U prefix at the map boundaries (three round trips before)
+		int* d_uo = sc.alloc<int>(B + 1);
+		int* d_ui = sc.alloc<int>(B + 1);
+		h2d(ctx, d_ui, in.u_off.data(), (B + 1) * sizeof(int));
+		hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, d_ui, B + 1, d_uo);
+		const size_t nmg = sizeof(MGroup) * (size_t)G / sizeof(int);
+		int* d_pack = sc.alloc<int>(nmg + 2 * (size_t)(B + 1));
+		CopyBatch cp(ctx);
+		cp.d2d(d_pack, d_mg, sizeof(MGroup) * (size_t)G);
+		cp.d2d(d_pack + nmg, d_rb, sizeof(int) * (size_t)(B + 1));
+		cp.d2d(d_pack + nmg + (B + 1), d_uo, sizeof(int) * (size_t)(B + 1));
+		cp.flush();
+		std::vector<int> hp(nmg + 2 * (size_t)(B + 1));
+		d2h_ints(ctx, d_pack, hp.data(), hp.size());
+		memcpy(mg.data(), hp.data(), sizeof(MGroup) * (size_t)G);
+		std::copy(hp.begin() + nmg, hp.begin() + nmg + (B + 1), rb.begin());
+		std::copy(hp.begin() + nmg + (B + 1), hp.end(), uo.begin());
+		for (int g = 0; g < G; g++)
+			if (mg[g].pair && (mg[g].P1 < 0 || mg[g].P2 < 0 || mg[g].C1 < 0 || mg[g].C2 < 0))
+				LSFM_FAIL(LSFM_ERR_ARG, "Mono join: shared reference / scale pose missing in pair " + std::to_string(g));
+		if (plan) { plan->join_rb = rb; plan->join_uo = uo; }
 	}
 
 	out = DevBatch();
@@ -488,24 +507,6 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	dev_zero(ctx, eP, (size_t)MY * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
 
 	// ---- U ----
-	int* keepU = sc.alloc<int>(in.NU + 1);
-	int* KU = sc.alloc<int>(in.NU + 2);
-	if (in.NU) hipLaunchKernelGGL(k_mono_u_fl, dim3((in.NU + 255) / 256), dim3(256), 0, s, in.NU, in.Ui, in.Uj, in.pose_map, d_mg);
-	hipLaunchKernelGGL(k_mono_u_flags, dim3((in.NU + 256) / 256), dim3(256), 0, s, in.NU, in.Ui, in.Uj, in.pose_map, d_mg, keepU);
-	dev_exclusive_scan(ctx, keepU, KU, in.NU);
-	std::vector<int> uo(B + 1);
-	{
-		int* d_uo = sc.alloc<int>(B + 1);
-		int* d_ui = sc.alloc<int>(B + 1);
-		h2d(ctx, d_ui, in.u_off.data(), (B + 1) * sizeof(int));
-		if (warm) uo = plan->join_uo;
-		else
-		{
-			hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, d_ui, B + 1, d_uo);
-			d2h_ints(ctx, d_uo, uo.data(), B + 1);
-			if (plan) plan->join_uo = uo;
-		}
-	}
 	out.NU = uo[B];
 	for (int g = 0; g <= G; g++) out.u_off[g] = uo[std::min(2 * g, B)];
 	out.U = ar.alloc<double>((size_t)out.NU * 36); out.Ui = ar.alloc<int>(out.NU); out.Uj = ar.alloc<int>(out.NU);

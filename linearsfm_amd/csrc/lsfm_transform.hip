@@ -1257,7 +1257,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	// stream's part rejoins it through evB above).  A first run also stops here so that a failure surfaces at its stage --
 	// unless its consumer was laid out inside the hook: that one goes on enqueuing (its solve stops for the device soon
 	// enough), so that the host's part of the solve's analysis runs beside these kernels, not after them.
-	if (!warm && !hook) LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	if (!warm && !hook && !ctx->in_tree_run) LSFM_CHECK_HIP(hipStreamSynchronize(s)); // (a level of a tree run is only enqueued: errors are read at the end of the run)
 	if (!hook) ctx->scratch.release(smark); // with a hook its allocations outlive this call: the caller releases
 }
 

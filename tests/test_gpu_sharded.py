@@ -98,3 +98,47 @@ def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono, top, backend,
         tol = 1e-8 if mono else 1e-9
         assert pose_param_err(got["stVal"], single["stVal"], single["stno"]) < tol
         assert feat_param_err(got["stVal"], single["stVal"], single["stno"]) < tol
+
+
+@pytest.mark.parametrize("mono,n_maps,nslices", [(False, 24, 3), (True, 12, 4), (False, 5, 1)])
+def test_device_slice_packs_equal_the_numpy_slices(ctx, mono, n_maps, nslices):
+    """lsfm_tree_export_slice_dev against linearsfm_amd.distributed.slice_map: the final map of a tree cut by feature label on the
+    device, every pack uploaded again as a one-map tree and downloaded, must be the slice numpy cuts from the downloaded map --
+    labels, state, V, W blocks and their order, run pointers -- and the slices must add up to the map."""
+    import torch
+    from linearsfm_amd.distributed import merge_slices, slice_map
+    maps = _make(n_maps, mono)
+    t = ctx.tree_upload([dict(m.__dict__) for m in maps], mono)
+    packs = []
+    try:
+        _, rc = ctx.tree_run(t)
+        assert rc == 0
+        m, n, stno, stVal = ctx.tree_download_state(t)
+        full = ctx.tree_download(t)
+        assert (m, n) == (full["m"], full["n"]) and np.array_equal(stno, full["stno"]) and np.array_equal(stVal, full["stVal"])
+        sizes = ctx.tree_export_slice_sizes(t, nslices)
+        for g in range(nslices):
+            buf = torch.empty(sizes[g], dtype=torch.uint8, device="cuda")
+            ctx.tree_export_slice_dev(t, nslices, g, buf.data_ptr(), sizes[g])
+            packs.append(buf)
+    finally:
+        ctx.tree_free(t)
+    got = []
+    for g, buf in enumerate(packs):
+        ts = ctx.tree_upload_dev([buf.data_ptr()], mono)
+        try:
+            ctx.tree_set_final_reanchor(ts, False)
+            _, rc = ctx.tree_run(ts)  # one map, nothing to join: the resident input is the result
+            assert rc == 0
+            d = ctx.tree_download(ts)
+        finally:
+            ctx.tree_free(ts)
+        exp = slice_map(full, nslices, g)
+        assert d["m"] == exp["m"] and d["n"] == exp["n"] and d["Ref"] == full["Ref"] and d["FRef"] == full["FRef"]
+        for k in ("stno", "stVal", "Ui", "Uj", "U", "V", "W", "photo", "feature", "FBlock"):
+            assert np.array_equal(np.asarray(d[k]).reshape(-1), np.asarray(exp[k]).reshape(-1)), (g, k)
+        got.append(d)
+    order = np.asarray(full["stno"])[6 * full["m"]::3]
+    back = merge_slices(got, order)
+    for k in ("stno", "stVal", "V", "W", "photo", "feature", "FBlock"):
+        assert np.array_equal(np.asarray(back[k]).reshape(-1), np.asarray(full[k]).reshape(-1)), k

@@ -351,7 +351,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					t->plans.clear();
 					continue;
 				}
-				if (rs.not_converged && attempt < 2)
+				if ((rs.not_converged || st->not_converged) && attempt < 2) // (a level that records its plan reports through the stats, not the device record)
 				{
 					// A system was left above its bound although every level asked after every step.  Seen in one synth-16k Mono tree
 					// out of fifteen: the last 6x6 block of the root's top separator -- what is left of 1e6..1e8-sized entries after

@@ -10,11 +10,15 @@ mono = typ == "Monocular"
 ctx = api.Context(0)
 t = ctx.tree_upload([m.__dict__ for m in maps], mono)
 del maps
-ctx.tree_set_plans(t, False)
+plans = len(sys.argv) > 3 and sys.argv[3] == "plans"
+ctx.tree_set_plans(t, plans)
 res = []
+times = []
 for i in range(n):
     st, rc = ctx.tree_run(t)
+    times.append(st["t_total_ms"])
     res.append((rc, st["not_converged"], float("%.2e" % st["max_rel_residual"]), st["pcg_iterations"], st["attempts"]))
 bad = [r for r in res if r[0] != 0 or r[2] > 1e-8]
-print("runs", n, "failed", len(bad), bad[:6], "repeated", sum(1 for r in res if r[4] > 1), "worst ok", max(r[2] for r in res if r not in bad))
+import numpy as _np
+print("plans" if plans else "analysing", "mean ms %.1f" % _np.mean(times), "runs", n, "failed", len(bad), bad[:6], "repeated", sum(1 for r in res if r[4] > 1), "worst ok", max(r[2] for r in res if r not in bad))
 ctx.tree_free(t)

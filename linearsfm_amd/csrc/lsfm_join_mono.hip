@@ -558,6 +558,13 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 		LSFM_CHECK_HIP(hipMemsetAsync(jf, 0xff, sizeof(int) * (size_t)in.NF, s));
 		hipLaunchKernelGGL(k_mono_w_index, dim3((NFY + 255) / 256), dim3(256), 0, s, NFY, srcE, srcC, in.fptr, in.photo, out.feat_map, d_mg, pnew, out.fptr,
 		                   out.photo, out.feature, dst, jf);
+		// the joint maps' index arrays are final here (U's were written by k_mono_u_fill): a level that analyses builds the pattern of S
+		// on the side stream from this point, beside the kernel that moves the W blocks and the right-hand sides (solve_batch)
+		if (!warm && !eP_out && !eF_out && !ctx->comm)
+		{
+			LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s));
+			ctx->pattern_dep = true;
+		}
 		if (in.NF)
 			hipLaunchKernelGGL(k_mono_w_copy, dim3((in.NF + MWC_TILE - 1) / MWC_TILE), dim3(256), 0, s, in.NF, in.fptr, in.photo, in.W, in.feat_map,
 			                   in.W_alias, in.d_alias, dst, jf, srcC, out.feat_map, d_mg, pnew, prior, in.feat, out.W, eP, eF);

@@ -316,13 +316,17 @@ __global__ void k_tr_flags(const int* __restrict__ Ui, const int* __restrict__ U
 	if (i == 0) { keepU[NU] = 0; keepW[NW] = 0; }
 }
 
+// (+ the target-not-found flag and, Mono, the sign of every map's new scale: everything the host reads of a transform that
+// analyses, in one copy)
 __global__ void k_tr_gather_counts(const int* __restrict__ KU, const int* __restrict__ KW, const int* __restrict__ uoff, const int* __restrict__ woff,
-                                   int B, int* __restrict__ out)
+                                   int B, int* __restrict__ out, const TMap* __restrict__ tm, const int* __restrict__ err)
 {
 	int b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b > B) return;
 	out[b] = KU[uoff[b]];
 	out[B + 1 + b] = KW[woff[b]];
+	if (b < B) out[2 * (B + 1) + b] = tm[b].active > 0 ? tm[b].sign1 : 0;
+	else out[2 * (B + 1) + B] = *err;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1164,17 +1168,20 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	}
 	dev_exclusive_scan(ctx, keepU, KU, in.NU);
 	dev_exclusive_scan(ctx, keepW, KW, in.NW);
-	int* d_cnt = ctx->scratch.alloc<int>(2 * (B + 1));
+	int* d_cnt = ctx->scratch.alloc<int>(3 * (B + 1));
 	LevelPlan* plan = ctx->plan;
 	const bool warm = ctx->warm();
-	std::vector<int> cnt(2 * (B + 1));
+	std::vector<int> cnt(2 * (B + 1)), dev_sign;
 	if (warm) cnt = plan->tr_cnt; // the structure of this level is known from an earlier run of the same tree: no round trip
 	else
 	{
-		hipLaunchKernelGGL(k_tr_gather_counts, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, d_uoff, d_woff, B, d_cnt);
+		hipLaunchKernelGGL(k_tr_gather_counts, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, d_uoff, d_woff, B, d_cnt, d_tm, d_err);
 		ctx->mark("tr_enq");
-		d2h_ints(ctx, d_cnt, cnt.data(), cnt.size());
-		int err = d2h_int(ctx, d_err);
+		std::vector<int> all(3 * (size_t)(B + 1));
+		d2h_ints(ctx, d_cnt, all.data(), all.size());
+		std::copy(all.begin(), all.begin() + 2 * (B + 1), cnt.begin());
+		dev_sign.assign(all.begin() + 2 * (B + 1), all.begin() + 2 * (B + 1) + B);
+		const int err = all[3 * (size_t)(B + 1) - 1];
 		ctx->mark("tr_cnt");
 		if (err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(err - 1));
 		if (plan) plan->tr_cnt = cnt;
@@ -1230,9 +1237,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		}
 		else
 		{
-			std::vector<TMap> dev(B);
-			d2h(ctx, dev.data(), d_tm, sizeof(TMap) * B);
-			for (int b = 0; b < B; b++) if (dev[b].active > 0) out.Sign[b] = dev[b].sign1;
+			for (int b = 0; b < B; b++) if (tm[b].active && dev_sign[b]) out.Sign[b] = dev_sign[b]; // (read with the counts)
 			if (plan) plan->tr_sign = out.Sign;
 		}
 	}

@@ -285,8 +285,6 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				ctx->timed.clear(); ctx->ev_next = 0;
 				static const bool no_hints = getenv("LSFM_NO_STEP_HINTS") != nullptr; // debug: every run asks after every refinement step
 				if (no_hints) t->step_hint.clear();
-				bool hinted = false;
-				for (int h : t->step_hint) hinted |= h > 0;
 				ctx->timeline_on = getenv("LSFM_TIMELINE") != nullptr;
 				ctx->timeline.clear();
 				const double t0 = now_ms();
@@ -331,33 +329,24 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
 				if (rs.chol_err)
 					LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
-				if (rs.plan_stale && attempt == 0)
+				// Repeating a run.  A plan that met values it does not fit (LevelPlan::tr_sign), refinement steps enqueued by a count
+				// from an earlier run that did not suffice this time (`undone`), or a system left above its bound although every level
+				// asked after every step -- seen in one synth-16k Mono tree out of fifteen: the last 6x6 block of the root's top
+				// separator, what is left of 1e6..1e8-sized entries after 16 000 columns of updates whose atomic sums land in another
+				// order every run, came out slightly indefinite and its factor, taken by magnitude (k_sn_panel), was too poor a
+				// preconditioner.  In each case the tree is joined again without what the earlier runs left (plans, step counts): the
+				// rounding falls differently.  At most three times; what is still not converged then is reported (LSFM_NOT_CONVERGED).
+				const bool more = attempt < 3;
+				if (rs.plan_stale)
 				{
-					// a plan met values it does not fit (LevelPlan::tr_sign): this run's result is void, repeat it analysing
+					if (!more) LSFM_FAIL(LSFM_ERR_INTERNAL, "level plans kept being reported stale");
 					t->plans.clear();
 					continue;
 				}
-				if (rs.plan_stale) LSFM_FAIL(LSFM_ERR_INTERNAL, "a level plan was reported stale in a run without plans");
-				if ((rs.not_converged || rs.undone) && attempt == 0 && hinted)
+				if ((rs.not_converged || rs.undone || st->not_converged) && more) // (a level that records its plan reports through the stats, not the device record)
 				{
-					// the steps of a level were enqueued by a count from an earlier run and did not suffice this time: forget the counts
 					t->step_hint.clear();
-					if (!t->use_plans) continue;
-				}
-				if ((rs.not_converged || rs.undone) && attempt == 0 && t->use_plans)
-				{
-					// a planned run enqueues the refinement steps the first run needed; if a system asks for more this time,
-					// drop the plans and run the levels the slow way again (reads the state of every step back)
 					t->plans.clear();
-					continue;
-				}
-				if ((rs.not_converged || st->not_converged) && attempt < 2) // (a level that records its plan reports through the stats, not the device record)
-				{
-					// A system was left above its bound although every level asked after every step.  Seen in one synth-16k Mono tree
-					// out of fifteen: the last 6x6 block of the root's top separator -- what is left of 1e6..1e8-sized entries after
-					// 16 000 columns of updates whose atomic sums land in another order every run -- came out slightly indefinite and
-					// its factor, taken by magnitude (k_sn_panel), was too poor a preconditioner.  The tree is joined again (at most
-					// twice): the rounding falls differently.  What is still not converged then is reported (LSFM_NOT_CONVERGED).
 					continue;
 				}
 				st->not_converged += rs.not_converged;

@@ -2209,11 +2209,12 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	// (a run that counts its steps does not stop to ask before the first one either: systems that start below their bound
 	// are frozen on the device, the step costs them nothing)
 	int its = 0, ndone = 0;
-	// (a level that needed two steps or more is ill-conditioned enough for its count to vary from run to run -- one synth-16k run in
+	// (a level that needed two steps or more -- three with the fp32 preconditioner, where two is the rule -- is ill-conditioned enough
+	// for its count to vary from run to run -- one synth-16k run in
 	// eight asked for one more than the run before and had to be repeated as a whole: such levels get one step of margin; systems
 	// that are done are frozen on the device, the extra step costs them the launches only)
 	const int base_steps = hinted ? ctx->step_hint : (planned_run ? sp->its : maxit);
-	const int planned = (planned_run && base_steps >= 2) ? std::min(base_steps + 1, maxit) : base_steps;
+	const int planned = (planned_run && base_steps >= (mixed ? 3 : 2)) ? std::min(base_steps + 1, maxit) : base_steps;
 	while ((planned_run ? its < planned : (ndone < nseg && its < maxit)))
 	{
 		const int cur = its & 1;

@@ -125,9 +125,9 @@ int main(int argc, char** argv)
 		        stats.not_converged, stats.max_rel_residual);
 	printf("Total Used Time:  %lf  sec\n\n", stats.t_total_ms * 1e-3); // Imp.cpp:2072
 	if (want_stats)
-		fprintf(stderr, "lsfm: total %.3f ms (transform %.3f, join %.3f [schur %.3f, pcg %.3f, backsub %.3f]), pcg its %ld, max rel resid %.2e, not converged %d\n",
+		fprintf(stderr, "lsfm: total %.3f ms (transform %.3f, join %.3f [schur %.3f, pcg %.3f, backsub %.3f]), pcg its %ld, max rel resid %.2e, not converged %d, attempts %d\n",
 		        stats.t_total_ms, stats.t_transform_ms, stats.t_join_ms, stats.t_schur_ms, stats.t_pcg_ms, stats.t_backsub_ms, stats.pcg_iterations,
-		        stats.max_rel_residual, stats.not_converged);
+		        stats.max_rel_residual, stats.not_converged, stats.attempts);
 	const int r = 6 * out.m + 3 * out.n;
 	if (!st.empty()) lsfm_save_state(st.c_str(), out.stVal, out.stno, r);
 	if (!pose.empty() && !fea.empty()) lsfm_save_poses(pose.c_str(), fea.c_str(), out.stno, out.stVal, r); // only together (Imp.cpp:2078)

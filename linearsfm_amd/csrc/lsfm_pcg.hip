@@ -664,6 +664,23 @@ __device__ __forceinline__ int sn_idx(int s, int u, int t) { return t * s - t * 
 //                latency, not work, is what a level costs.)  Used while a level's panels have few enough rows
 //                (chol_factor); beyond that the pairs would take more rounds of work-groups than the two launches.
 typedef double sn_v4d __attribute__((ext_vector_type(4)));
+// Profiling aid (make K9_TIMING=1): lane 0 of the first chunk's work-group of every group adds up the shader clocks of the phases
+// of k_sn_panel: [0] index set-up, [1] blocks -> LDS, [2] the column loop, [3] right-hand side + inverse diagonal + stores, [4] rank
+// update (fused), [5] work-groups counted, [6] sum of s.  Compiled out otherwise.
+#ifdef LSFM_K9_TIMING
+__device__ unsigned long long g_sn_t[16];
+#define SNT_DECL unsigned long long snt_prev = __builtin_readcyclecounter()
+#define SNT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_sn_t[(FUSED ? 8 : 0) + (i)], n_ - snt_prev); snt_prev = n_; } } while (0)
+extern "C" void lsfm_debug_sn(unsigned long long* out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sn_t), sizeof(unsigned long long) * 16);
+	if (reset) { unsigned long long z[16] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sn_t), z, sizeof(z)); }
+}
+#else
+#define SNT_DECL do { } while (0)
+#define SNT(i) do { } while (0)
+#endif
 template <bool FUSED>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Lg,
@@ -699,6 +716,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	else if (blockIdx.y > 0 && (int)blockIdx.y * SN_RB >= nr) return;
 	const bool diag_pair = !FUSED || ca == cb; // this work-group writes its (first) chunk's rows of the factor
 	const int tid = threadIdx.x, nt = blockDim.x;
+	SNT_DECL;
 	const int nb = s * (s + 1) / 2, n6 = 6 * s;
 	// where every block of the run's diagonal part sits in the block storage / in the dense rows (one lane per block)
 	for (int t = tid; t < s; t += nt) sCol[t] = colptr[c0 + t];
@@ -739,6 +757,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		}
 	}
 	__syncthreads();
+	SNT(0);
 	// blocks -> dense rows, two doubles per load, SN_LD loads in flight per lane (a dependent load costs ~1.5 us)
 	const int nd2 = nb * 18, np2 = SN_RB * s * 18; // pairs of doubles: diagonal part, panel slots
 	for (int base = 0; base < nd2 + np2; base += nt * SN_LD)
@@ -775,6 +794,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	const bool with_fv = fv && diag_pair;
 	if (with_fv && tid < n6) Ms[XR * xs + tid] = fv[(size_t)c0 * 6 + tid];
 	__syncthreads();
+	SNT(1);
 	// row of Ms this lane owns (-1: none)
 	const int ri = tid < LD ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? LD + (tid - 128) : ((with_fv && tid == 128 + 6 * SN_RB) ? XR : -1));
 	const bool panel_lane = ri >= LD && (ri == XR || sRow[(ri - LD) / 6] >= 0);
@@ -881,6 +901,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		}
 		__syncthreads();
 	}
+	SNT(2);
 	if (bad && tid == 0) atomicExch(err, 1 + c0);
 	if (with_fv)
 	{
@@ -931,6 +952,10 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			const double* x = &Xs[(6 * il + w / 6) * xs + 6 * t + w % 6];
 			*reinterpret_cast<double2*>(Lg + (size_t)(sCol[t] + (s - t) + row) * 36 + w) = make_double2(x[0], x[1]);
 		}
+	SNT(3);
+#ifdef LSFM_K9_TIMING
+	if (threadIdx.x == 0 && blockIdx.y == 0) { atomicAdd(&g_sn_t[(FUSED ? 8 : 0) + 5], 1ull); atomicAdd(&g_sn_t[(FUSED ? 8 : 0) + 6], (unsigned long long)s); }
+#endif
 	if constexpr (FUSED)
 	{
 		if (nr == 0) return;
@@ -979,6 +1004,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 			const int p = idx / 36, q = idx - p * 36, ps = spos[p];
 			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[(6 * (p / HB) + q / 6) * TS + 6 * (p % HB) + q % 6]);
 		}
+		SNT(4);
 	}
 }
 

@@ -261,8 +261,13 @@ def main():
     # per-rank busy time of the timed steps (where a multi-GPU run loses its efficiency): device time of the trees the rank ran
     busy = torch.zeros(world, dtype=torch.float64, device=rdev)
     busy[rank] = acc.get("t_total_ms", 0.0) / args.steps
+    # ... and the wall clock of its three phases (own block, exchange of the slices, feature-sharded top levels), every rank's
+    phases = torch.zeros(world, 3, dtype=torch.float64, device=rdev)
+    for k, name in enumerate(("phase_block_ms", "phase_exchange_ms", "phase_top_ms")):
+        phases[rank, k] = acc.get(name, 0.0) / args.steps
     if world > 1:
         dist.all_reduce(busy, op=dist.ReduceOp.SUM)
+        dist.all_reduce(phases, op=dist.ReduceOp.SUM)
 
     # (feature-sharded top: every rank holds a slice of the final map's features -- the download is collective)
     out = tree.download(full=False) if (world > 1 and args.top == "shard") else (tree.download() if rank == 0 else None)
@@ -325,8 +330,10 @@ def main():
             "upload_note": "upload_ms: building the lsfm_map views of this rank's block in Python + lsfm_tree_upload (pageable host memory -> "
                            "pinned ring -> HBM), before the timed region; upload_c_abi_ms: lsfm_tree_upload alone (lsfm_stats.upload_ms)",
             "per_rank_device_ms": [float(v) for v in busy.tolist()],
-            "rank0_phases_ms": ({k: acc.get(k, 0.0) / args.steps for k in ("phase_block_ms", "phase_exchange_ms", "phase_top_ms")}
-                                if "phase_top_ms" in acc else None),
+            "per_rank_phases_ms": ({"block": [float(v) for v in phases[:, 0].tolist()], "exchange": [float(v) for v in phases[:, 1].tolist()],
+                                    "top": [float(v) for v in phases[:, 2].tolist()],
+                                    "note": "host wall clock per step on every rank: its own block (+ cutting the root into slices), the all-to-all of "
+                                            "the slices (+ unpacking), the feature-sharded top levels"} if "phase_top_ms" in acc else None),
             "device_breakdown_ms": {k: acc.get(k, 0.0) / args.steps for k in
                                     ("t_total_ms", "t_transform_ms", "t_join_ms", "t_schur_ms", "t_pcg_ms", "t_backsub_ms")},
             "pcg_iterations_per_step": acc.get("pcg_iterations", 0) / args.steps,

@@ -9,7 +9,7 @@ python - <<PY
 import json
 try:
     l=[x for x in open("$D/bench_onegpu${n}_$top.log") if x.startswith("{")]
-    d=json.loads(l[0]); print("$n $top", round(d["value"],1), round(d["resolve_ms"],1), [round(v,1) for v in d["per_rank_device_ms"]], d["rank0_phases_ms"], d["max_rel_residual"], d["not_converged"], d["config"]["workload"][-60:])
+    d=json.loads(l[0]); print("$n $top", round(d["value"],1), round(d["resolve_ms"],1), [round(v,1) for v in d["per_rank_device_ms"]], d["per_rank_phases_ms"], d["max_rel_residual"], d["not_converged"], d["config"]["workload"][-60:])
 except Exception as e:
     print("$n $top ERR", e); print(open("$D/bench_onegpu${n}_$top.err").read()[-1500:])
 PY

@@ -142,3 +142,20 @@ def test_device_slice_packs_equal_the_numpy_slices(ctx, mono, n_maps, nslices):
     back = merge_slices(got, order)
     for k in ("stno", "stVal", "V", "W", "photo", "feature", "FBlock"):
         assert np.array_equal(np.asarray(back[k]).reshape(-1), np.asarray(full[k]).reshape(-1)), k
+
+
+def test_comm_buffer_too_small_is_reported(ctx):
+    """The arrays the library sums over the ranks live in the caller's buffer: one that cannot hold a camera system is an
+    error of the call (LSFM_ERR_ARG with the size needed), not a write past its end."""
+    from linearsfm_amd import api
+    from linearsfm_amd.distributed import ShardedTree
+    maps = _make(12, False)
+    st = ShardedTree(ctx, maps, 0, len(maps), False, top="shard", shard_single=True, comm_bytes=4096)
+    try:
+        with pytest.raises(api.LsfmError, match="too small"):
+            st.run()
+    finally:
+        st.close()
+    # the context is usable afterwards
+    out, _, rc = ctx.divide_conquer([dict(m.__dict__) for m in maps], False)
+    assert rc == 0 and out["m"] == 12

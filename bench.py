@@ -165,12 +165,32 @@ def main():
                                                           "(N=1, default configuration sizes only); 0: skip")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself (torch.distributed.run as a CHILD,
+        # before anything here has touched the GPU -- never an exec from a process that has), relays what they print (rank 0's
+        # JSON line) and ends with their status
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # the line's n_gpus must be what was asked for: a launcher that started another number of ranks is an error, not a silent 1-GPU run
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or run `python bench.py --gpus N` alone: it starts them)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("LSFM_BENCH_ONE_GPU"):

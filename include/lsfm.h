@@ -82,6 +82,11 @@ typedef struct lsfm_stats {
 	/* how many times the tree was joined by this call: 1, or more when a run was repeated (a plan or step count of an earlier run
 	 * that did not fit the values, a system left above its bound by an unlucky rounding of its factorisation) */
 	int attempts;
+	/* LSFM_FACTOR_DIGEST=1 in the environment (a debug / test aid, off by default: two more passes over every factor): sums
+	 * modulo 2^64 of the mixed bit patterns of every camera system as assembled (s_digest) and of every Cholesky factor the run
+	 * computed (factor_digest), over all levels.  The factorisation accumulates its updates in fixed point (integer atomics), so two
+	 * runs with equal s_digest have equal factor_digest, whatever order the work-groups ran in. */
+	unsigned long long s_digest, factor_digest;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -144,6 +149,16 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
                     const double* W, const double* V, const int* Ui, const int* Uj, const int* photo,
                     const int* feature, int m, int n, int nU, int nW, int Ref, int ScaP, int Fix, int Sign,
                     int FixBlk, const double* x0);
+
+/* replaces pba_inverseV (Imp.h:213, Imp.cpp:3022-3042): V^-1 of the n 3x3 feature blocks, IN PLACE like the reference's (which
+ * inverts V in place and restores it afterwards, Imp.cpp:2210-2212, 2365): the upper triangle of the computed inverse, mirrored.
+ * m is unused, as in the reference. */
+int lsfm_inverse_v(lsfm_context* ctx, double* V, int m, int n);
+/* replaces pba_solveFeatures (Imp.h:214, Imp.cpp:2980-3020), same argument list + context: the features' back-substitution
+ * dpb_f = IV_f (eb_f - sum_p W_pf^T dpa_p) for given pose values dpa[6m]; IV[9n] as lsfm_inverse_v leaves it, W[18 nW] sorted by
+ * feature with mapCor[f] blocks for feature f (the reference's mapPhoto), photo[nW] their poses.  ea is unused, as in the reference. */
+int lsfm_solve_features(lsfm_context* ctx, const double* W, const double* IV, const double* ea, const double* eb, const double* dpa, double* dpb,
+                        int m, int n, const int* mapCor, const int* photo);
 
 /* Test / debug entry: the BLOCK PATTERN of the camera system S = U - W V^-1 W^T as the device builds it for a joint map
  * given by its index arrays alone (hash set of the pose pairs that share a feature, plus U's pattern; sorted into block

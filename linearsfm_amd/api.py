@@ -36,7 +36,8 @@ class LsfmStats(C.Structure):
                 ("max_rel_residual", C.c_double), ("levels", C.c_int), ("joins", C.c_int), ("transforms", C.c_int),
                 ("not_converged", C.c_int), ("schur_launches", C.c_long), ("trf_launches", C.c_long),
                 ("schur_ms", C.c_double), ("schur_bytes", C.c_double), ("trf_ms", C.c_double), ("trf_bytes", C.c_double),
-                ("schur_flops", C.c_double), ("upload_ms", C.c_double), ("attempts", C.c_int)]
+                ("schur_flops", C.c_double), ("upload_ms", C.c_double), ("attempts", C.c_int),
+                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -105,6 +106,8 @@ def lib():
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
         L.lsfm_schur_pattern.argtypes = [vp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, C.c_int, ip]
         L.lsfm_symbolic_analyse.argtypes = [C.c_int, ip, ip, ip, C.c_int, ip, ip, ip, C.c_int, ip, dp]
+        L.lsfm_inverse_v.argtypes = [vp, dp, C.c_int, C.c_int]
+        L.lsfm_solve_features.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int, C.c_int, ip, ip]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
         L.lsfm_wstream_bench.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, dp]
         _LIB = L
@@ -117,7 +120,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_tree_download", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
-           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse"]
+           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
 
 
 def _c(a, dtype):
@@ -341,6 +344,25 @@ class Context:
         finally:
             self.tree_free(t)
         return out, stats, rc
+
+    def inverse_v(self, V):
+        """lsfm_inverse_v (the reference's pba_inverseV, Imp.cpp:3022): V^-1 of the 3x3 feature blocks, [n, 9]."""
+        IV = np.array(np.asarray(V, np.float64).reshape(-1), copy=True)
+        n = IV.size // 9
+        self._check(lib().lsfm_inverse_v(self._h, _ptr(IV, C.c_double), 0, n), "lsfm_inverse_v")
+        return IV.reshape(n, 9)
+
+    def solve_features(self, j, IV, eb, dpa):
+        """lsfm_solve_features (the reference's pba_solveFeatures, Imp.cpp:2980): the features' back-substitution for the given pose
+        values dpa[6m] on the system of joint-map dict j."""
+        m, n = int(j["m"]), int(j["n"])
+        W = _c(j["W"], np.float64); ph = _c(j["photo"], np.int32); fe = _c(j["feature"], np.int32)
+        cnt = np.bincount(fe, minlength=n).astype(np.int32)
+        IV = _c(IV, np.float64); eb = _c(eb, np.float64); dpa = _c(dpa, np.float64)
+        dpb = np.zeros(3 * n)
+        self._check(lib().lsfm_solve_features(self._h, _ptr(W, C.c_double), _ptr(IV, C.c_double), None, _ptr(eb, C.c_double), _ptr(dpa, C.c_double),
+                                              _ptr(dpb, C.c_double), m, n, _ptr(cnt, C.c_int), _ptr(ph, C.c_int)), "lsfm_solve_features")
+        return dpb
 
     def schur_pattern(self, j):
         """Upper block pattern (rowptr, colidx) of the camera system of a joint map dict, as the device builds it."""

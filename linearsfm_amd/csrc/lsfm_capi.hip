@@ -287,9 +287,16 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				if (no_hints) t->step_hint.clear();
 				ctx->timeline_on = getenv("LSFM_TIMELINE") != nullptr;
 				ctx->timeline.clear();
-				const double t0 = now_ms();
 				ctx->mark("run");
-				tree_pass(ctx, t, st);
+				// feature-sharded run: an error of this rank alone (LSFM_FAIL inside the pass) must still reach the exchange of the flags
+				// below, or its peers would wait there for a sum this rank never joins; it is rethrown after the exchange
+				std::unique_ptr<Error> pass_error;
+				if (ctx->comm)
+				{
+					try { tree_pass(ctx, t, st); }
+					catch (const Error& e) { pass_error.reset(new Error(e)); (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); }
+				}
+				else tree_pass(ctx, t, st);
 				st->t_total_ms = now_ms() - t_begin; // (repeated attempts included; the stage times below are the last attempt's)
 				ctx->mark("end");
 				if (ctx->timeline_on)
@@ -313,7 +320,8 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					Comm& cm = *ctx->comm;
 					cm.restart();
 					long long* d_fl = cm.alloc<long long>(8);
-					long long fl[8] = { rs.tr_err != 0, rs.chol_err != 0, rs.plan_stale != 0, rs.not_converged, rs.undone, 0, 0, 0 };
+					// (st->not_converged: what the levels that recorded a plan reported through the stats; fl[6]: this rank's pass threw)
+					long long fl[8] = { rs.tr_err != 0, rs.chol_err != 0, rs.plan_stale != 0, rs.not_converged, rs.undone, st->not_converged, pass_error ? 1 : 0, 0 };
 					LSFM_CHECK_HIP(hipMemcpyAsync(d_fl, fl, sizeof fl, hipMemcpyHostToDevice, ctx->stream));
 					LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 					cm.allreduce(ctx->stream, d_fl, 8, LSFM_DTYPE_I64);
@@ -324,6 +332,9 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					rs.plan_stale = fl[2] != 0;
 					rs.not_converged = (int)((fl[3] + cm.world - 1) / cm.world); // (every rank solves every system: the count, not its multiple)
 					rs.undone = (int)((fl[4] + cm.world - 1) / cm.world);
+					st->not_converged = (int)((fl[5] + cm.world - 1) / cm.world); // (the same verdict on every rank: the repeat test below reads it)
+					if (pass_error) throw *pass_error;
+					if (fl[6]) LSFM_FAIL(LSFM_ERR_INTERNAL, "another rank of the feature-sharded run failed");
 				}
 				if (rs.floored && getenv("LSFM_DEBUG_CONV")) fprintf(stderr, "[lsfm conv] %d pivot(s) of the separators held at their lower bound in this run\n", rs.floored);
 				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
@@ -353,6 +364,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				st->max_rel_residual = std::max(st->max_rel_residual, rs.max_rel_residual);
 				st->upload_ms = t->upload_ms;
 				st->schur_flops += 108.0 * (double)rs.k2;
+				st->s_digest = rs.s_digest; st->factor_digest = rs.factor_digest;
 				break;
 			}
 			ctx->flush_times();
@@ -735,6 +747,51 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
 	int rc = solve_raw(ctx, stVal, eb, ea, U, W, V, Ui, Uj, photo, feature, m, n, nU, nW, x0, Ref, Fix);
 	if (rc >= 0) stVal[Fix] = Sign;
 	return rc;
+}
+
+int lsfm_inverse_v(lsfm_context* ctx, double* V, int m, int n)
+{
+	(void)m;
+	if (n < 0 || (n && !V)) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas((size_t)n * 400 + ((size_t)64 << 20));
+		ctx->arena[0].reset(); ctx->scratch.reset();
+		double* dV = ctx->arena[0].alloc<double>((size_t)n * 9);
+		double* dIV = ctx->arena[0].alloc<double>((size_t)n * 9);
+		h2d(ctx, dV, V, (size_t)n * 9 * sizeof(double));
+		vinv_only(ctx, n, dV, dIV);
+		d2h(ctx, V, dIV, (size_t)n * 9 * sizeof(double));
+		return LSFM_OK;
+	});
+}
+
+int lsfm_solve_features(lsfm_context* ctx, const double* W, const double* IV, const double* ea, const double* eb, const double* dpa, double* dpb,
+                        int m, int n, const int* mapCor, const int* photo)
+{
+	(void)ea;
+	if (m <= 0 || n < 0 || !dpa || (n && (!W || !IV || !eb || !dpb || !mapCor || !photo))) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		std::vector<int> fptr((size_t)n + 1, 0);
+		for (int f = 0; f < n; f++)
+		{
+			if (mapCor[f] < 0) LSFM_FAIL(LSFM_ERR_ARG, "negative block count of a feature");
+			fptr[f + 1] = fptr[f] + mapCor[f];
+		}
+		const int nW = fptr[n];
+		for (int j = 0; j < nW; j++) if (photo[j] < 0 || photo[j] >= m) LSFM_FAIL(LSFM_ERR_ARG, "photo index out of range");
+		ctx->ensure_arenas((size_t)nW * 200 + (size_t)n * 300 + (size_t)m * 100 + ((size_t)64 << 20));
+		ctx->arena[0].reset(); ctx->scratch.reset();
+		Arena& ar = ctx->arena[0];
+		double* dW = ar.alloc<double>((size_t)nW * 18); int* dph = ar.alloc<int>(nW); int* dfp = ar.alloc<int>((size_t)n + 1);
+		double* dIV = ar.alloc<double>((size_t)n * 9); double* deb = ar.alloc<double>((size_t)n * 3);
+		double* dxp = ar.alloc<double>((size_t)m * 6); double* dxf = ar.alloc<double>((size_t)n * 3);
+		h2d(ctx, dW, W, (size_t)nW * 18 * sizeof(double)); h2d(ctx, dph, photo, (size_t)nW * sizeof(int));
+		h2d(ctx, dfp, fptr.data(), ((size_t)n + 1) * sizeof(int)); h2d(ctx, dIV, IV, (size_t)n * 9 * sizeof(double));
+		h2d(ctx, deb, eb, (size_t)n * 3 * sizeof(double)); h2d(ctx, dxp, dpa, (size_t)m * 6 * sizeof(double));
+		backsub_only(ctx, n, dfp, dph, dW, dIV, deb, dxp, dxf);
+		d2h(ctx, dpb, dxf, (size_t)n * 3 * sizeof(double));
+		return LSFM_OK;
+	});
 }
 
 int lsfm_schur_pattern(lsfm_context* ctx, const int* Ui, const int* Uj, const int* photo, const int* feature, int m, int n, int nU, int nW, int* rowptr,

@@ -118,6 +118,7 @@ struct RunStatsDev {
 	int undone;            // systems whose refinement was enqueued with a step count from an earlier run and had not met its stopping rule when the steps ran out
 	int floored;           // pivots of the separators replaced by their lower bound (static pivoting, lsfm_pcg.hip k_sn_panel)
 	double max_rel_residual;
+	unsigned long long s_digest, factor_digest; // LSFM_FACTOR_DIGEST=1 (lsfm_stats)
 	unsigned long long k2;  // sum over the levels of sum over the features of (W run length)^2: K9's pose pairs, for its algorithmic flop count
 };
 
@@ -385,6 +386,9 @@ struct SolveIO {
 	std::vector<int> seg_rows;         // host: block rows per segment
 };
 int solve_batch(lsfm_context* ctx, const SolveIO& io);
+// the two feature-side pieces of the solve on their own (C ABI: lsfm_inverse_v / lsfm_solve_features); device pointers
+void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV);
+void backsub_only(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb, const double* xp, double* xf);
 // what the early pattern is made from: X = the level's input batch (index arrays only), per joint feature its source
 // features in X (srcE / srcC, -1: none), per map of X its hub pose
 struct EarlyPatternIn {

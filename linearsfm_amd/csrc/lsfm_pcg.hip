@@ -17,6 +17,7 @@
 // With the exact factor CG is iterative refinement: 2-3 iterations to 1e-12.
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <numeric>
@@ -77,7 +78,8 @@ struct CholDev {
 	float* Lgf = nullptr;   // mixed precision: its fp32 copy
 	double* L = nullptr;    // [nnzL*36] block values, column major by blocks, each block row-major 6x6
 	double* Dinv = nullptr; // [M*36] inverse of the diagonal Cholesky factors (lower triangular)
-	double* diag0 = nullptr; // [M*6] diagonal of S as it was scattered (new numbering): the scale a pivot of the separators is held against
+	double* diag0 = nullptr; // [M*6] diagonal of the scaled S as it was scattered (new numbering): what a pivot of the separators is held against
+	double* dscale = nullptr; // [M*6] the scaling D^-1/2 (powers of two; new numbering): right-hand sides enter and solutions leave through it
 	int* d_err = nullptr;
 };
 
@@ -87,10 +89,41 @@ __device__ __forceinline__ int find_row(const int* __restrict__ rowidx, int lo, 
 	return lo;
 }
 
-// A (upper blocks of S, old numbering) -> lower blocks of P S P^T in L's storage
-__global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ keys, const double* __restrict__ S, const int* __restrict__ pinv,
-                               const int* __restrict__ colptr, const int* __restrict__ rowidx, const unsigned char* __restrict__ fixed,
-                               double* __restrict__ L, double* __restrict__ diag0)
+// ---------------------------------------------------------------------------------------------------------------
+// Scaled matrix, fixed-point accumulators.  The factorisation works on  D^-1/2 (P S P^T) D^-1/2  with D the diagonal of S rounded
+// to powers of four: an exact scaling (no rounding: Cholesky commutes with it), after which every diagonal entry lies in
+// [1/8, 1) and -- the matrix and all its Schur complements being positive definite -- every entry, and every partial sum of
+// the updates  sum_k l_ik l_jk  an entry ever receives (Cauchy-Schwarz over any subset of the columns), lies in (-1, 1).
+// The blocks of the supernode-group columns, the ones several work-groups of a launch add to, are therefore kept as 64-bit
+// FIXED-POINT numbers in units of 2^-61 while they accumulate: integer atomics are associative, so the sum no longer depends
+// on the order the atomics land in (two runs on the same S give the same factor bit for bit; round 3's fp64 atomics made the
+// root system of a 16 384-map monocular tree come out indefinite in one run out of fifteen), and it is more accurate than
+// the fp64 sum it replaces: every addend is rounded once to 2^-62 of the diagonal, instead of every partial sum to 2^-53 of
+// its own size.  The panel kernel converts a block back when it loads it.  Leaf columns (one work-group owns each: no
+// atomics) stay doubles.  Right-hand sides enter scaled (k_perm_in) and leave unscaled (k_perm_out_dot).
+// ---------------------------------------------------------------------------------------------------------------
+#define FX_ONE 0x1p61
+#define FX_INV 0x1p-61
+__device__ __forceinline__ long long fx_from(double v) { return __double2ll_rn(fmin(fmax(v, -2.0), 2.0) * FX_ONE); }
+__device__ __forceinline__ double fx_to(long long a) { return (double)a * FX_INV; }
+__device__ __forceinline__ void fx_atomic_sub(double* slot, double t)
+{
+	// (no return value used: global_atomic_add_u64 without a round trip)
+	__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)fx_from(-t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// power of two s with s^2 d in [1/8, 1): the scale of a scalar row / column whose diagonal entry is d
+__device__ __forceinline__ int scale_exp(double d)
+{
+	if (!(d > 0) || !(d < 1e300)) return 0; // (not positive definite: reported by the pivot test)
+	return (__builtin_amdgcn_frexp_exp(d) + 1) >> 1;
+}
+
+// A (upper blocks of S, old numbering) -> lower blocks of the scaled P S P^T in L's storage (fixed point in the group columns:
+// col_task[j] >= ntask0), its diagonal to diag0, the scale factors to dscale
+__global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ keys, const double* __restrict__ S, const int* __restrict__ srow,
+                               const int* __restrict__ pinv, const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                               const unsigned char* __restrict__ fixed, const int* __restrict__ col_task, int ntask0, double* __restrict__ L,
+                               double* __restrict__ diag0, double* __restrict__ dscale)
 {
 	int e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= nnzb) return;
@@ -103,13 +136,25 @@ __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ 
 	const double* s = S + (size_t)e * 36;
 	double* d = L + (size_t)pos * 36;
 	const int rowp = tr ? q : p, colp = tr ? p : q; // old indices of the block's rows / columns
+	// scales from the diagonal blocks of S (the first block of every block row)
+	const double* dr = S + (size_t)srow[rowp] * 36;
+	const double* dc = S + (size_t)srow[colp] * 36;
+	int kr[6], kc[6];
+	for (int r = 0; r < 6; r++)
+	{
+		kr[r] = scale_exp((fixed && fixed[(size_t)rowp * 6 + r]) ? 1.0 : dr[r * 7]);
+		kc[r] = scale_exp((fixed && fixed[(size_t)colp * 6 + r]) ? 1.0 : dc[r * 7]);
+	}
+	const bool fx = col_task[j] >= ntask0;
 	for (int r = 0; r < 6; r++)
 		for (int c = 0; c < 6; c++)
 		{
 			double v = tr ? s[c * 6 + r] : s[r * 6 + c];
 			if (fixed && (fixed[(size_t)rowp * 6 + r] || fixed[(size_t)colp * 6 + c])) v = (rowp == colp && r == c) ? 1.0 : 0.0;
-			d[r * 6 + c] = v;
-			if (i == j && r == c) diag0[(size_t)j * 6 + r] = v;
+			v = ldexp(v, -(kr[r] + kc[c]));
+			if (fx) reinterpret_cast<long long*>(d)[r * 6 + c] = fx_from(v);
+			else d[r * 6 + c] = v;
+			if (i == j && r == c) { diag0[(size_t)j * 6 + r] = v; dscale[(size_t)j * 6 + r] = ldexp(1.0, -kr[r]); }
 		}
 }
 
@@ -224,6 +269,7 @@ __device__ void chol_column_update_inner(int j, int m, const int* __restrict__ c
 // work-group adds block after block with consecutive lanes on consecutive doubles (one lane per block scatters 64
 // rows per wave instruction: ~0.1 TB/s)
 #define CHOL_OUT_THREADS 128
+template <bool FX>
 __device__ void chol_column_update_outer(int j, int m, const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L, int first, int stride)
 {
 	__shared__ double sT[CHOL_OUT_THREADS * 37];
@@ -258,7 +304,11 @@ __device__ void chol_column_update_outer(int j, int m, const int* __restrict__ c
 		{
 			const int p = idx / 36, q = idx - p * 36;
 			const int ps = spos[p];
-			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[p * 37 + q]);
+			if (ps >= 0)
+			{
+				if (FX) fx_atomic_sub(L + (size_t)ps * 36 + q, sT[p * 37 + q]); // (targets are supernode-group columns: fixed point)
+				else atomic_add_f64(L + (size_t)ps * 36 + q, -sT[p * 37 + q]);
+			}
 		}
 		__syncthreads();
 	}
@@ -361,12 +411,13 @@ __device__ void chol_factor_task_global(int task, const int* __restrict__ task_p
 	}
 }
 // the deferred updates of the level's tasks, into the columns above them: one column per blockIdx.x, pairs split over blockIdx.y
+template <bool FX>
 __global__ void __launch_bounds__(CHOL_OUT_THREADS) k_chol_update_outer(const int* __restrict__ cols, const int* __restrict__ col_nin,
                                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                                                          double* __restrict__ L)
 {
 	const int j = cols[blockIdx.x];
-	chol_column_update_outer(j, col_nin[j], colptr, rowidx, L, blockIdx.y * CHOL_OUT_THREADS, gridDim.y * CHOL_OUT_THREADS);
+	chol_column_update_outer<FX>(j, col_nin[j], colptr, rowidx, L, blockIdx.y * CHOL_OUT_THREADS, gridDim.y * CHOL_OUT_THREADS);
 }
 // Triangular solves by task.  The entries of v that belong to the task's own columns live in LDS while the work-group
 // walks the task: a column step inside a task then costs LDS latency instead of a global atomic + fence round trip
@@ -696,6 +747,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	// diagonal rows, lanes 128..223 (two other waves, other SIMDs) the panel rows: the same recurrence, in step
 	__shared__ double sD[36];
 	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
+	__shared__ double sFl[6 * CHOL_GS];   // diagonal of the (scaled) S at the run's columns: what a pivot is held against
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
 	__shared__ int sRow[SN_RB];  // common row (position below the run) of every panel slot, -1: empty slot
 	__shared__ int spos[(SN_RB / 2) * (SN_RB / 2)]; // FUSED: block of L every (a, b) product goes to, -1: none
@@ -720,6 +772,8 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	const int nb = s * (s + 1) / 2, n6 = 6 * s;
 	// where every block of the run's diagonal part sits in the block storage / in the dense rows (one lane per block)
 	for (int t = tid; t < s; t += nt) sCol[t] = colptr[c0 + t];
+	// (fetched here, once: in the column loop this load sat between the two barriers of every block column -- a memory round trip per column)
+	for (int t = tid; t < 6 * s; t += nt) sFl[t] = diag0[(size_t)c0 * 6 + t];
 	if (tid < SN_RB)
 	{
 		int row;
@@ -758,34 +812,35 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	}
 	__syncthreads();
 	SNT(0);
-	// blocks -> dense rows, two doubles per load, SN_LD loads in flight per lane (a dependent load costs ~1.5 us)
-	const int nd2 = nb * 18, np2 = SN_RB * s * 18; // pairs of doubles: diagonal part, panel slots
+	// blocks -> dense rows, two numbers per load, SN_LD loads in flight per lane (a dependent load costs ~1.5 us).  The blocks are
+	// the fixed-point accumulators of the group columns: converted as they are stored to LDS
+	const int nd2 = nb * 18, np2 = SN_RB * s * 18; // pairs of numbers: diagonal part, panel slots
 	for (int base = 0; base < nd2 + np2; base += nt * SN_LD)
 	{
-		double2 v[SN_LD];
+		longlong2 v[SN_LD];
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
 			const int q = base + i * nt + tid;
-			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const double2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
+			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const longlong2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
 			else if (q < nd2 + np2)
 			{
 				const int qq = q - nd2, blk = qq / 18, il = blk / s, t = blk - il * s, row = sRow[il];
-				if (row >= 0) v[i] = *reinterpret_cast<const double2*>(L + (size_t)(sCol[t] + (s - t) + row) * 36 + 2 * (qq - blk * 18));
+				if (row >= 0) v[i] = *reinterpret_cast<const longlong2*>(L + (size_t)(sCol[t] + (s - t) + row) * 36 + 2 * (qq - blk * 18));
 			}
 		}
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
 			const int q = base + i * nt + tid;
-			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * xs + w % 6]; d[0] = v[i].x; d[1] = v[i].y; }
+			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * xs + w % 6]; d[0] = fx_to(v[i].x); d[1] = fx_to(v[i].y); }
 			else if (q < nd2 + np2)
 			{
 				const int qq = q - nd2, blk = qq / 18, w = 2 * (qq - blk * 18), il = blk / s, t = blk - il * s;
 				if (sRow[il] >= 0)
 				{
 					double* d = &Xs[(6 * il + w / 6) * xs + 6 * t + w % 6];
-					d[0] = v[i].x; d[1] = v[i].y;
+					d[0] = fx_to(v[i].x); d[1] = fx_to(v[i].y);
 				}
 			}
 		}
@@ -802,9 +857,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	for (int t = 0; t < s; t++)
 	{
 		const int k0 = 6 * t;
-		double a[6], flr[6]; // (the pivot bounds of the column: fetched here, used after the barrier -- not on the critical path)
-#pragma unroll
-		for (int k = 0; k < 6; k++) flr[k] = diag0[(size_t)(c0 + t) * 6 + k];
+		double a[6];
 		const bool mine = panel_lane || (ri >= k0 && ri < n6);
 		if (mine)
 		{
@@ -851,7 +904,8 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 				// below by piv_floor x the entry S had: the factor is the exact factor of S plus a small perturbation in those one
 				// or two directions, which the CG around it removes in a few steps.  Only a pivot that is negative on the scale
 				// of S itself (or not a number) means the system is not positive definite.
-				const double fl = piv_floor * flr[k], neg = piv_floor > 0 ? -0.01 * flr[k] : 0.0; // (piv_floor = 0: any non-positive pivot is an error)
+				const double flr = sFl[k0 + k];
+				const double fl = piv_floor * flr, neg = piv_floor > 0 ? -0.01 * flr : 0.0; // (piv_floor = 0: any non-positive pivot is an error)
 				if (!(pv > fl))
 				{
 					if (!(pv == pv) || !(pv > neg) || !(fl > 0)) { bad = true; pv = 1.0; }
@@ -1002,7 +1056,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		for (int idx = tid; idx < HB * HB * 36; idx += nt)
 		{
 			const int p = idx / 36, q = idx - p * 36, ps = spos[p];
-			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[(6 * (p / HB) + q / 6) * TS + 6 * (p % HB) + q % 6]);
+			if (ps >= 0) fx_atomic_sub(L + (size_t)ps * 36 + q, sT[(6 * (p / HB) + q / 6) * TS + 6 * (p % HB) + q % 6]);
 		}
 		SNT(4);
 	}
@@ -1062,7 +1116,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 		{
 			const int p = idx / 36, q = idx - p * 36;
 			const int ps = spos[p];
-			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[p * 37 + q]);
+			if (ps >= 0) fx_atomic_sub(L + (size_t)ps * 36 + q, sT[p * 37 + q]);
 		}
 		__syncthreads();
 	}
@@ -1181,7 +1235,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_syrk(const int* __restrict__ 
 		for (int idx = tid; idx < HB * HB * 36; idx += nt)
 		{
 			const int pp = idx / 36, q = idx - pp * 36, ps = spos[pp];
-			if (ps >= 0) atomic_add_f64(L + (size_t)ps * 36 + q, -sT[(6 * (pp / HB) + q / 6) * TS + 6 * (pp % HB) + q % 6]);
+			if (ps >= 0) fx_atomic_sub(L + (size_t)ps * 36 + q, sT[(6 * (pp / HB) + q / 6) * TS + 6 * (pp % HB) + q % 6]);
 		}
 		__syncthreads(); // spos and the staged products are overwritten by the next pair
 	}
@@ -1388,18 +1442,19 @@ __global__ void k_to_float(size_t n, const double* __restrict__ a, float* __rest
 	if (i < n) b[i] = (float)a[i];
 }
 
+// v = D^-1/2 P r  (the factor is the scaled matrix's: k_chol_scatter)
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
-                          double* __restrict__ v)
+                          const double* __restrict__ dscale, double* __restrict__ v)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (size_t)M * 6) return;
 	const size_t src = (size_t)perm[i / 6] * 6 + i % 6;
-	v[i] = (fixed && fixed[src]) ? 0.0 : r[src];
+	v[i] = (fixed && fixed[src]) ? 0.0 : r[src] * dscale[i];
 }
-// z = P^T v ; rz[nxt] += r . z
+// z = P^T D^-1/2 v ; rz[nxt] += r . z
 __global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double* __restrict__ v, const double* __restrict__ r,
-                               const unsigned char* __restrict__ fixed, const int* __restrict__ pose_seg, double* __restrict__ z, double* dot,
-                               int dot_stride)
+                               const unsigned char* __restrict__ fixed, const double* __restrict__ dscale, const int* __restrict__ pose_seg,
+                               double* __restrict__ z, double* dot, int dot_stride)
 {
 	int row = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool ok = row < M;
@@ -1409,9 +1464,10 @@ __global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double
 	{
 		sg = pose_seg[row];
 		const double* src = v + (size_t)pinv[row] * 6;
+		const double* sc = dscale + (size_t)pinv[row] * 6;
 		for (int i = 0; i < 6; i++)
 		{
-			double zz = src[i];
+			double zz = src[i] * sc[i];
 			if (fixed && fixed[(size_t)row * 6 + i]) zz = 0.0;
 			z[(size_t)row * 6 + i] = zz;
 			acc = fma(zz, r[(size_t)row * 6 + i], acc);
@@ -1446,8 +1502,11 @@ static void chol_alloc_values(lsfm_context* ctx, CholDev& ch)
 	ch.L = sc.alloc<double>((size_t)ch.nnzL * 36); ch.Dinv = sc.alloc<double>((size_t)ch.M * 36);
 	ch.wv = sc.alloc<double>((size_t)ch.M * 6);
 	ch.diag0 = sc.alloc<double>((size_t)ch.M * 6);
+	ch.dscale = sc.alloc<double>((size_t)ch.M * 6);
 	ch.Lg = ch.ngroups ? sc.alloc<double>((size_t)ch.nnzL * 36) : nullptr; // (every block of a group column is written by the factorisation)
 	dev_zero(ctx, ch.L, (size_t)ch.nnzL * 36 * sizeof(double));
+	static const bool digest = getenv("LSFM_FACTOR_DIGEST") != nullptr; // (the digest reads all of Lg: the leaf columns' slots, never written, must not be noise)
+	if (digest && ch.Lg) dev_zero(ctx, ch.Lg, (size_t)ch.nnzL * 36 * sizeof(double));
 }
 
 // What a first solve of a tree level leaves for the next runs of the same tree (LevelPlan::solve): the block pattern of S
@@ -1478,7 +1537,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	SolvePlan& P = *sp;
 	P.sy = sy; P.ch = ch; P.its = its; P.mixed = ch.Lf != nullptr; P.rel_tol = ctx->pcg.rel_tol;
 	P.sy.S = nullptr; P.sy.E = nullptr; P.sy.IV = nullptr;
-	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.Lg = nullptr; P.ch.Lgf = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr; P.ch.Lf = nullptr; P.ch.Dinvf = nullptr;
+	P.ch.L = nullptr; P.ch.Dinv = nullptr; P.ch.diag0 = nullptr; P.ch.dscale = nullptr; P.ch.Lg = nullptr; P.ch.Lgf = nullptr; P.ch.d_err = nullptr; P.ch.wv = nullptr; P.ch.Lf = nullptr; P.ch.Dinvf = nullptr;
 	std::vector<Item> items = {
 		{ sy.rowptr, (M + 1) * 4, (void**)&P.sy.rowptr }, { sy.colidx, (nnzb + 1) * 4, (void**)&P.sy.colidx },
 		{ sy.upper_keys, nnzb * 8, (void**)&P.sy.upper_keys }, { sy.longrows, (M + 1) * 4, (void**)&P.sy.longrows },
@@ -1689,12 +1748,20 @@ static bool chol_group_solve(const CholDev& ch)
 
 // fwd_v != null (chol_group_solve(ch) holds): a right-hand side in elimination order; on return it holds what the forward
 // substitution leaves (leaf columns in place, group columns in ch.wv) -- chol_apply(..., fwd_done) does the rest
+// the scaled, permuted S into the factor's storage; also leaves the scaling (ch.dscale) that k_perm_in / k_perm_out_dot apply:
+// before anything is permuted in
+static void chol_scatter(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch)
+{
+	static const bool groups = !getenv("LSFM_NO_GROUPS");
+	// (the columns above the leaf tasks -- what the supernode groups factor -- accumulate in fixed point; LSFM_NO_GROUPS: none does)
+	const int ntask0 = (groups && ch.tlevel_ptr.size() > 1) ? ch.tlevel_ptr[1] : INT_MAX;
+	if (sy.nnzb)
+		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, ctx->stream, sy.nnzb, sy.upper_keys, sy.S, sy.rowptr, ch.pinv, ch.colptr, ch.rowidx,
+		                   fixed, ch.col_task, ntask0, ch.L, ch.diag0, ch.dscale);
+}
 static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch, double* fwd_v = nullptr)
 {
 	hipStream_t s = ctx->stream;
-	if (sy.nnzb)
-		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, s, sy.nnzb, sy.upper_keys, sy.S, ch.pinv, ch.colptr, ch.rowidx,
-		                   fixed, ch.L, ch.diag0);
 	static const bool groups = !getenv("LSFM_NO_GROUPS");
 	for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
 	{
@@ -1706,7 +1773,12 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(l ? 256 : 128), nsm ? (size_t)ch.tlevel_small_lds[l] : 0, s, nsm, ch.task_ptr + ch.tlevel_ptr[l],
 		                   ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
 		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
-		if (mp > 0) hipLaunchKernelGGL(k_chol_update_outer, dim3(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64)), dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
+		if (mp > 0)
+		{
+			const dim3 grid(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64));
+			if (groups) hipLaunchKernelGGL(k_chol_update_outer<true>, grid, dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
+			else hipLaunchKernelGGL(k_chol_update_outer<false>, grid, dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
+		}
 	}
 	if (fwd_v)
 	{
@@ -1769,7 +1841,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 static void chol_perm_in(lsfm_context* ctx, const CholDev& ch, const double* r, const unsigned char* fixed, double* v)
 {
 	const size_t ns = (size_t)ch.M * 6;
-	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ch.M, ch.perm, r, fixed, v);
+	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ch.M, ch.perm, r, fixed, ch.dscale, v);
 }
 
 // fwd_done: v already went through the forward substitution (chol_factor with fwd_v)
@@ -1806,7 +1878,7 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		};
 		if (ch.Lf) sweep(float(), (const float*)ch.Lf, (const float*)ch.Lgf, (const float*)ch.Dinvf); // mixed precision: the factor applied in fp32
 		else sweep(double(), (const double*)ch.L, (const double*)ch.Lg, (const double*)ch.Dinv);
-		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
+		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride);
 		return;
 	}
 	if (task_solve && (size_t)task_max * CHOL_TASK_LDS_PER_COL <= 56 * 1024) // a task's per-column data must fit LDS; else one launch per tree level
@@ -1822,7 +1894,7 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
 			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 		}
-		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
+		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride);
 		return;
 	}
 	for (int l = 0; l < ch.nlevels; l++)
@@ -1837,7 +1909,7 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
 		if (n) hipLaunchKernelGGL(k_chol_bwd_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 	}
-	hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, pose_seg, z, dot, dot_stride);
+	hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2011,6 +2083,19 @@ __global__ void k_pcg_debug(int nseg, int M, const PcgSeg* __restrict__ seg)
 		printf("[lsfm conv] M=%d nseg=%d system %d: rel %.3e its %d done %d slow %d rr_prev/ee %.3e thresh/ee %.3e ee %.3e pAp %.3e rz %.3e %.3e\n", M, nseg, g, rel, seg[g].its,
 		       seg[g].done, seg[g].slow, seg[g].rr_prev / fin.ee, seg[g].thresh / fin.ee, fin.ee, seg[g].pAp, seg[g].rz[0], seg[g].rz[1]);
 }
+// LSFM_FACTOR_DIGEST=1: order-independent digest of an array of 8-byte words (a sum modulo 2^64 of position-mixed bit patterns)
+__global__ void k_digest(size_t n, const unsigned long long* __restrict__ a, unsigned long long* out)
+{
+	unsigned long long h = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+	{
+		unsigned long long b = a[i];
+		if (b == 0x8000000000000000ull) b = 0; // (-0.0 == 0.0)
+		b ^= b >> 31; b *= 0x9E3779B97F4A7C15ull * (2 * (unsigned long long)i + 1); b ^= b >> 29;
+		h += b;
+	}
+	atomicAdd(out, h);
+}
 __global__ void k_chol_err_to_run(const int* err, RunStatsDev* run)
 {
 	if (*err && !run->chol_err) run->chol_err = *err;
@@ -2070,6 +2155,8 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		std::shared_ptr<void> pre_keep = ctx->pre;
 		ctx->pre.reset();
 		PreLevel* pre = static_cast<PreLevel*>(pre_keep.get());
+		// (drop_prepared() no longer sees the object: whatever throws below, it must not go while the helper thread still works on it)
+		struct PreGuard { lsfm_context* c; PreLevel* p; ~PreGuard() { try { pre_wait(c, p); } catch (...) {} } } pre_guard{ ctx, pre };
 		if (pre && !(pre->M == M && !ctx->comm)) pre_wait(ctx, pre); // (not used: nothing of it may go while the helper thread reads it)
 		if (pre && pre->M == M && !ctx->comm)
 		{
@@ -2189,6 +2276,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 1);
 	const bool mixed = ctx->pcg.mixed;
 	const bool fused_fwd = !mixed && chol_group_solve(ch); // (mixed: the factor is applied from its fp32 copy, made after the factorisation)
+	chol_scatter(ctx, sy, io.d_fixed, ch);
 	if (fused_fwd) chol_perm_in(ctx, ch, r, io.d_fixed, v);
 	chol_factor(ctx, sy, io.d_fixed, ch, fused_fwd ? v : nullptr);
 	if (mixed)
@@ -2205,6 +2293,18 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		}
 		hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, nd, ch.Dinv, ch.Dinvf);
 	}
+	static const bool digest = getenv("LSFM_FACTOR_DIGEST") != nullptr;
+	if (digest && ctx->d_run)
+	{
+		auto dg = [&](const double* a, size_t n, unsigned long long* out) {
+			if (a && n) hipLaunchKernelGGL(k_digest, dim3(256), dim3(256), 0, s, n, reinterpret_cast<const unsigned long long*>(a), out);
+		};
+		dg(sy.S, (size_t)sy.nnzb * 36, &ctx->d_run->s_digest);
+		// leaf columns: factored in place in L; group columns: in Lg (their slots of L hold the spent accumulators: integers, summed alike)
+		dg(ch.Dinv, (size_t)ch.M * 36, &ctx->d_run->factor_digest);
+		dg(ch.L, (size_t)ch.nnzL * 36, &ctx->d_run->factor_digest);
+		if (ch.Lg) dg(ch.Lg, (size_t)ch.nnzL * 36, &ctx->d_run->factor_digest);
+	}
 	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
 	double tw2 = wall();
 	chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[0], SEG_STRIDE, fused_fwd);
@@ -2220,7 +2320,10 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		const int cerr = d2h_int(ctx, d_err);
 		if (cerr) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
 	};
-	if (deferred) hipLaunchKernelGGL(k_chol_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run); // reported at the end of the run
+	// (a feature-sharded run never throws for it in the middle of a pass: the ranks' factorisations are their own, and a rank that left
+	// the pass alone would leave its peers in a sum it never joins -- the flags are exchanged at the end of the run)
+	const bool err_to_run = deferred || (ctx->comm && ctx->d_run);
+	if (err_to_run) hipLaunchKernelGGL(k_chol_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run); // reported at the end of the run
 
 	// One refinement step: x += alpha p, true residual, convergence test per system (converged systems freeze), then the
 	// preconditioner for the next step.  A first run reads the number of finished systems back after every step; a warm
@@ -2257,7 +2360,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			ctx->mark("cg_enq");
 			ndone = d2h_int(ctx, d_misc + 1);
 			ctx->mark("cg_sync");
-			if (its == 1 && !deferred) check_factor(); // (the stream is drained: this costs no second wait)
+			if (its == 1 && !err_to_run) check_factor(); // (the stream is drained: this costs no second wait)
 			if (ndone >= nseg) break;
 		}
 		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
@@ -2344,6 +2447,22 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		if (!(rel < 1e-8) || (hs2[g].done != 1 && !(rel < 1e-9))) notconv++;
 	}
 	if (ctx->stats) ctx->stats->max_rel_residual = std::max(ctx->stats->max_rel_residual, maxrel);
+	if (ctx->comm)
+	{
+		// feature-sharded run: the verdict (and with it whether this level keeps a plan, i.e. whether the NEXT run of the level is
+		// warm) must be the same on every rank -- a rank that is cold alone would issue pattern all-reduces nobody joins.  Every
+		// rank solved the same system; the residuals they computed differ in the last bit at most, but a count taken at a
+		// threshold may: summed over the ranks, any rank's doubt is everybody's.
+		Comm& cm = *ctx->comm;
+		long long* d_v = cm.alloc<long long>(2);
+		long long hv[2] = { notconv, 0 };
+		LSFM_CHECK_HIP(hipMemcpyAsync(d_v, hv, sizeof hv, hipMemcpyHostToDevice, s));
+		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		cm.allreduce(s, d_v, 2, LSFM_DTYPE_I64);
+		LSFM_CHECK_HIP(hipMemcpyAsync(hv, d_v, sizeof hv, hipMemcpyDeviceToHost, s));
+		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		notconv = (int)((hv[0] + cm.world - 1) / cm.world);
+	}
 	// what depends on the structure only stays with the tree level for its next runs
 	if (lp && !lp->solve && notconv == 0) lp->solve = solve_plan_store(ctx, sy, ch, std::max(its, 1));
 	return notconv;

@@ -1152,6 +1152,24 @@ void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy,
 		                   io.d_feat_seg, io.d_seg_active, io.x_feat);
 }
 
+void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV)
+{
+	if (!NF) return;
+	const size_t mk = ctx->scratch.mark();
+	double* LY = ctx->scratch.alloc<double>((size_t)NF * 9);
+	double* eb = ctx->scratch.alloc<double>((size_t)NF * 3);
+	dev_zero(ctx, eb, (size_t)NF * 3 * sizeof(double));
+	hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, ctx->stream, NF, V, eb, IV, LY);
+	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+	ctx->scratch.release(mk);
+}
+void backsub_only(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb, const double* xp, double* xf)
+{
+	if (NF)
+		hipLaunchKernelGGL(k_backsub, dim3((NF + BSUB_TILE - 1) / BSUB_TILE), dim3(256), 0, ctx->stream, NF, fptr, photo, W, IV, eb, xp,
+		                   (const int*)nullptr, (const unsigned char*)nullptr, xf);
+}
+
 // y = S x for an externally supplied symmetric block matrix (upper block CSR): measurement entry of the C ABI
 int spmv_external(lsfm_context* ctx, int m, const int* rowptr, const int* colidx, const double* val, const double* x, double* y, int reps,
                   double* avg_ms, double* bytes)

@@ -452,13 +452,17 @@ class ShardedTree:
             else:
                 allt = [t]
             self.slice_sizes = [[int(v) for v in a.tolist()] for a in allt]
+        elif [int(v) for v in mine] != self.slice_sizes[me]:
+            raise RuntimeError("the slices of this rank's sub-tree root changed their sizes between two runs of a resident tree")
         self._exchange_slices(self.slice_sizes)
         parts = [(self.slice_out[me] if b == me else self.slice_in[b]) for b in range(G) if self.nonempty[b]]
         ptrs = [b.data_ptr() for b in parts]
         if self.top_tree is None:
             self.top_tree = ctx.tree_upload_dev(ptrs, self.mono)
             ctx.tree_set_plans(self.top_tree, self.plans)
-            self.comm_buf = torch.zeros(self.comm_bytes, dtype=torch.uint8, device=self.device)
+            # (not zeroed: the library zeroes every region it carves out, on its own stream -- a fill on torch's stream would race it)
+            self.comm_buf = torch.empty(self.comm_bytes, dtype=torch.uint8, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
             self.comm_cb = self._allreduce_callback()
             ctx.tree_set_comm(self.top_tree, me, G, self.comm_cb, self.comm_buf.data_ptr(), self.comm_bytes)
         else:
@@ -511,6 +515,20 @@ class ShardedTree:
         """Returns (stats of the last tree run on this rank or None, worst return code on this rank)."""
         if self.top == "shard":
             return self._run_shard()
+        try:
+            return self._run_merge()
+        finally:
+            # whatever ended the run: no receive posted by it may be left behind (the next run posts its own, and untagged
+            # messages would then meet the wrong buffers)
+            for slot in list(self.pending):
+                _, _, w0, w1 = self.pending.pop(slot)
+                for w in (w0, w1):
+                    try:
+                        w.wait()
+                    except Exception:
+                        pass
+
+    def _run_merge(self):
         ctx = self.ctx
         cur, stats, worst = None, None, 0
         # the partners' nodes may start travelling as soon as they exist: post every receive of this run whose buffer is known

@@ -8,6 +8,12 @@ MAPKEYS = ("Ref", "FRef", "m", "n", "ScaP", "Fix", "Sign", "FScaP", "FFix", "stn
            "photo", "feature", "V", "FBlock")
 
 
+# fixtures made by the REAL reference (tests/golden/make_golden.py): whole small trees (every join, every re-anchoring transform,
+# inputs and result), and the top joins of two mid-size trees (m = 64-90 poses, lap closures, features with 20-30 W blocks)
+GOLD_SMALL = ["stereo_n2.npz", "stereo_n3.npz", "stereo_n5.npz", "stereo_n8.npz", "mono_n2.npz", "mono_n3.npz", "mono_n5.npz", "mono_n8.npz"]
+GOLD_MID = ["stereo_n64_top1.npz", "mono_n88_top2.npz"]
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
@@ -85,6 +91,22 @@ def pose_param_err(stA, stB, stno):
     mask = stno <= 0
     a, b = np.asarray(stA)[mask], np.asarray(stB)[mask]
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def pose_param_true_rel_err(stA, stB, stno):
+    """max over pose scalars of |a-b| / |b| -- the relative error proper, without the unit floor of pose_param_err; scalars
+    smaller than 1e-3 of the largest of their kind (translations / angles) are held against that 1e-3 instead (a relative
+    error of a number that happens to be ~0 says nothing)."""
+    stno = np.asarray(stno)
+    mask = stno <= 0
+    a, b = np.asarray(stA)[mask].reshape(-1, 6), np.asarray(stB)[mask].reshape(-1, 6)
+    if not a.size:
+        return 0.0
+    worst = 0.0
+    for cols in (slice(0, 3), slice(3, 6)):
+        fl = 1e-3 * max(1e-300, float(np.max(np.abs(b[:, cols]))))
+        worst = max(worst, float(np.max(np.abs(a[:, cols] - b[:, cols]) / np.maximum(fl, np.abs(b[:, cols])))))
+    return worst
 
 
 def feat_param_err(stA, stB, stno):

@@ -43,6 +43,7 @@ from refdump import read_dump, sub  # noqa: E402
 from common import dense_reference_solve  # noqa: E402
 
 REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+MID_STEREO_PATH = dict(lap=16, home=4, revisit=0.5)  # laps of 16 frames that all start and end at the same place: the top join closes them
 MAPKEYS = ("Ref", "FRef", "m", "n", "ScaP", "Fix", "Sign", "FScaP", "FFix", "stno", "stVal", "U", "Ui", "Uj", "W",
            "photo", "feature", "V", "FBlock")
 
@@ -63,7 +64,7 @@ def write_blobs(path, arrays):
             f.write(a.tobytes())
 
 
-def solve_stage_pins(typ, mono, J, eP, eF, sa, sr, store, tag, tmp):
+def solve_stage_pins(typ, mono, J, eP, eF, sa, sr, store, tag, tmp, tol=1e-10):
     """dense_sol + the real reference's CHOLMOD-free solve-stage methods on the reference-assembled system; the oracle's
     restatement of each piece is checked against them on the spot."""
     m, n = int(J["m"]), int(J["n"])
@@ -102,7 +103,7 @@ def solve_stage_pins(typ, mono, J, eP, eF, sa, sr, store, tag, tmp):
     assert rc == 0 and rcx == 0
     e_d = float(np.max(np.abs(st - xd) / np.maximum(1, np.abs(xd))))
     e_x = float(np.max(np.abs(stx - xd) / np.maximum(1, np.abs(xd))))
-    assert e_d < 1e-10 and e_x < 1e-10, (tag, e_d, e_x)  # the twin inverts V in long double, dense_sol uses the fp64 parts.IV
+    assert e_d < tol and e_x < tol, (tag, e_d, e_x)  # the twin inverts V in long double, dense_sol uses the fp64 parts.IV
     return worst, e_d, e_x
 
 
@@ -193,6 +194,89 @@ def run(typ, maps, out_path, tmp):
           f"{worst_solve[0]:.2e} (long double twin {worst_solve[1]:.2e}), {os.path.getsize(out_path) / 1024:.0f} KiB")
 
 
+def run_top(typ, maps, out_path, tmp, keep):
+    """Mid-size fixtures: the same tree, but only its LAST `keep` joins are stored (their inputs A and B come from the oracle's
+    evaluation of the levels below -- they are just inputs; what is pinned is what the REAL reference makes of them): join{k}.A/B,
+    end.* (lmj_Transform_PF3D*), solve.* (what lmj_LinearLS_PF3D* assembled), joint.*, parts.IV / parts.dpb / parts.Ap / parts.Aii
+    (pba_inverseV, pba_solveFeatures, pba_constructAuxCSS*), dense_sol.  The scalar CSC of S (parts.Sx, ~nnzb * 36 * 12 bytes) and S
+    itself are NOT stored at this size (the small fixtures pin pba_constructCSS*).  Joins this far up have m = 40-90 poses, features
+    with dozens of W blocks and lap-closure matches: the sizes at which the device takes its 32/48/64-slot Schur panels, k_schur_w,
+    the supernode groups of the factorisation and the 64-entry pose table of the Mono transform."""
+    mono = typ == "Monocular"
+    LM = [po.localmap_to_dict(m) for m in maps]
+    # which joins are the last `keep`: count them first
+    total, c = 0, len(LM)
+    while c > 1:
+        total += c // 2
+        c = (c + 1) // 2
+    first_kept = total - keep
+    store = {"type": np.array(typ), "N": np.array(len(maps)), "njoins": np.array(keep)}
+    count, L, step, worst = len(LM), 0, 0, 0.0
+    worst_solve = [0.0, 0.0]
+    while count > 1:
+        N2 = count % 2
+        count = int(count / 2.0 + 0.5)
+        for i in range(count):
+            num = 2 if (i < count - 1 or N2 == 0) else 1
+            G = LM[2 * i]
+            if num == 2:
+                A, B = G, LM[2 * i + 1]
+                E = po.transform(A, mono, B["Ref"], B["ScaP"], B["Fix"])
+                J, eP, eF, sa, Ew, Bw = po.join_assemble(E, B, mono)
+                if step >= first_kept:
+                    fa, fb, fo = (os.path.join(tmp, x) for x in ("A.txt", "B.txt", "o.bin"))
+                    write_map(fa, A, mono)
+                    write_map(fb, B, mono)
+                    subprocess.check_call([REF_DUMP, "pair", typ, fa, fb, fo])
+                    D = read_dump(fo)
+                    tag = f"join{step - first_kept}"
+                    store[f"{tag}.level"] = np.array(L)
+                    put(store, f"{tag}.A", A, MAPKEYS)
+                    put(store, f"{tag}.B", B, MAPKEYS)
+                    for k, v in D.items():
+                        store[f"{tag}.{k}"] = v
+                    er = sub(D, "end")
+                    for k in ("stno", "Ui", "Uj", "photo", "feature", "FBlock"):
+                        assert np.array_equal(np.asarray(E[k]).ravel(), er[k].ravel()), (tag, k)
+                    for k in ("stVal", "U", "W", "V"):
+                        worst = max(worst, check_close(E[k], er[k], f"{tag}.end.{k}"))
+                    sr = sub(D, "solve")
+                    for k in ("Ui", "Uj", "photo", "feature"):
+                        assert np.array_equal(J[k], sr[k]), (tag, k)
+                    assert np.array_equal(J["stno"], D["joint.stno"]) and np.array_equal(J["FBlock"], D["joint.FBlock"])
+                    for k, x in (("U", J["U"]), ("W", J["W"]), ("V", J["V"]), ("ea", eP), ("eb", eF)):
+                        worst = max(worst, check_close(x, sr[k], f"{tag}.solve.{k}"))
+                    if mono:
+                        assert sa == [sr["Ref"], sr["ScaP"], sr["Fix"], sr["Sign"], sr["FixBlk"]], (sa, sr)
+                    full = {}
+                    w2, e_d, e_x = solve_stage_pins(typ, mono, J, eP, eF, sa, sr, full, tag, tmp, tol=1e-8)
+                    for k, v in full.items():  # without the scalar CSC and S itself
+                        if not any(k.endswith(x) for x in (".parts.Sx", ".parts.Si", ".parts.Sp", ".parts_in.S")):
+                            store[k] = v
+                    worst = max(worst, w2)
+                    worst_solve[0] = max(worst_solve[0], e_d)
+                    worst_solve[1] = max(worst_solve[1], e_x)
+                st, rc, stats = po.solve(J, eP, eF, mono, sa)
+                assert rc == 0
+                J["stVal"] = st
+                if step >= first_kept:
+                    store[f"join{step - first_kept}.sol"] = st
+                G = J
+                step += 1
+            if (i + 1) % 2 == 0 and G["Ref"] > G["FRef"]:
+                G = po.transform(G, mono, G["FRef"], G["FScaP"], G["FFix"])
+            LM[i] = G
+        L += 1
+    # (the final re-anchoring transform is not stored at this size: the small fixtures pin it, join{k}.end pins the transform here)
+    np.savez_compressed(out_path, **store)
+    ms = [int(store[f"join{k}.solve.m"][0]) for k in range(keep)]
+    ns = [int(store[f"join{k}.solve.n"][0]) for k in range(keep)]
+    lens = [int(np.bincount(store[f"join{k}.solve.feature"]).max()) for k in range(keep)]
+    print(f"{out_path}: last {keep} of {total} joins (m = {ms}, n = {ns}, longest feature run {lens}), worst oracle-vs-reference rel err "
+          f"{worst:.2e}; oracle solve vs dense LAPACK expected value {worst_solve[0]:.2e} (long double twin {worst_solve[1]:.2e}), "
+          f"{os.path.getsize(out_path) / 1024:.0f} KiB")
+
+
 def reanchor(typ, mono, G, store, tag, tmp):
     fa, fo = os.path.join(tmp, "A.txt"), os.path.join(tmp, "o.bin")
     write_map(fa, G, mono)
@@ -223,6 +307,14 @@ def main():
         run("Stereo", synth.make_stereo_set(8, new_per_frame=3, vis=5, seed=12), os.path.join(out, "stereo_n8.npz"), tmp)
         run("Monocular", synth.make_mono_set(5, new_per_frame=6, vis=4, seed=13), os.path.join(out, "mono_n5.npz"), tmp)
         run("Monocular", synth.make_mono_set(8, new_per_frame=5, vis=5, seed=14), os.path.join(out, "mono_n8.npz"), tmp)
+        # the two smallest trees there are
+        run("Stereo", synth.make_stereo_set(2, new_per_frame=5, vis=4, seed=15), os.path.join(out, "stereo_n2.npz"), tmp)
+        run("Stereo", synth.make_stereo_set(3, new_per_frame=5, vis=4, seed=16), os.path.join(out, "stereo_n3.npz"), tmp)
+        run("Monocular", synth.make_mono_set(2, new_per_frame=6, vis=4, seed=17), os.path.join(out, "mono_n2.npz"), tmp)
+        run("Monocular", synth.make_mono_set(3, new_per_frame=6, vis=4, seed=18), os.path.join(out, "mono_n3.npz"), tmp)
+        # mid-size: the top joins of an 88-map Mono set on the returning path and of a 64-map Stereo set whose laps close
+        run_top("Monocular", synth.make_mono_set(88, new_per_frame=4, vis=4, seed=19, **synth.SPIRAL), os.path.join(out, "mono_n88_top2.npz"), tmp, 2)
+        run_top("Stereo", synth.make_stereo_set(64, new_per_frame=4, vis=5, seed=20, **MID_STEREO_PATH), os.path.join(out, "stereo_n64_top1.npz"), tmp, 1)
 
 
 if __name__ == "__main__":

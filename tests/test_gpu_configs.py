@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from common import feat_param_err, get_map, golden_system, load_golden, pose_param_err, rel_err
+from common import GOLD_MID, GOLD_SMALL, feat_param_err, get_map, golden_system, load_golden, pose_param_err, rel_err
 from linearsfm_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -230,7 +230,7 @@ def test_mixed_precision_mono_vs_oracle(ctx, oracle, config, n_maps):
 # ---------------------------------------------------------------------------------------------------------------------
 # whole trees of the reference fixtures; the device's pattern of S
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["stereo_n5.npz", "stereo_n8.npz", "mono_n5.npz", "mono_n8.npz"])
+@pytest.mark.parametrize("name", GOLD_SMALL)
 def test_whole_tree_from_fixture_inputs_to_fixture_result(ctx, name):
     """lsfm_divide_conquer on the fixture's input maps (`in*`) against the fixture's final map (`result.*`): the state that
     went through the REAL reference's transform and assembly at every join and re-anchoring (tests/golden/make_golden.py
@@ -256,7 +256,7 @@ def _pairs_from_csc(Ap, Aii):
     return [(int(Aii[k]), j) for j in range(len(Ap) - 1) for k in range(Ap[j], Ap[j + 1])]
 
 
-@pytest.mark.parametrize("name", ["stereo_n5.npz", "stereo_n8.npz", "mono_n5.npz", "mono_n8.npz"])
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
 def test_device_schur_pattern_vs_reference_aux_css(ctx, name):
     """The block pattern of S the DEVICE builds (hash set of pose pairs + U's pattern -> block CSR: lsfm_schur_pattern) on
     the index arrays of all 22 reference-assembled systems, against the pattern the REAL pba_constructAuxCSS{LM,GN}

@@ -6,8 +6,8 @@ the dense expected value."""
 import numpy as np
 import pytest
 
-from common import (assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
-                    pose_param_err, ref_map, rel_err)
+from common import (GOLD_MID, GOLD_SMALL, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
+                    pose_param_err, pose_param_true_rel_err, ref_map, rel_err)
 from linearsfm_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -15,10 +15,18 @@ pytestmark = pytest.mark.gpu
 STAGE_TOL = 1e-9
 SOLVE_TOL = 1e-9   # one join's solve vs the oracle's direct solve of the same system
 DENSE_TOL = 1e-10  # one solve vs the dense LAPACK expected value (tests/common.py dense_reference_solve)
+# the top joins of the mid-size trees (tests/golden/*_top*.npz): a monocular camera system of 66 / 90 poses is conditioned ~1e4 x worse
+# than the 8-pose ones -- the oracle's own direct solve is 6e-11 from the dense expected value there, its long-double twin 7e-11
+# -- and the library stops refining a system at a relative RESIDUAL of 1e-12 (lsfm_set_pcg), which leaves its solution within
+# cond(S) x 1e-12 of the exact one where a direct solve (the reference's, the oracle's) leaves cond(S) x 1e-16: 1.7e-8 on the 66-pose
+# system.  The dense-LAPACK test below therefore also refines those systems to stagnation (rel_tol 1e-15) and holds THAT at 1e-9.
+MID_SOLVE_TOL = {"stereo_n64_top1.npz": 1e-9, "mono_n88_top2.npz": 1e-7}
+STEREO_GOLD = [n for n in GOLD_SMALL + GOLD_MID if n.startswith("stereo")]
+MONO_GOLD = [n for n in GOLD_SMALL + GOLD_MID if n.startswith("mono")]
 TREE_TOL = 1e-6    # BASELINE.json: 1e-6 relative on pose parameters
 
 
-@pytest.mark.parametrize("name", ["stereo_n5.npz", "stereo_n8.npz", "mono_n5.npz", "mono_n8.npz"])
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
 def test_transform_vs_reference_golden(ctx, name):
     z = load_golden(name)
     mono = str(z["type"]) == "Monocular"
@@ -40,9 +48,10 @@ def test_transform_vs_reference_golden(ctx, name):
         assert_maps_close(got, exp, STAGE_TOL, f"{name} {key}", canonical_u=mono)
 
 
-@pytest.mark.parametrize("name", ["stereo_n5.npz", "stereo_n8.npz"])
+@pytest.mark.parametrize("name", STEREO_GOLD)
 def test_join_assembly_and_solve_vs_golden(ctx, name):
     z = load_golden(name)
+    SOLVE_TOL = MID_SOLVE_TOL.get(name, 1e-9)
     for j in range(int(z["njoins"])):
         E, B = ref_map(z, f"join{j}.end"), get_map(z, f"join{j}.B")
         E["FRef"] = int(z[f"join{j}.A.FRef"])
@@ -65,24 +74,35 @@ def test_join_assembly_and_solve_vs_golden(ctx, name):
         assert np.max(np.abs(joint["stVal"] - xd) / np.maximum(1, np.abs(xd))) < SOLVE_TOL
 
 
-@pytest.mark.parametrize("name", ["stereo_n5.npz", "stereo_n8.npz", "mono_n5.npz", "mono_n8.npz"])
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
 def test_solve_every_reference_assembled_system_vs_dense_lapack(ctx, name):
     """lsfm_solve_{stereo,mono} (the reference's argument lists) on all 22 systems the REAL reference assembled, against an
     expected value that never passes through the oracle's Schur complement or sparse Cholesky: the dense LAPACK solution
     of the full normal equations, refined in extended precision (stored in the fixture AND recomputed here).  Mono: the 7
     gauge scalars (reference pose, Fix) removed, x[Fix] = Sign."""
     z = load_golden(name)
+    DENSE_TOL = MID_SOLVE_TOL.get(name, 1e-10)
     for j in range(int(z["njoins"])):
         J, ea, eb, mono, sa = golden_system(z, j)
         st, rc = ctx.solve(J, ea, eb, mono, sa)
         assert rc == 0
         xd = z[f"join{j}.dense_sol"]
         live = dense_reference_solve(J, ea, eb, mono, sa, IV=z[f"join{j}.parts.IV"])
-        assert np.max(np.abs(live - xd) / np.maximum(1, np.abs(xd))) < 1e-14
+        assert np.max(np.abs(live - xd) / np.maximum(1, np.abs(xd))) < 1e-13
         m = J["m"]
         ep = float(np.max(np.abs(st[:6 * m] - xd[:6 * m]) / np.maximum(1, np.abs(xd[:6 * m]))))
         ef = float(np.max(np.abs(st[6 * m:] - xd[6 * m:]) / np.maximum(1, np.abs(xd[6 * m:]))))
         assert ep < DENSE_TOL and ef < DENSE_TOL, (name, j, ep, ef)
+        if name in MID_SOLVE_TOL and mono:
+            # the same system refined until the true residual stops shrinking: what is left is the arithmetic, not the stopping rule
+            ctx.set_pcg(1e-15, 0)
+            try:
+                st2, rc2 = ctx.solve(J, ea, eb, mono, sa)
+            finally:
+                ctx.set_pcg(1e-12, 0)
+            e2 = float(np.max(np.abs(st2 - xd) / np.maximum(1, np.abs(xd))))
+            print(f"{name} join {j}: m = {m}, default stopping rule {max(ep, ef):.2e}, refined to stagnation {e2:.2e} (rc {rc2})")
+            assert e2 < 1e-9, (name, j, e2)
         if mono:
             assert st[sa[2]] == sa[3] and np.all(st[6 * sa[0]:6 * sa[0] + 6] == 0.0)
         # the features alone, for the pose values the fixture handed to the reference's pba_solveFeatures: same pose values
@@ -90,6 +110,26 @@ def test_solve_every_reference_assembled_system_vs_dense_lapack(ctx, name):
         # DENSE_TOL, and here on the reference's own output
         dpb = z[f"join{j}.parts.dpb"]
         assert np.max(np.abs(st[6 * m:] - dpb) / np.maximum(1, np.abs(dpb))) < 10 * DENSE_TOL
+
+
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
+def test_inverse_v_and_solve_features_vs_reference_methods(ctx, name):
+    """lsfm_inverse_v / lsfm_solve_features (K7 k_vinv, K11 k_backsub alone) against the outputs of the REAL reference's
+    pba_inverseV (Imp.cpp:3022) and pba_solveFeatures (Imp.cpp:2980) on every reference-assembled system: the same V in, the same
+    (IV, eb, pose values) in -- fixture parts.IV / parts.dpb, made by oracle/_ref/ref_dump."""
+    z = load_golden(name)
+    for j in range(int(z["njoins"])):
+        J, ea, eb, mono, sa = golden_system(z, j)
+        IV = ctx.inverse_v(J["V"])
+        exp = z[f"join{j}.parts.IV"].reshape(-1, 9)
+        assert IV.shape == exp.shape
+        # per block, relative to the block's largest entry (the blocks span orders of magnitude)
+        e = np.max(np.abs(IV - exp), axis=1) / np.max(np.abs(exp), axis=1)
+        assert float(e.max()) < 1e-12, (name, j, float(e.max()))
+        assert np.array_equal(IV[:, [1, 2, 5]], IV[:, [3, 6, 7]])  # symmetric, like the reference's write-back (Imp.cpp:3027-3040)
+        dpb = ctx.solve_features(J, exp, eb, z[f"join{j}.parts_in.dpa"])
+        ref = z[f"join{j}.parts.dpb"]
+        assert float(np.max(np.abs(dpb - ref) / np.maximum(1, np.abs(ref)))) < 1e-11, (name, j)
 
 
 def test_solver_entry_point_residual(ctx, oracle):
@@ -224,9 +264,10 @@ def test_no_device_no_fallback_message():
 # ------------------------------------------------------------------------------------------------------------
 # Monocular
 # ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["mono_n5.npz", "mono_n8.npz"])
+@pytest.mark.parametrize("name", MONO_GOLD)
 def test_mono_join_assembly_and_solve_vs_golden(ctx, oracle, name):
     z = load_golden(name)
+    SOLVE_TOL = MID_SOLVE_TOL.get(name, 1e-9)
     for j in range(int(z["njoins"])):
         A = get_map(z, f"join{j}.A")
         E, B = ref_map(z, f"join{j}.end"), get_map(z, f"join{j}.B")

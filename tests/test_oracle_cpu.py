@@ -7,14 +7,14 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import assert_maps_close, dense_reference_solve, get_map, golden_system, load_golden, ref_map, rel_err
+from common import GOLD_MID, GOLD_SMALL, assert_maps_close, dense_reference_solve, get_map, golden_system, load_golden, ref_map, rel_err
 from linearsfm_amd import synth
 from refdump import dense_info
 
-GOLD = ["stereo_n5.npz", "stereo_n8.npz", "mono_n5.npz", "mono_n8.npz"]
+GOLD = GOLD_SMALL
 
 
-@pytest.mark.parametrize("name", GOLD)
+@pytest.mark.parametrize("name", GOLD + GOLD_MID)
 def test_oracle_transform_and_assembly_vs_reference(oracle, name):
     z = load_golden(name)
     mono = str(z["type"]) == "Monocular"
@@ -106,6 +106,39 @@ def test_oracle_solve_stage_vs_reference_methods_and_dense_lapack(oracle, name):
         stx, rc, _ = oracle.solve(J, ea, eb, mono, sa, extended=True)
         assert rc == 0
         assert np.max(np.abs(stx - xd) / np.maximum(1, np.abs(xd))) < 1e-10
+
+
+@pytest.mark.parametrize("name", GOLD_MID)
+def test_oracle_solve_stage_vs_reference_at_mid_size(oracle, name):
+    """The top joins of the 64-map Stereo and the 88-map Mono tree (m = 64 / 66 / 90 poses), as the REAL reference assembled
+    them: the oracle's V^-1 and back-substitution against pba_inverseV / pba_solveFeatures, its block pattern of S against
+    pba_constructAuxCSS{LM,GN}, its solution against the dense LAPACK expected value (stored and recomputed).  The scalar CSC of S
+    is not stored at this size (the small fixtures pin pba_constructCSS*)."""
+    z = load_golden(name)
+    for j in range(int(z["njoins"])):
+        J, ea, eb, mono, sa = golden_system(z, j)
+        m = J["m"]
+        rowptr, colidx, S, E, IV = oracle.schur(J, ea, eb, 1 if mono else 0)
+        assert rel_err(IV, z[f"join{j}.parts.IV"]) < 1e-13
+        assert np.array_equal(rowptr, z[f"join{j}.parts_in.rowptr"]) and np.array_equal(colidx, z[f"join{j}.parts_in.colidx"])
+        cols = [[] for _ in range(m)]
+        for p in range(m):
+            for k in range(rowptr[p], rowptr[p + 1]):
+                cols[colidx[k]].append(p)
+        if mono:
+            ref = sa[0]
+            cols = [[r - (r > ref) for r in c if r != ref] for q, c in enumerate(cols) if q != ref]
+        assert np.array_equal(np.cumsum([0] + [len(c) for c in cols]).astype(np.int32), z[f"join{j}.parts.Ap"])
+        assert np.array_equal(np.concatenate(cols).astype(np.int32), z[f"join{j}.parts.Aii"])
+        dpb = oracle.solve_features(J, z[f"join{j}.parts.IV"], eb, z[f"join{j}.parts_in.dpa"])
+        assert rel_err(dpb, z[f"join{j}.parts.dpb"]) < 1e-12
+        xd = z[f"join{j}.dense_sol"]
+        live = dense_reference_solve(J, ea, eb, mono, sa, IV=z[f"join{j}.parts.IV"])
+        assert np.max(np.abs(live - xd) / np.maximum(1, np.abs(xd))) < 1e-13
+        # (a monocular system of 90 poses is conditioned ~1e4 x worse than the 8-pose ones: 1e-9 here, 1e-10 there)
+        st, rc, _ = oracle.solve(J, ea, eb, mono, sa)
+        assert rc == 0
+        assert np.max(np.abs(st - xd) / np.maximum(1, np.abs(xd))) < 1e-9
 
 
 @pytest.mark.parametrize("name", GOLD)

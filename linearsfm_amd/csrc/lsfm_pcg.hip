@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int
 #define SN_XS (6 * CHOL_GS + 1)     /* odd row stride of the panel rows in LDS */
 #define SN_THREADS 256               /* 96 lanes own rows; the rest is there to keep more loads in flight */
 #define SN_LD 8                      /* loads in flight per lane in the copy loops (a dependent load costs ~1.5 us) */
+#define SN_PT (SN_THREADS + 64)      /* k_sn_panel: one more wave, the pivot wave (look-ahead factorisation of the diagonal blocks) */
 // 1 / sqrt(x) without the ~300-cycle IEEE sqrt + divide chains (they sat on the critical path of every column step):
 // hardware estimate + three Newton steps (full double precision up to an ulp or two -- the factor is a preconditioner
 // under iterative refinement)
@@ -691,6 +692,24 @@ __device__ __forceinline__ double fast_rsqrt(double x)
 	r = r * fma(-h * r, r, 1.5);
 	r = r * fma(-h * r, r, 1.5);
 	return r;
+}
+// the double that lane `lane` (a compile-time constant) of the wave holds in v, as a wave-uniform value in scalar registers:
+// two v_readlane_b32.  LDS reads in which every lane asks for the same address were measured at ~28 clocks per wave instruction
+// on this chip (four waves on a CU share the LDS pipe): the 36 pivot-row entries of a block of dot products cost 18 of them per
+// wave, 2 400 clocks per block and CU; one lane each loading one entry and 72 v_readlane_b32 cost the wave ~300 clocks of its own SIMD
+__device__ __forceinline__ double wave_bcast(double v, int lane)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+	return __hiloint2double(hi, lo);
+}
+// the same to full double precision with a shorter dependent chain, for the pivot wave (the chain of six of them per diagonal
+// block is what a block column costs when its dot products are short): one Halley step, cubic -- the hardware estimate is good to
+// ~2^-23, the step leaves ~2^-66 -- five dependent operations instead of nine
+__device__ __forceinline__ double fast_rsqrt_h(double x)
+{
+	const double y = __builtin_amdgcn_rsq(x);
+	const double e = fma(-x, y * y, 1.0);
+	return fma(y, e * fma(0.375, e, 0.5), y);
 }
 __device__ __forceinline__ int sn_idx(int s, int u, int t) { return t * s - t * (t - 1) / 2 + (u - t); }
 
@@ -719,21 +738,35 @@ typedef double sn_v4d __attribute__((ext_vector_type(4)));
 // of k_sn_panel: [0] index set-up, [1] blocks -> LDS, [2] the column loop, [3] right-hand side + inverse diagonal + stores, [4] rank
 // update (fused), [5] work-groups counted, [6] sum of s.  Compiled out otherwise.
 #ifdef LSFM_K9_TIMING
-__device__ unsigned long long g_sn_t[16];
+__device__ unsigned long long g_sn_t[32];
 #define SNT_DECL unsigned long long snt_prev = __builtin_readcyclecounter()
-#define SNT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_sn_t[(FUSED ? 8 : 0) + (i)], n_ - snt_prev); snt_prev = n_; } } while (0)
+#define SNT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_sn_t[(FUSED ? 16 : 0) + (i)], n_ - snt_prev); snt_prev = n_; } } while (0)
+// inside the column loop: summed in registers, flushed once after the loop (an atomic per mark would be waited for at the next barrier)
+#define SNL_DECL unsigned long long snl_[2] = { 0, 0 }
+#define SNL(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); snl_[i] += n_ - snt_prev; snt_prev = n_; } } while (0)
+#define SNL_FLUSH do { if (threadIdx.x == 0 && blockIdx.y == 0) { atomicAdd(&g_sn_t[(FUSED ? 16 : 0) + 8], snl_[0]); atomicAdd(&g_sn_t[(FUSED ? 16 : 0) + 9], snl_[1]); } \
+	if (threadIdx.x == 128 && blockIdx.y == 0) for (int q_ = 0; q_ < 6; q_++) atomicAdd(&g_sn_t[(FUSED ? 16 : 0) + 10 + q_], snp_[q_]); } while (0)
+// the same for the first panel lane (tid 128, a lane that works in every phase): [0] slot reads [1] finish arithmetic [2] writes [3] wait at the barrier after B
+// [4] dot products [5] wait at the barrier after A
+#define SNP_DECL unsigned long long snp_[6] = { 0, 0, 0, 0, 0, 0 }, snp_prev = __builtin_readcyclecounter()
+#define SNP(i) do { if (threadIdx.x == 128 && blockIdx.y == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); const unsigned long long n_ = __builtin_readcyclecounter(); snp_[i] += n_ - snp_prev; snp_prev = n_; } } while (0)
 extern "C" void lsfm_debug_sn(unsigned long long* out, int reset)
 {
 	(void)hipDeviceSynchronize();
-	if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sn_t), sizeof(unsigned long long) * 16);
-	if (reset) { unsigned long long z[16] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sn_t), z, sizeof(z)); }
+	if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sn_t), sizeof(unsigned long long) * 32);
+	if (reset) { unsigned long long z[32] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sn_t), z, sizeof(z)); }
 }
 #else
 #define SNT_DECL do { } while (0)
 #define SNT(i) do { } while (0)
+#define SNL_DECL do { } while (0)
+#define SNL(i) do { } while (0)
+#define SNL_FLUSH do { } while (0)
+#define SNP_DECL do { } while (0)
+#define SNP(i) do { } while (0)
 #endif
 template <bool FUSED>
-__global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
+__global__ void __launch_bounds__(SN_PT) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Lg,
                                                           double* __restrict__ Dinv, int* err, const int* __restrict__ rowidx, double* __restrict__ fv,
                                                           double* __restrict__ fw, int smax, const double* __restrict__ diag0, double piv_floor, int* nfloor)
@@ -746,6 +779,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	// rows 0 .. 6 GS - 1: L_dd (dense scalar rows); rows 6 GS ..: the panel rows of this work-group.  Lanes 0..95 own the
 	// diagonal rows, lanes 128..223 (two other waves, other SIMDs) the panel rows: the same recurrence, in step
 	__shared__ double sD[36];
+	__shared__ double sLp[2 * 28];        // the pivot wave's L_tt (lower triangle, 21) and 1 / diag (6), two slots in turn
 	__shared__ double sInvD[6 * CHOL_GS]; // 1 / L_kk of the run
 	__shared__ double sFl[6 * CHOL_GS];   // diagonal of the (scaled) S at the run's columns: what a pivot is held against
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
@@ -791,23 +825,22 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		sDst[e] = 6 * u * xs + 6 * t;
 	}
 	const int rows0 = sCol[s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
+	int upd_pos = -1;
 	if constexpr (FUSED)
 	{
-		// targets of the rank update, fetched now: the loads fly while the factorisation runs
+		// targets of the rank update, fetched now: the loads fly while the blocks arrive (the position is parked in LDS after them)
 		if (tid < HB * HB)
 		{
 			const int a = tid / HB, b = tid - a * HB;
 			const int ia = sRow[a], ib = ca == cb ? sRow[b] : sRow[HB + b];
-			int pos = -1;
 			if (ia >= 0 && ib >= 0 && ia >= ib)
 			{
 				const int ra = rowidx[rows0 + ia], rb = rowidx[rows0 + ib];
 				// the rows of the run from rb on are a subset of column rb's rows; nested patterns put the target at the same offset
 				const int cbk = colptr[rb], nbk = colptr[rb + 1] - cbk;
-				pos = cbk + (ia - ib);
-				if (!(ia - ib < nbk && rowidx[pos] == ra)) pos = find_row(rowidx, cbk, cbk + nbk, ra);
+				upd_pos = cbk + (ia - ib);
+				if (!(ia - ib < nbk && rowidx[upd_pos] == ra)) upd_pos = find_row(rowidx, cbk, cbk + nbk, ra);
 			}
-			spos[tid] = pos;
 		}
 	}
 	__syncthreads();
@@ -815,13 +848,15 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	// blocks -> dense rows, two numbers per load, SN_LD loads in flight per lane (a dependent load costs ~1.5 us).  The blocks are
 	// the fixed-point accumulators of the group columns: converted as they are stored to LDS
 	const int nd2 = nb * 18, np2 = SN_RB * s * 18; // pairs of numbers: diagonal part, panel slots
-	for (int base = 0; base < nd2 + np2; base += nt * SN_LD)
+	const bool pivot_wave = tid >= SN_THREADS;
+	if (pivot_wave && tid - SN_THREADS < 36) sD[tid - SN_THREADS] = fx_to(reinterpret_cast<const long long*>(L)[(size_t)sCol[0] * 36 + (tid - SN_THREADS)]);
+	for (int base = 0; base < (pivot_wave ? 0 : nd2 + np2); base += SN_THREADS * SN_LD)
 	{
 		longlong2 v[SN_LD];
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
-			const int q = base + i * nt + tid;
+			const int q = base + i * SN_THREADS + tid;
 			if (q < nd2) { const int e = q / 18; v[i] = *reinterpret_cast<const longlong2*>(L + (size_t)sSrc[e] + 2 * (q - e * 18)); }
 			else if (q < nd2 + np2)
 			{
@@ -832,7 +867,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 #pragma unroll
 		for (int i = 0; i < SN_LD; i++)
 		{
-			const int q = base + i * nt + tid;
+			const int q = base + i * SN_THREADS + tid;
 			if (q < nd2) { const int e = q / 18, w = 2 * (q - e * 18); double* d = &Ls[sDst[e] + (w / 6) * xs + w % 6]; d[0] = fx_to(v[i].x); d[1] = fx_to(v[i].y); }
 			else if (q < nd2 + np2)
 			{
@@ -848,115 +883,199 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 	const int XR = LD + 6 * SN_RB; // row of the right-hand side, owned by lane 128 + 6 SN_RB
 	const bool with_fv = fv && diag_pair;
 	if (with_fv && tid < n6) Ms[XR * xs + tid] = fv[(size_t)c0 * 6 + tid];
+	if constexpr (FUSED) { if (tid < HB * HB) spos[tid] = upd_pos; }
+	bool bad = false;
+	// the 6x6 Cholesky of the block in sD by every lane of the pivot wave alike, published in slot (t & 1): L_tt (lower triangle) and 1 / diag
+	auto pivot_chol = [&](int t) {
+		const int k0 = 6 * t, pl = tid - SN_THREADS;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier(); // (one wave: its LDS accesses are served in order; the compiler must keep them so)
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		double d[21], di[6];
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+#pragma unroll
+			for (int c = 0; c <= r; c++) d[r * (r + 1) / 2 + c] = sD[r * 6 + c];
+#pragma unroll
+		for (int k = 0; k < 6; k++)
+		{
+			double pv = d[k * (k + 1) / 2 + k];
+			// Modified Cholesky for the separators.  What is left of the last diagonal blocks of a top separator after everything
+			// below them has been eliminated is, for the weakly observable directions of a long monocular chain (scale drift),
+			// the difference of numbers a thousand to 1e13 times larger.  A pivot is taken by its magnitude, bounded below by
+			// piv_floor x the entry the (scaled) S had: the factor is the exact factor of S plus a small perturbation in those one
+			// or two directions, which the CG around it removes in a few steps.  Only a pivot that is negative on the scale of S
+			// itself (or not a number) means the system is not positive definite.
+			const double flr = sFl[k0 + k];
+			const double fl = piv_floor * flr, neg = piv_floor > 0 ? -0.01 * flr : 0.0; // (piv_floor = 0: any non-positive pivot is an error)
+			if (!(pv > fl))
+			{
+				if (!(pv == pv) || !(pv > neg) || !(fl > 0)) { bad = true; pv = 1.0; }
+				else { pv = fmax(fabs(pv), fl); if (nfloor && pl == 0 && blockIdx.y == 0) atomicAdd(nfloor, 1); }
+			}
+#ifdef LSFM_DEBUG_PIVOT
+			if (pl == 0 && blockIdx.y == 0 && c0 + t >= 16380)
+				printf("[piv] col %d k %d pv %.6e fl %.3e raw %.6e\n", c0 + t, k, pv, fl, d[k * (k + 1) / 2 + k]);
+#endif
+			di[k] = fast_rsqrt_h(pv);
+			d[k * (k + 1) / 2 + k] = pv * di[k];
+#pragma unroll
+			for (int r = k + 1; r < 6; r++) d[r * (r + 1) / 2 + k] *= di[k];
+#pragma unroll
+			for (int r = k + 1; r < 6; r++)
+#pragma unroll
+				for (int c = k + 1; c <= r; c++) d[r * (r + 1) / 2 + c] -= d[r * (r + 1) / 2 + k] * d[c * (c + 1) / 2 + k];
+		}
+		if (pl == 0)
+		{
+			double* slot = sLp + (t & 1) * 28;
+#pragma unroll
+			for (int q = 0; q < 21; q++) slot[q] = d[q];
+#pragma unroll
+			for (int k = 0; k < 6; k++) slot[21 + k] = di[k];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	};
+	// ... and its rows into the dense rows (nobody reads the diagonal block's place before the end of the loop; the lanes that own
+	// these rows have nothing to do for column t), 1 / diag with them
+	auto pivot_rows = [&](int t) {
+		const int k0 = 6 * t, pl = tid - SN_THREADS;
+		const double* slot = sLp + (t & 1) * 28;
+		if (pl < 36)
+		{
+			const int r = pl / 6, c = pl - 6 * r;
+			Ls[(k0 + r) * xs + k0 + c] = c <= r ? slot[r * (r + 1) / 2 + c] : 0.0;
+			if (pl < 6) sInvD[k0 + pl] = slot[21 + pl];
+		}
+	};
+	// the first diagonal block: fetched by the pivot wave itself before the block loads (sD), factored while they arrive
+	if (pivot_wave) pivot_chol(0);
 	__syncthreads();
 	SNT(1);
-	// row of Ms this lane owns (-1: none)
+	// row of Ms this lane owns (-1: none).  The lanes of the last wave (tid >= SN_THREADS) own none: it is the pivot wave
 	const int ri = tid < LD ? tid : ((tid >= 128 && tid < 128 + 6 * SN_RB) ? LD + (tid - 128) : ((with_fv && tid == 128 + 6 * SN_RB) ? XR : -1));
 	const bool panel_lane = ri >= LD && (ri == XR || sRow[(ri - LD) / 6] >= 0);
-	bool bad = false;
+	// The column loop, with the factorisation of the 6x6 diagonal blocks taken off everybody's path (look-ahead).  Per block
+	// column t a lane that owns a row below block t does  A(t): a = its six entries of the column minus the dot products with the
+	// columns before;  B(t): finish them against L_tt.  L_tt = chol(D_tt) is a chain of six dependent reciprocal square roots:
+	// round 3 had every lane run it between the two barriers of every column.  Now the PIVOT WAVE does: while the others are in
+	// A(t) it forms D_tt itself from the finished rows of block t (36 lanes, one entry each, dot products of length 6t), factors
+	// it, publishes L_tt and 1 / diag(L_tt) in one of two slots and puts the block's rows in place; B(t) is 27 numbers through
+	// scalar registers and 27 multiply-adds.  Two barriers per column, as before.
+	auto pivot_step = [&](int t) {
+		const int k0 = 6 * t, pl = tid - SN_THREADS;
+		if (pl < 36)
+		{
+			const int r = pl / 6, c = pl - 6 * r;
+			const double* xr = &Ls[(k0 + r) * xs];
+			const double* xc = &Ls[(k0 + c) * xs];
+			double d0 = c <= r ? xr[k0 + c] : xc[k0 + r], d1 = 0.0, d2 = 0.0; // (the lower triangle of the symmetric block)
+			for (int j = 0; j < k0; j += 6) // (twelve reads in flight per step: a dependent LDS read costs ~150 clocks)
+			{
+				double p[6], q[6];
+#pragma unroll
+				for (int k = 0; k < 6; k++) { p[k] = xr[j + k]; q[k] = xc[j + k]; }
+				d0 = fma(-p[0], q[0], d0); d1 = fma(-p[1], q[1], d1); d2 = fma(-p[2], q[2], d2);
+				d0 = fma(-p[3], q[3], d0); d1 = fma(-p[4], q[4], d1); d2 = fma(-p[5], q[5], d2);
+			}
+			sD[pl] = d0 + (d1 + d2);
+		}
+		pivot_chol(t);
+		pivot_rows(t);
+	};
+	double a[6];
+	// A(0): nothing before the first column
+	if (!pivot_wave && (panel_lane || (ri >= 6 && ri < n6)))
+	{
+		const double* xi = &Ms[ri * xs];
+#pragma unroll
+		for (int c = 0; c < 6; c++) a[c] = xi[c];
+	}
+	if (pivot_wave) pivot_rows(0);
+	__syncthreads();
+	SNT(7); // (the first diagonal block's rows put in place)
+	SNL_DECL;
+	SNP_DECL;
 	for (int t = 0; t < s; t++)
 	{
 		const int k0 = 6 * t;
-		double a[6];
-		const bool mine = panel_lane || (ri >= k0 && ri < n6);
-		if (mine)
+		// ---- B(t): finish column t against the published L_tt (rows below block t; the block's own rows are the pivot wave's).  The
+		// 27 numbers of the slot are the same for every lane: lane l loads number l, they arrive through scalar registers ----
+		const bool mineB = !pivot_wave && (panel_lane || (ri >= k0 + 6 && ri < n6));
+		if (__builtin_amdgcn_ballot_w64(mineB) != 0ull)
 		{
-			const double* xi = &Ms[ri * xs];
+			const double sv = sLp[(t & 1) * 28 + ((tid & 63) < 27 ? (tid & 63) : 27)];
+			SNP(0);
 #pragma unroll
-			for (int c = 0; c < 6; c++) a[c] = xi[k0 + c];
-			for (int v = 0; v < t; v++) // block by block: 42 LDS reads in flight, then 36 multiply-adds
+			for (int c = 0; c < 6; c++)
 			{
-				double xv[6];
+				double v = a[c];
 #pragma unroll
-				for (int k = 0; k < 6; k++) xv[k] = xi[6 * v + k];
-#pragma unroll
-				for (int c = 0; c < 6; c++)
-				{
-					const double* lr = &Ls[(k0 + c) * xs + 6 * v];
-#pragma unroll
-					for (int k = 0; k < 6; k++) a[c] = fma(-xv[k], lr[k], a[c]);
-				}
+				for (int k = 0; k < c; k++) v = fma(-a[k], wave_bcast(sv, c * (c + 1) / 2 + k), v);
+				a[c] = v * wave_bcast(sv, 21 + c);
+				__builtin_amdgcn_sched_barrier(0); // (a row of L_tt at a time in scalar registers)
 			}
-			if (ri < k0 + 6)
-#pragma unroll
-				for (int c = 0; c < 6; c++) sD[(ri - k0) * 6 + c] = a[c];
-		}
-		__syncthreads();
-		if (mine)
-		{
-			// 6x6 Cholesky of D (lower triangle of the symmetric block), by every lane; di[k] = 1 / L_kk
-			double d[21], di[6];
-#pragma unroll
-			for (int r = 0; r < 6; r++)
-#pragma unroll
-				for (int c = 0; c <= r; c++) d[r * (r + 1) / 2 + c] = sD[r * 6 + c];
-#pragma unroll
-			for (int k = 0; k < 6; k++)
+			SNP(1);
+			if (mineB)
 			{
-				double pv = d[k * (k + 1) / 2 + k];
-				// Modified Cholesky for the separators.  What is left of the last diagonal blocks of a top separator after everything
-				// below them has been eliminated is, for the weakly observable directions of a long monocular chain (scale drift),
-				// the difference of numbers a thousand to 1e13 times larger, with off-diagonal noise that depends on the order the
-				// atomic sums landed in: one synth-16k root system in fifteen found the last 6x6 block slightly indefinite
-				// (a pivot of -1e-3 x the entry S had there).  Forcing such a pivot to 1 -- what this code did -- put 1e3..1e7-sized
-				// columns into the factor, the next pivots went to -1e15, -1e31, and the preconditioner returned numbers of size
-				// 1e80: the refinement ended at the residual it started with.  Now a pivot is taken by its magnitude, bounded
-				// below by piv_floor x the entry S had: the factor is the exact factor of S plus a small perturbation in those one
-				// or two directions, which the CG around it removes in a few steps.  Only a pivot that is negative on the scale
-				// of S itself (or not a number) means the system is not positive definite.
-				const double flr = sFl[k0 + k];
-				const double fl = piv_floor * flr, neg = piv_floor > 0 ? -0.01 * flr : 0.0; // (piv_floor = 0: any non-positive pivot is an error)
-				if (!(pv > fl))
-				{
-					if (!(pv == pv) || !(pv > neg) || !(fl > 0)) { bad = true; pv = 1.0; }
-					else { pv = fmax(fabs(pv), fl); if (nfloor && ri == k0 + k) atomicAdd(nfloor, 1); }
-				}
-#ifdef LSFM_DEBUG_PIVOT
-				if (ri == k0 + k && blockIdx.y == 0 && c0 + t >= 16380)
-					printf("[piv] col %d k %d pv %.6e fl %.3e raw %.6e sD %.6e\n", c0 + t, k, pv, fl, d[k * (k + 1) / 2 + k], sD[k * 6 + k]);
-#endif
-				di[k] = fast_rsqrt(pv);
-				d[k * (k + 1) / 2 + k] = pv * di[k];
-#pragma unroll
-				for (int r = k + 1; r < 6; r++) d[r * (r + 1) / 2 + k] *= di[k];
-#pragma unroll
-				for (int r = k + 1; r < 6; r++)
-#pragma unroll
-					for (int c = k + 1; c <= r; c++) d[r * (r + 1) / 2 + c] -= d[r * (r + 1) / 2 + k] * d[c * (c + 1) / 2 + k];
-			}
-			double* xo = &Ms[ri * xs + k0];
-			if (ri < k0 + 6)
-			{
-				// a row of the diagonal block itself: row (ri - k0) of the factor, zeros above the diagonal
-				// (static indices only: a run-time index into d[] would put the whole array into scratch memory)
-				const int r = ri - k0;
-#pragma unroll
-				for (int rr = 0; rr < 6; rr++)
-					if (rr == r)
-					{
-#pragma unroll
-						for (int c = 0; c < 6; c++) xo[c] = c <= rr ? d[rr * (rr + 1) / 2 + c] : 0.0;
-						sInvD[k0 + rr] = di[rr];
-					}
-			}
-			else
-			{
-#pragma unroll
-				for (int c = 0; c < 6; c++)
-				{
-					double v = a[c];
-#pragma unroll
-					for (int k = 0; k < c; k++) v = fma(-a[k], d[c * (c + 1) / 2 + k], v);
-					a[c] = v * di[c];
-				}
+				double* xo = &Ms[ri * xs + k0];
 #pragma unroll
 				for (int c = 0; c < 6; c++) xo[c] = a[c];
 			}
+			SNP(2);
 		}
 		__syncthreads();
+		SNP(3);
+		SNL(1);
+		if (t + 1 < s)
+		{
+			// ---- the pivot wave: L of the next diagonal block; everybody else A(t + 1): the dot products of the next column ----
+			const int k1 = k0 + 6;
+			if (pivot_wave) pivot_step(t + 1);
+			else
+			{
+				// rows below block t + 1.  The 36 entries of the pivot rows that a block of dot products needs are the same for every
+				// lane: lane l < 36 of every wave loads entry l, they reach the multiply-adds through scalar registers (wave_bcast)
+				const int k2 = k1 + 6;
+				const bool mine = panel_lane || (ri >= k2 && ri < n6);
+				if (__builtin_amdgcn_ballot_w64(mine) != 0ull) // (wave-uniform: every lane of the wave takes part in the loads)
+				{
+					const int lane = tid & 63, pe = lane < 36 ? lane : lane - 36 < 28 ? lane - 36 : 0;
+					const double* pp = &Ls[(k1 + pe / 6) * xs + pe % 6];
+					const double* xi = &Ms[(mine ? ri : 0) * xs];
+#pragma unroll
+					for (int c = 0; c < 6; c++) a[c] = xi[k1 + c];
+					double pv = pp[0];
+					for (int v = 0; v <= t; v++)
+					{
+						const double pn = pp[v < t ? 6 * (v + 1) : 0]; // (the next block's entry is under way while this one is used)
+						double xv[6];
+#pragma unroll
+						for (int k = 0; k < 6; k++) xv[k] = xi[6 * v + k];
+#pragma unroll
+						for (int k = 0; k < 6; k++)
+						{
+							// (a column of the 6x6 at a time: six independent multiply-adds.  Scheduling barriers that keep the v_readlane of a
+							// block from being hoisted all at once -- they need more scalar registers than there are -- were measured slower:
+							// 4 400 / 3 840 clocks per column with one per row / per two columns against 3 260 without)
+#pragma unroll
+							for (int c = 0; c < 6; c++) a[c] = fma(-xv[k], wave_bcast(pv, c * 6 + k), a[c]);
+						}
+						pv = pn;
+					}
+				}
+				SNP(4);
+			}
+			__syncthreads();
+			SNP(5);
+			SNL(0);
+		}
 	}
+	SNL_FLUSH;
 	SNT(2);
-	if (bad && tid == 0) atomicExch(err, 1 + c0);
+	if (bad && tid == SN_THREADS) atomicExch(err, 1 + c0);
 	if (with_fv)
 	{
 		const double* yg = &Ms[XR * xs];
@@ -1008,7 +1127,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		}
 	SNT(3);
 #ifdef LSFM_K9_TIMING
-	if (threadIdx.x == 0 && blockIdx.y == 0) { atomicAdd(&g_sn_t[(FUSED ? 8 : 0) + 5], 1ull); atomicAdd(&g_sn_t[(FUSED ? 8 : 0) + 6], (unsigned long long)s); }
+	if (threadIdx.x == 0 && blockIdx.y == 0) { atomicAdd(&g_sn_t[(FUSED ? 16 : 0) + 5], 1ull); atomicAdd(&g_sn_t[(FUSED ? 16 : 0) + 6], (unsigned long long)s); }
 #endif
 	if constexpr (FUSED)
 	{
@@ -1024,13 +1143,13 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 		constexpr int NTL = (6 * HB) / 16; // 16-row tiles per side: 3
 		constexpr int TS = 6 * HB + 1;     // row stride of the products in LDS
 		double* sT = Ms; // (over the diagonal rows, and into the X rows when the diagonal part is small: hence the barrier below)
-		constexpr int TPW = (NTL * NTL + SN_THREADS / 64 - 1) / (SN_THREADS / 64);
+		constexpr int TPW = (NTL * NTL + SN_PT / 64 - 1) / (SN_PT / 64);
 		sn_v4d acc[TPW];
 #pragma unroll
 		for (int i = 0; i < TPW; i++)
 		{
 			acc[i] = (sn_v4d){ 0.0, 0.0, 0.0, 0.0 };
-			const int q = wave + (SN_THREADS / 64) * i;
+			const int q = wave + (SN_PT / 64) * i;
 			if (q < NTL * NTL)
 			{
 				const int ti = q / NTL, tj = q - ti * NTL;
@@ -1043,7 +1162,7 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_panel(const int* __restrict__
 #pragma unroll
 		for (int i = 0; i < TPW; i++)
 		{
-			const int q = wave + (SN_THREADS / 64) * i;
+			const int q = wave + (SN_PT / 64) * i;
 			if (q < NTL * NTL)
 			{
 				const int ti = q / NTL, tj = q - ti * NTL;
@@ -1811,11 +1930,11 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			if (mnr <= fuse_max)
 			{
 				const int nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2);
-				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_PT), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
 				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr);
 				continue;
 			}
-			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_THREADS), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_PT), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
 			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr);
 			static const bool scalar_update = getenv("LSFM_SN_SCALAR_UPDATE") != nullptr; // the round-2 kernel, kept for comparison
 			if (scalar_update)

@@ -87,6 +87,11 @@ typedef struct lsfm_stats {
 	 * computed (factor_digest), over all levels.  The factorisation accumulates its updates in fixed point (integer atomics), so two
 	 * runs with equal s_digest have equal factor_digest, whatever order the work-groups ran in. */
 	unsigned long long s_digest, factor_digest;
+	/* feature-sharded runs: tree levels whose camera systems were factored distributed over the ranks (lsfm_tree_set_comm_blocks) */
+	int dist_solves;
+	/* ... and, over those levels, the block products (6x6x6 multiply-adds) of the numeric factorisations: all of them / those of the
+	 * shared separator columns, which every rank repeats (the replicated share: an Amdahl bound of the distributed solve) */
+	double dist_work_total, dist_work_shared;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -252,6 +257,16 @@ int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* tree, const void* const* 
 typedef int (*lsfm_allreduce_fn)(void* user, size_t offset_bytes, size_t count, int dtype, void* hip_stream);
 /* fn == NULL: off (the default).  world == 1 is allowed (every sum is then this rank's own: a way to exercise the caller's function) */
 int lsfm_tree_set_comm(lsfm_tree* tree, int rank, int world, lsfm_allreduce_fn fn, void* user, void* dev_buf, size_t dev_bytes);
+/* Distributes the POSE-side solve of such a tree as well (SURVEY 8e "P2"; the reference factors every camera system in one
+ * CHOLMOD call, Imp.cpp:2444-2445).  block_maps = 2^k: rank r joined block r of block_maps consecutive local maps of the whole
+ * tree before this tree took over (the pose origins inside the packs say which local map brought a pose).  The nested dissection
+ * of every camera system follows the join tree, so a pose whose separator level lies inside one block is only ever coupled to
+ * poses of that block and to the separators between blocks: rank r factors the columns of block r's poses and collects their
+ * updates of the inter-block separator columns (64-bit fixed-point accumulators); those are summed over the ranks with ONE integer
+ * all-reduce -- exact, so every rank holds the same bits -- and every rank factors the separators.  The triangular solves go the
+ * same way (own columns, sum of the shared rows, shared columns | shared columns, own columns, sum of the solution).  0 (default):
+ * every rank factors everything.  Set on every rank alike, before the first run. */
+int lsfm_tree_set_comm_blocks(lsfm_tree* tree, int block_maps);
 /* The final map of a finished tree cut into `nslices` packs (same format as lsfm_tree_export_dev: every pack holds ALL poses
  * and U blocks, and the features with feat_id % nslices == slice in their order, with their V and W blocks).
  *   lsfm_tree_export_slice_sizes  bytes of every slice pack, sizes[nslices]

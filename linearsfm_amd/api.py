@@ -37,7 +37,7 @@ class LsfmStats(C.Structure):
                 ("not_converged", C.c_int), ("schur_launches", C.c_long), ("trf_launches", C.c_long),
                 ("schur_ms", C.c_double), ("schur_bytes", C.c_double), ("trf_ms", C.c_double), ("trf_bytes", C.c_double),
                 ("schur_flops", C.c_double), ("upload_ms", C.c_double), ("attempts", C.c_int),
-                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong)]
+                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong), ("dist_solves", C.c_int), ("dist_work_total", C.c_double), ("dist_work_shared", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -92,6 +92,7 @@ def lib():
         L.lsfm_tree_upload_dev.argtypes = [vp, P(vp), C.c_int, C.c_int, P(vp)]
         L.lsfm_tree_reload_dev.argtypes = [vp, vp, P(vp), C.c_int]
         L.lsfm_tree_set_comm.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp, vp, C.c_size_t]
+        L.lsfm_tree_set_comm_blocks.argtypes = [vp, C.c_int]
         L.lsfm_tree_export_slice_sizes.argtypes = [vp, vp, C.c_int, P(C.c_size_t)]
         L.lsfm_tree_export_slice_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t]
         L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
@@ -118,7 +119,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
-           "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
+           "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_set_comm_blocks", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
 
@@ -333,6 +334,10 @@ class Context:
         cb = fn if fn is not None else C.cast(None, ALLREDUCE_FN)
         self._check(lib().lsfm_tree_set_comm(tree, int(rank), int(world), cb, None, C.c_void_p(int(dev_ptr) if dev_ptr else None),
                                              int(dev_bytes)), "lsfm_tree_set_comm")
+
+    def tree_set_comm_blocks(self, tree, block_maps):
+        """block_maps = 2^k > 0: the pose-side factorisation of the feature-sharded tree is distributed by block ownership; 0: replicated."""
+        self._check(lib().lsfm_tree_set_comm_blocks(tree, int(block_maps)), "lsfm_tree_set_comm_blocks")
 
     def divide_conquer(self, maps, mono, final_reanchor=True):
         t = self.tree_upload(maps, mono)

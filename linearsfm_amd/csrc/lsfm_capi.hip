@@ -540,8 +540,17 @@ int lsfm_tree_set_comm(lsfm_tree* t, int rank, int world, lsfm_allreduce_fn fn, 
 	if (!t) return LSFM_ERR_ARG;
 	if (!fn) { t->comm = Comm(); return LSFM_OK; }
 	if (world < 1 || rank < 0 || rank >= world || !dev_buf || dev_bytes < 4096) return LSFM_ERR_ARG;
+	if (t->comm.rank != rank || t->comm.world != world) t->plans.clear();
 	t->comm.rank = rank; t->comm.world = world; t->comm.fn = fn; t->comm.user = user;
 	t->comm.buf = static_cast<char*>(dev_buf); t->comm.cap = dev_bytes; t->comm.off = 0;
+	return LSFM_OK;
+}
+
+int lsfm_tree_set_comm_blocks(lsfm_tree* t, int block_maps)
+{
+	if (!t || block_maps < 0 || (block_maps & (block_maps - 1))) return LSFM_ERR_ARG; // (blocks of the reference's pairing are 2^k local maps)
+	if (t->comm.block_maps != block_maps) t->plans.clear(); // (the plans hold the ownership of every factorisation)
+	t->comm.block_maps = block_maps;
 	return LSFM_OK;
 }
 

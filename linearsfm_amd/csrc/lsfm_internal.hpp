@@ -131,6 +131,9 @@ struct Comm {
 	void* user = nullptr;
 	char* buf = nullptr;
 	size_t cap = 0, off = 0;
+	// > 0: the pose-side factorisation is distributed too -- rank r owns what lies inside block r of block_maps consecutive local
+	// maps of the whole tree (lsfm_tree_set_comm_blocks); 0: every rank factors everything
+	int block_maps = 0;
 	void restart() { off = 0; }
 	void* alloc_bytes(size_t bytes)
 	{

@@ -70,6 +70,12 @@ struct CholDev {
 	std::vector<int> glevel_ptr;    // host: groups of level l = [glevel_ptr[l], glevel_ptr[l+1])
 	std::vector<int> glevel_maxnr;  // host: most rows below a run of the level
 	std::vector<int> glevel_maxs;   // host: most block columns of a run of the level (LDS of k_sn_panel)
+	// distributed factorisation (lsfm_symbolic.hpp): owner of every column (-1: shared), null when off; the shared columns are the
+	// last ones, from first_shared on (their blocks: from block shared_blk0 of L on)
+	int* col_owner = nullptr;
+	int first_shared = 0, shared_blk0 = 0;
+	double work_total = 0, work_shared = 0;
+	std::vector<char> glevel_owned, glevel_shared;
 	int* blob = nullptr;    // all index arrays above are slices of this one allocation
 	size_t blob_ints = 0;
 	float *Lf = nullptr, *Dinvf = nullptr; // mixed precision: the factor rounded to fp32 for the triangular solves (null: fp64)
@@ -83,6 +89,13 @@ struct CholDev {
 	int* d_err = nullptr;
 };
 
+// Distributed factorisation (feature-sharded tree runs, lsfm_symbolic.hpp col_owner): which of a launch's work-groups take
+// part -- the ones whose first column belongs to `want` (a rank's block, or -1: the shared separator columns).  col_owner == null: all.
+struct OwnFilter {
+	const int* col_owner = nullptr;
+	int want = 0;
+	__device__ __forceinline__ bool skip(int col) const { return col_owner && col_owner[col] != want; }
+};
 __device__ __forceinline__ int find_row(const int* __restrict__ rowidx, int lo, int hi, int target)
 {
 	while (lo < hi) { int mid = (lo + hi) >> 1; if (rowidx[mid] < target) lo = mid + 1; else hi = mid; }
@@ -123,7 +136,7 @@ __device__ __forceinline__ int scale_exp(double d)
 __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ keys, const double* __restrict__ S, const int* __restrict__ srow,
                                const int* __restrict__ pinv, const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                const unsigned char* __restrict__ fixed, const int* __restrict__ col_task, int ntask0, double* __restrict__ L,
-                               double* __restrict__ diag0, double* __restrict__ dscale)
+                               double* __restrict__ diag0, double* __restrict__ dscale, const int* __restrict__ col_owner, int rank)
 {
 	int e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= nnzb) return;
@@ -146,14 +159,20 @@ __global__ void k_chol_scatter(int nnzb, const unsigned long long* __restrict__ 
 		kc[r] = scale_exp((fixed && fixed[(size_t)colp * 6 + r]) ? 1.0 : dc[r * 7]);
 	}
 	const bool fx = col_task[j] >= ntask0;
+	// (distributed: a rank starts the columns of its own block from S, rank 0 the shared ones too; everybody else's stay zero --
+	// the scaling and the diagonal are everybody's)
+	const bool put = !col_owner || col_owner[j] == rank || (col_owner[j] < 0 && rank == 0);
 	for (int r = 0; r < 6; r++)
 		for (int c = 0; c < 6; c++)
 		{
 			double v = tr ? s[c * 6 + r] : s[r * 6 + c];
 			if (fixed && (fixed[(size_t)rowp * 6 + r] || fixed[(size_t)colp * 6 + c])) v = (rowp == colp && r == c) ? 1.0 : 0.0;
 			v = ldexp(v, -(kr[r] + kc[c]));
-			if (fx) reinterpret_cast<long long*>(d)[r * 6 + c] = fx_from(v);
-			else d[r * 6 + c] = v;
+			if (put)
+			{
+				if (fx) reinterpret_cast<long long*>(d)[r * 6 + c] = fx_from(v);
+				else d[r * 6 + c] = v;
+			}
 			if (i == j && r == c) { diag0[(size_t)j * 6 + r] = v; dscale[(size_t)j * 6 + r] = ldexp(1.0, -kr[r]); }
 		}
 }
@@ -414,9 +433,10 @@ __device__ void chol_factor_task_global(int task, const int* __restrict__ task_p
 template <bool FX>
 __global__ void __launch_bounds__(CHOL_OUT_THREADS) k_chol_update_outer(const int* __restrict__ cols, const int* __restrict__ col_nin,
                                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx,
-                                                                         double* __restrict__ L)
+                                                                         double* __restrict__ L, OwnFilter of)
 {
 	const int j = cols[blockIdx.x];
+	if (of.skip(j)) return;
 	chol_column_update_outer<FX>(j, col_nin[j], colptr, rowidx, L, blockIdx.y * CHOL_OUT_THREADS, gridDim.y * CHOL_OUT_THREADS);
 }
 // Triangular solves by task.  The entries of v that belong to the task's own columns live in LDS while the work-group
@@ -447,11 +467,12 @@ template <class FT>
 __global__ void __launch_bounds__(256) k_chol_fwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                          const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
-                                                         const FT* __restrict__ Dinv, double* __restrict__ v)
+                                                         const FT* __restrict__ Dinv, double* __restrict__ v, OwnFilter of)
 {
 	extern __shared__ double lds[];
 	__shared__ double sy[6];
 	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x, nc = e - b;
+	if (of.skip(task_cols[b])) return;
 	const int tid = threadIdx.x, nt = blockDim.x;
 	double* lv = lds;
 	double* sD = lds + 6 * nc;
@@ -488,12 +509,13 @@ template <class FT>
 __global__ void __launch_bounds__(256) k_chol_bwd_tasks(const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                          const int* __restrict__ col_task, const int* __restrict__ col_lpos, int task0,
                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
-                                                         const FT* __restrict__ Dinv, double* __restrict__ v)
+                                                         const FT* __restrict__ Dinv, double* __restrict__ v, OwnFilter of)
 {
 	extern __shared__ double lds[];
 	__shared__ double red[256];
 	__shared__ double ss[6];
 	const int b = task_ptr[blockIdx.x], e = task_ptr[blockIdx.x + 1], me = task0 + blockIdx.x, nc = e - b;
+	if (of.skip(task_cols[b])) return;
 	const int tid = threadIdx.x, nt = blockDim.x;
 	const int c = tid % 6, g = tid / 6, ng = nt / 6;
 	double* lv = lds;
@@ -655,8 +677,9 @@ __device__ void chol_factor_task_lds(int task, const int* __restrict__ task_ptr,
 // their columns in memory; both kinds run side by side
 __global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int* __restrict__ task_ptr, const int* __restrict__ task_cols,
                                                             const int* __restrict__ col_nin, const int* __restrict__ colptr,
-                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err)
+                                                            const int* __restrict__ rowidx, double* __restrict__ L, double* __restrict__ Dinv, int* err, OwnFilter of)
 {
+	if (of.skip(task_cols[task_ptr[blockIdx.x]])) return;
 	if ((int)blockIdx.x < nsmall) chol_factor_task_lds(blockIdx.x, task_ptr, task_cols, col_nin, colptr, rowidx, L, Dinv, err);
 	else chol_factor_task_global(blockIdx.x, task_ptr, task_cols, col_nin, colptr, rowidx, L, Dinv, err);
 }
@@ -769,7 +792,7 @@ template <bool FUSED>
 __global__ void __launch_bounds__(SN_PT) k_sn_panel(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                           const int* __restrict__ colptr, double* __restrict__ L, double* __restrict__ Lg,
                                                           double* __restrict__ Dinv, int* err, const int* __restrict__ rowidx, double* __restrict__ fv,
-                                                          double* __restrict__ fw, int smax, const double* __restrict__ diag0, double piv_floor, int* nfloor)
+                                                          double* __restrict__ fw, int smax, const double* __restrict__ diag0, double piv_floor, int* nfloor, OwnFilter of)
 {
 	// LDS by the widest run of the LEVEL (smax block columns), not by CHOL_GS: most levels of most systems hold runs of 1-6
 	// columns, and at 150 KB a work-group had a CU to itself -- a level of 2 000 small work-groups took 8 rounds
@@ -788,6 +811,7 @@ __global__ void __launch_bounds__(SN_PT) k_sn_panel(const int* __restrict__ grp_
 	double* const Ls = Ms;
 	double* const Xs = Ms + LD * xs;
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	if (of.skip(c0)) return;
 	constexpr int HB = SN_RB / 2;
 	int ca = 0, cb = 0;
 	if constexpr (FUSED)
@@ -1187,11 +1211,12 @@ __global__ void __launch_bounds__(SN_PT) k_sn_panel(const int* __restrict__ grp_
 // products are subtracted from the ancestors' (still unfactored) blocks in L
 __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                                           const double* __restrict__ Lg)
+                                                           const double* __restrict__ Lg, OwnFilter of)
 {
 	__shared__ double sT[SN_PAIRS * 37];
 	__shared__ int spos[SN_PAIRS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	if (of.skip(c0)) return;
 	const int npairs = nr * (nr + 1) / 2;
 	const int tid = threadIdx.x;
 	const int rows0 = colptr[c0 + s - 1] + 1; // the common rows: what the last column of the run holds below its diagonal
@@ -1249,14 +1274,14 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_update(const int* __restrict_
 // tallest panel, capped: a work-group walks pairs gridDim.y apart).
 __global__ void __launch_bounds__(SN_THREADS) k_sn_syrk(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                          const int* __restrict__ colptr, const int* __restrict__ rowidx, double* __restrict__ L,
-                                                         const double* __restrict__ Lg, int smax)
+                                                         const double* __restrict__ Lg, int smax, OwnFilter of)
 {
 	extern __shared__ double Ms[];
 	constexpr int HB = SN_RB / 2, NTL = (6 * HB) / 16, TS = 6 * HB + 1, TPW = (NTL * NTL + SN_THREADS / 64 - 1) / (SN_THREADS / 64);
 	__shared__ int spos[HB * HB];
 	__shared__ int sCol[CHOL_GS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
-	if (nr == 0) return;
+	if (nr == 0 || of.skip(c0)) return;
 	const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int n6 = 6 * s, n6r = (n6 + 3) & ~3;
 	const int xs = ((6 * smax + 3) & ~3) + 1; // odd row stride, room for the zero padding of the MFMA k step
@@ -1430,13 +1455,14 @@ __device__ __forceinline__ void sn_load_diag(int s, int c0, const int* __restric
 template <class FT>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
-                                                        const FT* __restrict__ Dinv, double* __restrict__ v, double* __restrict__ w)
+                                                        const FT* __restrict__ Dinv, double* __restrict__ v, double* __restrict__ w, OwnFilter of)
 {
 	__shared__ double Ls[6 * CHOL_GS * SN_XS];
 	__shared__ double sDi[CHOL_GS * 36];
 	__shared__ double sA[6], sY[6 * CHOL_GS];
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	if (of.skip(c0)) return;
 	const int tid = threadIdx.x, n6 = 6 * s;
 	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = (double)Dinv[(size_t)c0 * 36 + q];
 	double acc = tid < n6 ? v[(size_t)c0 * 6 + tid] : 0.0;
@@ -1496,13 +1522,14 @@ __global__ void __launch_bounds__(SN_THREADS) k_sn_fwd(const int* __restrict__ g
 template <class FT>
 __global__ void __launch_bounds__(SN_THREADS) k_sn_bwd(const int* __restrict__ grp_c0, const int* __restrict__ grp_s, const int* __restrict__ grp_nr,
                                                         const int* __restrict__ colptr, const int* __restrict__ rowidx, const FT* __restrict__ L,
-                                                        const FT* __restrict__ Dinv, double* __restrict__ v, const double* __restrict__ w)
+                                                        const FT* __restrict__ Dinv, double* __restrict__ v, const double* __restrict__ w, OwnFilter of)
 {
 	__shared__ double Ls[6 * CHOL_GS * SN_XS];
 	__shared__ double sDi[CHOL_GS * 36];
 	__shared__ double sA[6], sZ[6 * CHOL_GS], sX[6 * CHOL_GS];
 	__shared__ int sSrc[CHOL_GS * (CHOL_GS + 1) / 2], sDst[CHOL_GS * (CHOL_GS + 1) / 2], sCol[CHOL_GS];
 	const int g = blockIdx.x, c0 = grp_c0[g], s = grp_s[g], nr = grp_nr[g];
+	if (of.skip(c0)) return;
 	const int tid = threadIdx.x, n6 = 6 * s;
 	for (int q = tid; q < s * 36; q += SN_THREADS) sDi[q] = (double)Dinv[(size_t)c0 * 36 + q];
 	if (tid < n6) sZ[tid] = w[(size_t)c0 * 6 + tid];
@@ -1563,17 +1590,18 @@ __global__ void k_to_float(size_t n, const double* __restrict__ a, float* __rest
 
 // v = D^-1/2 P r  (the factor is the scaled matrix's: k_chol_scatter)
 __global__ void k_perm_in(int M, const int* __restrict__ perm, const double* __restrict__ r, const unsigned char* __restrict__ fixed,
-                          const double* __restrict__ dscale, double* __restrict__ v)
+                          const double* __restrict__ dscale, double* __restrict__ v, int zero_from)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (size_t)M * 6) return;
 	const size_t src = (size_t)perm[i / 6] * 6 + i % 6;
-	v[i] = (fixed && fixed[src]) ? 0.0 : r[src] * dscale[i];
+	// (distributed: the shared rows collect the ranks' partial sums; only rank 0 starts them from the right-hand side: zero_from = first shared row elsewhere)
+	v[i] = ((fixed && fixed[src]) || (long)(i / 6) >= (long)zero_from) ? 0.0 : r[src] * dscale[i];
 }
 // z = P^T D^-1/2 v ; rz[nxt] += r . z
 __global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double* __restrict__ v, const double* __restrict__ r,
                                const unsigned char* __restrict__ fixed, const double* __restrict__ dscale, const int* __restrict__ pose_seg,
-                               double* __restrict__ z, double* dot, int dot_stride)
+                               double* __restrict__ z, double* dot, int dot_stride, const int* __restrict__ col_owner, int rank)
 {
 	int row = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool ok = row < M;
@@ -1588,9 +1616,25 @@ __global__ void k_perm_out_dot(int M, const int* __restrict__ pinv, const double
 		{
 			double zz = src[i] * sc[i];
 			if (fixed && fixed[(size_t)row * 6 + i]) zz = 0.0;
+			// (distributed: a rank holds the solution at its own block's columns, rank 0 at the shared ones too; the sum over the ranks is z)
+			if (col_owner) { const int ow = col_owner[pinv[row]]; if (!(ow == rank || (ow < 0 && rank == 0))) zz = 0.0; }
 			z[(size_t)row * 6 + i] = zz;
 			acc = fma(zz, r[(size_t)row * 6 + i], acc);
 		}
+	}
+	if (dot) wave_scatter_add<1>(dot + (size_t)sg * dot_stride, &acc, ok);
+}
+// rz[nxt] += r . z  alone (distributed: z is complete only after the ranks' parts have been summed)
+__global__ void k_rz_dot(int M, const double* __restrict__ z, const double* __restrict__ r, const int* __restrict__ pose_seg, double* dot, int dot_stride)
+{
+	int row = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool ok = row < M;
+	double acc = 0;
+	int sg = 0;
+	if (ok)
+	{
+		sg = pose_seg[row];
+		for (int i = 0; i < 6; i++) acc = fma(z[(size_t)row * 6 + i], r[(size_t)row * 6 + i], acc);
 	}
 	wave_scatter_add<1>(dot + (size_t)sg * dot_stride, &acc, ok);
 }
@@ -1682,7 +1726,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 	auto rebase = [&](int*& p) { if (p) p = (int*)((char*)p + shift); };
 	rebase(P.ch.colptr); rebase(P.ch.rowidx); rebase(P.ch.perm); rebase(P.ch.pinv); rebase(P.ch.order); rebase(P.ch.task_cols);
 	rebase(P.ch.task_ptr); rebase(P.ch.col_task); rebase(P.ch.col_lpos); rebase(P.ch.col_nin); rebase(P.ch.grp_c0); rebase(P.ch.grp_s);
-	rebase(P.ch.grp_nr);
+	rebase(P.ch.grp_nr); rebase(P.ch.col_owner);
 	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 	return sp;
 }
@@ -1698,10 +1742,12 @@ static void chol_upload_index(lsfm_context* ctx, const CholSymbolic& sym, CholDe
 	ch.tlevel_ptr = sym.tlevel_ptr; ch.tlevel_maxsize = sym.tlevel_maxsize; ch.tlevel_col0 = sym.tlevel_col0; ch.tlevel_nsmall = sym.tlevel_nsmall;
 	ch.tlevel_small_lds = sym.tlevel_small_lds; ch.tlevel_outer = sym.tlevel_outer;
 	ch.ngroups = sym.ngroups; ch.glevel_ptr = sym.glevel_ptr; ch.glevel_maxnr = sym.glevel_maxnr; ch.glevel_maxs = sym.glevel_maxs;
+	ch.work_total = sym.work_total; ch.work_shared = sym.work_shared;
+	ch.first_shared = sym.first_shared; ch.shared_blk0 = sym.colptr[sym.first_shared]; ch.glevel_owned = sym.glevel_owned; ch.glevel_shared = sym.glevel_shared;
 	const struct { int** dst; const std::vector<int>* v; } parts[] = {
 		{ &ch.grp_c0, &sym.grp_c0 }, { &ch.grp_s, &sym.grp_s }, { &ch.grp_nr, &sym.grp_nr }, { &ch.col_nin, &sym.col_nin }, { &ch.col_task, &sym.col_task },
 		{ &ch.col_lpos, &sym.col_lpos }, { &ch.task_cols, &sym.task_cols }, { &ch.task_ptr, &sym.task_ptr }, { &ch.colptr, &sym.colptr },
-		{ &ch.rowidx, &sym.rowidx }, { &ch.perm, &sym.perm }, { &ch.pinv, &sym.pinv }, { &ch.order, &sym.order } };
+		{ &ch.rowidx, &sym.rowidx }, { &ch.perm, &sym.perm }, { &ch.pinv, &sym.pinv }, { &ch.order, &sym.order }, { &ch.col_owner, &sym.col_owner } };
 	size_t total = 0;
 	for (const auto& pt : parts) total += pt.v->size();
 	static thread_local std::vector<int> blob;
@@ -1711,7 +1757,7 @@ static void chol_upload_index(lsfm_context* ctx, const CholSymbolic& sym, CholDe
 	for (const auto& pt : parts)
 	{
 		if (!pt.v->empty()) memcpy(blob.data() + off, pt.v->data(), pt.v->size() * sizeof(int));
-		*pt.dst = d_blob + off;
+		*pt.dst = pt.v->empty() ? nullptr : d_blob + off;
 		off += pt.v->size();
 	}
 	h2d(ctx, d_blob, blob.data(), total * sizeof(int));
@@ -1738,7 +1784,7 @@ static void chol_upload_symbolic(lsfm_context* ctx, const CholSymbolic& sym, Cho
 static void chol_analyse(lsfm_context* ctx, const SchurSystem& sy, const CholHostIn& in, CholDev& ch)
 {
 	static thread_local CholSymbolic sym;
-	chol_symbolic(in.keys.data(), sy.nnzb, in.origin.data(), sy.M, sym);
+	chol_symbolic(in.keys.data(), sy.nnzb, in.origin.data(), sy.M, sym, ctx->comm ? ctx->comm->block_maps : 0);
 	chol_upload_symbolic(ctx, sym, ch);
 }
 
@@ -1869,19 +1915,46 @@ static bool chol_group_solve(const CholDev& ch)
 // substitution leaves (leaf columns in place, group columns in ch.wv) -- chol_apply(..., fwd_done) does the rest
 // the scaled, permuted S into the factor's storage; also leaves the scaling (ch.dscale) that k_perm_in / k_perm_out_dot apply:
 // before anything is permuted in
+// the factorisation of this system is distributed over the ranks of a feature-sharded run (CholDev::col_owner)
+static bool chol_distributed(const lsfm_context* ctx, const CholDev& ch)
+{
+	return ctx->comm && ctx->comm->world > 1 && ch.col_owner && ch.first_shared < ch.M && chol_group_solve(ch) && !getenv("LSFM_NO_GROUPS");
+}
+// sums `count` 8-byte numbers at p over the ranks (through the caller's buffer: p lives in this context's arenas)
+static void comm_sum(lsfm_context* ctx, void* p, size_t count, int dtype)
+{
+	if (!count) return;
+	Comm& cm = *ctx->comm;
+	const size_t mk = cm.off;
+	void* b = cm.alloc_bytes(count * 8);
+	LSFM_CHECK_HIP(hipMemcpyAsync(b, p, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+	cm.allreduce(ctx->stream, b, count, dtype);
+	LSFM_CHECK_HIP(hipMemcpyAsync(p, b, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+	cm.off = mk; // (consumed in stream order: the next sum may take the same place)
+}
+
+// the scaled, permuted S into the factor's storage; also leaves the scaling (ch.dscale) that k_perm_in / k_perm_out_dot apply:
+// before anything is permuted in
 static void chol_scatter(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch)
 {
 	static const bool groups = !getenv("LSFM_NO_GROUPS");
 	// (the columns above the leaf tasks -- what the supernode groups factor -- accumulate in fixed point; LSFM_NO_GROUPS: none does)
 	const int ntask0 = (groups && ch.tlevel_ptr.size() > 1) ? ch.tlevel_ptr[1] : INT_MAX;
+	const bool dist = chol_distributed(ctx, ch);
 	if (sy.nnzb)
 		hipLaunchKernelGGL(k_chol_scatter, dim3((sy.nnzb + 127) / 128), dim3(128), 0, ctx->stream, sy.nnzb, sy.upper_keys, sy.S, sy.rowptr, ch.pinv, ch.colptr, ch.rowidx,
-		                   fixed, ch.col_task, ntask0, ch.L, ch.diag0, ch.dscale);
+		                   fixed, ch.col_task, ntask0, ch.L, ch.diag0, ch.dscale, dist ? ch.col_owner : (const int*)nullptr, dist ? ctx->comm->rank : 0);
 }
+// Distributed (chol_distributed): phase 1 -- every rank factors the columns of its own block (leaf sub-trees, then its supernode
+// groups level by level), whose updates into the shared separator columns it collects in its own copy of them; then the shared
+// columns' accumulators -- 64-bit integers: the sum is exact and the same bits on every rank -- and the shared rows of the forward
+// substitution's vector are summed over the ranks; phase 2 -- every rank factors the shared columns, alike.
 static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned char* fixed, CholDev& ch, double* fwd_v = nullptr)
 {
 	hipStream_t s = ctx->stream;
 	static const bool groups = !getenv("LSFM_NO_GROUPS");
+	const bool dist = chol_distributed(ctx, ch);
+	const OwnFilter mine{ dist ? ch.col_owner : nullptr, dist ? ctx->comm->rank : 0 }, shared{ dist ? ch.col_owner : nullptr, -1 };
 	for (size_t l = 0; l + 1 < ch.tlevel_ptr.size(); l++)
 	{
 		if (groups && l > 0) break; // the chains above the leaf tasks go by supernode groups below
@@ -1890,13 +1963,13 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		static const bool use_small = !getenv("LSFM_NO_SMALL_TASKS");
 		const int nsm = use_small ? ch.tlevel_nsmall[l] : 0;
 		hipLaunchKernelGGL(k_chol_factor_level, dim3(n), dim3(l ? 256 : 128), nsm ? (size_t)ch.tlevel_small_lds[l] : 0, s, nsm, ch.task_ptr + ch.tlevel_ptr[l],
-		                   ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err);
+		                   ch.task_cols, ch.col_nin, ch.colptr, ch.rowidx, ch.L, ch.Dinv, ch.d_err, mine);
 		const int c0 = ch.tlevel_col0[l], nc = ch.tlevel_col0[l + 1] - c0, mp = ch.tlevel_outer[l];
 		if (mp > 0)
 		{
 			const dim3 grid(nc, std::min((mp + CHOL_OUT_THREADS - 1) / CHOL_OUT_THREADS, 64));
-			if (groups) hipLaunchKernelGGL(k_chol_update_outer<true>, grid, dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
-			else hipLaunchKernelGGL(k_chol_update_outer<false>, grid, dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L);
+			if (groups) hipLaunchKernelGGL(k_chol_update_outer<true>, grid, dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L, mine);
+			else hipLaunchKernelGGL(k_chol_update_outer<false>, grid, dim3(CHOL_OUT_THREADS), 0, s, ch.task_cols + c0, ch.col_nin, ch.colptr, ch.rowidx, ch.L, mine);
 		}
 	}
 	if (fwd_v)
@@ -1904,7 +1977,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		// the leaf sub-trees are factored: their part of the forward substitution, before the groups take theirs
 		const int n0 = ch.tlevel_ptr.size() > 1 ? ch.tlevel_ptr[1] - ch.tlevel_ptr[0] : 0;
 		const size_t lds0 = (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL + 8;
-		if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, (const double*)ch.L, (const double*)ch.Dinv, fwd_v);
+		if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, (const double*)ch.L, (const double*)ch.Dinv, fwd_v, mine);
 	}
 	if (groups)
 	{
@@ -1922,32 +1995,42 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 			return true;
 		}();
 		(void)lds_set;
-		for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++)
+		for (int phase = 0; phase < (dist ? 2 : 1); phase++)
 		{
-			const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0, mnr = ch.glevel_maxnr[l];
-			if (!ng) continue;
-			const int smax = l < ch.glevel_maxs.size() ? ch.glevel_maxs[l] : CHOL_GS;
-			if (mnr <= fuse_max)
+			const OwnFilter of = phase == 0 ? mine : shared;
+			if (phase == 1)
 			{
-				const int nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2);
-				hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_PT), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr);
-				continue;
+				comm_sum(ctx, ch.L + (size_t)ch.shared_blk0 * 36, ((size_t)ch.nnzL - ch.shared_blk0) * 36, LSFM_DTYPE_I64);
+				if (fwd_v) comm_sum(ctx, fwd_v + (size_t)ch.first_shared * 6, ((size_t)ch.M - ch.first_shared) * 6, LSFM_DTYPE_F64);
 			}
-			hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_PT), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
-			                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr);
-			static const bool scalar_update = getenv("LSFM_SN_SCALAR_UPDATE") != nullptr; // the round-2 kernel, kept for comparison
-			if (scalar_update)
+			for (size_t l = 0; l + 1 < ch.glevel_ptr.size(); l++)
 			{
-				const long np = (long)mnr * (mnr + 1) / 2;
-				hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
-				                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg);
-			}
-			else
-			{
-				const long nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2), npair = nch * (nch + 1) / 2;
-				hipLaunchKernelGGL(k_sn_syrk, dim3(ng, (unsigned)std::max<long>(1, std::min<long>(npair, 8192))), dim3(SN_THREADS), sn_syrk_lds(smax), s,
-				                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg, smax);
+				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0, mnr = ch.glevel_maxnr[l];
+				if (!ng) continue;
+				if (dist && !(phase == 0 ? ch.glevel_owned[l] : ch.glevel_shared[l])) continue;
+				const int smax = l < ch.glevel_maxs.size() ? ch.glevel_maxs[l] : CHOL_GS;
+				if (mnr <= fuse_max)
+				{
+					const int nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2);
+					hipLaunchKernelGGL(k_sn_panel<true>, dim3(ng, std::max(1, nch * (nch + 1) / 2)), dim3(SN_PT), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+					                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr, of);
+					continue;
+				}
+				hipLaunchKernelGGL(k_sn_panel<false>, dim3(ng, std::max(1, (mnr + SN_RB - 1) / SN_RB)), dim3(SN_PT), sn_panel_lds(smax), s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0,
+				                   ch.colptr, ch.L, ch.Lg, ch.Dinv, ch.d_err, ch.rowidx, fwd_v, ch.wv, smax, ch.diag0, piv_floor, ctx->d_run ? &ctx->d_run->floored : nullptr, of);
+				static const bool scalar_update = getenv("LSFM_SN_SCALAR_UPDATE") != nullptr; // the round-2 kernel, kept for comparison
+				if (scalar_update)
+				{
+					const long np = (long)mnr * (mnr + 1) / 2;
+					hipLaunchKernelGGL(k_sn_update, dim3(ng, (unsigned)std::max<long>(1, std::min<long>((np + SN_PAIRS - 1) / SN_PAIRS, 4096))), dim3(SN_THREADS), 0, s,
+					                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg, of);
+				}
+				else
+				{
+					const long nch = (mnr + SN_RB / 2 - 1) / (SN_RB / 2), npair = nch * (nch + 1) / 2;
+					hipLaunchKernelGGL(k_sn_syrk, dim3(ng, (unsigned)std::max<long>(1, std::min<long>(npair, 8192))), dim3(SN_THREADS), sn_syrk_lds(smax), s,
+					                   ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, ch.L, ch.Lg, smax, of);
+				}
 			}
 		}
 		// the solves that walk columns by task or by level read ONE array: give them the group columns there
@@ -1960,10 +2043,14 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 static void chol_perm_in(lsfm_context* ctx, const CholDev& ch, const double* r, const unsigned char* fixed, double* v)
 {
 	const size_t ns = (size_t)ch.M * 6;
-	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ch.M, ch.perm, r, fixed, ch.dscale, v);
+	// (distributed: the shared rows start from the right-hand side on rank 0 only -- they collect the sum of the ranks' parts)
+	const int zero_from = (chol_distributed(ctx, ch) && ctx->comm->rank != 0) ? ch.first_shared : INT_MAX;
+	hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ch.M, ch.perm, r, fixed, ch.dscale, v, zero_from);
 }
 
-// fwd_done: v already went through the forward substitution (chol_factor with fwd_v)
+// fwd_done: v already went through the forward substitution (chol_factor with fwd_v).
+// Distributed: forward -- own columns, then the shared rows of v summed over the ranks, then the shared columns (alike on every
+// rank); backward -- the shared columns, then the own ones; z is the sum of the ranks' parts (z: in the caller's exchange buffer).
 static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, double* v, double* z, const unsigned char* fixed, const int* pose_seg,
                        double* dot, int dot_stride, bool fwd_done = false)
 {
@@ -1973,31 +2060,52 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 	int task_max = 0;
 	for (int m : ch.tlevel_maxsize) task_max = std::max(task_max, m);
 	static const bool group_solve = !getenv("LSFM_NO_GROUPS") && !getenv("LSFM_TASK_SOLVE");
+	const OwnFilter all{};
 	if (task_solve && group_solve && !ch.tlevel_ptr.empty() && (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL <= 56 * 1024)
 	{
 		// leaf sub-trees (task level 0) by task, everything above them by supernode group
 		const int n0 = ch.tlevel_ptr.size() > 1 ? ch.tlevel_ptr[1] - ch.tlevel_ptr[0] : 0;
 		const size_t lds0 = (size_t)ch.tlevel_maxsize[0] * CHOL_TASK_LDS_PER_COL + 8;
 		const int ngl = (int)ch.glevel_ptr.size() - 1;
+		const bool dist = chol_distributed(ctx, ch);
+		const OwnFilter mine{ dist ? ch.col_owner : nullptr, dist ? ctx->comm->rank : 0 }, shared{ dist ? ch.col_owner : nullptr, -1 };
 		// (Lx: the leaf columns' factor, in place in L; Gx: the group columns' factor, in its own array)
 		auto sweep = [&](auto tag, const auto* Lx, const auto* Gx, const auto* Dx) {
 			typedef decltype(tag) FT;
-			if (n0 && !fwd_done) hipLaunchKernelGGL(k_chol_fwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
-			for (int l = 0; l < ngl && !fwd_done; l++)
+			if (!fwd_done)
 			{
-				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
-				if (ng) hipLaunchKernelGGL(k_sn_fwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Gx, Dx, v, ch.wv);
+				if (n0) hipLaunchKernelGGL(k_chol_fwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v, mine);
+				for (int phase = 0; phase < (dist ? 2 : 1); phase++)
+				{
+					if (phase == 1) comm_sum(ctx, v + (size_t)ch.first_shared * 6, ((size_t)ch.M - ch.first_shared) * 6, LSFM_DTYPE_F64);
+					for (int l = 0; l < ngl; l++)
+					{
+						const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
+						if (!ng || (dist && !(phase == 0 ? ch.glevel_owned[l] : ch.glevel_shared[l]))) continue;
+						hipLaunchKernelGGL(k_sn_fwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Gx, Dx, v, ch.wv, phase == 0 ? mine : shared);
+					}
+				}
 			}
-			for (int l = ngl - 1; l >= 0; l--)
-			{
-				const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
-				if (ng) hipLaunchKernelGGL(k_sn_bwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Gx, Dx, v, ch.wv);
-			}
-			if (n0) hipLaunchKernelGGL(k_chol_bwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v);
+			for (int phase = (dist ? 1 : 0); phase >= 0; phase--) // backward: the shared columns first
+				for (int l = ngl - 1; l >= 0; l--)
+				{
+					const int g0 = ch.glevel_ptr[l], ng = ch.glevel_ptr[l + 1] - g0;
+					if (!ng || (dist && !(phase == 0 ? ch.glevel_owned[l] : ch.glevel_shared[l]))) continue;
+					hipLaunchKernelGGL(k_sn_bwd<FT>, dim3(ng), dim3(SN_THREADS), 0, s, ch.grp_c0 + g0, ch.grp_s + g0, ch.grp_nr + g0, ch.colptr, ch.rowidx, Gx, Dx, v, ch.wv, (dist && phase == 1) ? shared : mine);
+				}
+			if (n0) hipLaunchKernelGGL(k_chol_bwd_tasks<FT>, dim3(n0), dim3(128), lds0, s, ch.task_ptr + ch.tlevel_ptr[0], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[0], ch.colptr, ch.rowidx, Lx, Dx, v, mine);
 		};
 		if (ch.Lf) sweep(float(), (const float*)ch.Lf, (const float*)ch.Lgf, (const float*)ch.Dinvf); // mixed precision: the factor applied in fp32
 		else sweep(double(), (const double*)ch.L, (const double*)ch.Lg, (const double*)ch.Dinv);
-		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride);
+		if (dist)
+		{
+			hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, (double*)nullptr, dot_stride,
+			                   ch.col_owner, ctx->comm->rank);
+			ctx->comm->allreduce(s, z, (size_t)ch.M * 6, LSFM_DTYPE_F64);
+			hipLaunchKernelGGL(k_rz_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, z, r, pose_seg, dot, dot_stride);
+		}
+		else
+			hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride, (const int*)nullptr, 0);
 		return;
 	}
 	if (task_solve && (size_t)task_max * CHOL_TASK_LDS_PER_COL <= 56 * 1024) // a task's per-column data must fit LDS; else one launch per tree level
@@ -2006,14 +2114,14 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		for (int l = 0; l < ntl; l++)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+			if (n) hipLaunchKernelGGL(k_chol_fwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v, all);
 		}
 		for (int l = ntl - 1; l >= 0; l--)
 		{
 			const int n = ch.tlevel_ptr[l + 1] - ch.tlevel_ptr[l];
-			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
+			if (n) hipLaunchKernelGGL(k_chol_bwd_tasks<double>, dim3(n), dim3(l ? 256 : 128), (size_t)ch.tlevel_maxsize[l] * CHOL_TASK_LDS_PER_COL + 8, s, ch.task_ptr + ch.tlevel_ptr[l], ch.task_cols, ch.col_task, ch.col_lpos, ch.tlevel_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v, all);
 		}
-		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride);
+		hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride, (const int*)nullptr, 0);
 		return;
 	}
 	for (int l = 0; l < ch.nlevels; l++)
@@ -2028,7 +2136,7 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 		const int n = ch.level_ptr[l + 1] - ch.level_ptr[l];
 		if (n) hipLaunchKernelGGL(k_chol_bwd_level, dim3(n), dim3(64), 0, s, ch.order + ch.level_ptr[l], ch.colptr, ch.rowidx, ch.L, ch.Dinv, v);
 	}
-	hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride);
+	hipLaunchKernelGGL(k_perm_out_dot, dim3((ch.M + 127) / 128), dim3(128), 0, s, ch.M, ch.pinv, v, r, fixed, ch.dscale, pose_seg, z, dot, dot_stride, (const int*)nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2385,7 +2493,8 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	h2d(ctx, seg, hseg.data(), sizeof(PcgSeg) * 2 * nseg);
 	double* x = io.x_pose;
 	const size_t nscal = (size_t)M * 6;
-	double* r = sc.alloc<double>(nscal); double* z = sc.alloc<double>(nscal); double* p = sc.alloc<double>(nscal);
+	// (feature-sharded run: z is a sum over the ranks when the factorisation is distributed -- it lives in the exchange buffer)
+	double* r = sc.alloc<double>(nscal); double* z = ctx->comm ? ctx->comm->alloc<double>(nscal) : sc.alloc<double>(nscal); double* p = sc.alloc<double>(nscal);
 	double* Ap = sc.alloc<double>(nscal); double* v = sc.alloc<double>(nscal);
 	const int nbr = (M + 127) / 128, nbs = (nseg + 127) / 128;
 	const unsigned nbe = (unsigned)((nscal + 255) / 256);
@@ -2395,6 +2504,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 1);
 	const bool mixed = ctx->pcg.mixed;
 	const bool fused_fwd = !mixed && chol_group_solve(ch); // (mixed: the factor is applied from its fp32 copy, made after the factorisation)
+	if (ctx->stats && chol_distributed(ctx, ch)) { ctx->stats->dist_solves++; ctx->stats->dist_work_total += ch.work_total; ctx->stats->dist_work_shared += ch.work_shared; }
 	chol_scatter(ctx, sy, io.d_fixed, ch);
 	if (fused_fwd) chol_perm_in(ctx, ch, r, io.d_fixed, v);
 	chol_factor(ctx, sy, io.d_fixed, ch, fused_fwd ? v : nullptr);

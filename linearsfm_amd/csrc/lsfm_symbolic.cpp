@@ -45,7 +45,7 @@ Workspace& workspace()
 
 } // namespace
 
-void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& ch)
+void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& ch, int block_maps)
 {
 	Workspace& w = workspace();
 	// ---- separators: greedy vertex cover of the crossing edges, top level first --------------------------------------
@@ -152,6 +152,25 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		for (int i = 0; i < M; i++) perm[cnt[sep[i]]++] = i;
 		for (int i = 0; i < M; i++) pinv[perm[i]] = i;
 	}
+	// ---- ownership (distributed factorisation): an edge between poses of different blocks crosses a cut of level > kb, and one of
+	// its endpoints sits in that cut's separator -- so a pose with sep <= kb sees, and ever gets filled to, only poses of its own
+	// block and separator poses above: its column is its block's; the columns with sep > kb (the tail of the ordering) are shared
+	ch.col_owner.clear();
+	ch.first_shared = M;
+	if (block_maps > 0)
+	{
+		const int kb = bitlen((unsigned)(block_maps - 1)); // (blocks are 2^k local maps: origins of one block differ in their low kb bits only)
+		ch.col_owner.resize(M);
+		int fs = M;
+		for (int j = 0; j < M; j++)
+		{
+			const int p = perm[j];
+			const bool shared = sep[p] > kb;
+			ch.col_owner[j] = shared ? -1 : origin[p] / block_maps;
+			if (shared && j < fs) fs = j;
+		}
+		ch.first_shared = fs;
+	}
 	// ---- strict lower adjacency by row, new numbering ------------------------------------------------------------------
 	std::vector<int>&rcnt = w.rcnt, &radj = w.radj, &fill = w.fill;
 	rcnt.assign(M + 1, 0);
@@ -190,6 +209,13 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	colptr.assign(M + 1, 0);
 	for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
 	const int nnzL = colptr[M];
+	ch.work_total = ch.work_shared = 0;
+	for (int j = 0; j < M; j++)
+	{
+		const double w = 0.5 * (double)ccount[j] * (ccount[j] + 1);
+		ch.work_total += w;
+		if (j >= ch.first_shared) ch.work_shared += w;
+	}
 	rowidx.resize(nnzL);
 	w.cfill.assign(M, 1);
 	for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
@@ -234,6 +260,8 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	size.assign(ccount.begin(), ccount.end());
 	ntc.assign(M, 0); topchild.assign(M, -1); task.assign(M, -1); tlev.clear();
 	for (int j = 0; j < M; j++) if (parent[j] >= 0) size[parent[j]] += size[j];
+	// (distributed factorisation: a shared column is never part of a leaf task -- those run before the ranks' sums are exchanged)
+	for (int j = ch.first_shared; j < M; j++) size[j] = std::max(size[j], task_x + 1);
 	for (int j = 0; j < M; j++)
 		if (size[j] > task_x && parent[j] >= 0) { ntc[parent[j]]++; topchild[parent[j]] = j; }
 	int ntasks = 0;
@@ -317,7 +345,8 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		for (int j = 0; j < M; j++)
 		{
 			if (size[j] <= task_x) continue;
-			const bool join = j > 0 && size[j - 1] > task_x && parent[j - 1] == j && ccount[j - 1] == ccount[j] + 1 && gs[grp[j - 1]] < CHOL_GS;
+			const bool join = j > 0 && size[j - 1] > task_x && parent[j - 1] == j && ccount[j - 1] == ccount[j] + 1 && gs[grp[j - 1]] < CHOL_GS &&
+			                  j != ch.first_shared; // (a run never spans interior and shared columns)
 			if (join) { grp[j] = grp[j - 1]; gs[grp[j]]++; }
 			else { grp[j] = (int)gc0.size(); gc0.push_back(j); gs.push_back(1); glev.push_back(0); }
 		}
@@ -344,6 +373,8 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		}
 		ch.ngroups = ng;
 		ch.glevel_ptr = gl_count;
+		ch.glevel_owned.assign(ngl, 0); ch.glevel_shared.assign(ngl, 0);
+		for (int g = 0; g < ng; g++) (gc0[g] >= ch.first_shared ? ch.glevel_shared : ch.glevel_owned)[glev[g]] = 1;
 	}
 }
 

@@ -22,10 +22,21 @@ struct CholSymbolic {
 	// for the debug census
 	std::vector<int> parent, ccount;
 	int task_x = 0;
+	// Distributed factorisation (block_maps > 0): the poses whose separator level lies inside one block of block_maps consecutive
+	// local maps are INTERIOR to that block -- their columns, and everything those columns update below the inter-block
+	// separators, belong to the rank that owns the block; the columns of the inter-block separators (the last columns of the
+	// ordering, from first_shared on) are shared.  col_owner[j] (new numbering): block of column j, -1: shared.  Empty when off.
+	std::vector<int> col_owner;
+	int first_shared = 0;
+	std::vector<char> glevel_owned, glevel_shared; // per group level: holds groups of interior / of shared columns
+	// block products of the numeric factorisation (sum over the columns of c (c + 1) / 2, c = blocks of the column): all of them / those of
+	// the shared columns, which every rank repeats -- the replicated share of a distributed factorisation
+	double work_total = 0, work_shared = 0;
 };
 
 // keys[nnzb]: sorted (row << 32 | col) of the upper block pattern of S (every diagonal block present); origin[M]: index of
 // the local map that brought each pose (drives the nested dissection along the join tree).
-void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& out);
+// block_maps > 0: also the ownership of a factorisation distributed over the ranks that joined blocks of block_maps local maps each.
+void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& out, int block_maps = 0);
 
 } // namespace lsfm

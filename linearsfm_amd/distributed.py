@@ -246,17 +246,21 @@ class ShardedTree:
     run() joins the whole tree and leaves the final map on rank 0 (download()).  run() can be repeated: the block trees
     and the merge trees keep their allocations and their plans, the packed buffers are reused."""
 
-    def __init__(self, ctx, maps_block, lo, n_total, mono, group=None, device=None, top="shard", comm_bytes=0, shard_single=False):
+    def __init__(self, ctx, maps_block, lo, n_total, mono, group=None, device=None, top="shard", comm_bytes=0, shard_single=False, solve="owned"):
         """top: "shard" -- the levels above the blocks run feature-sharded on ALL ranks (all-reduces per level); "merge" --
         pairwise merge rounds on half of the remaining ranks each (no collective in the data path).  comm_bytes: size of the
         device buffer the all-reduced arrays live in (0: 512 MiB; it must hold the largest camera system, 288 bytes per block).
         shard_single: take the feature-sharded path with ONE rank too (tests: the whole collective path on one GPU)."""
-        assert top in ("shard", "merge")
+        assert top in ("shard", "merge") and solve in ("owned", "replicated")
+        # solve: how the camera systems of the feature-sharded top levels are factored -- "owned": rank r factors the columns of
+        # block r's poses, the inter-block separators are summed and factored by everybody (lsfm_tree_set_comm_blocks);
+        # "replicated": every rank factors everything (round 3)
+        self.solve = solve
         self.ctx, self.mono, self.group = ctx, bool(mono), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        _, self.bounds = shard_bounds(n_total, self.world)
+        self.block_maps, self.bounds = shard_bounds(n_total, self.world)
         assert self.bounds[self.rank][0] == lo and self.bounds[self.rank][1] - lo == len(maps_block), \
             "maps_block must be exactly this rank's block (shard_bounds)"
         self.nonempty = [hi > a for a, hi in self.bounds]
@@ -421,7 +425,7 @@ class ShardedTree:
         out = {}
         for k in set(a) | set(b):
             x, y = a.get(k, 0), b.get(k, 0)
-            out[k] = max(x, y) if k in ("max_rel_residual", "spmv_nnzb_upper_last", "spmv_rows_last", "upload_ms") else x + y
+            out[k] = max(x, y) if k in ("max_rel_residual", "spmv_nnzb_upper_last", "spmv_rows_last", "upload_ms", "s_digest", "factor_digest") else x + y
         return out
 
     def _run_shard(self):
@@ -465,6 +469,7 @@ class ShardedTree:
             torch.cuda.current_stream(self.device).synchronize()
             self.comm_cb = self._allreduce_callback()
             ctx.tree_set_comm(self.top_tree, me, G, self.comm_cb, self.comm_buf.data_ptr(), self.comm_bytes)
+            ctx.tree_set_comm_blocks(self.top_tree, self.block_maps if self.solve == "owned" else 0)
         else:
             ctx.tree_reload_dev(self.top_tree, ptrs)
         self.comm_error = None

@@ -27,7 +27,10 @@ def _make(n_maps, mono):
     return synth.make_mono_set(n_maps, 8, 4, seed=41, **synth.SPIRAL) if mono else synth.make_stereo_set(n_maps, 8, 5, seed=41, lap=30, home=5)
 
 
-def _worker(rank, world, port, n_maps, mono, q, top="merge", backend="gloo", plans=True):
+def _worker(rank, world, port, n_maps, mono, q, top="merge", backend="gloo", plans=True, solve="owned"):
+    # (leaf sub-trees of at most 12 blocks instead of 90, so that sets this small have supernode groups and inter-block separators
+    # above them: the distributed factorisation is then what runs, not its replicated fallback; read once, when the library loads)
+    os.environ["LSFM_TASK_X"] = "12"
     import torch
     import torch.distributed as dist
     from linearsfm_amd import api
@@ -43,13 +46,16 @@ def _worker(rank, world, port, n_maps, mono, q, top="merge", backend="gloo", pla
     _, bounds = shard_bounds(n_maps, world)
     lo, hi = bounds[rank]
     ctx = api.Context(0)
-    st = ShardedTree(ctx, maps[lo:hi], lo, n_maps, mono, top=top, shard_single=True, comm_bytes=64 << 20)
+    st = ShardedTree(ctx, maps[lo:hi], lo, n_maps, mono, top=top, shard_single=True, comm_bytes=64 << 20, solve=solve)
     st.set_plans(plans)
     outs = []
     for _ in range(3):  # repeated steps reuse the resident trees, their plans and the packed buffers
         dist.barrier()
-        _, rc = st.run()
+        stats, rc = st.run()
         assert rc == 0
+        if top == "shard" and world > 1 and n_maps >= 16:
+            # the camera systems of the top levels were factored by block ownership (or, asked so, by every rank in full)
+            assert (stats["dist_solves"] > 0) == (solve == "owned"), (solve, stats["dist_solves"])
         if top == "shard":
             o = st.download()  # collective: every rank hands its feature slice to rank 0
             if rank == 0:
@@ -66,22 +72,26 @@ def _worker(rank, world, port, n_maps, mono, q, top="merge", backend="gloo", pla
 
 # top = "merge": sub-tree sharding with pairwise merge rounds; "shard": the levels above the blocks feature-sharded over ALL ranks
 # (three all-reduces per level through the library's lsfm_allreduce_fn hook; without plans also the union of the ranks' patterns)
-@pytest.mark.parametrize("world,n_maps,mono,top,backend,plans", [
-    (2, 64, False, "merge", "gloo", True), (4, 100, False, "merge", "gloo", True), (2, 40, True, "merge", "gloo", True),
-    (3, 21, False, "merge", "gloo", True),
-    (2, 64, False, "shard", "gloo", True), (4, 100, False, "shard", "gloo", True), (2, 40, True, "shard", "gloo", True),
-    (3, 21, False, "shard", "gloo", True), (4, 100, False, "shard", "gloo", False), (4, 52, True, "shard", "gloo", False),
-    (4, 3, False, "shard", "gloo", True),
+# solve = "owned": the camera systems of the feature-sharded levels are factored by block ownership (rank r the columns of block r's
+# poses, one exact integer all-reduce of the inter-block separators' accumulators, the separators by everybody); "replicated": by
+# every rank in full (round 3)
+@pytest.mark.parametrize("world,n_maps,mono,top,backend,plans,solve", [
+    (2, 64, False, "merge", "gloo", True, "owned"), (4, 100, False, "merge", "gloo", True, "owned"), (2, 40, True, "merge", "gloo", True, "owned"),
+    (3, 21, False, "merge", "gloo", True, "owned"),
+    (2, 64, False, "shard", "gloo", True, "owned"), (4, 100, False, "shard", "gloo", True, "owned"), (2, 40, True, "shard", "gloo", True, "owned"),
+    (3, 21, False, "shard", "gloo", True, "owned"), (4, 100, False, "shard", "gloo", False, "owned"), (4, 52, True, "shard", "gloo", False, "owned"),
+    (4, 3, False, "shard", "gloo", True, "owned"), (4, 200, True, "shard", "gloo", True, "owned"),
+    (2, 64, False, "shard", "gloo", True, "replicated"), (4, 52, True, "shard", "gloo", False, "replicated"),
     # one rank, RCCL: the library's sums go through torch's all_reduce on device pointers under the library's own stream
-    (1, 48, False, "shard", "nccl", True), (1, 24, True, "shard", "nccl", False)])
-def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono, top, backend, plans):
+    (1, 48, False, "shard", "nccl", True, "owned"), (1, 24, True, "shard", "nccl", False, "owned")])
+def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono, top, backend, plans, solve):
     maps = _make(n_maps, mono)
     single, _, rc = ctx.divide_conquer([dict(m.__dict__) for m in maps], mono)
     assert rc == 0
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, n_maps, mono, q, top, backend, plans)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n_maps, mono, q, top, backend, plans, solve)) for r in range(world)]
     for p in procs:
         p.start()
     outs = q.get(timeout=600)

@@ -199,7 +199,7 @@ int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, l
 	if (!out || !maps || N <= 0) return LSFM_ERR_ARG;
 	*out = nullptr;
 	return guarded(ctx, [&]() {
-		ctx->ensure_arenas(estimate_arena(maps, N, tree_levels(N)));
+		ctx->ensure_arenas(estimate_arena(maps, N, tree_levels(N)), true);
 		lsfm_tree* t = new lsfm_tree();
 		t->mono = mono != 0; t->N = N; t->slot = 0;
 		ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->scratch.reset();
@@ -296,7 +296,18 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					try { tree_pass(ctx, t, st); }
 					catch (const Error& e) { pass_error.reset(new Error(e)); (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); }
 				}
-				else tree_pass(ctx, t, st);
+				else
+				{
+					// (the arenas start at an eighth of the upper bound the upload asked for: a run that exhausts one doubles them and starts over)
+					try { tree_pass(ctx, t, st); }
+					catch (const Error& e)
+					{
+						if (e.code != LSFM_ERR_OOM || !ctx->grow_arenas()) throw;
+						if (getenv("LSFM_DEBUG")) fprintf(stderr, "[lsfm] arenas grown to %zu MiB each after: %s\n", ctx->arena_bytes >> 20, e.msg.c_str());
+						attempt--; // (not a numerical repeat)
+						continue;
+					}
+				}
 				st->t_total_ms = now_ms() - t_begin; // (repeated attempts included; the stage times below are the last attempt's)
 				ctx->mark("end");
 				if (ctx->timeline_on)

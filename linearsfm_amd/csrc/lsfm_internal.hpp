@@ -284,7 +284,13 @@ struct lsfm_context {
 	hipEvent_t pool_event();
 	void defer_time(hipEvent_t a, hipEvent_t b, double* sink) { timed.push_back(Timed{ a, b, sink }); }
 	void flush_times(); // after the stream has been synchronised
-	void ensure_arenas(size_t bytes_each);
+	// bytes_each: an upper bound of what a call may need (the estimates ignore that joins merge their common features: an order of
+	// magnitude at depth).  start_small: allocate an eighth of it and let grow_arenas() double it when a run exhausts an arena --
+	// a cold process paid 2.5-3 s of hipMalloc for the 4 x 26 GB the NC3500-like estimate asks for, of which a run touches 3 GB
+	void ensure_arenas(size_t bytes_each, bool start_small = false);
+	bool grow_arenas(); // false: already at the bound
+	bool arena_small = false;
+	size_t arena_bound = 0; // what the arenas may grow to (the capped request)
 };
 
 namespace lsfm {

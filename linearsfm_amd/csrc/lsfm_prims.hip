@@ -257,28 +257,48 @@ void lsfm_context::flush_times()
 	(void)hipGetLastError();
 }
 
-void lsfm_context::ensure_arenas(size_t bytes_each)
+static void alloc_arenas(lsfm_context* c, size_t bytes_each)
+{
+	c->arena[0].destroy(); c->arena[1].destroy(); c->arena[2].destroy(); c->scratch.destroy(); c->sarena[0].destroy(); c->sarena[1].destroy();
+	c->pre.reset();
+	c->arena[0].init(bytes_each);
+	c->arena[1].init(bytes_each);
+	c->arena[2].init(bytes_each);
+	c->scratch.init(bytes_each);
+	c->sarena[0].init(std::max<size_t>((size_t)96 << 20, bytes_each / 6));
+	c->sarena[1].init(std::max<size_t>((size_t)96 << 20, bytes_each / 6));
+	c->arena_bytes = bytes_each;
+}
+void lsfm_context::ensure_arenas(size_t bytes_each, bool start_small)
 {
 	generation++; // every caller is about to reset the arenas
-	if (arena_req >= bytes_each && arena[0].base) return;
-	LSFM_CHECK_HIP(hipStreamSynchronize(stream));
+	// (what is there suffices: by its size -- or, for a caller that can grow the arenas, by the bound they were made for)
+	if (arena[0].base && (arena_bytes >= bytes_each || (start_small && arena_req >= bytes_each))) return;
+	LSFM_CHECK_HIP(hipDeviceSynchronize());
 	const size_t requested = bytes_each;
 	// the estimate is an upper bound that ignores the merging of common features (an order of magnitude at depth): never
 	// ask for more than a share of what the device has free; a tree that really needs more fails with LSFM_ERR_OOM at
 	// the allocation that overflows its arena
 	arena[0].destroy(); arena[1].destroy(); arena[2].destroy(); scratch.destroy(); sarena[0].destroy(); sarena[1].destroy();
-	pre.reset();
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)4 << 30))
 		bytes_each = std::min(bytes_each, (free_b - ((size_t)2 << 30)) / 5);
-	arena[0].init(bytes_each);
-	arena[1].init(bytes_each);
-	arena[2].init(bytes_each);
-	scratch.init(bytes_each);
-	sarena[0].init(std::max<size_t>((size_t)96 << 20, bytes_each / 6));
-	sarena[1].init(std::max<size_t>((size_t)96 << 20, bytes_each / 6));
-	arena_bytes = bytes_each;
+	arena_bound = bytes_each;
+	static const int div = getenv("LSFM_ARENA_DIV") ? std::max(1, atoi(getenv("LSFM_ARENA_DIV"))) : 8;
+	arena_small = start_small && div > 1;
+	static const size_t floor_b = (size_t)(getenv("LSFM_ARENA_MIN_MB") ? std::max(1, atoi(getenv("LSFM_ARENA_MIN_MB"))) : 1024) << 20; // (tests: a small floor)
+	if (arena_small) bytes_each = std::min(bytes_each, std::max<size_t>(floor_b, bytes_each / div));
+	alloc_arenas(this, bytes_each);
 	arena_req = requested;
+}
+bool lsfm_context::grow_arenas()
+{
+	if (!arena_small || arena_bytes >= arena_bound) return false;
+	(void)hipDeviceSynchronize();
+	(void)hipGetLastError();
+	alloc_arenas(this, std::min(arena_bound, 2 * arena_bytes));
+	generation++;
+	return true;
 }
 
 extern "C" {

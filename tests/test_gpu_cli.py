@@ -108,3 +108,23 @@ def test_rccl_allreduce_hook_from_cpp(tmp_path, typ, n):
     r = subprocess.run([exe, "-path", str(d), "-num", str(n), "-type", typ], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all-reduces" in r.stdout
+
+
+def test_cli_arenas_grow_when_a_run_exhausts_them(oracle, tmp_path):
+    """The device arenas start at a fraction of the upper bound the upload asks for (a cold process paid seconds of hipMalloc for the
+    whole bound) and are doubled when a run exhausts one -- the run starts over, the result is the same.  Here: a floor of 1 MiB and
+    1/4096 of the bound, so that a small tree has to grow them several times."""
+    maps = synth.make_stereo_set(40, 30, 5, seed=44, lap=20, home=5)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    full = {}
+    for tag, env in (("grown", {"LSFM_ARENA_DIV": "4096", "LSFM_ARENA_MIN_MB": "1", "LSFM_DEBUG": "1"}), ("whole", {"LSFM_ARENA_DIV": "1"})):
+        s = str(tmp_path / f"{tag}_full.txt")
+        r = subprocess.run([exe, "-path", str(d), "-num", "40", "-type", "Stereo", "-full", s], capture_output=True, text=True, check=True,
+                           env=dict(os.environ, **env))
+        full[tag] = (_table(s), r.stderr)
+    assert "arenas grown to" in full["grown"][1] and "arenas grown to" not in full["whole"][1]
+    a, b = full["grown"][0], full["whole"][0]
+    assert np.array_equal(a[:, 0], b[:, 0])
+    assert np.max(np.abs(a[:, 1] - b[:, 1]) / np.maximum(1.0, np.abs(b[:, 1]))) < 1e-9

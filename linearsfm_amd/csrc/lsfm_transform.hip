@@ -597,12 +597,52 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 			{
 				if (act)
 				{
-					double T[18], Cf[18], R[9];
+					double Cf[18], R[9];
+					if constexpr (NH == 1) ld<9>(R, fd);
+					if constexpr (NH == 1)
+					{
+						// C_f = [-R | T_f] (k_tr_feat_pre): R is in registers already, only the feature's own 9 numbers are fetched
+#pragma unroll
+						for (int m = 0; m < 3; m++)
+#pragma unroll
+							for (int c = 0; c < 3; c++) { Cf[6 * m + c] = -R[3 * m + c]; Cf[6 * m + 3 + c] = fd[9 + 6 * m + 3 + c]; }
+					}
+					else ld<18>(Cf, fd + 9 + 18 * s);
+					// pose row of G_s: W C_s,f  [6x6] into the tile's LDS table.  The lanes of a wave that share a pose (a tile's 128
+					// features are seen by a dozen poses: ~4 lanes per pose and wave) used to add element (r, c) of their products to
+					// the SAME address in the same instruction, 36 times -- an LDS double-precision atomic serialises the lanes of an
+					// address at ~11 clocks each, CU-wide (tools/microbench/lds_ops.hip: 8 clocks per conflict-free instruction, 92
+					// with 8 lanes per address): 20 % of this kernel.  Now a lane parks half a product (18 numbers) in its own row
+					// of sT and adds them in an order rotated by its lane number: lanes of one pose hit different elements.
+					double* gl = sl >= 0 ? &gvals[(s * GCAP + sl) * 36] : nullptr;
+					double* gg = Gpose + (size_t)s * M * 36 + (size_t)k * 36;
+					double* my = &sT[tid * 18];
+					const int rot = (tid & 63) % 18;
+#pragma unroll
+					for (int half = 0; half < 2; half++)
+					{
+#pragma unroll
+						for (int i = 0; i < 18; i++)
+						{
+							const int r = 3 * half + i / 6, c = i % 6;
+							my[i] = W[3 * r] * Cf[c] + W[3 * r + 1] * Cf[6 + c] + W[3 * r + 2] * Cf[12 + c];
+							if (i % 6 == 5) __builtin_amdgcn_sched_barrier(0); // (a row at a time: 18 products formed before the first store do not fit the registers)
+						}
+#pragma unroll 1
+						for (int e = 0; e < 18; e++)
+						{
+							int i = e + rot;
+							if (i >= 18) i -= 18;
+							const double v = my[i];
+							if (gl) lds_add_f64(gl + 18 * half + i, v); else atomic_add_f64(gg + 18 * half + i, v);
+						}
+					}
+					// (W^T C_s,k only now: its 18 numbers are not alive while the pose rows are formed -- the kernel is at its register budget)
+					double T[18];
 					zero<18>(T);
 					if constexpr (NH == 1)
 					{
 						// C_k = [-R T_k; 0 DD_k] (zero for the hub pose): W^T C_k from the 18 packed numbers and R = D_f
-						ld<9>(R, fd);
 						if (!is_hub)
 						{
 							double TK[9], DDk[9];
@@ -649,28 +689,8 @@ k_tr_entries(int NF, int M, const int4* __restrict__ finfo, const int* __restric
 								}
 							}
 					}
-					st<18>(&sT[tid * 18], T);
-					if constexpr (NH == 1)
-					{
-						// C_f = [-R | T_f] (k_tr_feat_pre): R is in registers already, only the feature's own 9 numbers are fetched
-#pragma unroll
-						for (int m = 0; m < 3; m++)
-#pragma unroll
-							for (int c = 0; c < 3; c++) { Cf[6 * m + c] = -R[3 * m + c]; Cf[6 * m + 3 + c] = fd[9 + 6 * m + 3 + c]; }
-					}
-					else ld<18>(Cf, fd + 9 + 18 * s);
-					TRT(5); // C_k load, W^T C_k, C_f load
-					// pose row of G_s: W C_s,f   [6x6], one row at a time
-					double* gl = sl >= 0 ? &gvals[(s * GCAP + sl) * 36] : nullptr;
-					double* gg = Gpose + (size_t)s * M * 36 + (size_t)k * 36;
-#pragma unroll
-					for (int r = 0; r < 6; r++)
-#pragma unroll
-						for (int c = 0; c < 6; c++)
-						{
-							const double v = W[3 * r] * Cf[c] + W[3 * r + 1] * Cf[6 + c] + W[3 * r + 2] * Cf[12 + c];
-							if (gl) lds_add_f64(gl + r * 6 + c, v); else atomic_add_f64(gg + r * 6 + c, v);
-						}
+					TRT(5); // C_k load, W^T C_k
+					st<18>(&sT[tid * 18], T); // (the lane's row of W^T C_s,k for the feature sums below, over the parking place)
 				}
 				TRT(8); // pose rows: 36 LDS atomic adds
 				__syncthreads();

@@ -291,6 +291,29 @@ __device__ __forceinline__ void tile_scatter_add(int* keys, double* vals, int ca
 		for (int i = 0; i < N; i++) { if (sl >= 0) lds_add_f64(vals + sl * N + i, x[i]); else atomic_add_f64(gdst + i, x[i]); }
 	}
 }
+// The same, for keys that many lanes of a wave share (the hub pose of a map: every U block of the map adds to its row).  An LDS
+// double-precision atomic serialises the lanes of one address at ~11 clocks each, CU-wide (tools/microbench/lds_ops.hip): 64
+// lanes adding element i of their N numbers to the same accumulator, N times, is what made k_tr_ublocks 200 us per launch.  Here
+// a lane parks its N numbers in its own LDS row `stage` and adds them in an order rotated by its lane number, so that the lanes of
+// one key are spread over the N elements.  Must be called by all 64 lanes.
+template <int N>
+__device__ __forceinline__ void tile_scatter_add_rot(int* keys, double* vals, int cap, int key, double* gdst, const double* x, bool valid, double* stage)
+{
+	if (__ballot(valid) == 0ull) return;
+	if (!valid) return;
+	const int sl = lds_slot(keys, cap, key);
+#pragma unroll
+	for (int i = 0; i < N; i++) stage[i] = x[i];
+	const int rot = (threadIdx.x & (LSFM_WAVE - 1)) % N;
+#pragma unroll 1
+	for (int e = 0; e < N; e++)
+	{
+		int i = e + rot;
+		if (i >= N) i -= N;
+		const double v = stage[i];
+		if (sl >= 0) lds_add_f64(vals + sl * N + i, v); else atomic_add_f64(gdst + i, v);
+	}
+}
 // after a __syncthreads(): every touched accumulator leaves the work-group once, N contiguous adds at gbase + key*N
 template <int N>
 __device__ __forceinline__ void tile_flush(const int* keys, const double* vals, int cap, double* gbase)

@@ -825,6 +825,7 @@ k_tr_ublocks(int NU, int M, const TMap* __restrict__ tm, const int* __restrict__
 	constexpr int GCAP = 64;
 	__shared__ int gkeys[GCAP];
 	__shared__ double gvals[NH * GCAP * 36];
+	__shared__ double sStage[128 * 37]; // a lane's 36 numbers on their way to the table (tile_scatter_add_rot); odd stride
 	for (int q = threadIdx.x; q < GCAP; q += blockDim.x) gkeys[q] = -1;
 	for (int q = threadIdx.x; q < NH * GCAP * 36; q += blockDim.x) gvals[q] = 0.0;
 	__syncthreads();
@@ -881,14 +882,14 @@ k_tr_ublocks(int NU, int M, const TMap* __restrict__ tm, const int* __restrict__
 			ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)b * 36);
 			mm<6, 6, 6, false>(U, C, Y);
 		}
-		tile_scatter_add<36>(gkeys, gvals + s * GCAP * 36, GCAP, a, Gpose + (size_t)s * M * 36 + (size_t)a * 36, Y, act);
+		tile_scatter_add_rot<36>(gkeys, gvals + s * GCAP * 36, GCAP, a, Gpose + (size_t)s * M * 36 + (size_t)a * 36, Y, act, &sStage[threadIdx.x * 37]);
 		const bool off = act && a != b;
 		if (off)
 		{
 			ld<36>(C, Cp + (size_t)s * M * 36 + (size_t)a * 36);
 			mtm<6, 6, 6, false>(U, C, Y);
 		}
-		tile_scatter_add<36>(gkeys, gvals + s * GCAP * 36, GCAP, b, Gpose + (size_t)s * M * 36 + (size_t)b * 36, Y, off);
+		tile_scatter_add_rot<36>(gkeys, gvals + s * GCAP * 36, GCAP, b, Gpose + (size_t)s * M * 36 + (size_t)b * 36, Y, off, &sStage[threadIdx.x * 37]);
 	}
 	__syncthreads();
 #pragma unroll

@@ -92,6 +92,10 @@ typedef struct lsfm_stats {
 	/* ... and, over those levels, the block products (6x6x6 multiply-adds) of the numeric factorisations: all of them / those of the
 	 * shared separator columns, which every rank repeats (the replicated share: an Amdahl bound of the distributed solve) */
 	double dist_work_total, dist_work_shared;
+	/* LSFM_FACTOR_DIGEST=1: every camera system of the run is factored TWICE (the work-groups of the two factorisations are scheduled
+	 * differently, their atomics land in another order); the number of systems whose two factors were not the same bits.  Must be 0:
+	 * the accumulation is in fixed point. */
+	int refactor_mismatch;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */

@@ -37,7 +37,7 @@ class LsfmStats(C.Structure):
                 ("not_converged", C.c_int), ("schur_launches", C.c_long), ("trf_launches", C.c_long),
                 ("schur_ms", C.c_double), ("schur_bytes", C.c_double), ("trf_ms", C.c_double), ("trf_bytes", C.c_double),
                 ("schur_flops", C.c_double), ("upload_ms", C.c_double), ("attempts", C.c_int),
-                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong), ("dist_solves", C.c_int), ("dist_work_total", C.c_double), ("dist_work_shared", C.c_double)]
+                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong), ("dist_solves", C.c_int), ("dist_work_total", C.c_double), ("dist_work_shared", C.c_double), ("refactor_mismatch", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

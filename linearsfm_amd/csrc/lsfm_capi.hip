@@ -375,7 +375,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				st->max_rel_residual = std::max(st->max_rel_residual, rs.max_rel_residual);
 				st->upload_ms = t->upload_ms;
 				st->schur_flops += 108.0 * (double)rs.k2;
-				st->s_digest = rs.s_digest; st->factor_digest = rs.factor_digest;
+				st->s_digest = rs.s_digest; st->factor_digest = rs.factor_digest; st->refactor_mismatch = rs.refactor_mismatch;
 				break;
 			}
 			ctx->flush_times();

@@ -119,6 +119,7 @@ struct RunStatsDev {
 	int floored;           // pivots of the separators replaced by their lower bound (static pivoting, lsfm_pcg.hip k_sn_panel)
 	double max_rel_residual;
 	unsigned long long s_digest, factor_digest; // LSFM_FACTOR_DIGEST=1 (lsfm_stats)
+	int refactor_mismatch, pad_;                // ... systems whose second factorisation gave other bits than the first
 	unsigned long long k2;  // sum over the levels of sum over the features of (W run length)^2: K9's pose pairs, for its algorithmic flop count
 };
 

@@ -2323,6 +2323,10 @@ __global__ void k_digest(size_t n, const unsigned long long* __restrict__ a, uns
 	}
 	atomicAdd(out, h);
 }
+__global__ void k_digest_compare(const unsigned long long* d, int* mismatch)
+{
+	if (d[0] != d[1]) atomicAdd(mismatch, 1);
+}
 __global__ void k_chol_err_to_run(const int* err, RunStatsDev* run)
 {
 	if (*err && !run->chol_err) run->chol_err = *err;
@@ -2530,9 +2534,26 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		};
 		dg(sy.S, (size_t)sy.nnzb * 36, &ctx->d_run->s_digest);
 		// leaf columns: factored in place in L; group columns: in Lg (their slots of L hold the spent accumulators: integers, summed alike)
-		dg(ch.Dinv, (size_t)ch.M * 36, &ctx->d_run->factor_digest);
-		dg(ch.L, (size_t)ch.nnzL * 36, &ctx->d_run->factor_digest);
-		if (ch.Lg) dg(ch.Lg, (size_t)ch.nnzL * 36, &ctx->d_run->factor_digest);
+		auto factor_digest = [&](unsigned long long* out) {
+			dg(ch.Dinv, (size_t)ch.M * 36, out);
+			dg(ch.L, (size_t)ch.nnzL * 36, out);
+			if (ch.Lg) dg(ch.Lg, (size_t)ch.nnzL * 36, out);
+		};
+		factor_digest(&ctx->d_run->factor_digest);
+		if (!ctx->comm)
+		{
+			// ... and the SAME system factored a second time (its work-groups will be scheduled differently, the atomics land in another
+			// order): the two factors must be the same bits.  d[0], d[1]: the digests of this system's two factors alone
+			unsigned long long* d = sc.alloc<unsigned long long>(2);
+			dev_zero(ctx, d, 2 * sizeof(unsigned long long));
+			factor_digest(d);
+			dev_zero(ctx, ch.L, (size_t)ch.nnzL * 36 * sizeof(double));
+			if (ch.Lg) dev_zero(ctx, ch.Lg, (size_t)ch.nnzL * 36 * sizeof(double));
+			chol_scatter(ctx, sy, io.d_fixed, ch);
+			chol_factor(ctx, sy, io.d_fixed, ch, nullptr);
+			factor_digest(d + 1);
+			hipLaunchKernelGGL(k_digest_compare, dim3(1), dim3(1), 0, s, d, &ctx->d_run->refactor_mismatch);
+		}
 	}
 	if (dbg) { LSFM_CHECK_HIP(hipStreamSynchronize(s)); }
 	double tw2 = wall();

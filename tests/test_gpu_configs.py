@@ -398,3 +398,34 @@ def test_early_schur_pattern_equals_the_joint_maps(ctx, oracle, monkeypatch, N, 
     assert orc == 0
     _same_structure(got, exp)
     assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < TREE_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the factorisation gives the same bits whatever order its work-groups run in
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("config,n_maps", [("nc3500", 600), ("rs468", 200)])
+def test_factorisation_is_bit_reproducible(config, n_maps):
+    """LSFM_FACTOR_DIGEST=1 (read when the library loads: a process of its own): every camera system of every level is factored
+    TWICE -- scatter, leaf sub-trees, supernode groups with their rank updates into the ancestors -- and the two factors (leaf columns,
+    group columns, inverse diagonal blocks, the spent accumulators) are compared through an order-independent digest on the device.
+    The updates that several work-groups of a launch add to one block are 64-bit fixed-point integers (lsfm_pcg.hip): whatever order
+    the atomics land in, the sum is the same.  Round 3 added doubles there and two runs never gave the same factor."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from linearsfm_amd import api, synth\n"
+        "typ, maps = synth.make_config(%r, %d)\n"
+        "ctx = api.Context(0)\n"
+        "t = ctx.tree_upload([m.__dict__ for m in maps], typ == 'Monocular')\n"
+        "ctx.tree_set_plans(t, False)\n"
+        "tot = 0\n"
+        "for _ in range(3):\n"
+        "    st, rc = ctx.tree_run(t)\n"
+        "    assert rc == 0 and st['factor_digest'] != 0\n"
+        "    tot += st['refactor_mismatch']\n"
+        "print('MISMATCH', tot, 'LEVELS', st['levels'])\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), config, n_maps))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LSFM_FACTOR_DIGEST="1"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("MISMATCH")][0].split()
+    assert int(line[1]) == 0 and int(line[3]) >= 8, line

@@ -20,7 +20,11 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <queue>
+#include <thread>
 #include <utility>
 
 namespace lsfm {
@@ -47,6 +51,174 @@ Workspace& workspace()
 
 } // namespace
 
+// A few host threads that live as long as the process, for the chunks of independent systems of one analysis (threads started per
+// call fault their fresh workspaces in under the process's memory lock, one after the other: no gain).  One analysis at a time uses
+// them; a second caller (another context's helper thread) runs its chunks itself.
+struct SymPool {
+	std::vector<std::thread> th;
+	std::mutex m, user;
+	std::condition_variable cv, done_cv;
+	const std::function<void(int)>* job = nullptr;
+	int next = 0, total = 0, running = 0, epoch = 0;
+	bool quit = false;
+	~SymPool()
+	{
+		{ std::lock_guard<std::mutex> l(m); quit = true; }
+		cv.notify_all();
+		for (auto& t : th) if (t.joinable()) t.join();
+	}
+	void worker()
+	{
+		std::unique_lock<std::mutex> l(m);
+		int seen = 0;
+		for (;;)
+		{
+			cv.wait(l, [&] { return quit || (job && epoch != seen && next < total); });
+			if (quit) return;
+			while (job && next < total)
+			{
+				const int c = next++;
+				running++;
+				l.unlock();
+				(*job)(c);
+				l.lock();
+				running--;
+			}
+			seen = epoch;
+			if (running == 0) done_cv.notify_all();
+		}
+	}
+	void run(int n, const std::function<void(int)>& fn)
+	{
+		std::unique_lock<std::mutex> u(user, std::try_to_lock);
+		if (!u.owns_lock()) { for (int c = 0; c < n; c++) fn(c); return; }
+		std::unique_lock<std::mutex> l(m);
+		const int want = std::min(n - 1, 7);
+		while ((int)th.size() < want) th.emplace_back([this] { worker(); });
+		job = &fn; next = 0; total = n; epoch++;
+		cv.notify_all();
+		while (next < total) // the caller takes chunks too
+		{
+			const int c = next++;
+			running++;
+			l.unlock();
+			fn(c);
+			l.lock();
+			running--;
+		}
+		done_cv.wait(l, [&] { return running == 0; });
+		job = nullptr;
+	}
+};
+static SymPool& sym_pool()
+{
+	static SymPool p;
+	return p;
+}
+
+// greedy vertex cover of the crossing edges among keys[kb, ke) -- the rows of a set of whole systems -- top level first: sep[pose] =
+// level of the separator the pose was put into (0: none).  Writes sep at the poses of these rows only.
+static void cover_edges(const unsigned long long* keys, int kb, int ke, const int* origin, int M, std::vector<int>& sep, Workspace& w)
+{
+	// the off-diagonal edges bucketed by the tree level they cross (counting sort, order inside a level kept)
+	const int nk = ke - kb;
+	w.edge_lev.resize(nk); w.edge_a.resize(nk); w.edge_b.resize(nk); w.eorder.resize(nk);
+	w.lev_cnt.assign(35, 0);
+	int ne = 0;
+	for (int e = kb; e < ke; e++)
+	{
+		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+		if (p == q) continue;
+		const int l = bitlen((unsigned)(origin[p] ^ origin[q]));
+		w.edge_a[ne] = p; w.edge_b[ne] = q; w.edge_lev[ne] = l;
+		w.lev_cnt[l + 1]++;
+		ne++;
+	}
+	for (int l = 0; l < 34; l++) w.lev_cnt[l + 1] += w.lev_cnt[l];
+	{
+		int pos[35];
+		for (int l = 0; l < 35; l++) pos[l] = w.lev_cnt[l];
+		for (int e = 0; e < ne; e++) w.eorder[pos[w.edge_lev[e]]++] = e;
+	}
+	if ((int)w.vid.size() != M) w.vid.assign(M, -1); // (left all -1 by every call)
+	std::vector<std::pair<int, int>> live;
+	for (int l = 33; l >= 1; l--)
+	{
+		const int b0 = w.lev_cnt[l], b1 = w.lev_cnt[l + 1];
+		if (b0 == b1) continue;
+		// uncovered edges of the level
+		live.clear();
+		for (int t = b0; t < b1; t++)
+		{
+			const int e = w.eorder[t], p = w.edge_a[e], q = w.edge_b[e];
+			if (sep[p] < l && sep[q] < l) live.emplace_back(p, q);
+		}
+		if (live.empty()) continue;
+		// their endpoints, ascending (the tie-break of the heap below is the pose index), with a dense local numbering
+		std::vector<int>& verts = w.verts;
+		verts.clear();
+		for (const auto& pq : live)
+		{
+			if (w.vid[pq.first] < 0) { w.vid[pq.first] = 0; verts.push_back(pq.first); }
+			if (w.vid[pq.second] < 0) { w.vid[pq.second] = 0; verts.push_back(pq.second); }
+		}
+		std::sort(verts.begin(), verts.end());
+		const int nv = (int)verts.size();
+		for (int i = 0; i < nv; i++) w.vid[verts[i]] = i;
+		w.cdeg.assign(nv, 0);
+		for (const auto& pq : live) { w.cdeg[w.vid[pq.first]]++; w.cdeg[w.vid[pq.second]]++; }
+		w.start.resize(nv + 1);
+		w.start[0] = 0;
+		for (int i = 0; i < nv; i++) w.start[i + 1] = w.start[i] + w.cdeg[i];
+		w.adj.resize(w.start[nv]);
+		w.cur.assign(nv, 0); // fill counters first, live degrees afterwards
+		for (int e = 0; e < (int)live.size(); e++)
+		{
+			const int a = w.vid[live[e].first], b = w.vid[live[e].second];
+			w.adj[w.start[a] + w.cur[a]++] = e;
+			w.adj[w.start[b] + w.cur[b]++] = e;
+		}
+		w.covered.assign(live.size(), 0);
+		// the pose with the most uncovered crossing edges first, the higher pose index on a tie: ONE max-heap of (degree, local
+		// vertex number) keys (verts is ascending, so local order = pose order) whose entries are refreshed lazily -- covering an
+		// edge only lowers the other endpoint's live degree; a popped entry whose degree is stale goes back with the live one.
+		// (Round 3 pushed an entry into a per-degree heap at every decrement: ~1 M heap pushes for the top system of a
+		// 16 384-map monocular tree, 57 of the 78 ms of its analysis.)  The vertex selected is the same one.
+		for (int i = 0; i < nv; i++) w.cur[i] = w.cdeg[i];
+		std::vector<unsigned long long>& hp = w.heap;
+		hp.resize(nv);
+		for (int i = 0; i < nv; i++) hp[i] = ((unsigned long long)(unsigned)w.cdeg[i] << 32) | (unsigned)i;
+		std::make_heap(hp.begin(), hp.end());
+		while (!hp.empty())
+		{
+			std::pop_heap(hp.begin(), hp.end());
+			const unsigned long long key = hp.back();
+			hp.pop_back();
+			const int iv = (int)(key & 0xffffffffull), d = (int)(key >> 32);
+			const int live_d = w.cur[iv];
+			if (live_d <= 0) continue; // (all its edges are covered)
+			if (live_d != d)
+			{
+				hp.push_back(((unsigned long long)(unsigned)live_d << 32) | (unsigned)iv);
+				std::push_heap(hp.begin(), hp.end());
+				continue;
+			}
+			const int v = verts[iv];
+			sep[v] = l;
+			for (int t = w.start[iv]; t < w.start[iv + 1]; t++)
+			{
+				const int e = w.adj[t];
+				if (w.covered[e]) continue;
+				w.covered[e] = 1;
+				const int u = live[e].first == v ? live[e].second : live[e].first;
+				--w.cur[w.vid[u]];
+			}
+			w.cur[iv] = 0;
+		}
+		for (int v : verts) w.vid[v] = -1;
+	}
+}
+
 void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& ch, int block_maps)
 {
 	Workspace& w = workspace();
@@ -57,104 +229,43 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	// ---- separators: greedy vertex cover of the crossing edges, top level first --------------------------------------
 	std::vector<int>& sep = w.sep;
 	sep.assign(M, 0);
+	sep.assign(M, 0);
+	// Independent systems of the level (no edge between them) are analysed side by side: the rows are cut where no key crosses into
+	// chunks of about equal numbers of keys, one host thread each for the vertex cover here and for the row sub-tree walks below
+	// (elimination tree, column counts, column patterns: a row only ever touches columns of its own system).  A 16 384-map monocular
+	// tree spent 330 ms of an analysing run's 570 in this function, on one thread, while the device waited.
+	std::vector<int> cut_row(1, 0), cut_key(1, 0); // chunk c: rows [cut_row[c], cut_row[c+1]), keys [cut_key[c], cut_key[c+1])
 	{
-		// the off-diagonal edges bucketed by the tree level they cross (counting sort, order inside a level kept)
-		w.edge_lev.resize(nnzb); w.edge_a.resize(nnzb); w.edge_b.resize(nnzb); w.eorder.resize(nnzb);
-		w.lev_cnt.assign(35, 0);
-		int ne = 0;
-		for (int e = 0; e < nnzb; e++)
+		static const int max_threads = getenv("LSFM_SYM_THREADS") ? std::max(1, atoi(getenv("LSFM_SYM_THREADS"))) : 8;
+		const int want = (nnzb < 60000 || block_maps > 0) ? 1 : std::min<int>(max_threads, std::max(1u, std::thread::hardware_concurrency() / 2));
+		if (want > 1)
 		{
-			const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-			if (p == q) continue;
-			const int l = bitlen((unsigned)(origin[p] ^ origin[q]));
-			w.edge_a[ne] = p; w.edge_b[ne] = q; w.edge_lev[ne] = l;
-			w.lev_cnt[l + 1]++;
-			ne++;
-		}
-		for (int l = 0; l < 34; l++) w.lev_cnt[l + 1] += w.lev_cnt[l];
-		{
-			int pos[35];
-			for (int l = 0; l < 35; l++) pos[l] = w.lev_cnt[l];
-			for (int e = 0; e < ne; e++) w.eorder[pos[w.edge_lev[e]]++] = e;
-		}
-		w.vid.assign(M, -1);
-		std::vector<std::pair<int, int>> live;
-		for (int l = 33; l >= 1; l--)
-		{
-			const int b0 = w.lev_cnt[l], b1 = w.lev_cnt[l + 1];
-			if (b0 == b1) continue;
-			// uncovered edges of the level
-			live.clear();
-			for (int t = b0; t < b1; t++)
+			const long target = (nnzb + want - 1) / want;
+			int maxq = -1, row = -1;
+			for (int e = 0; e <= nnzb; e++)
 			{
-				const int e = w.eorder[t], p = w.edge_a[e], q = w.edge_b[e];
-				if (sep[p] < l && sep[q] < l) live.emplace_back(p, q);
-			}
-			if (live.empty()) continue;
-			// their endpoints, ascending (the tie-break of the heap below is the pose index), with a dense local numbering
-			std::vector<int>& verts = w.verts;
-			verts.clear();
-			for (const auto& pq : live)
-			{
-				if (w.vid[pq.first] < 0) { w.vid[pq.first] = 0; verts.push_back(pq.first); }
-				if (w.vid[pq.second] < 0) { w.vid[pq.second] = 0; verts.push_back(pq.second); }
-			}
-			std::sort(verts.begin(), verts.end());
-			const int nv = (int)verts.size();
-			for (int i = 0; i < nv; i++) w.vid[verts[i]] = i;
-			w.cdeg.assign(nv, 0);
-			for (const auto& pq : live) { w.cdeg[w.vid[pq.first]]++; w.cdeg[w.vid[pq.second]]++; }
-			w.start.resize(nv + 1);
-			w.start[0] = 0;
-			for (int i = 0; i < nv; i++) w.start[i + 1] = w.start[i] + w.cdeg[i];
-			w.adj.resize(w.start[nv]);
-			w.cur.assign(nv, 0); // fill counters first, live degrees afterwards
-			for (int e = 0; e < (int)live.size(); e++)
-			{
-				const int a = w.vid[live[e].first], b = w.vid[live[e].second];
-				w.adj[w.start[a] + w.cur[a]++] = e;
-				w.adj[w.start[b] + w.cur[b]++] = e;
-			}
-			w.covered.assign(live.size(), 0);
-			// the pose with the most uncovered crossing edges first, the higher pose index on a tie: ONE max-heap of (degree, local
-			// vertex number) keys (verts is ascending, so local order = pose order) whose entries are refreshed lazily -- covering an
-			// edge only lowers the other endpoint's live degree; a popped entry whose degree is stale goes back with the live one.
-			// (Round 3 pushed an entry into a per-degree heap at every decrement: ~1 M heap pushes for the top system of a
-			// 16 384-map monocular tree, 57 of the 78 ms of its analysis.)  The vertex selected is the same one.
-			for (int i = 0; i < nv; i++) w.cur[i] = w.cdeg[i];
-			std::vector<unsigned long long>& hp = w.heap;
-			hp.resize(nv);
-			for (int i = 0; i < nv; i++) hp[i] = ((unsigned long long)(unsigned)w.cdeg[i] << 32) | (unsigned)i;
-			std::make_heap(hp.begin(), hp.end());
-			while (!hp.empty())
-			{
-				std::pop_heap(hp.begin(), hp.end());
-				const unsigned long long key = hp.back();
-				hp.pop_back();
-				const int iv = (int)(key & 0xffffffffull), d = (int)(key >> 32);
-				const int live_d = w.cur[iv];
-				if (live_d <= 0) continue; // (all its edges are covered)
-				if (live_d != d)
+				const int p = e < nnzb ? (int)(keys[e] >> 32) : M;
+				if (p != row)
 				{
-					hp.push_back(((unsigned long long)(unsigned)live_d << 32) | (unsigned)iv);
-					std::push_heap(hp.begin(), hp.end());
-					continue;
+					// rows row+1 .. p-1 hold no key (cannot happen: every row has its diagonal block); a cut before row p is valid when nothing reaches p
+					if (row >= 0 && maxq < p && e - cut_key.back() >= target && p < M) { cut_row.push_back(p); cut_key.push_back(e); }
+					row = p;
 				}
-				const int v = verts[iv];
-				sep[v] = l;
-				for (int t = w.start[iv]; t < w.start[iv + 1]; t++)
-				{
-					const int e = w.adj[t];
-					if (w.covered[e]) continue;
-					w.covered[e] = 1;
-					const int u = live[e].first == v ? live[e].second : live[e].first;
-					--w.cur[w.vid[u]];
-				}
-				w.cur[iv] = 0;
+				if (e < nnzb) maxq = std::max(maxq, (int)(keys[e] & 0xffffffffull));
 			}
-			for (int v : verts) w.vid[v] = -1;
 		}
+		cut_row.push_back(M); cut_key.push_back(nnzb);
 	}
+	const int nchunk = (int)cut_row.size() - 1;
+	auto par_chunks = [&](auto&& fn) {
+		if (nchunk == 1) { fn(0); return; }
+		sym_pool().run(nchunk, std::function<void(int)>([&fn](int c) { fn(c); }));
+	};
+	par_chunks([&](int c) {
+		const double t0 = sym_timing ? tnow() : 0;
+		cover_edges(keys, cut_key[c], cut_key[c + 1], origin, M, sep, workspace());
+		if (sym_timing) fprintf(stderr, "[sym]   chunk %d: rows %d..%d, %d keys, cover %.3f ms\n", c, cut_row[c], cut_row[c + 1], cut_key[c + 1] - cut_key[c], tnow() - t0);
+	});
 	tick("separators");
 	// ---- permutation: by separator level, original order inside a level (a stable counting sort) ---------------------
 	std::vector<int>&perm = ch.perm, &pinv = ch.pinv;
@@ -207,20 +318,36 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	// ---- elimination tree (ancestor path compression), column counts, column patterns by row sub-tree walks ----------
 	std::vector<int>&parent = ch.parent, &ccount = ch.ccount, &anc = w.anc, &mark = w.mark;
 	parent.assign(M, -1); anc.assign(M, -1);
-	for (int k = 0; k < M; k++)
-		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-		{
-			int i = radj[t];
-			while (i != -1 && i < k) { const int nx = anc[i]; anc[i] = k; if (nx == -1) parent[i] = k; i = nx; }
-		}
+	// the rows (new numbering) of every chunk, ascending: perm is sorted by (separator level, old index)
+	std::vector<std::vector<int>> crow(nchunk);
+	if (nchunk > 1)
+	{
+		std::vector<int> chunk_of(M);
+		for (int c = 0; c < nchunk; c++) { crow[c].reserve(cut_row[c + 1] - cut_row[c]); for (int p = cut_row[c]; p < cut_row[c + 1]; p++) chunk_of[p] = c; }
+		for (int k = 0; k < M; k++) crow[chunk_of[perm[k]]].push_back(k);
+	}
+	auto for_rows = [&](int c, auto&& body) {
+		if (nchunk == 1) { for (int k = 0; k < M; k++) body(k); }
+		else for (int k : crow[c]) body(k);
+	};
+	par_chunks([&](int c) {
+		for_rows(c, [&](int k) {
+			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+			{
+				int i = radj[t];
+				while (i != -1 && i < k) { const int nx = anc[i]; anc[i] = k; if (nx == -1) parent[i] = k; i = nx; }
+			}
+		});
+	});
 	tick("etree");
 	mark.assign(M, -1); ccount.assign(M, 1);
-	for (int k = 0; k < M; k++)
-	{
-		mark[k] = k;
-		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-			for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
-	}
+	par_chunks([&](int c) {
+		for_rows(c, [&](int k) {
+			mark[k] = k;
+			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+				for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
+		});
+	});
 	tick("column counts");
 	std::vector<int>&colptr = ch.colptr, &rowidx = ch.rowidx;
 	colptr.assign(M + 1, 0);
@@ -237,12 +364,13 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	w.cfill.assign(M, 1);
 	for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
 	std::fill(mark.begin(), mark.end(), -1);
-	for (int k = 0; k < M; k++)
-	{
-		mark[k] = k;
-		for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-			for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + w.cfill[i]++] = k; mark[i] = k; }
-	}
+	par_chunks([&](int c) {
+		for_rows(c, [&](int k) {
+			mark[k] = k;
+			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+				for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + w.cfill[i]++] = k; mark[i] = k; }
+		});
+	});
 	tick("column patterns");
 	// ---- level sets (height above the leaves); the narrow top (<= 2 columns per level) becomes the tail ---------------
 	std::vector<int>& lev = w.lev;

@@ -215,6 +215,18 @@ int lsfm_tree_set_final_reanchor(lsfm_tree* tree, int on);
  * analyses from scratch (what a first run costs; lsfm_stats.t_total_ms of the first run reports it too). */
 int lsfm_tree_set_plans(lsfm_tree* tree, int on);
 int lsfm_tree_download(lsfm_context* ctx, lsfm_tree* tree, lsfm_map* out);
+/* Level checkpoint / resume (the reference keeps every node of the tree in RAM, m_LMsetS[i] = m_GMapS, Imp.cpp:2032, and
+ * writes none).  lsfm_tree_set_stop_level(tree, L > 0): a run ends after L tree levels, leaving the ceil(N / 2^L) nodes of that level
+ * -- each with its state, its information matrix, its first frame (FRef / FScaP / FFix) and the origins of its poses, odd-indexed ones
+ * not yet taken back to their first frame: exactly what the reference's loop holds at that point (Imp.cpp:1997-2025 re-anchors while it
+ * builds the NEXT level).  lsfm_tree_node_count: nodes of the level the last run ended at (1 after a whole tree; 0: not run /
+ * overwritten).  lsfm_tree_download_node: node k of it (library-allocated, lsfm_map_release).  The nodes uploaded as the maps of a new
+ * tree (lsfm_tree_upload: FRef, FScaP, FFix and pose_origin are honoured) and run to the end give the map the uninterrupted tree
+ * gives; lsfm_write_localmap stores a node with a trailer the reference's reader never reaches, lsfm_read_localmap restores it.
+ * L = 0 (default): the whole tree. */
+int lsfm_tree_set_stop_level(lsfm_tree* tree, int levels);
+int lsfm_tree_node_count(lsfm_context* ctx, lsfm_tree* tree);
+int lsfm_tree_download_node(lsfm_context* ctx, lsfm_tree* tree, int k, lsfm_map* out);
 /* the state vector of the final map alone (no information blocks): *m poses, *n features; stno / stVal (each optional, caller's
  * arrays of cap >= 6 m + 3 n entries) in the layout of lsfm_map -- both NULL: sizes only */
 int lsfm_tree_download_state(lsfm_context* ctx, lsfm_tree* tree, int* m, int* n, int* stno, double* stVal, size_t cap);

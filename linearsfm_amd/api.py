@@ -96,6 +96,9 @@ def lib():
         L.lsfm_tree_export_slice_sizes.argtypes = [vp, vp, C.c_int, P(C.c_size_t)]
         L.lsfm_tree_export_slice_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t]
         L.lsfm_tree_download.argtypes = [vp, vp, P(LsfmMap)]
+        L.lsfm_tree_set_stop_level.argtypes = [vp, C.c_int]
+        L.lsfm_tree_node_count.argtypes = [vp, vp]
+        L.lsfm_tree_download_node.argtypes = [vp, vp, C.c_int, P(LsfmMap)]
         L.lsfm_tree_download_state.argtypes = [vp, vp, ip, ip, ip, dp, C.c_size_t]
         L.lsfm_tree_free.argtypes = [vp, vp]
         L.lsfm_tree_free.restype = None
@@ -118,7 +121,7 @@ def lib():
 EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_set_precision", "lsfm_set_spmv_variant", "lsfm_last_error", "lsfm_stream",
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
-           "lsfm_tree_download", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
+           "lsfm_tree_download", "lsfm_tree_set_stop_level", "lsfm_tree_node_count", "lsfm_tree_download_node", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_set_comm_blocks", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
@@ -284,6 +287,21 @@ class Context:
         self._check(lib().lsfm_tree_download(self._h, tree, C.byref(out)), "lsfm_tree_download")
         return map_to_dict(out)
 
+    # ---- level checkpoint / resume (include/lsfm.h) ------------------------------------------------------
+    def tree_set_stop_level(self, tree, levels):
+        """The next runs of `tree` end after `levels` tree levels (0: the whole tree)."""
+        if lib().lsfm_tree_set_stop_level(tree, int(levels)):
+            raise LsfmError("lsfm_tree_set_stop_level: bad argument")
+
+    def tree_node_count(self, tree):
+        return int(lib().lsfm_tree_node_count(self._h, tree))
+
+    def tree_download_node(self, tree, k):
+        """Node k of the level the last run ended at, as a map dict that tree_upload takes back (FRef, FScaP, FFix, pose_origin)."""
+        out = LsfmMap()
+        self._check(lib().lsfm_tree_download_node(self._h, tree, int(k), C.byref(out)), "lsfm_tree_download_node")
+        return map_to_dict(out)
+
     def tree_download_state(self, tree):
         """(m, n, stno, stVal) of the final map: the state vector without the information blocks."""
         m, n = C.c_int(0), C.c_int(0)
@@ -420,6 +438,9 @@ def symbolic_analyse(rowptr, colidx, origin=None, reps=1):
     if rc:
         raise LsfmError(f"lsfm_symbolic_analyse failed (rc={rc}): malformed pattern")
     return dict(perm=perm, colptr=colptr, rowidx=rowidx[:int(info[0])], info=info, ms=ms.value)
+
+
+LSFM_NODE_MAGIC = 1279870541  # first token of the tree-node trailer of a local-map file (lsfm_io.cpp)
 
 
 def read_localmap(path, mono):

@@ -19,6 +19,7 @@ struct lsfm_tree {
 	int slot = 0;
 	bool done = false;
 	bool final_reanchor = true;
+	int stop_level = 0; // > 0: a run ends after this many tree levels (lsfm_tree_set_stop_level)
 	unsigned long long generation = 0; // ctx->generation when the run ended: the result lives in the context's arenas
 	// what the first run leaves for the next ones (structure only: the resident inputs never change): one plan per tree
 	// level + one for the final re-anchoring transform
@@ -239,7 +240,7 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	const int nlev = tree_levels(t->N);
 	if ((int)t->plans.size() != nlev + 1) t->plans.assign(nlev + 1, LevelPlan());
 	int level = 0;
-	while (t->level.B > 1) run_level(ctx, t, st, level++);
+	while (t->level.B > 1 && (t->stop_level <= 0 || level < t->stop_level)) run_level(ctx, t, st, level++);
 	// final map back to its first frame (Imp.cpp:2039-2063 / 6613-6630)
 	DevBatch& X = t->level;
 	if (t->final_reanchor && X.B == 1 && X.Ref[0] > X.FRef[0])
@@ -600,6 +601,31 @@ int lsfm_tree_export_slice_dev(lsfm_context* ctx, lsfm_tree* t, int nslices, int
 		batch_pack_slice(ctx, t->level, t->mono, nslices, slice, t->slice_nf[slice], t->slice_nw[slice], dst, cap);
 		LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream)); // the caller hands dst to another library / stream next
 		ctx->scratch.release(mk);
+		return LSFM_OK;
+	});
+}
+
+int lsfm_tree_set_stop_level(lsfm_tree* t, int levels)
+{
+	if (!t || levels < 0) return LSFM_ERR_ARG;
+	t->stop_level = levels;
+	return LSFM_OK;
+}
+
+int lsfm_tree_node_count(lsfm_context* ctx, lsfm_tree* t)
+{
+	if (!ctx || !t || !t->done || t->generation != ctx->generation) return 0;
+	return t->level.B;
+}
+
+int lsfm_tree_download_node(lsfm_context* ctx, lsfm_tree* t, int k, lsfm_map* out)
+{
+	if (!t || !out) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		if (!t->done) LSFM_FAIL(LSFM_ERR_ARG, "tree has not been run");
+		if (t->generation != ctx->generation) LSFM_FAIL(LSFM_ERR_ARG, "the result of this tree was overwritten by a later call on the same context");
+		if (k < 0 || k >= t->level.B) LSFM_FAIL(LSFM_ERR_ARG, "node index out of range");
+		batch_download_map(ctx, t->level, k, t->mono, out);
 		return LSFM_OK;
 	});
 }

@@ -3,7 +3,9 @@
 //   LinearSFM -path <dir> -num <N> -type Monocular|Stereo [-p <poses>] [-f <features>] [-st <state>] [-help]
 // Extra flags that do not collide with the reference's: -gpu <ordinal>, -tol <pcg rel tol>, -full <file> (final state
 // at %.17g), -info <file> (final map WITH its information matrix in the local-map format), -stats 1 (timing breakdown
-// on stderr: device stages of the join tree, then the wall seconds of every phase from files to files).
+// on stderr: device stages of the join tree, then the wall seconds of every phase from files to files), -levels <L> -nodes <dir>
+// (level checkpoint: stop after L tree levels and write the nodes of that level as <dir>/localmap_1.txt ...; a later run with
+// -path <dir> -num <nodes> finishes the tree and gives the result of the uninterrupted run), -quiet 1 (no progress lines).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,8 +33,8 @@ static void print_help()
 
 int main(int argc, char** argv)
 {
-	std::string path, st, pose, fea, full, info;
-	int num = 0, type = -1, gpu = 0, want_stats = 0;
+	std::string path, st, pose, fea, full, info, nodes;
+	int num = 0, type = -1, gpu = 0, want_stats = 0, levels = 0, quiet = 0;
 	bool has_path = false, has_num = false;
 	double tol = 0;
 	for (int i = 1; i < argc; i++)
@@ -59,11 +61,15 @@ int main(int argc, char** argv)
 		else if (name == "full") full = next();
 		else if (name == "info") info = next();
 		else if (name == "stats") want_stats = atoi(next());
+		else if (name == "levels") levels = atoi(next());
+		else if (name == "nodes") nodes = next();
+		else if (name == "quiet") quiet = atoi(next());
 	}
 	if (!has_path) { printf("LinerSFM Error: Please Input Right File Path:\n"); return 0; }
 	if (!has_num) { printf("LinerSFM Error: Please Set Local Map Number:\n"); return 0; }
 	if (type < 0) { printf("LinerSFM Error: Please Set Data Type:\n"); return 0; }
 	if (num <= 0) { fprintf(stderr, "LinearSFM: -num must be positive (got %d)\n", num); return 1; }
+	if ((levels > 0) != !nodes.empty() || levels < 0) { fprintf(stderr, "LinearSFM: -levels <L > 0> and -nodes <dir> go together\n"); return 1; }
 
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double w0 = now();
@@ -83,9 +89,10 @@ int main(int argc, char** argv)
 	if (rc) { fprintf(stderr, "LinearSFM: no HIP device (rc=%d); this build has no CPU path\n", rc); return 2; }
 	if (tol > 0) lsfm_set_pcg(ctx, tol, 0);
 	// progress lines of the reference (Imp.cpp:1952, 1995)
+	if (!quiet)
 	{
 		int cnt = num, L = 0;
-		while (cnt > 1)
+		while (cnt > 1 && (levels <= 0 || L < levels))
 		{
 			int N2 = cnt % 2;
 			cnt = (int)(cnt / 2.0 + 0.5);
@@ -107,10 +114,31 @@ int main(int argc, char** argv)
 	rc = lsfm_tree_upload(ctx, maps.data(), num, type, &tree);
 	if (rc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
 	lsfm_tree_set_plans(tree, 0); // one run: nothing to keep for a next one
+	if (levels > 0) lsfm_tree_set_stop_level(tree, levels);
 	const double w3 = now();
 	rc = lsfm_tree_run(ctx, tree, &stats);
 	if (rc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
 	const double w4 = now();
+	const int nnodes = lsfm_tree_node_count(ctx, tree);
+	if (levels > 0 && nnodes > 1)
+	{
+		// level checkpoint: the nodes of the level the run ended at, named like a set of local maps
+		for (int k = 0; k < nnodes; k++)
+		{
+			lsfm_map node;
+			if (lsfm_tree_download_node(ctx, tree, k, &node) < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
+			const std::string fn = nodes + "/localmap_" + std::to_string(k + 1) + ".txt";
+			const int wrc = lsfm_write_localmap(fn.c_str(), type, &node);
+			lsfm_map_release(&node);
+			if (wrc) { fprintf(stderr, "LinearSFM: cannot write %s\n", fn.c_str()); return 1; }
+		}
+		printf("Stopped After Level %d: %d Nodes Written To %s\n", levels, nnodes, nodes.c_str());
+		printf("Total Used Time:  %lf  sec\n\n", stats.t_total_ms * 1e-3);
+		lsfm_tree_free(ctx, tree);
+		for (auto& g : maps) lsfm_map_release(&g);
+		lsfm_context_destroy(ctx);
+		return rc == LSFM_NOT_CONVERGED ? 4 : 0;
+	}
 	{
 		const int drc = lsfm_tree_download(ctx, tree, &out);
 		if (drc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }

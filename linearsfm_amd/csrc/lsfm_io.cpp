@@ -20,6 +20,8 @@ template <class T> T* xalloc(size_t n) { return static_cast<T*>(malloc((n ? n : 
 #include <string>
 #include <thread>
 
+#define LSFM_NODE_MAGIC 1279870541 /* 'LSFM': first token of the tree-node trailer of a local-map file */
+
 namespace {
 
 struct Tok {
@@ -129,6 +131,25 @@ int parse_localmap(const char* buf, size_t len, int mono, lsfm_map* g)
 	for (long i = 0; i < 9L * g->n && t.ok; i++) g->V[i] = t.getd();
 	for (int i = 0; i < g->n && t.ok; i++) g->FBlock[i] = t.geti();
 	if (!t.ok) { lsfm_map_release(g); return LSFM_ERR_IO; }
+	// optional trailer of a TREE NODE written by lsfm_write_localmap (the reference's fscanf sequence ends with FBlock and never
+	// looks further): LSFM_NODE_MAGIC, then FRef FScaP FFix and the m pose origins -- what a node that is joined further needs
+	t.skip();
+	if (t.p < t.end)
+	{
+		Tok u = t;
+		if (u.geti() == LSFM_NODE_MAGIC && u.ok)
+		{
+			g->FRef = u.geti(); g->FScaP = u.geti(); g->FFix = u.geti();
+			const int no = u.geti();
+			if (!u.ok || (no != 0 && no != g->m)) { lsfm_map_release(g); return LSFM_ERR_IO; }
+			if (no)
+			{
+				g->pose_origin = xalloc<int>(g->m);
+				for (int i = 0; i < g->m && u.ok; i++) g->pose_origin[i] = u.geti();
+			}
+			if (!u.ok) { lsfm_map_release(g); return LSFM_ERR_IO; }
+		}
+	}
 	return LSFM_OK;
 }
 
@@ -227,6 +248,13 @@ int lsfm_write_localmap(const char* path, int mono, const lsfm_map* g)
 		std::vector<int> fb(g->n, -1);
 		for (int j = g->nW - 1; j >= 0; j--) if (g->feature[j] >= 0 && g->feature[j] < g->n) fb[g->feature[j]] = j;
 		itg(fb.data(), g->n);
+	}
+	// a node of a join tree that is to be joined further (its first frame is not its reference frame, or it carries the origins of its
+	// poses): the trailer parse_localmap reads; the reference's reader stops at FBlock
+	if (g->FRef != g->Ref || g->pose_origin || (mono && (g->FScaP != g->ScaP || g->FFix != g->Fix)))
+	{
+		fprintf(f, "%d\n%d %d %d\n%d\n", LSFM_NODE_MAGIC, g->FRef, mono ? g->FScaP : 0, mono ? g->FFix : 0, g->pose_origin ? g->m : 0);
+		if (g->pose_origin) itg(g->pose_origin, g->m);
 	}
 	const bool ok = !ferror(f);
 	return (fclose(f) == 0 && ok) ? LSFM_OK : LSFM_ERR_IO;

@@ -1,0 +1,98 @@
+"""Level checkpoint / resume (include/lsfm.h lsfm_tree_set_stop_level ...).  The reference keeps the nodes of every
+level in RAM (m_LMsetS[i] = m_GMapS, LinearSFMImp.cpp:2032) and can neither store nor reload them; here a run can end after L
+levels, its nodes go through the local-map text format (with the trailer the reference's reader never reaches) and a second tree
+built from them finishes the job -- with the result of the uninterrupted run."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from linearsfm_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RESUME_TOL = 1e-9   # both runs solve the same camera systems to a 1e-10 residual; the nodes travel at %.17g (exact)
+
+
+def _sets(mono, n):
+    return synth.make_mono_set(n, 8, 4, seed=77) if mono else synth.make_stereo_set(n, 6, 4, seed=77)
+
+
+@pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("n_maps,stop", [(13, 1), (13, 2), (16, 3), (7, 1)])
+def test_resume_from_the_nodes_of_a_level(ctx, tmp_path, mono, n_maps, stop):
+    maps = [m.__dict__ for m in _sets(mono, n_maps)]
+    t = ctx.tree_upload(maps, mono)
+    _, rc = ctx.tree_run(t)
+    assert rc == 0 and ctx.tree_node_count(t) == 1
+    whole = ctx.tree_download(t)
+    # the same tree, stopped after `stop` levels
+    ctx.tree_set_stop_level(t, stop)
+    st, rc = ctx.tree_run(t)
+    assert rc == 0
+    want = n_maps
+    for _ in range(stop):
+        want = (want + 1) // 2
+    assert ctx.tree_node_count(t) == want and st["joins"] > 0
+    with pytest.raises(api.LsfmError):
+        ctx.tree_download(t)            # there is no final map yet
+    with pytest.raises(api.LsfmError):
+        ctx.tree_download_node(t, want)
+    nodes = [ctx.tree_download_node(t, k) for k in range(want)]
+    # a stop level is a property of the tree, not of one run: 0 gives the whole tree back
+    ctx.tree_set_stop_level(t, 0)
+    _, rc = ctx.tree_run(t)
+    again = ctx.tree_download(t)
+    ctx.tree_free(t)
+    assert rc == 0 and np.array_equal(again["stno"], whole["stno"])
+    # every pose of a node knows the local map it came from; the nodes partition the poses of the inputs
+    org = np.concatenate([nd["pose_origin"] for nd in nodes])
+    assert org.min() >= 0 and org.max() == n_maps - 1
+    # through the files
+    d = tmp_path / "nodes"
+    d.mkdir()
+    for k, nd in enumerate(nodes):
+        api.write_localmap(d / f"localmap_{k + 1}.txt", nd, mono)
+    back = api.read_localmaps(d, want, mono)
+    for a, b in zip(nodes, back):
+        for key in ("Ref", "FRef", "m", "n", "nU", "nW") + (("ScaP", "Fix", "Sign", "FScaP", "FFix") if mono else ()):
+            assert a[key] == b[key], key
+        for key in ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V", "pose_origin"):
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key   # %.17g: the identity
+    t2 = ctx.tree_upload(back, mono)
+    _, rc = ctx.tree_run(t2)
+    assert rc == 0
+    res = ctx.tree_download(t2)
+    ctx.tree_free(t2)
+    for key in ("Ref", "FRef", "m", "n", "nU", "nW"):
+        assert res[key] == whole[key], key
+    for key in ("stno", "Ui", "Uj", "photo", "feature", "pose_origin"):
+        assert np.array_equal(res[key], whole[key]), key
+    for key in ("stVal", "U", "W", "V"):
+        a, b = np.asarray(res[key]), np.asarray(whole[key])
+        assert np.max(np.abs(a - b)) <= RESUME_TOL * max(1.0, np.max(np.abs(b))), key
+
+
+def test_cli_stops_after_a_level_and_resumes_from_the_written_nodes(tmp_path):
+    maps = synth.make_stereo_set(11, 6, 4, seed=5)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    full, part, nodes = str(tmp_path / "full.txt"), str(tmp_path / "part.txt"), tmp_path / "nodes"
+    nodes.mkdir()
+    subprocess.run([exe, "-path", str(d), "-num", "11", "-type", "Stereo", "-full", full], capture_output=True, text=True, check=True)
+    r = subprocess.run([exe, "-path", str(d), "-num", "11", "-type", "Stereo", "-levels", "2", "-nodes", str(nodes)],
+                       capture_output=True, text=True, check=True)
+    assert "Stopped After Level 2: 3 Nodes Written" in r.stdout and "Generate Level 3" not in r.stdout
+    assert sorted(os.listdir(nodes)) == ["localmap_1.txt", "localmap_2.txt", "localmap_3.txt"]
+    r = subprocess.run([exe, "-path", str(nodes), "-num", "3", "-type", "Stereo", "-full", part, "-quiet", "1"],
+                       capture_output=True, text=True, check=True)
+    assert "Join Level" not in r.stdout and "Total Used Time:" in r.stdout
+    a = np.array([[float(x) for x in l.split()] for l in open(full)])
+    b = np.array([[float(x) for x in l.split()] for l in open(part)])
+    assert np.array_equal(a[:, 0], b[:, 0])
+    assert np.max(np.abs(a[:, 1] - b[:, 1])) <= RESUME_TOL * max(1.0, np.max(np.abs(a[:, 1])))
+    # flags that make no sense alone are refused
+    r = subprocess.run([exe, "-path", str(d), "-num", "11", "-type", "Stereo", "-levels", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "go together" in r.stderr

@@ -307,6 +307,47 @@ def test_localmap_writer_roundtrip(oracle, tmp_path, mono):
 
 
 @pytest.mark.parametrize("mono", [False, True])
+def test_tree_node_trailer_roundtrip_and_invisible_to_the_reference_reader(oracle, tmp_path, mono):
+    """A node of a join tree written for a later resume carries FRef / FScaP / FFix and the origins of its poses behind FBlock:
+    lsfm_read_localmap restores them, the fscanf port of the reference's reader (Imp.cpp:3044-3132 / 6660-6754) reads the same map
+    and never reaches them, a file without the trailer reads as a local map (first frame = reference frame), a damaged one fails."""
+    from linearsfm_amd import api
+    maps = synth.make_mono_set(5, 6, 4, seed=4) if mono else synth.make_stereo_set(5, 6, 4, seed=4)
+    out, _, rc = oracle.divide_conquer([oracle.localmap_to_dict(m) for m in maps], mono)
+    assert rc == 0
+    node = dict(out)
+    node["FRef"] = out["stno"][0] * 0 + 1
+    node["Ref"] = 3
+    node["pose_origin"] = (np.arange(out["m"]) % 5).astype(np.int32)
+    if mono:
+        node["FScaP"], node["FFix"] = 2, 1
+    p = str(tmp_path / "node.txt")
+    api.write_localmap(p, node, mono)
+    back = api.read_localmap(p, mono)
+    assert back["Ref"] == 3 and back["FRef"] == 1 and np.array_equal(back["pose_origin"], node["pose_origin"])
+    if mono:
+        assert (back["FScaP"], back["FFix"]) == (2, 1) and (back["ScaP"], back["Fix"]) == (node["ScaP"], node["Fix"])
+    ref = oracle.map_to_dict(oracle.read_map(p, mono))
+    for key in ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V"):
+        assert np.array_equal(np.asarray(ref[key]).ravel(), np.asarray(back[key]).ravel()), key
+    # no trailer: a local map
+    plain = dict(out); plain.pop("pose_origin", None); plain["FRef"] = plain["Ref"]
+    if mono:
+        plain["FScaP"], plain["FFix"] = plain["ScaP"], plain["Fix"]
+    q = str(tmp_path / "plain.txt")
+    api.write_localmap(q, plain, mono)
+    assert str(api.LSFM_NODE_MAGIC) not in open(q).read().split()
+    b2 = api.read_localmap(q, mono)
+    assert b2["FRef"] == b2["Ref"] and "pose_origin" not in b2
+    # a trailer cut short is an error, not a silently different map
+    text = open(p).read().split()
+    cut = str(tmp_path / "cut.txt")
+    open(cut, "w").write(" ".join(text[:-2]) + "\n")
+    with pytest.raises(api.LsfmError):
+        api.read_localmap(cut, mono)
+
+
+@pytest.mark.parametrize("mono", [False, True])
 def test_threaded_oracle_tree_is_identical(oracle, mono):
     """orc_divide_conquer_omp (the multi-core CPU figure of bench.py) computes every join exactly like the serial tree."""
     maps = synth.make_mono_set(11, 6, 4, seed=8) if mono else synth.make_stereo_set(13, 6, 5, seed=8)

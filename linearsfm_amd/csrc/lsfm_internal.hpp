@@ -236,6 +236,7 @@ struct lsfm_context {
 	const lsfm::DevBatch* tr_in = nullptr;
 	const int* tr_hub = nullptr;        // [B] global pose index of the hub column of every transformed map, -1: passed through
 	std::shared_ptr<void> early;        // the build in flight (null: none)
+	hipEvent_t ev_k9[2] = { nullptr, nullptr }; // K9: the 32-slot panel variant of a level runs on the side stream, beside the others (lsfm_schur_panel.hip)
 	hipStream_t stream3 = nullptr;      // its own stream: the side stream carries the transform's U stage, which waits for the block kernel
 	// One level ahead (Stereo tree runs that analyse): while the device factors and refines level L, the pattern of level
 	// L + 1's system is put together on stream3 from level L's joint maps (their index arrays are final long before the

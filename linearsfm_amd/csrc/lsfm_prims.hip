@@ -326,6 +326,7 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 			LSFM_CHECK_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest));
 		}
+		for (auto& e : c->ev_k9) LSFM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
@@ -376,6 +377,7 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream3) (void)hipStreamDestroy(c->stream3);
+	for (auto& e : c->ev_k9) if (e) (void)hipEventDestroy(e);
 	if (c->evA) (void)hipEventDestroy(c->evA);
 	if (c->evB) (void)hipEventDestroy(c->evB);
 	if (c->evC) (void)hipEventDestroy(c->evC);

@@ -405,51 +405,33 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 #undef PM_GO
 }
 
-// `only` == nullptr: every tile; tiles with more than SMAX poses are flagged in `fallback`.  `only` != nullptr (the second
-// pass with the larger variant): just the flagged tiles; a tile it can take is un-flagged, the rest stays for k_schur_w.
-// SMAX = 8 / 16: for levels whose systems have at most that many poses (the bottom of the tree: thousands of tiny joins).
-// A tile is then all latency -- hashing, eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
-// work-groups share a CU instead of 2.
-template <int SMAX, int THREADS>
-#ifndef LSFM_K9_OCC16
-#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
-#endif
-__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : LSFM_K9_OCC16))
-k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
-              const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, const unsigned char* only, K9Cache kc)
+// The tile's poses -> slots, once per tile and level, ahead of the panel variants (k_schur_panel): which poses see the tile's
+// features (a 64-entry hash table in LDS), the slot of every W block, which blocks repeat a (pose, feature) pair of the tile.
+// The joins keep both blocks when a feature was seen from the hub pose on either side (the reference concatenates, Imp.cpp:1277;
+// its pair loop adds them up): the first block of a pair is staged with plain stores, the repeats are added after it -- an LDS
+// atomic add of a double costs ~4 clocks per LANE on this chip, and as the only way into the panel it was 40 % of the kernel.
+// Leaves ns[tile] (poses; -poses / -1000: more than the widest panel takes / than the table holds -- the tile goes to k_schur_w),
+// pose[tile][slot], eslot[block].  It is structure: a resident tree's later runs take it from the plan of the level.  As a
+// launch of its own (round 4) every variant knows its tiles before it starts, so the variants of a level run side by side.
+struct SlotShared {
+	int hkey[PM_HASH];
+	int hslot[PM_HASH];
+	int pose_of[PM_SMAX_MAX];
+	int nslots, bad;
+	int fpt[PM_TILE + 1];
+	unsigned char eslot[PM_MAXE];
+};
+__global__ void __launch_bounds__(PM_THREADS) k_schur_slots(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, unsigned char* fallback, K9Cache kc)
 {
-	if (only && !only[blockIdx.x]) return;
-	K9T_DECL;
-	__shared__ PmShared<SMAX> sh;
+	__shared__ SlotShared sh;
 	const int tid = threadIdx.x;
 	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
-	// ---- a later run of the same resident tree: the tile's slots are structure, kept by the plan of the level ----
-	if (kc.ns && !kc.record)
-	{
-		const int cns = kc.ns[blockIdx.x];
-		if (cns < 0 || cns > SMAX)
-		{
-			if (tid == 0) fallback[blockIdx.x] = 1; // another variant's tile (-1: no panel variant took it)
-			return;
-		}
-		for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
-		if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid];
-		if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
-		__syncthreads();
-		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-		for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
-		if (only && tid == 0) fallback[blockIdx.x] = 0;
-		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot);
-		return;
-	}
-	for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
+	for (int i = tid; i <= f1 - f0; i += PM_THREADS) sh.fpt[i] = fptr[f0 + i];
 	if (tid < PM_HASH) { sh.hkey[tid] = -1; sh.hslot[tid] = -1; }
 	if (tid == 0) { sh.nslots = 0; sh.bad = 0; }
 	__syncthreads();
 	const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-	// ---- the tile's poses -> slots ----
-	for (int j = jb + tid; j < je; j += THREADS)
+	for (int j = jb + tid; j < je; j += PM_THREADS)
 	{
 		const int key = photo[j];
 		unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
@@ -469,29 +451,27 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		if (j - jb < PM_MAXE) sh.eslot[j - jb] = (unsigned char)h; // table position now, slot number once slots are dealt
 	}
 	__syncthreads();
-	if (tid < PM_HASH && sh.hkey[tid] != -1)
+	// slots in the order of the table, not of arrival: the same tile gets the same slots in every run
+	if (tid < PM_HASH)
 	{
-		const int id = atomicAdd(&sh.nslots, 1);
-		sh.hslot[tid] = id;
-		if (id < SMAX) sh.pose_of[id] = sh.hkey[tid];
+		const bool used = sh.hkey[tid] != -1;
+		const unsigned long long m = __ballot(used);
+		if (used)
+		{
+			const int id = __popcll(m & ((1ull << tid) - 1ull));
+			sh.hslot[tid] = id;
+			sh.pose_of[id] = sh.hkey[tid];
+		}
+		if (tid == 0) sh.nslots = __popcll(m);
 	}
 	__syncthreads();
 	const int ns = sh.nslots;
-	if (ns > SMAX || sh.bad == 2)
+	if (sh.bad == 2)
 	{
-		if (tid == 0)
-		{
-			fallback[blockIdx.x] = 1;
-			if (kc.ns && kc.record) kc.ns[blockIdx.x] = sh.bad == 2 ? -1000 : -ns; // (a larger variant that takes the tile overwrites this)
-		}
+		if (tid == 0) { fallback[blockIdx.x] = 1; kc.ns[blockIdx.x] = -1000; }
 		return;
 	}
-	if (only && tid == 0) fallback[blockIdx.x] = 0; // taken here (pm_body flags it again if a V^-1 has no Cholesky factor)
-	// slot numbers; and which blocks repeat a (pose, feature) pair of the tile.  The joins keep both blocks when a feature
-	// was seen from the hub pose on either side (the reference concatenates, Imp.cpp:1277; its pair loop adds them up): the
-	// first block of a pair is staged with plain stores, the repeats are added after it -- an LDS atomic add of a double
-	// costs ~4 clocks per LANE on this chip, and as the only way into the panel it was 40 % of the kernel
-	for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = (unsigned char)sh.hslot[sh.eslot[e]];
+	for (int e = tid; e < je - jb && e < PM_MAXE; e += PM_THREADS) sh.eslot[e] = (unsigned char)sh.hslot[sh.eslot[e]];
 	__syncthreads();
 	if (tid < f1 - f0)
 	{
@@ -506,30 +486,61 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			seen |= bit;
 		}
 	}
-	if (kc.ns && kc.record)
+	__syncthreads();
+	if (tid == 0) kc.ns[blockIdx.x] = ns;
+	if (tid < ns) kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid] = sh.pose_of[tid];
+	for (int e = tid; e < je - jb; e += PM_THREADS)
 	{
-		// first run of a resident tree: leave the tile's slots for the later ones (the blocks past the LDS list too)
-		__syncthreads();
-		if (tid == 0) kc.ns[blockIdx.x] = ns;
-		if (tid < ns) kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid] = sh.pose_of[tid];
-		for (int e = tid; e < je - jb; e += THREADS)
+		unsigned char v;
+		if (e < PM_MAXE) v = sh.eslot[e];
+		else
 		{
-			unsigned char v;
-			if (e < PM_MAXE) v = sh.eslot[e];
-			else
-			{
-				const int key = photo[jb + e];
-				unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-				while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
-				v = (unsigned char)(sh.hslot[h] | PM_DUP); // added after the first blocks, like a repeat
-			}
-			kc.eslot[jb + e] = v;
+			// (the blocks past the LDS list too)
+			const int key = photo[jb + e];
+			unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
+			while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
+			v = (unsigned char)(sh.hslot[h] | PM_DUP); // added after the first blocks, like a repeat
 		}
+		kc.eslot[jb + e] = v;
 	}
+}
+
+// One variant per panel width; a tile belongs to the narrowest variant launched that holds its poses: lo < ns <= SMAX (lo: the
+// width of the next narrower variant launched, 0: none).  `last`: the widest variant launched flags the tiles nobody takes (ns
+// beyond its panel, or the slots kernel gave up) for k_schur_w.
+// SMAX = 8 / 16: for levels whose systems have at most that many poses (the bottom of the tree: thousands of tiny joins).
+// A tile is then all latency -- eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
+// work-groups share a CU instead of 2.
+template <int SMAX, int THREADS>
+#ifndef LSFM_K9_OCC16
+#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
+#endif
+__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : LSFM_K9_OCC16))
+k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
+              const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, int lo, int last, K9Cache kc)
+{
+	const int cns = kc.ns[blockIdx.x];
+	if (cns >= 0 && cns <= lo) return; // a narrower variant's tile
+	const int tid = threadIdx.x;
+	if (cns < 0 || cns > SMAX)
+	{
+		if (last && tid == 0) fallback[blockIdx.x] = 1;
+		return;
+	}
+	K9T_DECL;
+	__shared__ PmShared<SMAX> sh;
+	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
+	for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
+	if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid];
+	if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
+	__syncthreads();
+	const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
+	for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
 	// (visible to the passes through the barrier at the top of the first pass)
 	K9T(0);
 	K9T_FLUSH(0, 1);
-	k9_go<SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, (const unsigned char*)nullptr);
+	k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot);
 }
 
 int schur_panel_tile() { return PM_TILE; }
@@ -543,36 +554,57 @@ extern "C" void lsfm_debug_k9(unsigned long long* out, int reset)
 }
 #endif
 
+void launch_schur_slots(lsfm_context* ctx, int NF, const int* fptr, const int* photo, unsigned char* fallback, K9Cache kc)
+{
+	if (!NF) return;
+	hipLaunchKernelGGL(k_schur_slots, dim3((NF + PM_TILE - 1) / PM_TILE), dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, fallback, kc);
+}
+
+// kc: the tiles' slots (launch_schur_slots of this run, or the plan of the level).
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
                         int max_poses_per_system, K9Cache kc)
 {
 	if (!NF) return;
 	const dim3 grid((NF + PM_TILE - 1) / PM_TILE);
+	hipStream_t s = ctx->stream;
 	// no tile can be seen by more poses than its system has
 	if (max_poses_per_system <= 8)
 	{
-		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-		                   (const unsigned char*)nullptr, kc);
+		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, 1, kc);
 		return;
 	}
 	if (max_poses_per_system <= 16)
 	{
-		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-		                   (const unsigned char*)nullptr, kc);
+		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, 1, kc);
 		return;
 	}
 	// By tile, not by level: most tiles of the upper levels are seen by a dozen poses (12.1 on average on the NC3500-like
 	// set) and fit the 16-slot variant, which is three work-groups to a CU instead of two and a third less work per pass;
-	// the tiles it flags go to the 32-slot variant, what that one flags to the 48-slot one, the rest to k_schur_w
-	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-	                   (const unsigned char*)nullptr, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E,
-	                   fallback, (const unsigned char*)fallback, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE>), grid, dim3(PM_WIDE), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-	                   (const unsigned char*)fallback, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, ctx->stream, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback,
-	                   (const unsigned char*)fallback, kc);
+	// wider tiles go to the 32-, 48- and 64-slot variants, the rest to k_schur_w.  The 32-slot variant runs BESIDE the others, on
+	// the side stream (until round 4 the variants ran one after the other, each behind the tail of the one before, while the tiles
+	// of the 16-slot variant wait for HBM half of their time and those of the wide ones keep the matrix pipes busy): the slots
+	// kernel has told every variant its tiles.
+	// (measured on the NC3500-like set: K9 7.7 -> 7.2 ms per tree with the 32-slot variant on the side stream; streams of their
+	// own for the variants -- five streams on the context -- slowed EVERY launch of the run down, 40 -> 55 ms per tree, and the
+	// next-level stream (stream3) has the pattern of the next level queued at this point.  LSFM_K9_SERIAL=1: one after the other.)
+	static const bool serial = getenv("LSFM_K9_SERIAL") != nullptr;
+	hipStream_t s1 = serial ? s : ctx->stream2;
+	if (!serial)
+	{
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[0], s));
+		LSFM_CHECK_HIP(hipStreamWaitEvent(s1, ctx->ev_k9[0], 0));
+	}
+	// the wide variant first: few long work-groups, the narrow ones fill in around them
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 16, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE>), grid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, PM_SMAX, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, PM_SMAX_BIG, 1, kc);
+	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, 0, kc);
+	if (!serial)
+	{
+		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[1], s1));
+		LSFM_CHECK_HIP(hipStreamWaitEvent(s, ctx->ev_k9[1], 0));
+	}
 }
 
 } // namespace lsfm

@@ -1096,15 +1096,15 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
 		int most = 0;
 		for (int r : io.seg_rows) most = std::max(most, r);
-		// the per-tile slots of the panel kernel: from the plan of the level, or recorded now when this run leaves one
-		if (!sy.k9.ns && ctx->plan && ctx->plan != &ctx->pre_plan) // (a plan made one level ahead lives for one level: nothing to record for)
+		// the per-tile slots of the panel variants: from the plan of the level, or worked out now (and left for the plan, if this
+		// run makes one)
+		if (!sy.k9.ns)
 		{
 			sy.k9.ns = sc.alloc<int>(ntiles + 1);
 			sy.k9.pose = sc.alloc<int>((size_t)ntiles * 64 + 1);
 			sy.k9.eslot = sc.alloc<unsigned char>((size_t)io.NW + 1);
-			sy.k9.record = 1;
 			sy.k9_tiles = ntiles; sy.k9_NW = io.NW;
-			LSFM_CHECK_HIP(hipMemsetAsync(sy.k9.ns, 0xff, sizeof(int) * (size_t)ntiles, s));
+			launch_schur_slots(ctx, NF, io.fptr, io.photo, fb, sy.k9);
 		}
 		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, sy.S, sy.E, fb, most, sy.k9);
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);

@@ -11,7 +11,7 @@ struct K9Cache {
 	int* ns = nullptr;            // [tiles]
 	int* pose = nullptr;          // [tiles * 64]
 	unsigned char* eslot = nullptr; // [NW]
-	int record = 0;
+	int record = 0; // (unused since the slots have a kernel of their own)
 };
 
 struct SchurSystem {
@@ -47,6 +47,7 @@ void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long lo
 void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, double* y, const unsigned char* fixed, const double* dotw,
                  const int* pose_seg, double* dot, int dot_stride);
 double spmv_bytes(const SchurSystem& sy);
+void launch_schur_slots(lsfm_context* ctx, int NF, const int* fptr, const int* photo, unsigned char* fallback, K9Cache kc);
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
                         int max_poses_per_system, K9Cache kc);

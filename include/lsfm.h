@@ -302,7 +302,18 @@ int lsfm_read_localmaps(const char* dir, int first, int count, int mono, int thr
 /* one map in the local-map text format at %.17g (write -> lsfm_read_localmap is the identity): stores a tree node with its
  * information matrix, which the reference computes (DOC.pdf p.1) but never writes */
 int lsfm_write_localmap(const char* path, int mono, const lsfm_map* map);
+/* Binary cache of a set of local maps ("optional binary cache with identical semantics" beside the parallel parser of
+ * lmj_readInformation*'s files, Imp.cpp:3044-3132 / 6660-6754): one file, the arrays the text reader produced, bit for bit (layout:
+ * lsfm_io.cpp).  lsfm_write_mapset writes maps[N] (atomically: a temporary file renamed); lsfm_mapset_info gives N and the type
+ * (LSFM_ERR_IO: missing / not a cache); lsfm_read_mapset reads maps first .. first+count-1 (0-based) on `threads` host threads into
+ * out[count] (library-allocated; LSFM_ERR_IO and nothing kept when the file is truncated, foreign or of the other map type). */
+int lsfm_write_mapset(const char* path, const lsfm_map* maps, int N, int mono);
+int lsfm_mapset_info(const char* path, int* N, int* mono);
+int lsfm_read_mapset(const char* path, int mono, int first, int count, int threads, lsfm_map* out);
 int lsfm_save_state(const char* path, const double* st, const int* stno, int n);
+/* the same state vector as raw doubles (parity tooling): int32 n, int32 0, stno[n] (+ 4 bytes of padding when n is odd),
+ * st[n] float64 */
+int lsfm_save_state_bin(const char* path, const double* st, const int* stno, int n);
 int lsfm_save_poses(const char* pose_path, const char* feat_path, const int* stno, const double* st, int n);
 
 /* ---- stand-alone kernel entry for measurement: y = S x on a symmetric 6x6-block matrix given as upper block

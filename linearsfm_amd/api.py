@@ -106,6 +106,10 @@ def lib():
         L.lsfm_read_localmap.argtypes = [C.c_char_p, C.c_int, P(LsfmMap)]
         L.lsfm_write_localmap.argtypes = [C.c_char_p, C.c_int, P(LsfmMap)]
         L.lsfm_read_localmaps.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P(LsfmMap), P(C.c_int)]
+        L.lsfm_write_mapset.argtypes = [C.c_char_p, P(LsfmMap), C.c_int, C.c_int]
+        L.lsfm_mapset_info.argtypes = [C.c_char_p, P(C.c_int), P(C.c_int)]
+        L.lsfm_read_mapset.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P(LsfmMap)]
+        L.lsfm_save_state_bin.argtypes = [C.c_char_p, P(C.c_double), P(C.c_int), C.c_int]
         L.lsfm_save_state.argtypes = [C.c_char_p, dp, ip, C.c_int]
         L.lsfm_save_poses.argtypes = [C.c_char_p, C.c_char_p, ip, dp, C.c_int]
         L.lsfm_schur_pattern.argtypes = [vp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, C.c_int, ip]
@@ -123,7 +127,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_set_stop_level", "lsfm_tree_node_count", "lsfm_tree_download_node", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_set_comm_blocks", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
-           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_save_state", "lsfm_save_poses",
+           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_write_mapset", "lsfm_mapset_info", "lsfm_read_mapset", "lsfm_save_state_bin", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
 
 
@@ -457,6 +461,36 @@ def write_localmap(path, d, mono):
     rc = lib().lsfm_write_localmap(str(path).encode(), int(mono), C.byref(hm.c))
     if rc:
         raise LsfmError(f"lsfm_write_localmap({path}) failed (rc={rc})")
+
+
+def write_mapset(path, maps, mono):
+    """Binary cache of a set of maps (list of map dicts): one file, read back bit for bit by read_mapset."""
+    hms = [HostMap(d) for d in maps]
+    arr = (LsfmMap * len(hms))(*[h.c for h in hms])
+    rc = lib().lsfm_write_mapset(str(path).encode(), arr, len(hms), int(mono))
+    if rc:
+        raise LsfmError(f"lsfm_write_mapset({path}) failed (rc={rc})")
+
+
+def mapset_info(path):
+    """(N, mono) of a binary cache; None when the file is missing or not a cache."""
+    n, mono = C.c_int(0), C.c_int(0)
+    if lib().lsfm_mapset_info(str(path).encode(), C.byref(n), C.byref(mono)):
+        return None
+    return n.value, bool(mono.value)
+
+
+def read_mapset(path, mono, first=0, count=None, threads=0):
+    info = mapset_info(path)
+    if info is None:
+        raise LsfmError(f"{path}: not a map-set cache")
+    if count is None:
+        count = info[0] - first
+    arr = (LsfmMap * max(count, 1))()
+    rc = lib().lsfm_read_mapset(str(path).encode(), int(mono), int(first), int(count), int(threads), arr)
+    if rc:
+        raise LsfmError(f"lsfm_read_mapset({path}) failed (rc={rc})")
+    return [map_to_dict(arr[k]) for k in range(count)]
 
 
 def read_localmaps(directory, count, mono, first=1, threads=0):

@@ -98,6 +98,9 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		ctx->plan = &ctx->pre_plan;
 		LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evP, 0));
 	}
+	char rname[48];
+	snprintf(rname, sizeof rname, "lsfm level %d (%d maps)", level, t->level.B);
+	Range rlevel(rname);
 	ctx->mark("level");
 	if ((int)t->step_hint.size() <= level) t->step_hint.resize(level + 1, 0);
 	ctx->step_hint = t->step_hint[level];
@@ -129,8 +132,9 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 	DevBatch Xt, Y;
 	if (t->mono)
 	{
-		transform_batch(ctx, other, X, tref, tscap, tfix, true, Xt, true);
+		{ Range r("lsfm transform"); transform_batch(ctx, other, X, tref, tscap, tfix, true, Xt, true); }
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
+		Range r("lsfm join + solve");
 		join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
 	}
 	else
@@ -145,8 +149,9 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 			rd.wbase = js.wbase; rd.newf = js.newf; rd.W = Y.W; rd.photo = Y.photo; rd.feature = Y.feature; rd.srcf = js.srcf;
 			return rd;
 		};
-		transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); // (the join's layout kernels run inside)
+		{ Range r("lsfm transform"); transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); } // (the join's layout kernels run inside)
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
+		Range r("lsfm join + solve");
 		js.smark = smark; // everything of this level goes at once
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
 		if (ctx->pre_pending) ctx->drop_prepared(); // (a plan the level's solve did not take up)
@@ -221,6 +226,7 @@ int lsfm_tree_upload(lsfm_context* ctx, const lsfm_map* maps, int N, int mono, l
 // one pass over the tree; with valid plans nothing in here waits for the device before the final synchronisation
 static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 {
+	Range rrun("lsfm tree run");
 	// level 0 reads the resident inputs where they are (no level writes its input), so a tree can be run repeatedly
 	t->slot = -1;
 	t->done = false;

@@ -6,6 +6,8 @@
 // on stderr: device stages of the join tree, then the wall seconds of every phase from files to files), -levels <L> -nodes <dir>
 // (level checkpoint: stop after L tree levels and write the nodes of that level as <dir>/localmap_1.txt ...; a later run with
 // -path <dir> -num <nodes> finishes the tree and gives the result of the uninterrupted run), -quiet 1 (no progress lines).
+// -cache <file> (binary cache of the set: read instead of the text files when it holds -num maps of -type, written after the text files
+// were parsed otherwise), -fullbin <file> (final state as raw doubles), -json <file> (the run's lsfm_stats and phase times as one JSON object).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,7 +35,7 @@ static void print_help()
 
 int main(int argc, char** argv)
 {
-	std::string path, st, pose, fea, full, info, nodes;
+	std::string path, st, pose, fea, full, info, nodes, cache, fullbin, json;
 	int num = 0, type = -1, gpu = 0, want_stats = 0, levels = 0, quiet = 0;
 	bool has_path = false, has_num = false;
 	double tol = 0;
@@ -64,6 +66,9 @@ int main(int argc, char** argv)
 		else if (name == "levels") levels = atoi(next());
 		else if (name == "nodes") nodes = next();
 		else if (name == "quiet") quiet = atoi(next());
+		else if (name == "cache") cache = next();
+		else if (name == "fullbin") fullbin = next();
+		else if (name == "json") json = next();
 	}
 	if (!has_path) { printf("LinerSFM Error: Please Input Right File Path:\n"); return 0; }
 	if (!has_num) { printf("LinerSFM Error: Please Set Local Map Number:\n"); return 0; }
@@ -74,6 +79,16 @@ int main(int argc, char** argv)
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double w0 = now();
 	std::vector<lsfm_map> maps(num);
+	bool from_cache = false;
+	if (!cache.empty())
+	{
+		// the binary cache of an earlier run over this set: used when it holds what is asked for, (re)written otherwise
+		int cn = 0, cm = 0;
+		if (lsfm_mapset_info(cache.c_str(), &cn, &cm) == LSFM_OK && cn >= num && cm == type)
+			from_cache = lsfm_read_mapset(cache.c_str(), type, 0, num, 0, maps.data()) == LSFM_OK;
+		if (!from_cache && cn) fprintf(stderr, "LinearSFM: %s does not hold %d %s maps: reading the text files\n", cache.c_str(), num, type ? "Monocular" : "Stereo");
+	}
+	if (!from_cache)
 	{
 		// localmap_1.txt ... localmap_<num>.txt (Imp.cpp:125), parsed on all host cores
 		int bad = 0;
@@ -82,6 +97,7 @@ int main(int argc, char** argv)
 			fprintf(stderr, "LinearSFM: cannot read %s/localmap_%d.txt\n", path.c_str(), bad);
 			return 1;
 		}
+		if (!cache.empty() && lsfm_write_mapset(cache.c_str(), maps.data(), num, type)) fprintf(stderr, "LinearSFM: cannot write %s\n", cache.c_str());
 	}
 	const double w1 = now();
 	lsfm_context* ctx = nullptr;
@@ -165,6 +181,23 @@ int main(int argc, char** argv)
 		if (f) { for (int i = 0; i < r; i++) fprintf(f, "%d %.17g\n", out.stno[i], out.stVal[i]); fclose(f); }
 	}
 	if (!info.empty() && lsfm_write_localmap(info.c_str(), type, &out)) fprintf(stderr, "LinearSFM: cannot write %s\n", info.c_str());
+	if (!fullbin.empty() && lsfm_save_state_bin(fullbin.c_str(), out.stVal, out.stno, r)) fprintf(stderr, "LinearSFM: cannot write %s\n", fullbin.c_str());
+	if (!json.empty())
+	{
+		FILE* f = fopen(json.c_str(), "w");
+		if (f)
+		{
+			fprintf(f, "{\"maps\": %d, \"type\": \"%s\", \"from_cache\": %s, \"poses\": %d, \"features\": %d, \"rc\": %d, \"t_total_ms\": %.6f, \"t_transform_ms\": %.6f, "
+			           "\"t_join_ms\": %.6f, \"t_schur_ms\": %.6f, \"t_pcg_ms\": %.6f, \"t_backsub_ms\": %.6f, \"levels\": %d, \"joins\": %d, \"transforms\": %d, "
+			           "\"pcg_iterations\": %ld, \"max_rel_residual\": %.6e, \"not_converged\": %d, \"attempts\": %d, "
+			           "\"phases_s\": {\"read\": %.6f, \"context\": %.6f, \"upload\": %.6f, \"join_tree\": %.6f, \"download\": %.6f, \"write\": %.6f}}\n",
+			        num, type ? "Monocular" : "Stereo", from_cache ? "true" : "false", out.m, out.n, rc, stats.t_total_ms, stats.t_transform_ms, stats.t_join_ms,
+			        stats.t_schur_ms, stats.t_pcg_ms, stats.t_backsub_ms, stats.levels, stats.joins, stats.transforms, (long)stats.pcg_iterations,
+			        stats.max_rel_residual, stats.not_converged, stats.attempts, w1 - w0, w2 - w1, w3 - w2, w4 - w3, w5 - w4, now() - w5);
+			fclose(f);
+		}
+		else fprintf(stderr, "LinearSFM: cannot write %s\n", json.c_str());
+	}
 	if (want_stats)
 		fprintf(stderr, "lsfm_e2e: read %.3f s, context %.3f s, upload %.3f s, join tree %.3f s, download %.3f s, write %.3f s\n", w1 - w0, w2 - w1, w3 - w2,
 		        w4 - w3, w5 - w4, now() - w5);

@@ -205,6 +205,26 @@ struct HostWorker {
 
 } // namespace lsfm
 
+namespace lsfm {
+// LSFM_ROCTX=1: the phases of a tree run as roctx ranges (tree run > level k > transform | join + solve; the marks of LSFM_TIMELINE as
+// roctx marks), for `rocprofv3 --marker-trace --kernel-trace`.  The library is looked up at run time (librocprofiler-sdk-roctx /
+// libroctx64): nothing is linked, nothing happens without the variable.
+struct Roctx {
+	int (*push)(const char*) = nullptr;
+	int (*pop)() = nullptr;
+	void (*mark)(const char*) = nullptr;
+	Roctx();
+};
+Roctx& roctx();
+struct Range {
+	bool on;
+	explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+	~Range() { if (on) roctx().pop(); }
+	Range(const Range&) = delete;
+	Range& operator=(const Range&) = delete;
+};
+} // namespace lsfm
+
 struct lsfm_context {
 	int device = 0;
 	hipStream_t stream = nullptr;

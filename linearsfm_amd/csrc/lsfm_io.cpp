@@ -260,6 +260,164 @@ int lsfm_write_localmap(const char* path, int mono, const lsfm_map* g)
 	return (fclose(f) == 0 && ok) ? LSFM_OK : LSFM_ERR_IO;
 }
 
+// ---- binary cache of a set of local maps --------------------------------------------------------------------
+// One file for N maps: what the text reader produced, array by array, so that a second run over the same set skips the decimal
+// conversion.  Layout (little endian, as the host): 32-byte file header { magic "LSFMSET1", int32 version, N, mono, 0 0 0 },
+// N + 1 uint64 offsets of the maps' records (the last one = file size), then per map a 64-byte header of 16 int32 { Ref FRef ScaP Fix
+// Sign FScaP FFix m n nU nW has_origin, 0 0 0 0 } followed by the int32 arrays stno[6m+3n] Ui[nU] Uj[nU] photo[nW] feature[nW]
+// FBlock[n] pose_origin[m if has_origin], padding to 8 bytes, and the doubles stVal[6m+3n] U[36 nU] W[18 nW] V[9 n].
+// Semantics identical to the text files: reading a cache gives the arrays lsfm_read_localmaps gives, bit for bit.
+namespace {
+const char SET_MAGIC[8] = { 'L', 'S', 'F', 'M', 'S', 'E', 'T', '1' };
+struct SetHeader { char magic[8]; int version, N, mono, pad[3]; };
+static_assert(sizeof(SetHeader) == 32, "file header");
+size_t set_record_bytes(const lsfm_map* g)
+{
+	const size_t r = 6 * (size_t)g->m + 3 * (size_t)g->n;
+	size_t ints = r + 2 * (size_t)g->nU + 2 * (size_t)g->nW + (size_t)g->n + (g->pose_origin ? (size_t)g->m : 0);
+	ints += ints & 1;
+	return 64 + ints * 4 + (r + 36 * (size_t)g->nU + 18 * (size_t)g->nW + 9 * (size_t)g->n) * 8;
+}
+}
+
+int lsfm_write_mapset(const char* path, const lsfm_map* maps, int N, int mono)
+{
+	if (!path || !maps || N < 0) return LSFM_ERR_ARG;
+	const std::string tmp = std::string(path) + ".tmp"; // a reader never sees a half-written cache
+	FILE* f = fopen(tmp.c_str(), "wb");
+	if (!f) return LSFM_ERR_IO;
+	std::vector<char> big(4 << 20);
+	setvbuf(f, big.data(), _IOFBF, big.size());
+	SetHeader h;
+	memset(&h, 0, sizeof h);
+	memcpy(h.magic, SET_MAGIC, 8); h.version = 1; h.N = N; h.mono = mono ? 1 : 0;
+	std::vector<unsigned long long> off((size_t)N + 1);
+	off[0] = sizeof h + ((size_t)N + 1) * 8;
+	for (int k = 0; k < N; k++) off[k + 1] = off[k] + set_record_bytes(&maps[k]);
+	bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(off.data(), 8, off.size(), f) == off.size();
+	for (int k = 0; k < N && ok; k++)
+	{
+		const lsfm_map* g = &maps[k];
+		const size_t r = 6 * (size_t)g->m + 3 * (size_t)g->n;
+		const int hd[16] = { g->Ref, g->FRef, g->ScaP, g->Fix, g->Sign, g->FScaP, g->FFix, g->m, g->n, g->nU, g->nW, g->pose_origin ? 1 : 0, 0, 0, 0, 0 };
+		ok = fwrite(hd, 4, 16, f) == 16;
+		size_t ints = 0;
+		auto wi = [&](const int* v, size_t n) { if (ok && n) ok = fwrite(v, 4, n, f) == n; ints += n; };
+		auto wd = [&](const double* v, size_t n) { if (ok && n) ok = fwrite(v, 8, n, f) == n; };
+		wi(g->stno, r); wi(g->Ui, g->nU); wi(g->Uj, g->nU); wi(g->photo, g->nW); wi(g->feature, g->nW);
+		if (g->FBlock) wi(g->FBlock, g->n);
+		else
+		{
+			std::vector<int> fb(g->n, -1);
+			for (int j = g->nW - 1; j >= 0; j--) if (g->feature[j] >= 0 && g->feature[j] < g->n) fb[g->feature[j]] = j;
+			wi(fb.data(), g->n);
+		}
+		if (g->pose_origin) wi(g->pose_origin, g->m);
+		if (ints & 1) { const int z = 0; wi(&z, 1); }
+		wd(g->stVal, r); wd(g->U, 36 * (size_t)g->nU); wd(g->W, 18 * (size_t)g->nW); wd(g->V, 9 * (size_t)g->n);
+	}
+	ok = ok && !ferror(f);
+	ok = (fclose(f) == 0) && ok;
+	if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return LSFM_ERR_IO; }
+	return LSFM_OK;
+}
+
+int lsfm_mapset_info(const char* path, int* N, int* mono)
+{
+	if (!path) return LSFM_ERR_ARG;
+	FILE* f = fopen(path, "rb");
+	if (!f) return LSFM_ERR_IO;
+	SetHeader h;
+	const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, SET_MAGIC, 8) == 0 && h.version == 1 && h.N >= 0;
+	fclose(f);
+	if (!ok) return LSFM_ERR_IO;
+	if (N) *N = h.N;
+	if (mono) *mono = h.mono;
+	return LSFM_OK;
+}
+
+// maps first .. first+count-1 (0-based) of a cache on `threads` host threads; everything is checked against the file size before
+// a byte is copied (a truncated or foreign file is LSFM_ERR_IO, never a wild read)
+int lsfm_read_mapset(const char* path, int mono, int first, int count, int threads, lsfm_map* out)
+{
+	if (!path || !out || first < 0 || count < 0) return LSFM_ERR_ARG;
+	for (int k = 0; k < count; k++) memset(&out[k], 0, sizeof(lsfm_map));
+	FILE* f = fopen(path, "rb");
+	if (!f) return LSFM_ERR_IO;
+	SetHeader h;
+	std::vector<unsigned long long> off;
+	bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, SET_MAGIC, 8) == 0 && h.version == 1 && h.N >= 0 && (h.mono != 0) == (mono != 0) &&
+	          (long long)first + count <= h.N;
+	long fsize = 0;
+	if (ok)
+	{
+		off.resize((size_t)h.N + 1);
+		ok = fread(off.data(), 8, off.size(), f) == off.size() && fseek(f, 0, SEEK_END) == 0 && (fsize = ftell(f)) > 0 && off[h.N] == (unsigned long long)fsize;
+		for (int k = 0; k < h.N && ok; k++) ok = off[k] + 64 <= off[k + 1];
+	}
+	fclose(f);
+	if (!ok) return LSFM_ERR_IO;
+	if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+	threads = std::max(1, std::min(threads, count));
+	std::atomic<int> next(0), bad(0);
+	auto work = [&]() {
+		FILE* fh = fopen(path, "rb");
+		if (!fh) { bad = 1; return; }
+		for (;;)
+		{
+			const int k = next.fetch_add(1);
+			if (k >= count) break;
+			lsfm_map* g = &out[k];
+			const unsigned long long o = off[first + k], len = off[first + k + 1] - o;
+			int hd[16];
+			if (fseek(fh, (long)o, SEEK_SET) != 0 || fread(hd, 4, 16, fh) != 16) { bad = 1; continue; }
+			g->Ref = hd[0]; g->FRef = hd[1]; g->ScaP = hd[2]; g->Fix = hd[3]; g->Sign = hd[4]; g->FScaP = hd[5]; g->FFix = hd[6];
+			g->m = hd[7]; g->n = hd[8]; g->nU = hd[9]; g->nW = hd[10];
+			const bool org = hd[11] != 0;
+			if (g->m < 0 || g->n < 0 || g->nU < 0 || g->nW < 0) { memset(g, 0, sizeof *g); bad = 1; continue; }
+			lsfm_map probe = *g;
+			int one = 0;
+			probe.pose_origin = org ? &one : nullptr;
+			if (set_record_bytes(&probe) != len) { memset(g, 0, sizeof *g); bad = 1; continue; }
+			const size_t r = 6 * (size_t)g->m + 3 * (size_t)g->n;
+			size_t ints = 0;
+			bool good = true;
+			auto ri = [&](int*& v, size_t n) { v = xalloc<int>(n); good = good && v && (n == 0 || fread(v, 4, n, fh) == n); ints += n; };
+			auto rd = [&](double*& v, size_t n) { v = xalloc<double>(n); good = good && v && (n == 0 || fread(v, 8, n, fh) == n); };
+			ri(g->stno, r); ri(g->Ui, g->nU); ri(g->Uj, g->nU); ri(g->photo, g->nW); ri(g->feature, g->nW); ri(g->FBlock, g->n);
+			if (org) ri(g->pose_origin, g->m);
+			if (ints & 1) { int z; good = good && fread(&z, 4, 1, fh) == 1; }
+			rd(g->stVal, r); rd(g->U, 36 * (size_t)g->nU); rd(g->W, 18 * (size_t)g->nW); rd(g->V, 9 * (size_t)g->n);
+			if (!good) bad = 1;
+		}
+		fclose(fh);
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < threads; t++) pool.emplace_back(work);
+	work();
+	for (auto& th : pool) th.join();
+	if (bad.load())
+	{
+		for (int k = 0; k < count; k++) lsfm_map_release(&out[k]);
+		return LSFM_ERR_IO;
+	}
+	return LSFM_OK;
+}
+
+// the state vector as raw doubles behind its labels (a dump for parity tooling that loses nothing and needs no parser):
+// int32 n, int32 0, stno[n] int32 (+ one int32 of padding when n is odd), st[n] float64
+int lsfm_save_state_bin(const char* path, const double* st, const int* stno, int n)
+{
+	if (!path || !st || !stno || n < 0) return LSFM_ERR_ARG;
+	FILE* f = fopen(path, "wb");
+	if (!f) return LSFM_ERR_IO;
+	const int hd[2] = { n, 0 }, z = 0;
+	bool ok = fwrite(hd, 4, 2, f) == 2 && (n == 0 || fwrite(stno, 4, (size_t)n, f) == (size_t)n);
+	if (ok && (n & 1)) ok = fwrite(&z, 4, 1, f) == 1;
+	ok = ok && (n == 0 || fwrite(st, 8, (size_t)n, f) == (size_t)n) && !ferror(f);
+	return (fclose(f) == 0 && ok) ? LSFM_OK : LSFM_ERR_IO;
+}
+
 // Imp.cpp:2102-2117
 int lsfm_save_state(const char* path, const double* st, const int* stno, int n)
 {

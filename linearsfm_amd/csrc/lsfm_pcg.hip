@@ -2345,7 +2345,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	SolvePlan* sp = lp ? static_cast<SolvePlan*>(lp->solve.get()) : nullptr;
 	const bool warm = sp != nullptr || pending != nullptr; // pattern + symbolic factorisation known from an earlier run of the same tree level (or made one level ahead)
 	hipEvent_t ea = ctx->pool_event(), eb = ctx->pool_event(), ec = ctx->pool_event(), ed = ctx->pool_event();
-	LSFM_CHECK_HIP(hipEventRecord(ea, s));
+	LSFM_CHECK_HIP(hipEventRecord(ea, s)); if (roctx().mark) roctx().mark("lsfm schur: begin");
 	SchurSystem sy;
 	CholDev ch;
 	CholHostIn hin;
@@ -2359,7 +2359,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		sy = pending ? pending->sy : sp->sy;
 		schur_vinv(ctx, io, sy);
 		build_schur_values(ctx, io, sy);
-		LSFM_CHECK_HIP(hipEventRecord(eb, s));
+		LSFM_CHECK_HIP(hipEventRecord(eb, s)); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		if (pending)
 		{
@@ -2472,7 +2472,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			chol_fetch(ctx, sy, io.d_pose_origin, hin);
 		}
 		build_schur_values(ctx, io, sy);
-		LSFM_CHECK_HIP(hipEventRecord(eb, s));
+		LSFM_CHECK_HIP(hipEventRecord(eb, s)); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		tw0 = wall();
 		ctx->mark("k9_enq");
@@ -2645,10 +2645,10 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
 	LSFM_CHECK_HIP(hipEventRecord(es1, s));
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg2, 1);
-	LSFM_CHECK_HIP(hipEventRecord(ec, s));
+	LSFM_CHECK_HIP(hipEventRecord(ec, s)); if (roctx().mark) roctx().mark("lsfm back-substitution: begin");
 	launch_backsub(ctx, io, sy, x);
 	LSFM_CHECK_HIP(hipGetLastError());
-	LSFM_CHECK_HIP(hipEventRecord(ed, s));
+	LSFM_CHECK_HIP(hipEventRecord(ed, s)); if (roctx().mark) roctx().mark("lsfm solve: end");
 	if (ctx->stats)
 	{
 		lsfm_stats* st = ctx->stats;

@@ -1,4 +1,5 @@
 // Context, arenas and the two library primitives used off the hot path (prefix sum, radix sort: rocPRIM).
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -230,8 +231,28 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 
 } // namespace lsfm
 
+namespace lsfm {
+Roctx::Roctx()
+{
+	if (!getenv("LSFM_ROCTX")) return;
+	for (const char* name : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" })
+	{
+		void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		if (!h) continue;
+		push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+		pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+		mark = reinterpret_cast<void (*)(const char*)>(dlsym(h, "roctxMarkA"));
+		if (push && pop) return;
+		push = nullptr; pop = nullptr; mark = nullptr;
+	}
+	fprintf(stderr, "liblsfm_hip: LSFM_ROCTX is set but no roctx library could be loaded -- no ranges\n");
+}
+Roctx& roctx() { static Roctx r; return r; }
+} // namespace lsfm
+
 void lsfm_context::mark(const char* what)
 {
+	if (lsfm::roctx().mark) lsfm::roctx().mark(what);
 	if (!timeline_on) return;
 	timeline.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
 }

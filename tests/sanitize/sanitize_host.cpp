@@ -88,6 +88,50 @@ int main(int argc, char** argv)
 	      !memcmp(back.stVal, fin.stVal, sizeof(double) * r));
 	CHECK(lsfm_save_state((dir + "/state.txt").c_str(), fin.stVal, fin.stno, r) == 0);
 	CHECK(lsfm_save_poses((dir + "/pose.txt").c_str(), (dir + "/feat.txt").c_str(), fin.stno, fin.stVal, r) == 0);
+	CHECK(lsfm_save_state_bin((dir + "/state.bin").c_str(), fin.stVal, fin.stno, r) == 0);
+	// binary cache of the set: write, read back (whole and a sub-range, threaded), a node with pose origins, and damaged files
+	{
+		const std::string cf = dir + "/set.lsfmbin";
+		int cn = -1, cm = -1;
+		CHECK(lsfm_mapset_info(cf.c_str(), &cn, &cm) != 0);
+		CHECK(lsfm_write_mapset(cf.c_str(), set.data(), N, mono) == 0);
+		CHECK(lsfm_mapset_info(cf.c_str(), &cn, &cm) == 0 && cn == N && cm == (mono ? 1 : 0));
+		std::vector<lsfm_map> got(N);
+		CHECK(lsfm_read_mapset(cf.c_str(), mono, 0, N, 3, got.data()) == 0);
+		for (int k = 0; k < N; k++)
+		{
+			CHECK(got[k].m == set[k].m && got[k].nW == set[k].nW && !memcmp(got[k].W, set[k].W, sizeof(double) * 18 * set[k].nW) &&
+			      !memcmp(got[k].stno, set[k].stno, sizeof(int) * (6 * set[k].m + 3 * set[k].n)) && got[k].pose_origin == nullptr);
+			lsfm_map_release(&got[k]);
+		}
+		CHECK(lsfm_read_mapset(cf.c_str(), mono, 1, N - 1, 1, got.data()) == 0 && (N == 1 || got[0].m == set[1].m));
+		for (int k = 0; k < N - 1; k++) lsfm_map_release(&got[k]);
+		CHECK(lsfm_read_mapset(cf.c_str(), mono, 1, N, 1, got.data()) != 0);  // past the end
+		CHECK(lsfm_read_mapset(cf.c_str(), !mono, 0, N, 1, got.data()) != 0); // the other map type
+		std::vector<int> org(back.m, 3);
+		lsfm_map node = back;
+		node.pose_origin = org.data(); node.FRef = 1;
+		CHECK(lsfm_write_mapset((dir + "/node.lsfmbin").c_str(), &node, 1, mono) == 0);
+		lsfm_map nb;
+		CHECK(lsfm_read_mapset((dir + "/node.lsfmbin").c_str(), mono, 0, 1, 0, &nb) == 0 && nb.pose_origin && nb.pose_origin[back.m - 1] == 3 && nb.FRef == 1);
+		lsfm_map_release(&nb);
+		// truncated at every 97th byte, and with a size field blown up: errors, no wild reads
+		std::vector<char> raw;
+		{ FILE* f = fopen(cf.c_str(), "rb"); CHECK(f != nullptr); char tmp[4096]; size_t n; while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) raw.insert(raw.end(), tmp, tmp + n); fclose(f); }
+		for (size_t cut = 0; cut < raw.size(); cut += std::max<size_t>(97, raw.size() / 64))
+		{
+			FILE* f = fopen((dir + "/cut.lsfmbin").c_str(), "wb"); CHECK(f != nullptr); fwrite(raw.data(), 1, cut, f); fclose(f);
+			CHECK(lsfm_read_mapset((dir + "/cut.lsfmbin").c_str(), mono, 0, N, 2, got.data()) != 0);
+		}
+		{
+			std::vector<char> bad = raw;
+			const size_t rec0 = 32 + 8 * (size_t)(N + 1);
+			int huge = 0x7fffffff;
+			memcpy(bad.data() + rec0 + 4 * 10, &huge, 4); // nW of the first map
+			FILE* f = fopen((dir + "/bad.lsfmbin").c_str(), "wb"); CHECK(f != nullptr); fwrite(bad.data(), 1, bad.size(), f); fclose(f);
+			CHECK(lsfm_read_mapset((dir + "/bad.lsfmbin").c_str(), mono, 0, N, 1, got.data()) != 0);
+		}
+	}
 	// symbolic analysis of the final map's camera system: pose pairs that share a feature + U's pattern, upper, diagonal first
 	{
 		const int m = fin.m;

@@ -96,3 +96,37 @@ def test_cli_stops_after_a_level_and_resumes_from_the_written_nodes(tmp_path):
     # flags that make no sense alone are refused
     r = subprocess.run([exe, "-path", str(d), "-num", "11", "-type", "Stereo", "-levels", "2"], capture_output=True, text=True)
     assert r.returncode == 1 and "go together" in r.stderr
+
+
+def test_cli_binary_cache_json_and_binary_state(tmp_path):
+    """-cache: the first run parses the text files and leaves the cache, the second reads the cache (and says so in -json) and gives the
+    same files byte for byte; a cache of another set size is not trusted.  -fullbin holds the -full numbers exactly."""
+    import json
+    maps = synth.make_stereo_set(10, 6, 4, seed=8)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    cache = str(tmp_path / "set.lsfmbin")
+    outs = []
+    for run in range(2):
+        full, fb, js = (str(tmp_path / f"{n}{run}") for n in ("full", "fullbin", "json"))
+        subprocess.run([exe, "-path", str(d), "-num", "10", "-type", "Stereo", "-cache", cache, "-full", full, "-fullbin", fb, "-json", js, "-quiet", "1"],
+                       capture_output=True, text=True, check=True)
+        outs.append((open(full).read(), open(fb, "rb").read(), json.load(open(js))))
+    assert outs[0][2]["from_cache"] is False and outs[1][2]["from_cache"] is True
+    assert outs[0][2]["maps"] == 10 and outs[0][2]["rc"] == 0 and outs[0][2]["joins"] == 9 and outs[0][2]["t_total_ms"] > 0
+    assert set(outs[0][2]["phases_s"]) == {"read", "context", "upload", "join_tree", "download", "write"}
+    # same inputs bit for bit: the two runs may differ by the order of their atomic sums only
+    a = np.array([[float(x) for x in l.split()] for l in outs[0][0].splitlines()])
+    b = np.array([[float(x) for x in l.split()] for l in outs[1][0].splitlines()])
+    assert np.array_equal(a[:, 0], b[:, 0]) and np.max(np.abs(a[:, 1] - b[:, 1])) <= RESUME_TOL * max(1.0, np.max(np.abs(a[:, 1])))
+    raw = outs[0][1]
+    n = int(np.frombuffer(raw[:4], np.int32)[0])
+    assert n == len(a) and np.array_equal(np.frombuffer(raw[8:8 + 4 * n], np.int32), a[:, 0].astype(np.int32))
+    assert np.array_equal(np.frombuffer(raw[8 + 4 * (n + (n & 1)):], np.float64), a[:, 1])      # %.17g == the doubles
+    # asking for more maps than the cache holds: the text files are read (and the cache replaced)
+    synth.write_set(str(d), synth.make_stereo_set(12, 6, 4, seed=8))
+    js = str(tmp_path / "json2")
+    r = subprocess.run([exe, "-path", str(d), "-num", "12", "-type", "Stereo", "-cache", cache, "-json", js, "-quiet", "1"], capture_output=True, text=True, check=True)
+    assert "does not hold 12 Stereo maps" in r.stderr and json.load(open(js))["from_cache"] is False
+    assert api.mapset_info(cache) == (12, False)

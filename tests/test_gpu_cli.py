@@ -128,3 +128,20 @@ def test_cli_arenas_grow_when_a_run_exhausts_them(oracle, tmp_path):
     a, b = full["grown"][0], full["whole"][0]
     assert np.array_equal(a[:, 0], b[:, 0])
     assert np.max(np.abs(a[:, 1] - b[:, 1]) / np.maximum(1.0, np.abs(b[:, 1]))) < 1e-9
+
+
+def test_cli_with_roctx_ranges_switched_on(tmp_path):
+    """LSFM_ROCTX=1: the library looks up the roctx library at run time and brackets tree run / levels / stages; without a
+    profiler attached the ranges go nowhere and the run is the run it was (the profile: profiles/r04_roctx_marker_stats.csv)."""
+    maps = synth.make_stereo_set(6, 6, 4, seed=12)
+    d = tmp_path / "set"
+    synth.write_set(str(d), maps)
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    outs = []
+    for env in ({}, {"LSFM_ROCTX": "1"}):
+        full = str(tmp_path / f"full{len(outs)}.txt")
+        r = subprocess.run([exe, "-path", str(d), "-num", "6", "-type", "Stereo", "-full", full], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0 and "no roctx library" not in r.stderr, r.stderr
+        outs.append(_table(full))
+    assert np.array_equal(outs[0][:, 0], outs[1][:, 0]) and np.max(np.abs(outs[0][:, 1] - outs[1][:, 1])) < 1e-9

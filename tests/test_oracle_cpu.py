@@ -348,6 +348,65 @@ def test_tree_node_trailer_roundtrip_and_invisible_to_the_reference_reader(oracl
 
 
 @pytest.mark.parametrize("mono", [False, True])
+def test_binary_mapset_cache_equals_the_text_reader(oracle, tmp_path, mono):
+    """the binary cache of a set holds what the text reader (== the fscanf port of Imp.cpp:3044-3132 / 6660-6754, test
+    above) produced, bit for bit, for whole sets and sub-ranges; a truncated file, a foreign file, the other map type and a range
+    past the end are errors that leave nothing behind."""
+    from linearsfm_amd import api
+    maps = synth.make_mono_set(9, 6, 4, seed=6) if mono else synth.make_stereo_set(9, 6, 4, seed=6)
+    synth.write_set(str(tmp_path), maps)
+    text = api.read_localmaps(str(tmp_path), 9, mono, threads=2)
+    cache = str(tmp_path / "set.lsfmbin")
+    assert api.mapset_info(cache) is None
+    api.write_mapset(cache, text, mono)
+    assert api.mapset_info(cache) == (9, mono)
+    keys = ("stno", "stVal", "U", "Ui", "Uj", "W", "photo", "feature", "V", "FBlock")
+    scal = ("Ref", "FRef", "m", "n", "nU", "nW") + (("ScaP", "Fix", "Sign", "FScaP", "FFix") if mono else ())
+    for first, count, threads in ((0, 9, 3), (2, 4, 1), (8, 1, 0), (3, 0, 0)):
+        got = api.read_mapset(cache, mono, first, count, threads)
+        assert len(got) == count
+        for k in range(count):
+            for key in keys:
+                a, b = np.asarray(text[first + k][key]), np.asarray(got[k][key])
+                assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), (first, k, key)
+            for key in scal:
+                assert text[first + k][key] == got[k][key], key
+            assert "pose_origin" not in got[k]
+    # a tree node (pose origins, another first frame) survives too
+    node = dict(text[0]); node["FRef"] = 1; node["Ref"] = 2; node["pose_origin"] = np.arange(node["m"], dtype=np.int32)
+    api.write_mapset(str(tmp_path / "node.lsfmbin"), [node], mono)
+    back = api.read_mapset(str(tmp_path / "node.lsfmbin"), mono)[0]
+    assert back["FRef"] == 1 and back["Ref"] == 2 and np.array_equal(back["pose_origin"], node["pose_origin"])
+    # errors
+    raw = open(cache, "rb").read()
+    for name, data in (("cut", raw[:-16]), ("short", raw[:40]), ("foreign", b"not a cache at all" * 8), ("grown", raw + b"\0" * 8)):
+        q = str(tmp_path / f"{name}.lsfmbin")
+        open(q, "wb").write(data)
+        with pytest.raises(api.LsfmError):
+            api.read_mapset(q, mono)
+    with pytest.raises(api.LsfmError):
+        api.read_mapset(cache, not mono)
+    with pytest.raises(api.LsfmError):
+        api.read_mapset(cache, mono, 5, 5)
+    assert not os.path.exists(cache + ".tmp")
+
+
+def test_binary_state_dump(tmp_path):
+    from linearsfm_amd import api
+    import ctypes as C
+    for n in (0, 5, 8):
+        stno = np.arange(n, dtype=np.int32) - 3
+        st = np.linspace(-1e3, 1e-7, n) if n else np.zeros(0)
+        p = str(tmp_path / f"s{n}.bin")
+        rc = api.lib().lsfm_save_state_bin(p.encode(), st.ctypes.data_as(C.POINTER(C.c_double)), stno.ctypes.data_as(C.POINTER(C.c_int)), n)
+        assert rc == 0
+        raw = open(p, "rb").read()
+        assert np.frombuffer(raw[:8], np.int32).tolist() == [n, 0]
+        assert np.array_equal(np.frombuffer(raw[8:8 + 4 * n], np.int32), stno)
+        assert np.frombuffer(raw[8 + 4 * (n + (n & 1)):], np.float64).tobytes() == st.tobytes()
+
+
+@pytest.mark.parametrize("mono", [False, True])
 def test_threaded_oracle_tree_is_identical(oracle, mono):
     """orc_divide_conquer_omp (the multi-core CPU figure of bench.py) computes every join exactly like the serial tree."""
     maps = synth.make_mono_set(11, 6, 4, seed=8) if mono else synth.make_stereo_set(13, 6, 5, seed=8)

@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) k_chol_factor_level(int nsmall, const int
 //   k_sn_update  one lane per pair (a >= b) of common rows: block (r_a, r_b) -= sum_t X[a,t] X[b,t]^T, left through LDS
 //                as contiguous atomics (groups of one level share ancestors)
 // ---------------------------------------------------------------------------------------------------------------
-/* CHOL_GS (most block columns of a group, 16): lsfm_symbolic.hpp */
+/* CHOL_GS (most block columns of a group, 8): lsfm_symbolic.hpp */
 #define SN_RB 16                    /* block rows of the panel per work-group */
 #define SN_XS (6 * CHOL_GS + 1)     /* odd row stride of the panel rows in LDS */
 #define SN_THREADS 256               /* 96 lanes own rows; the rest is there to keep more loads in flight */

@@ -28,6 +28,9 @@
 #include <utility>
 
 namespace lsfm {
+// most block columns of a supernode group: CHOL_GS, or less (LSFM_GS, for measurements)
+static const int gs_cap = []() { const char* e = getenv("LSFM_GS"); const int v = e ? atoi(e) : CHOL_GS; return v >= 1 && v <= CHOL_GS ? v : CHOL_GS; }();
+
 
 namespace {
 
@@ -492,7 +495,7 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		for (int j = 0; j < M; j++)
 		{
 			if (size[j] <= task_x) continue;
-			const bool join = j > 0 && size[j - 1] > task_x && parent[j - 1] == j && ccount[j - 1] == ccount[j] + 1 && gs[grp[j - 1]] < CHOL_GS &&
+			const bool join = j > 0 && size[j - 1] > task_x && parent[j - 1] == j && ccount[j - 1] == ccount[j] + 1 && gs[grp[j - 1]] < gs_cap &&
 			                  j != ch.first_shared; // (a run never spans interior and shared columns)
 			if (join) { grp[j] = grp[j - 1]; gs[grp[j]]++; }
 			else { grp[j] = (int)gc0.size(); gc0.push_back(j); gs.push_back(1); glev.push_back(0); }

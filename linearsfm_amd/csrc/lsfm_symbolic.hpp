@@ -7,7 +7,12 @@
 
 namespace lsfm {
 
-#define CHOL_GS 16 /* most block columns of a supernode group (lsfm_pcg.hip: k_sn_panel keeps 6 * CHOL_GS dense scalar rows in LDS) */
+/* most block columns of a supernode group (lsfm_pcg.hip: k_sn_panel keeps 6 * CHOL_GS dense scalar rows in LDS).  8 since round 4 (16
+ * before): the panel kernel is left-looking inside a group -- the dot products of a column grow with the columns before it in the group
+ * -- while the update between groups runs on the matrix pipes of the whole chip; measured on the NC3500-like set (factorisation +
+ * refinement per tree): 16 columns 10.8 ms, 12 10.2, 8 9.4, 6 9.5, 4 9.9; RS468-like 5.76 -> 5.05, synth-16k 141 -> 131.
+ * LSFM_GS=<n <= CHOL_GS> narrows it further (measurements). */
+#define CHOL_GS 8
 
 struct CholSymbolic {
 	int M = 0, nnzL = 0, nlevels = 0, tail_begin = 0;

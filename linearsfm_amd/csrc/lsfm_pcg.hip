@@ -1985,7 +1985,7 @@ static void chol_factor(lsfm_context* ctx, const SchurSystem& sy, const unsigned
 		// 64 rows is 36 work-groups per group, each repeating the solve of its two chunks); taller ones take the panel kernel +
 		// the rank-update kernel (a synth-16k Mono tree, whose upper levels have panels of 100-300 rows: 684 ms against 826
 		// with everything fused)
-		static const int fuse_max = getenv("LSFM_SN_FUSE_MAX") ? atoi(getenv("LSFM_SN_FUSE_MAX")) : 64;
+		static const int fuse_max = getenv("LSFM_SN_FUSE_MAX") ? atoi(getenv("LSFM_SN_FUSE_MAX")) : 96; // (groups of <= 8 columns: 64 -> 96 rows, 9.5 -> 9.2 ms per NC3500 tree; 128 costs synth-16k 143 -> 169 ms)
 		static const double piv_floor = getenv("LSFM_PIVOT_FLOOR") ? atof(getenv("LSFM_PIVOT_FLOOR")) : 1e-13; // (0: none)
 		static const bool lds_set = []() {
 			// (dynamic LDS beyond 64 KB has to be asked for once per kernel)

@@ -590,9 +590,20 @@ def test_error_paths_of_the_c_abi(ctx):
         b["U"] = -np.asarray(b["U"])
     with pytest.raises(api.LsfmError, match="not positive definite"):
         ctx.divide_conquer(bad, False)
+    # the same through a resident tree whose first run records its plans (the level itself finds the pivot): every attempt fails,
+    # the error comes back, a tree of sound maps runs on the same context afterwards
+    bad4 = [oracle_free_dict(m) for m in synth.make_stereo_set(4, 6, 4, seed=3)]
+    for b in bad4:
+        b["V"] = -np.asarray(b["V"]); b["U"] = -np.asarray(b["U"])
+    t = ctx.tree_upload(bad4, False)
+    for plans in (True, False):
+        ctx.tree_set_plans(t, plans)
+        with pytest.raises(api.LsfmError, match="not positive definite"):
+            ctx.tree_run(t)
+    ctx.tree_free(t)
     # the context stays usable after an error
     out, stats, rc = ctx.divide_conquer(maps, False)
-    assert rc == 0 and int(out["m"]) == 2
+    assert rc == 0 and int(out["m"]) == 2 and stats["attempts"] == 1
 
 
 def oracle_free_dict(m):

@@ -24,8 +24,13 @@ plans = len(sys.argv) > 3 and sys.argv[3] == "plans"
 ctx.tree_set_plans(t, plans)
 res, times, dig = [], [], []
 want_digest = bool(os.environ.get("LSFM_FACTOR_DIGEST"))
+errors = []
 for i in range(n):
-    st, rc = ctx.tree_run(t)
+    try:
+        st, rc = ctx.tree_run(t)
+    except api.LsfmError as e:       # a run that ended with an error (e.g. a pivot far below zero): counted, the tree stays usable
+        errors.append((i, str(e)[-90:]))
+        continue
     times.append(st["t_total_ms"])
     res.append((rc, st["not_converged"], float("%.2e" % st["max_rel_residual"]), st["pcg_iterations"], st["attempts"]))
     if want_digest:
@@ -34,6 +39,8 @@ for i in range(n):
 bad = [r for r in res if r[0] != 0 or r[2] > 1e-8]
 print(cfg, "plans" if plans else "analysing", "mean ms %.1f" % np.mean(times), "runs", n, "failed", len(bad), bad[:6], "repeated",
       sum(1 for r in res if r[4] > 1), "worst ok", max([r[2] for r in res if r not in bad] or [0]), "steps/run", sorted(set(r[3] for r in res)))
+if errors:
+    print("   runs that ended with an ERROR: %d of %d: %s" % (len(errors), n, errors[:4]))
 if want_digest:
     by_s = {}
     for s, f, h, _ in dig:

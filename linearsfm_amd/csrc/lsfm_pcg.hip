@@ -1709,6 +1709,7 @@ static std::shared_ptr<void> solve_plan_store(lsfm_context* ctx, const SchurSyst
 		{ sy.gent, sy.gent ? nnzb * 16 : 0, (void**)&P.sy.gent }, { sy.goth, sy.goth ? nnzb * 8 : 0, (void**)&P.sy.goth },
 		{ sy.k9.ns, sy.k9.ns ? (size_t)sy.k9_tiles * 4 : 0, (void**)&P.sy.k9.ns }, { sy.k9.pose, sy.k9.pose ? (size_t)sy.k9_tiles * 64 * 4 : 0, (void**)&P.sy.k9.pose },
 		{ sy.k9.eslot, sy.k9.eslot ? (size_t)sy.k9_NW : 0, (void**)&P.sy.k9.eslot },
+		{ sy.k9.wlist, sy.k9.wlist ? (size_t)sy.k9_tiles * 3 * 4 : 0, (void**)&P.sy.k9.wlist }, { sy.k9.wcnt, sy.k9.wcnt ? (size_t)32 : (size_t)0, (void**)&P.sy.k9.wcnt },
 	};
 	P.sy.k9.record = 0;
 	size_t total = 0;

@@ -98,7 +98,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
                                         const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback,
-                                        const unsigned char* __restrict__ ces, int q0 = 0, bool first_sweep = true)
+                                        const unsigned char* __restrict__ ces, int tile, int q0 = 0, bool first_sweep = true)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
 	K9T_DECL;
@@ -303,7 +303,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	K9T(1);
 	if (sh.bad)
 	{
-		if (tid == 0) fallback[blockIdx.x] = 1;
+		if (tid == 0) fallback[tile] = 1;
 		return;
 	}
 	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair, in the (now free) panel ----
@@ -365,11 +365,11 @@ template <int SMAX, int THREADS>
 __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                       const double* __restrict__ W, const double* __restrict__ LY, const unsigned long long* __restrict__ tab,
                                       const int* __restrict__ val, unsigned long long mask, double* __restrict__ S, double* __restrict__ E,
-                                      unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces)
+                                      unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces, int tile)
 {
 	constexpr int NW = THREADS / 64;
 	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
-#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces)
+#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, tile)
 	if constexpr (SMAX <= 8)
 	{
 		if (tpw <= 1) PM_GO(1);
@@ -397,7 +397,7 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		{
 			for (int q0 = 0; q0 < NW * tpw; q0 += NW * TS)
 			{
-				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, q0, q0 == 0);
+				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, tile, q0, q0 == 0);
 				if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
 			}
 		}
@@ -505,42 +505,113 @@ __global__ void __launch_bounds__(PM_THREADS) k_schur_slots(int NF, const int* _
 	}
 }
 
-// One variant per panel width; a tile belongs to the narrowest variant launched that holds its poses: lo < ns <= SMAX (lo: the
-// width of the next narrower variant launched, 0: none).  `last`: the widest variant launched flags the tiles nobody takes (ns
-// beyond its panel, or the slots kernel gave up) for k_schur_w.
+// The tiles of the wide variants, listed in tile order (one work-group: a level has a few thousand tiles): a variant with an 80-157 KB
+// panel takes its tiles off its list with a few hundred work-groups instead of starting one per tile of the level that leaves at
+// once -- every one of those had to wait for a whole CU's LDS (the 64-slot variant's empty launch took 150 us of a level).
+__global__ void __launch_bounds__(256) k_schur_lists(int ntiles, K9Cache kc)
+{
+	__shared__ int cnt[3][256];
+	const int tid = threadIdx.x, per = (ntiles + 255) / 256, t0 = tid * per, t1 = min(t0 + per, ntiles);
+	int c[3] = { 0, 0, 0 };
+	for (int t = t0; t < t1; t++)
+	{
+		const int ns = kc.ns[t];
+		if (ns > 16) c[ns <= PM_SMAX ? 0 : (ns <= PM_SMAX_BIG ? 1 : 2)]++;
+	}
+	for (int v = 0; v < 3; v++) cnt[v][tid] = c[v];
+	__syncthreads();
+	if (tid < 3)
+	{
+		int run = 0;
+		for (int i = 0; i < 256; i++) { const int x = cnt[tid][i]; cnt[tid][i] = run; run += x; }
+		kc.wcnt[tid] = run;
+	}
+	__syncthreads();
+	int pos[3] = { cnt[0][tid], cnt[1][tid], cnt[2][tid] };
+	for (int t = t0; t < t1; t++)
+	{
+		const int ns = kc.ns[t];
+		if (ns > 16)
+		{
+			const int v = ns <= PM_SMAX ? 0 : (ns <= PM_SMAX_BIG ? 1 : 2);
+			kc.wlist[(size_t)v * ntiles + pos[v]++] = t;
+		}
+	}
+}
+
+// One variant per panel width; a tile belongs to the narrowest variant that holds its poses.  The 8- and 16-slot variants are
+// launched with one work-group per tile of the level (wlist == nullptr; `alone`: no wider variant is launched beside it -- a tile that
+// exceeds the panel is flagged for k_schur_w, like the tiles the slots kernel gave up on); the 32-, 48- and 64-slot variants
+// (LISTED) take their tiles off the list of their variant (k_schur_lists) with one work-group per CU; `lo`: tiles of at most that
+// many poses belong to a narrower variant launched beside a one-work-group-per-tile launch.
 // SMAX = 8 / 16: for levels whose systems have at most that many poses (the bottom of the tree: thousands of tiny joins).
 // A tile is then all latency -- eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
 // work-groups share a CU instead of 2.
-template <int SMAX, int THREADS>
+template <int SMAX, int THREADS, bool LISTED>
 #ifndef LSFM_K9_OCC16
 #define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
 #endif
 __global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : LSFM_K9_OCC16))
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
               const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, int lo, int last, K9Cache kc)
+              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, K9Cache kc)
 {
-	const int cns = kc.ns[blockIdx.x];
-	if (cns >= 0 && cns <= lo) return; // a narrower variant's tile
-	const int tid = threadIdx.x;
-	if (cns < 0 || cns > SMAX)
-	{
-		if (last && tid == 0) fallback[blockIdx.x] = 1;
-		return;
-	}
-	K9T_DECL;
 	__shared__ PmShared<SMAX> sh;
-	const int f0 = blockIdx.x * PM_TILE, f1 = min(f0 + PM_TILE, NF);
-	for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
-	if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid];
-	if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
-	__syncthreads();
-	const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-	for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
-	// (visible to the passes through the barrier at the top of the first pass)
-	K9T(0);
-	K9T_FLUSH(0, 1);
-	k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot);
+	const int tid = threadIdx.x;
+	// (LISTED is a template parameter, not a test of wlist: the loop around the tile cost the 16-slot variant, which sits at its
+	// register limit, ten spilled registers)
+	if constexpr (!LISTED)
+	{
+		const int tile = blockIdx.x;
+		const int cns = kc.ns[tile];
+		if (cns >= 0 && cns <= lo) return; // (lo: widest panel of the narrower variants launched beside this one)
+		if (cns < 0 || cns > SMAX)
+		{
+			// more poses than the hash table of the slots kernel holds, or -- where this is the only variant launched (levels of
+			// small systems; a tile may straddle systems and see more poses than any one of them has) -- than the panel: k_schur_w
+			if ((cns < 0 || alone) && tid == 0) fallback[tile] = 1;
+			return;
+		}
+		K9T_DECL;
+		const int f0 = tile * PM_TILE, f1 = min(f0 + PM_TILE, NF);
+		for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
+		if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)tile * PM_SMAX_MAX + tid];
+		if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
+		__syncthreads();
+		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
+		for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+		// (visible to the passes through the barrier at the top of the first pass)
+		K9T(0);
+		K9T_FLUSH(0, 1);
+		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot, tile);
+	}
+	else
+	{
+		__shared__ int s_it;
+		const int nlist = *wcnt;
+		for (int round = 0;; round++)
+		{
+			// the next tile of the list, whoever comes first (tiles differ in work by an order of magnitude)
+			if (round) __syncthreads(); // (the tile before is done with the panel and with s_it)
+			if (tid == 0) s_it = atomicAdd(cursor, 1);
+			__syncthreads();
+			const int it = s_it;
+			if (it >= nlist) break;
+			const int tile = wlist[it];
+			const int cns = kc.ns[tile];
+			K9T_DECL;
+			const int f0 = tile * PM_TILE, f1 = min(f0 + PM_TILE, NF);
+			for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
+			if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)tile * PM_SMAX_MAX + tid];
+			if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
+			__syncthreads();
+			const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
+			for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+			K9T(0);
+			K9T_FLUSH(0, 1);
+			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot, tile);
+		}
+	}
 }
 
 int schur_panel_tile() { return PM_TILE; }
@@ -557,7 +628,9 @@ extern "C" void lsfm_debug_k9(unsigned long long* out, int reset)
 void launch_schur_slots(lsfm_context* ctx, int NF, const int* fptr, const int* photo, unsigned char* fallback, K9Cache kc)
 {
 	if (!NF) return;
-	hipLaunchKernelGGL(k_schur_slots, dim3((NF + PM_TILE - 1) / PM_TILE), dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, fallback, kc);
+	const int ntiles = (NF + PM_TILE - 1) / PM_TILE;
+	hipLaunchKernelGGL(k_schur_slots, dim3(ntiles), dim3(PM_THREADS), 0, ctx->stream, NF, fptr, photo, fallback, kc);
+	hipLaunchKernelGGL(k_schur_lists, dim3(1), dim3(256), 0, ctx->stream, ntiles, kc);
 }
 
 // kc: the tiles' slots (launch_schur_slots of this run, or the plan of the level).
@@ -566,40 +639,47 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
                         int max_poses_per_system, K9Cache kc)
 {
 	if (!NF) return;
-	const dim3 grid((NF + PM_TILE - 1) / PM_TILE);
+	const int ntiles = (NF + PM_TILE - 1) / PM_TILE;
+	const dim3 grid(ntiles);
 	hipStream_t s = ctx->stream;
+	const int* none = nullptr;
 	// no tile can be seen by more poses than its system has
 	if (max_poses_per_system <= 8)
 	{
-		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, 1, kc);
+		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 1, none, none, (int*)nullptr, 0, kc);
 		return;
 	}
 	if (max_poses_per_system <= 16)
 	{
-		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, 1, kc);
+		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 1, none, none, (int*)nullptr, 0, kc);
 		return;
 	}
 	// By tile, not by level: most tiles of the upper levels are seen by a dozen poses (12.1 on average on the NC3500-like
 	// set) and fit the 16-slot variant, which is three work-groups to a CU instead of two and a third less work per pass;
-	// wider tiles go to the 32-, 48- and 64-slot variants, the rest to k_schur_w.  The 32-slot variant runs BESIDE the others, on
-	// the side stream (until round 4 the variants ran one after the other, each behind the tail of the one before, while the tiles
-	// of the 16-slot variant wait for HBM half of their time and those of the wide ones keep the matrix pipes busy): the slots
-	// kernel has told every variant its tiles.
-	// (measured on the NC3500-like set: K9 7.7 -> 7.2 ms per tree with the 32-slot variant on the side stream; streams of their
-	// own for the variants -- five streams on the context -- slowed EVERY launch of the run down, 40 -> 55 ms per tree, and the
-	// next-level stream (stream3) has the pattern of the next level queued at this point.  LSFM_K9_SERIAL=1: one after the other.)
+	// wider tiles go to the 32-, 48- and 64-slot variants, the rest to k_schur_w.  The slots kernel has told every variant its
+	// tiles, so the variants of a level run side by side (until round 4: one after the other, each behind the tail of the one
+	// before, every wide variant as one work-group per tile of the level -- nearly all of which left at once, but not before each
+	// had waited for 80-157 KB of a CU's LDS: the 64-slot launch of an NC3500 level took 150 us to do nothing).  The wide variants
+	// take their tiles off their lists with one work-group per CU, on the main stream; the 16-slot variant, one work-group per tile,
+	// follows on the side stream.  K9 per tree: NC3500-like 7.7 -> 7.2 ms, synth-16k 83 -> 64, RS468-like 2.8 -> 3.1-3.3.
+	// Measured and dropped: streams of their own for the variants (five streams on the context slowed EVERY launch of the run down,
+	// 40 -> 55 ms per tree); the next-level stream (it has the pattern of the next level queued at this point); a head start for
+	// part of the 32-slot list (7.9 -> 8.4); everything in one stream (8.5-9.1); half / twice as many work-groups on the lists.
+	// LSFM_K9_SERIAL=1: one stream.
 	static const bool serial = getenv("LSFM_K9_SERIAL") != nullptr;
+	static const int ncu = []() { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
 	hipStream_t s1 = serial ? s : ctx->stream2;
+	LSFM_CHECK_HIP(hipMemsetAsync(kc.wcnt + 4, 0, 4 * sizeof(int), s)); // the variants' cursors into their lists
 	if (!serial)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[0], s));
 		LSFM_CHECK_HIP(hipStreamWaitEvent(s1, ctx->ev_k9[0], 0));
 	}
-	// the wide variant first: few long work-groups, the narrow ones fill in around them
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 16, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE>), grid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, PM_SMAX, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE>), grid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, PM_SMAX_BIG, 1, kc);
-	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, 0, kc);
+	const dim3 wgrid(std::min(ntiles, ncu));
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + ntiles, kc.wcnt + 1, kc.wcnt + 5, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + 2 * (size_t)ntiles, kc.wcnt + 2, kc.wcnt + 6, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, none, none, (int*)nullptr, 0, kc);
 	if (!serial)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[1], s1));

@@ -1103,6 +1103,8 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			sy.k9.ns = sc.alloc<int>(ntiles + 1);
 			sy.k9.pose = sc.alloc<int>((size_t)ntiles * 64 + 1);
 			sy.k9.eslot = sc.alloc<unsigned char>((size_t)io.NW + 1);
+			sy.k9.wlist = sc.alloc<int>((size_t)3 * ntiles + 1);
+			sy.k9.wcnt = sc.alloc<int>(8);
 			sy.k9_tiles = ntiles; sy.k9_NW = io.NW;
 			launch_schur_slots(ctx, NF, io.fptr, io.photo, fb, sy.k9);
 		}

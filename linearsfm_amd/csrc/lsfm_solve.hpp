@@ -11,6 +11,8 @@ struct K9Cache {
 	int* ns = nullptr;            // [tiles]
 	int* pose = nullptr;          // [tiles * 64]
 	unsigned char* eslot = nullptr; // [NW]
+	int* wlist = nullptr;         // [3 * tiles] tiles of the 32- / 48- / 64-slot variants, wcnt[v] of them each
+	int* wcnt = nullptr;          // [8]: [0..2] tiles in the lists (structure, kept by a plan), [4..6] the cursors of a launch
 	int record = 0; // (unused since the slots have a kernel of their own)
 };
 

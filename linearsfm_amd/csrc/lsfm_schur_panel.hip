@@ -676,9 +676,11 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 		LSFM_CHECK_HIP(hipStreamWaitEvent(s1, ctx->ev_k9[0], 0));
 	}
 	const dim3 wgrid(std::min(ntiles, ncu));
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + ntiles, kc.wcnt + 1, kc.wcnt + 5, 0, kc);
+	// (widest first: a work-group of the 64-slot variant needs a CU's whole LDS to start -- behind the others it would wait for the
+	// 16-slot variant to drain even when its list is empty)
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + 2 * (size_t)ntiles, kc.wcnt + 2, kc.wcnt + 6, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + ntiles, kc.wcnt + 1, kc.wcnt + 5, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
 	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, none, none, (int*)nullptr, 0, kc);
 	if (!serial)
 	{

@@ -191,19 +191,21 @@ def test_synth64k_stereo_4096_maps_fp64_and_mixed_vs_oracle(ctx, oracle):
     assert e32 < TREE_TOL and f32 < TREE_TOL, (e32, f32)
 
 
-def test_synth64k_stereo_16384_maps_fp64_and_mixed_properties(ctx):
-    """16 384 local maps (16 384 poses, 1.05 M features, 14 levels) in both precisions.  Two fp64 evaluations of the reference
-    path differ by 1.2e-6 here (see above) and the oracle takes minutes, so: every system of every level solved to a direct
-    solve's residual in both modes, identical structure, and the two modes -- same assembled systems, preconditioner in fp64 /
-    fp32 -- agree far inside the bar (they differ only by what the refinement leaves: 1e-12 residuals)."""
-    typ, maps = synth.make_config("synth64k", 16384)
+@pytest.mark.parametrize("n_maps,levels", [(16384, 14), (65536, 16)])
+def test_synth64k_stereo_fp64_and_mixed_properties(ctx, n_maps, levels):
+    """16 384 local maps (16 384 poses, 1.05 M features, 14 levels) and the WHOLE set of BASELINE.json configs[4] (65 536 maps, 65 536
+    poses, 4.19 M features, 16 levels) in both precisions.  Two fp64 evaluations of the reference path differ by 1.2e-6 at 16 384
+    maps already (see above) and the oracle takes minutes, so: every system of every level solved to a direct solve's residual in
+    both modes, identical structure, and the two modes -- same assembled systems, preconditioner in fp64 / fp32 -- agree far inside
+    the bar (they differ only by what the refinement leaves: 1e-12 residuals)."""
+    typ, maps = synth.make_config("synth64k", n_maps)
     a, b, s64, s32 = _run_both_precisions(ctx, maps)
     del maps
-    assert int(a["m"]) == 16384 and s64["levels"] == 14 and a["Ref"] == a["FRef"] == 1
+    assert int(a["m"]) == n_maps and s64["levels"] == levels and a["Ref"] == a["FRef"] == 1
     _same_structure(b, a)
     e = pose_param_err(b["stVal"], a["stVal"], a["stno"])
     f = feat_param_err(b["stVal"], a["stVal"], a["stno"])
-    print(f"synth64k[:16384]: {a['n']} features, {a['nW']} W blocks; mixed vs fp64 pose {e:.2e} / features {f:.2e}; steps {s32['pcg_iterations']} vs "
+    print(f"synth64k[:{n_maps}]: {a['n']} features, {a['nW']} W blocks; mixed vs fp64 pose {e:.2e} / features {f:.2e}; steps {s32['pcg_iterations']} vs "
           f"{s64['pcg_iterations']}; residuals {s64['max_rel_residual']:.1e} / {s32['max_rel_residual']:.1e}; {s64['t_total_ms']:.0f} / {s32['t_total_ms']:.0f} ms")
     assert e < 1e-7 and f < 1e-7, (e, f)
 

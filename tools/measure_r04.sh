@@ -10,6 +10,8 @@ timeout 300 python bench.py --config aerial --steps 10 --warmup 2 > $D/bench_aer
 timeout 300 python bench.py --mixed --steps 10 --warmup 2 --cpu-baseline 0 --extras 0 > $D/bench_mixed.log 2>/dev/null
 timeout 600 python bench.py --config synth16k --steps 6 --warmup 1 --cpu-baseline 0 --extras 0 > $D/bench_synth16k.log 2>/dev/null
 timeout 600 python bench.py --config synth64k --maps 16384 --steps 3 --warmup 1 --cpu-baseline 0 --extras 0 > $D/bench_synth64k_16k.log 2>/dev/null
+timeout 900 python bench.py --config synth64k --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 > $D/bench_synth64k.log 2>/dev/null
+timeout 900 python bench.py --config synth64k --mixed --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 > $D/bench_synth64k_mixed.log 2>/dev/null
 export LSFM_FACTOR_DIGEST=1
 timeout 600 python tools/stability_16k.py 100 nc3500 > $D/stab.txt 2>&1
 timeout 600 python tools/stability_16k.py 100 rs468 >> $D/stab.txt 2>&1
@@ -23,7 +25,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_FETCH_SIZE 
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_WRITE_SIZE -o run -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 > $D/pmc_WRITE_SIZE.log 2>&1
 python - <<'PY'
 import json
-for f in ("default","rs468","rs90","aerial","mixed","synth16k","synth64k_16k","prof","prof_synth16k","prof_rs468"):
+for f in ("default","rs468","rs90","aerial","mixed","synth16k","synth64k_16k","synth64k","synth64k_mixed","prof","prof_synth16k","prof_rs468"):
     try:
         l=[x for x in open(f"gpurun_out/r04u/bench_{f}.log") if x.startswith("{")]
         d=json.loads(l[0]); print(f, round(d["value"],2), round(d["resolve_ms"],2), round(d["first_run_ms"],1), round(d["roofline"]["frac"],4), d["max_rel_residual"], d["not_converged"], (d.get("cpu_baseline") or {}).get("pose_param_max_rel_err_vs_oracle"), (d.get("e2e_cli") or {}).get("e2e_cli_s"))

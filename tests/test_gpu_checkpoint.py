@@ -74,6 +74,40 @@ def test_resume_from_the_nodes_of_a_level(ctx, tmp_path, mono, n_maps, stop):
         assert np.max(np.abs(a - b)) <= RESUME_TOL * max(1.0, np.max(np.abs(b))), key
 
 
+@pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("n_maps,stop", [(13, 2), (10, 1), (21, 3)])
+def test_nodes_of_a_level_equal_the_oracles_sub_trees(ctx, oracle, mono, n_maps, stop):
+    """What a stopped run holds is what the reference's loop holds at that point (Imp.cpp:1997-2032): node k of level L is the join of
+    local maps [k 2^L, (k + 1) 2^L) with its last re-anchoring still to come -- the oracle's tree over those maps without the final
+    re-anchoring (orc_set_final_reanchor(0)).  A node of one map is that map."""
+    from common import pose_param_err
+    maps = _sets(mono, n_maps)
+    dicts = [oracle.localmap_to_dict(m) for m in maps]
+    t = ctx.tree_upload(dicts, mono)
+    ctx.tree_set_stop_level(t, stop)
+    _, rc = ctx.tree_run(t)
+    assert rc == 0
+    span = 1 << stop
+    nn = (n_maps + span - 1) // span
+    assert ctx.tree_node_count(t) == nn
+    for k in range(nn):
+        node = ctx.tree_download_node(t, k)
+        sub = dicts[k * span:(k + 1) * span]
+        exp, _, orc = oracle.divide_conquer(sub, mono, final_reanchor=False)
+        assert orc == 0
+        for key in ("Ref", "FRef", "m", "n", "nU", "nW") + (("ScaP", "Fix", "FScaP", "FFix") if mono else ()):
+            assert node[key] == exp[key], (k, key, node[key], exp[key])
+        for key in ("stno", "Ui", "Uj", "photo", "feature"):
+            assert np.array_equal(node[key], exp[key]), (k, key)
+        assert pose_param_err(node["stVal"], exp["stVal"], exp["stno"]) < 1e-6, k
+        for key in ("U", "W", "V"):
+            a, b = np.asarray(node[key]), np.asarray(exp[key])
+            assert np.max(np.abs(a - b)) <= 1e-6 * max(1.0, np.max(np.abs(b))), (k, key)
+        org = np.asarray(node["pose_origin"])
+        assert org.min() >= k * span and org.max() < min((k + 1) * span, n_maps)
+    ctx.tree_free(t)
+
+
 def test_cli_stops_after_a_level_and_resumes_from_the_written_nodes(tmp_path):
     maps = synth.make_stereo_set(11, 6, 4, seed=5)
     d = tmp_path / "set"

@@ -74,6 +74,23 @@ def test_resume_from_the_nodes_of_a_level(ctx, tmp_path, mono, n_maps, stop):
         assert np.max(np.abs(a - b)) <= RESUME_TOL * max(1.0, np.max(np.abs(b))), key
 
 
+def test_a_stop_level_beyond_the_root_is_the_whole_tree(ctx):
+    maps = [m.__dict__ for m in _sets(False, 7)]
+    t = ctx.tree_upload(maps, False)
+    _, rc = ctx.tree_run(t)
+    whole = ctx.tree_download(t)
+    ctx.tree_set_stop_level(t, 9)          # 7 maps: three levels
+    st, rc2 = ctx.tree_run(t)
+    assert rc == 0 and rc2 == 0 and st["levels"] == 3 and ctx.tree_node_count(t) == 1
+    a, b = ctx.tree_download(t), ctx.tree_download_node(t, 0)
+    ctx.tree_free(t)
+    for g in (a, b):
+        assert g["Ref"] == whole["Ref"] == g["FRef"] and np.array_equal(g["stno"], whole["stno"])
+        assert np.max(np.abs(g["stVal"] - whole["stVal"])) <= RESUME_TOL * max(1.0, np.max(np.abs(whole["stVal"])))
+    with pytest.raises(api.LsfmError):
+        ctx.tree_set_stop_level(None, -1)
+
+
 @pytest.mark.parametrize("mono", [False, True])
 @pytest.mark.parametrize("n_maps,stop", [(13, 2), (10, 1), (21, 3)])
 def test_nodes_of_a_level_equal_the_oracles_sub_trees(ctx, oracle, mono, n_maps, stop):

@@ -34,6 +34,7 @@ extern "C" {
 #define LSFM_ERR_OOM (-4)
 #define LSFM_ERR_INTERNAL (-5)
 #define LSFM_ERR_IO (-6)
+#define LSFM_ERR_NOT_SPD (-7) /* a camera system whose factorisation met a pivot far below zero: the information matrices are not positive definite */
 #define LSFM_NOT_CONVERGED 1
 
 typedef struct lsfm_context lsfm_context; /* one per GPU / stream; thread-compatible, not thread-safe */
@@ -267,7 +268,13 @@ int lsfm_tree_reload_dev(lsfm_context* ctx, lsfm_tree* tree, const void* const* 
  * live in and a function that sums `count` elements at `offset_bytes` of that buffer over all ranks, in place, ordered after
  * the work already enqueued on `hip_stream` and before the work enqueued on it afterwards (RCCL: ncclAllReduce on that stream;
  * torch.distributed: all_reduce under torch.cuda.ExternalStream(hip_stream)).  Returns 0 on success.  Every rank must call
- * lsfm_tree_run on its slice tree at the same time; the number and sizes of the calls are the same on every rank. */
+ * lsfm_tree_run on its slice tree at the same time; the number and sizes of the calls are the same on every rank.
+ * Every sum is announced by a sum of 4 int64 at offset 0 of the buffer (the first 256 bytes are the library's): {ranks that have
+ * failed, ranks that have not, count, dtype}.  A rank whose run fails between two sums (out of memory, a HIP error, a buffer too
+ * small) does not leave its peers waiting: it follows their headers, adds zeros to every sum they make and reaches the exchange of
+ * the run's flags with them, where every rank learns of the failure -- lsfm_tree_run then returns an error on EVERY rank
+ * (the failed rank its own, the others LSFM_ERR_INTERNAL "another rank ... failed").  Only a failure of `fn` itself (non-zero
+ * return: the communicator is gone) cannot be matched; the caller must then tear the job down. */
 #define LSFM_DTYPE_F64 0
 #define LSFM_DTYPE_I64 1
 typedef int (*lsfm_allreduce_fn)(void* user, size_t offset_bytes, size_t count, int dtype, void* hip_stream);

@@ -130,9 +130,12 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 	other.reset();
 	mine.reset();
 	DevBatch Xt, Y;
+	// tests (tests/test_gpu_sharded.py): ONE rank of a feature-sharded run fails in the middle of a level, between two sums
+	const bool inject = ctx->inject_level == level;
 	if (t->mono)
 	{
 		{ Range r("lsfm transform"); transform_batch(ctx, other, X, tref, tscap, tfix, true, Xt, true); }
+		if (inject) LSFM_FAIL(LSFM_ERR_INTERNAL, "injected failure of this rank (LSFM_TEST_FAIL_RANK)");
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		Range r("lsfm join + solve");
 		join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
@@ -150,6 +153,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 			return rd;
 		};
 		{ Range r("lsfm transform"); transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); } // (the join's layout kernels run inside)
+		if (inject) LSFM_FAIL(LSFM_ERR_INTERNAL, "injected failure of this rank (LSFM_TEST_FAIL_RANK)");
 		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
 		Range r("lsfm join + solve");
 		js.smark = smark; // everything of this level goes at once
@@ -298,10 +302,28 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				// feature-sharded run: an error of this rank alone (LSFM_FAIL inside the pass) must still reach the exchange of the flags
 				// below, or its peers would wait there for a sum this rank never joins; it is rethrown after the exchange
 				std::unique_ptr<Error> pass_error;
+				ctx->inject_level = -1;
+				bool inject_undone = false;
 				if (ctx->comm)
 				{
+					// tests: LSFM_TEST_FAIL_RANK=r makes rank r's FIRST attempt fail -- LSFM_TEST_FAIL_KIND=throw (default): an error in the
+					// middle of level LSFM_TEST_FAIL_LEVEL (default 0); undone: a system reported above its bound at the end of the pass
+					static const char* frank = getenv("LSFM_TEST_FAIL_RANK");
+					static int injected = 0; // (once per process: the run after the failed one must go through)
+					if (frank && attempt == 0 && atoi(frank) == ctx->comm->rank && !injected++)
+					{
+						const char* kind = getenv("LSFM_TEST_FAIL_KIND");
+						if (kind && !strcmp(kind, "undone")) inject_undone = true;
+						else ctx->inject_level = getenv("LSFM_TEST_FAIL_LEVEL") ? atoi(getenv("LSFM_TEST_FAIL_LEVEL")) : 0;
+					}
 					try { tree_pass(ctx, t, st); }
-					catch (const Error& e) { pass_error.reset(new Error(e)); (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); }
+					catch (const Error& e)
+					{
+						pass_error.reset(new Error(e));
+						ctx->inject_level = -1;
+						(void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError();
+						ctx->drop_prepared();
+					}
 				}
 				else
 				{
@@ -311,7 +333,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					{
 						// a level that was recording its plan found a pivot far below zero itself (lsfm_pcg.hip check_factor): treated like the
 						// same finding at the end of a run, below -- the tree is joined again while attempts are left
-						if (e.code == LSFM_ERR_INTERNAL && attempt < 3 && e.msg.find("not positive definite") != std::string::npos)
+						if (e.code == LSFM_ERR_NOT_SPD && attempt < 3)
 						{
 							(void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError();
 							ctx->stats = st; ctx->plan = nullptr; // (tree_pass was left mid-level)
@@ -346,13 +368,24 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					// feature-sharded run: whether the run is repeated (below) must be decided alike on every rank -- a rank that
 					// went on alone would wait for sums nobody else takes part in
 					Comm& cm = *ctx->comm;
+					if (inject_undone) rs.undone++;
+					if (pass_error)
+					{
+						// this rank left the pass alone, somewhere between two sums: it takes part in its peers' sums (with zeros) until they
+						// are here too -- see Comm in lsfm_internal.hpp.  No healthy rank left, or the communicator itself failed: nothing to
+						// exchange, the error is this rank's own
+						bool there = false;
+						try { there = cm.follow(ctx->stream); } catch (const Error&) { there = false; }
+						if (!there) throw *pass_error;
+					}
 					cm.restart();
 					long long* d_fl = cm.alloc<long long>(8);
 					// (st->not_converged: what the levels that recorded a plan reported through the stats; fl[6]: this rank's pass threw)
 					long long fl[8] = { rs.tr_err != 0, rs.chol_err != 0, rs.plan_stale != 0, rs.not_converged, rs.undone, st->not_converged, pass_error ? 1 : 0, 0 };
 					LSFM_CHECK_HIP(hipMemcpyAsync(d_fl, fl, sizeof fl, hipMemcpyHostToDevice, ctx->stream));
 					LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-					cm.allreduce(ctx->stream, d_fl, 8, LSFM_DTYPE_I64);
+					if (pass_error) cm.call(ctx->stream, (size_t)(reinterpret_cast<char*>(d_fl) - cm.buf), 8, LSFM_DTYPE_I64); // (its header went with follow())
+					else cm.allreduce(ctx->stream, d_fl, 8, LSFM_DTYPE_I64, Comm::KIND_FINAL);
 					LSFM_CHECK_HIP(hipMemcpyAsync(fl, d_fl, sizeof fl, hipMemcpyDeviceToHost, ctx->stream));
 					LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 					if (fl[0] && !rs.tr_err) rs.tr_err = 1;
@@ -368,7 +401,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				if (rs.tr_err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(rs.tr_err - 1));
 				// (const bool more, below: attempts left)
 				if (rs.chol_err && !(attempt < 3))
-					LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
+					LSFM_FAIL(LSFM_ERR_NOT_SPD, "Schur system is not positive definite (block column " + std::to_string(rs.chol_err - 1) + " of the factor)");
 				// Repeating a run.  A plan that met values it does not fit (LevelPlan::tr_sign), refinement steps enqueued by a count
 				// from an earlier run that did not suffice this time (`undone`), or a system left above its bound although every level
 				// asked after every step -- seen in one synth-16k Mono tree out of fifteen: the last 6x6 block of the root's top
@@ -576,7 +609,7 @@ int lsfm_tree_set_comm(lsfm_tree* t, int rank, int world, lsfm_allreduce_fn fn, 
 	if (world < 1 || rank < 0 || rank >= world || !dev_buf || dev_bytes < 4096) return LSFM_ERR_ARG;
 	if (t->comm.rank != rank || t->comm.world != world) t->plans.clear();
 	t->comm.rank = rank; t->comm.world = world; t->comm.fn = fn; t->comm.user = user;
-	t->comm.buf = static_cast<char*>(dev_buf); t->comm.cap = dev_bytes; t->comm.off = 0;
+	t->comm.buf = static_cast<char*>(dev_buf); t->comm.cap = dev_bytes; t->comm.restart(); t->comm.broken = false;
 	return LSFM_OK;
 }
 

@@ -166,24 +166,23 @@ __device__ __forceinline__ void r_derivation(double Alpha, double Beta, double G
 	mul33(RG, DB, tmp); mul33(tmp, RA, dRB);
 	mul33(RG, RB, tmp); mul33(tmp, DA, dRA);
 }
-// lmj_dRi (Imp.cpp:282-307) when T==false, lmj_dRiTT (Imp.cpp:309-334) when T==true
-template <bool T>
-__device__ __forceinline__ void d_ri(double* dRid, const double* dRi, const double* Ri)
+// Rates of the three angles that inv_rmat_ypr (TRANSPOSED: inv_rmat_ypr_T) reads off a rotation matrix R, when R moves at dR:
+//   yaw = atan(R[a] / R[0]),  pitch = atan(-R[b] / hypot(R[0], R[a])),  roll = atan(R[c] / R[8])      (a, b, c) = (1, 2, 5) / (3, 6, 7)
+// by the quotient and chain rules.  What lmj_dRi / lmj_dRiTT compute (Imp.cpp:282-307 / 309-334); the operations are kept in the
+// reference's order -- the rates enter the Jacobians of every pose, and the fixtures of the real reference are compared at 1e-9.
+__device__ __forceinline__ double ratio_rate(double num, double dnum, double den, double dden) { return (dnum * den - num * dden) / (den * den); }
+__device__ __forceinline__ double atan_slope(double q) { return 1.0 / (1 + q * q); }
+template <bool TRANSPOSED>
+__device__ __forceinline__ void ypr_rates(double* rate, const double* dR, const double* R)
 {
-	const int i1 = T ? 3 : 1, i2 = T ? 6 : 2, i5 = T ? 7 : 5;
-	double F1 = Ri[i1] / Ri[0];
-	double F3 = Ri[i5] / Ri[8];
-	double F5 = Ri[0] * Ri[0] + Ri[i1] * Ri[i1];
-	double F4 = sqrt(F5);
-	double F2 = -Ri[i2] / F4;
-	double dAdF1 = 1.0 / (1 + F1 * F1), dBdF2 = 1.0 / (1 + F2 * F2), dGdF3 = 1.0 / (1 + F3 * F3);
-	double dF1d = (dRi[i1] * Ri[0] - Ri[i1] * dRi[0]) / (Ri[0] * Ri[0]);
-	double dF3d = (dRi[i5] * Ri[8] - Ri[i5] * dRi[8]) / (Ri[8] * Ri[8]);
-	double dF4dF5 = 1.0 / (2 * sqrt(F5));
-	double dF5d = 2 * Ri[0] * dRi[0] + 2 * Ri[i1] * dRi[i1];
-	double dF4d = dF4dF5 * dF5d;
-	double dF2d = (-dRi[i2] * F4 + Ri[i2] * dF4d) / F5;
-	dRid[0] = dAdF1 * dF1d; dRid[1] = dBdF2 * dF2d; dRid[2] = dGdF3 * dF3d;
+	constexpr int a = TRANSPOSED ? 3 : 1, b = TRANSPOSED ? 6 : 2, c = TRANSPOSED ? 7 : 5;
+	const double yaw_q = R[a] / R[0], roll_q = R[c] / R[8];
+	const double h2 = R[0] * R[0] + R[a] * R[a], h = sqrt(h2);
+	const double pitch_q = -R[b] / h;
+	const double dh = (1.0 / (2 * sqrt(h2))) * (2 * R[0] * dR[0] + 2 * R[a] * dR[a]);
+	rate[0] = atan_slope(yaw_q) * ratio_rate(R[a], dR[a], R[0], dR[0]);
+	rate[1] = atan_slope(pitch_q) * ((-dR[b] * h + R[b] * dh) / h2);
+	rate[2] = atan_slope(roll_q) * ratio_rate(R[c], dR[c], R[8], dR[8]);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -131,11 +131,20 @@ struct Comm {
 	lsfm_allreduce_fn fn = nullptr;
 	void* user = nullptr;
 	char* buf = nullptr;
-	size_t cap = 0, off = 0;
+	size_t cap = 0, off = 256; // (the first HDR_BYTES hold the header of the sum under way)
 	// > 0: the pose-side factorisation is distributed too -- rank r owns what lies inside block r of block_maps consecutive local
 	// maps of the whole tree (lsfm_tree_set_comm_blocks); 0: every rank factors everything
 	int block_maps = 0;
-	void restart() { off = 0; }
+	// Every sum is announced by a HEADER sum of 4 x int64 in the first bytes of the buffer: {ranks that failed, ranks that have not,
+	// count, dtype | kind << 8} (the last two from the healthy ranks, times their number).  A healthy rank never reads it -- it
+	// enqueues header and payload and goes on.  A rank whose pass threw between two sums (an error of its own: out of memory, a HIP
+	// error, a buffer too small) cannot know what its peers will sum next; it FOLLOWS them instead (follow(), lsfm_prims.hip): header
+	// after header it learns count and dtype of the payload, contributes zeros, and so reaches the exchange of the run's flags
+	// (kind FINAL) with every collective matched -- there all ranks learn of the failure and every one of them returns an error.
+	// Nobody waits for a sum the failed rank never joins (advisor, round 4).
+	enum { HDR_BYTES = 256, KIND_DATA = 0, KIND_FINAL = 1 };
+	bool broken = false;   // the caller's function itself failed: the communicator cannot be trusted to match anything any more
+	void restart() { off = HDR_BYTES; }
 	void* alloc_bytes(size_t bytes)
 	{
 		const size_t a = (off + 255) & ~size_t(255);
@@ -145,13 +154,17 @@ struct Comm {
 		return buf + a;
 	}
 	template <class T> T* alloc(size_t n) { return static_cast<T*>(alloc_bytes(n * sizeof(T))); }
-	// p: inside the buffer; count elements of 8 bytes
-	void allreduce(hipStream_t s, void* p, size_t count, int dtype) const
+	// p: inside the buffer; count elements of 8 bytes (the same count on every rank)
+	void allreduce(hipStream_t s, void* p, size_t count, int dtype, int kind = KIND_DATA);
+	void call(hipStream_t s, size_t offset, size_t count, int dtype)
 	{
-		if (!count) return;
-		const int rc = fn(user, (size_t)(static_cast<char*>(p) - buf), count, dtype, (void*)s);
-		if (rc) throw Error{ LSFM_ERR_INTERNAL, "the caller's all-reduce failed with code " + std::to_string(rc) };
+		const int rc = fn(user, offset, count, dtype, (void*)s);
+		if (rc) { broken = true; throw Error{ LSFM_ERR_INTERNAL, "the caller's all-reduce failed with code " + std::to_string(rc) }; }
 	}
+	// A rank whose pass failed: takes part in its peers' sums with zeros until they reach the exchange of the run's flags.
+	// true: the peers are at that exchange (the caller now sums its flags WITHOUT a header); false: no rank is healthy any more (all
+	// of them are following: nobody exchanges anything) or the communicator is broken
+	bool follow(hipStream_t s);
 };
 
 // One helper thread per context for host work that the enqueuing thread need not wait for at once (the symbolic factorisation
@@ -288,6 +301,7 @@ struct lsfm_context {
 	bool timeline_on = false;
 	void mark(const char* what);
 	bool in_tree_run = false;
+	int inject_level = -1; // tests: the level in which this rank's pass fails (LSFM_TEST_FAIL_RANK, lsfm_capi.hip), -1: none
 	// refinement steps of the level being run: step_hint > 0 = what an earlier run of this tree needed here (the steps are then
 	// enqueued without asking the device after each one; whether they sufficed is read at the end of the run), steps_used = what
 	// a level that did ask needed

@@ -2569,7 +2569,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	ctx->solved_keys = sy.upper_keys; ctx->solved_nnzb = sy.nnzb;
 	auto check_factor = [&]() {
 		const int cerr = d2h_int(ctx, d_err);
-		if (cerr) LSFM_FAIL(LSFM_ERR_INTERNAL, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
+		if (cerr) LSFM_FAIL(LSFM_ERR_NOT_SPD, "Schur system is not positive definite (block column " + std::to_string(cerr - 1) + " of the factor)");
 	};
 	// (a feature-sharded run never throws for it in the middle of a pass: the ranks' factorisations are their own, and a rank that left
 	// the pass alone would leave its peers in a sum it never joins -- the flags are exchanged at the end of the run)
@@ -2612,7 +2612,27 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			ndone = d2h_int(ctx, d_misc + 1);
 			ctx->mark("cg_sync");
 			if (its == 1 && !err_to_run) check_factor(); // (the stream is drained: this costs no second wait)
-			if (ndone >= nseg) break;
+			if (ctx->comm && ctx->comm->world > 1)
+			{
+				// feature-sharded run: whether another step follows must be the same answer on every rank -- the next step holds sums
+				// over the ranks when the factorisation is distributed (chol_apply), and the ranks' residuals, taken from floating-point
+				// atomic sums, may differ in the last bits: at a threshold one rank would leave the loop for the sum of x while another
+				// enters the sums of the preconditioner (advisor, round 4).  Any rank's doubt is everybody's: one 8-byte sum per step,
+				// in runs that ask after every step only.
+				Comm& cm = *ctx->comm;
+				const size_t mk = cm.off;
+				long long* d_more = cm.alloc<long long>(1);
+				long long more = ndone >= nseg ? 0 : 1;
+				LSFM_CHECK_HIP(hipMemcpyAsync(d_more, &more, sizeof more, hipMemcpyHostToDevice, s));
+				LSFM_CHECK_HIP(hipStreamSynchronize(s));
+				cm.allreduce(s, d_more, 1, LSFM_DTYPE_I64);
+				LSFM_CHECK_HIP(hipMemcpyAsync(&more, d_more, sizeof more, hipMemcpyDeviceToHost, s));
+				LSFM_CHECK_HIP(hipStreamSynchronize(s));
+				cm.off = mk;
+				if (!more) break;
+				ndone = std::min(ndone, nseg - 1); // (a peer goes on: so does this rank -- its finished systems are frozen on the device)
+			}
+			else if (ndone >= nseg) break;
 		}
 		chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[cur ^ 1], SEG_STRIDE);
 		hipLaunchKernelGGL(k_pcg_update2, dim3(nbr), dim3(128), 0, s, M, cur, z, io.d_pose_seg, p, Ap, seg, d_misc + 1);

@@ -229,6 +229,41 @@ void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 	if (bytes) LSFM_CHECK_HIP(hipMemsetAsync(d, 0, bytes, ctx->stream));
 }
 
+// ---- the sums of a feature-sharded run (Comm, lsfm_internal.hpp) ---------------------------------------------------------------
+__global__ void k_comm_header(long long* h, long long failed, long long healthy, long long count, long long what)
+{
+	h[0] = failed; h[1] = healthy; h[2] = count; h[3] = what;
+}
+void Comm::allreduce(hipStream_t s, void* p, size_t count, int dtype, int kind)
+{
+	if (!count) return;
+	if (broken) throw Error{ LSFM_ERR_INTERNAL, "the caller's all-reduce failed earlier in this run" };
+	hipLaunchKernelGGL(k_comm_header, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(buf), 0ll, 1ll, (long long)count, (long long)(dtype | (kind << 8)));
+	call(s, 0, 4, LSFM_DTYPE_I64);
+	call(s, (size_t)(static_cast<char*>(p) - buf), count, dtype);
+}
+bool Comm::follow(hipStream_t s)
+{
+	if (broken || !fn) return false;
+	// (at most as many sums as a run of a deep tree can hold: a peer that never reaches its exchange is a bug, not a reason to spin)
+	for (int guard = 0; guard < (1 << 20); guard++)
+	{
+		long long h[4] = { 0, 0, 0, 0 };
+		hipLaunchKernelGGL(k_comm_header, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(buf), 1ll, 0ll, 0ll, 0ll);
+		call(s, 0, 4, LSFM_DTYPE_I64);
+		LSFM_CHECK_HIP(hipMemcpyAsync(h, buf, sizeof h, hipMemcpyDeviceToHost, s));
+		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		if (h[1] <= 0) return false; // every rank is following: there is nobody left to follow
+		const long long count = h[2] / h[1], what = h[3] / h[1];
+		if ((what >> 8) == KIND_FINAL) return true;
+		if (count <= 0 || HDR_BYTES + (size_t)count * 8 > cap) { broken = true; return false; }
+		LSFM_CHECK_HIP(hipMemsetAsync(buf + HDR_BYTES, 0, (size_t)count * 8, s)); // (this rank's part of the sum: nothing)
+		call(s, HDR_BYTES, (size_t)count, (int)(what & 0xff));
+	}
+	broken = true;
+	return false;
+}
+
 } // namespace lsfm
 
 namespace lsfm {
@@ -280,6 +315,11 @@ void lsfm_context::flush_times()
 
 static void alloc_arenas(lsfm_context* c, size_t bytes_each)
 {
+	// The helper thread may still be analysing the level an error interrupted (prefetch_next_level hands it a raw pointer into what
+	// ctx->pre / ctx->pre_pending keep alive, and its index arrays live in sarena[]): wait for it and forget what was prepared BEFORE
+	// anything is freed -- grow_arenas() is called from the handler of an LSFM_ERR_OOM thrown mid-level
+	c->drop_prepared();
+	c->early.reset(); c->solved_keys = nullptr; c->solved_nnzb = 0; // (pointers into the arenas about to go)
 	c->arena[0].destroy(); c->arena[1].destroy(); c->arena[2].destroy(); c->scratch.destroy(); c->sarena[0].destroy(); c->sarena[1].destroy();
 	c->pre.reset();
 	c->arena[0].init(bytes_each);
@@ -300,6 +340,7 @@ void lsfm_context::ensure_arenas(size_t bytes_each, bool start_small)
 	// the estimate is an upper bound that ignores the merging of common features (an order of magnitude at depth): never
 	// ask for more than a share of what the device has free; a tree that really needs more fails with LSFM_ERR_OOM at
 	// the allocation that overflows its arena
+	drop_prepared(); // (waits for the helper thread: nothing it reads may be freed under it)
 	arena[0].destroy(); arena[1].destroy(); arena[2].destroy(); scratch.destroy(); sarena[0].destroy(); sarena[1].destroy();
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)4 << 30))

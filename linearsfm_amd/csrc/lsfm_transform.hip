@@ -131,7 +131,7 @@ __global__ void k_tr_params2(const double* __restrict__ npose, TMap* tm, int B)
 	const double* p = npose + (size_t)t.hub[0] * 6;
 	t.t[0] = p[0]; t.t[1] = p[1]; t.t[2] = p[2];
 	r_derivation(p[3], p[4], p[5], t.R, t.dRA, t.dRB, t.dRG);
-	d_ri<true>(t.dA, t.dRA, t.R); d_ri<true>(t.dB, t.dRB, t.R); d_ri<true>(t.dG, t.dRG, t.R);
+	ypr_rates<true>(t.dA, t.dRA, t.R); ypr_rates<true>(t.dB, t.dRB, t.R); ypr_rates<true>(t.dG, t.dRG, t.R);
 	t.Scale = 1.0; t.Scale2 = 1.0;
 	if (t.nh == 2)
 	{
@@ -204,12 +204,12 @@ k_tr_pose_jac(const double* __restrict__ npose, const int* __restrict__ pose_map
 		double R2[9], dRA2[9], dRB2[9], dRG2[9], Ri[9], dRi[9], ddA2[3], ddB2[3], ddG2[3], ddA[3], ddB[3], ddG[3];
 		r_derivation(p[3], p[4], p[5], R2, dRA2, dRB2, dRG2);
 		times_rrt(Ri, R2, t.R);
-		times_rrt(dRi, dRA2, t.R); d_ri<false>(ddA2, dRi, Ri);
-		times_rrt(dRi, dRB2, t.R); d_ri<false>(ddB2, dRi, Ri);
-		times_rrt(dRi, dRG2, t.R); d_ri<false>(ddG2, dRi, Ri);
-		times_rrt(dRi, R2, t.dRA); d_ri<false>(ddA, dRi, Ri);
-		times_rrt(dRi, R2, t.dRB); d_ri<false>(ddB, dRi, Ri);
-		times_rrt(dRi, R2, t.dRG); d_ri<false>(ddG, dRi, Ri);
+		times_rrt(dRi, dRA2, t.R); ypr_rates<false>(ddA2, dRi, Ri);
+		times_rrt(dRi, dRB2, t.R); ypr_rates<false>(ddB2, dRi, Ri);
+		times_rrt(dRi, dRG2, t.R); ypr_rates<false>(ddG2, dRi, Ri);
+		times_rrt(dRi, R2, t.dRA); ypr_rates<false>(ddA, dRi, Ri);
+		times_rrt(dRi, R2, t.dRB); ypr_rates<false>(ddB, dRi, Ri);
+		times_rrt(dRi, R2, t.dRG); ypr_rates<false>(ddG, dRi, Ri);
 		if (NH == 1)
 		{
 			double d[3] = { p[0] - t.t[0], p[1] - t.t[1], p[2] - t.t[2] }, tmp1[3], tmp2[3], tmp3[3];

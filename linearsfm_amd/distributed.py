@@ -31,6 +31,8 @@ the scheduling is covered by world-size-2/3/4 gloo tests without a GPU.
 """
 from __future__ import annotations
 
+import datetime
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -529,7 +531,9 @@ class ShardedTree:
                 _, _, w0, w1 = self.pending.pop(slot)
                 for w in (w0, w1):
                     try:
-                        w.wait()
+                        # (bounded: a peer that failed as well never sends, and an endless wait here would hide the exception
+                        # that ended the run)
+                        w.wait(timeout=datetime.timedelta(seconds=30))
                     except Exception:
                         pass
 

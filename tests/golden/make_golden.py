@@ -315,6 +315,13 @@ def main():
         # mid-size: the top joins of an 88-map Mono set on the returning path and of a 64-map Stereo set whose laps close
         run_top("Monocular", synth.make_mono_set(88, new_per_frame=4, vis=4, seed=19, **synth.SPIRAL), os.path.join(out, "mono_n88_top2.npz"), tmp, 2)
         run_top("Stereo", synth.make_stereo_set(64, new_per_frame=4, vis=5, seed=20, **MID_STEREO_PATH), os.path.join(out, "stereo_n64_top1.npz"), tmp, 1)
+        # wide: long tracks (every point stays visible for 34-44 frames), so that the ONE tile of 128 features of the top join is seen by
+        # 33-48 resp. 49-64 poses and features have runs of 33-64 W blocks: the sizes at which the device takes the 48- and the 64-slot
+        # variant of its Schur panel kernel off the tile lists (k_schur_lists), and the dense-revisit paths of the transform's pose table
+        run_top("Stereo", synth.make_stereo_set(48, new_per_frame=1, vis=40, seed=21), os.path.join(out, "stereo_n48_wide_top1.npz"), tmp, 1)
+        run_top("Stereo", synth.make_stereo_set(64, new_per_frame=1, vis=44, seed=22), os.path.join(out, "stereo_n64_wide_top1.npz"), tmp, 1)
+        run_top("Monocular", synth.make_mono_set(46, new_per_frame=1, vis=34, seed=23, **synth.SPIRAL), os.path.join(out, "mono_n46_wide_top1.npz"), tmp, 1)
+        run_top("Monocular", synth.make_mono_set(60, new_per_frame=1, vis=40, seed=24, **synth.SPIRAL), os.path.join(out, "mono_n60_wide_top1.npz"), tmp, 1)
 
 
 if __name__ == "__main__":

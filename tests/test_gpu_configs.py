@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from common import GOLD_MID, GOLD_SMALL, feat_param_err, get_map, golden_system, load_golden, pose_param_err, rel_err
+from common import GOLD_MID, GOLD_SMALL, GOLD_WIDE, feat_param_err, get_map, golden_system, load_golden, pose_param_err, rel_err
 from linearsfm_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -258,7 +258,7 @@ def _pairs_from_csc(Ap, Aii):
     return [(int(Aii[k]), j) for j in range(len(Ap) - 1) for k in range(Ap[j], Ap[j + 1])]
 
 
-@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID + GOLD_WIDE)
 def test_device_schur_pattern_vs_reference_aux_css(ctx, name):
     """The block pattern of S the DEVICE builds (hash set of pose pairs + U's pattern -> block CSR: lsfm_schur_pattern) on
     the index arrays of all 22 reference-assembled systems, against the pattern the REAL pba_constructAuxCSS{LM,GN}

@@ -6,7 +6,7 @@ the dense expected value."""
 import numpy as np
 import pytest
 
-from common import (GOLD_MID, GOLD_SMALL, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
+from common import (GOLD_MID, GOLD_SMALL, GOLD_WIDE, PANEL_SLOTS, tile_pose_counts, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
                     pose_param_err, pose_param_true_rel_err, ref_map, rel_err)
 from linearsfm_amd import synth
 
@@ -20,13 +20,14 @@ DENSE_TOL = 1e-10  # one solve vs the dense LAPACK expected value (tests/common.
 # -- and the library stops refining a system at a relative RESIDUAL of 1e-12 (lsfm_set_pcg), which leaves its solution within
 # cond(S) x 1e-12 of the exact one where a direct solve (the reference's, the oracle's) leaves cond(S) x 1e-16: 1.7e-8 on the 66-pose
 # system.  The dense-LAPACK test below therefore also refines those systems to stagnation (rel_tol 1e-15): 5.8e-9 there.
-MID_SOLVE_TOL = {"stereo_n64_top1.npz": 1e-9, "mono_n88_top2.npz": 1e-7}
-STEREO_GOLD = [n for n in GOLD_SMALL + GOLD_MID if n.startswith("stereo")]
-MONO_GOLD = [n for n in GOLD_SMALL + GOLD_MID if n.startswith("mono")]
+MID_SOLVE_TOL = {"stereo_n64_top1.npz": 1e-9, "mono_n88_top2.npz": 1e-7, "stereo_n48_wide_top1.npz": 1e-9, "stereo_n64_wide_top1.npz": 1e-9,
+                 "mono_n46_wide_top1.npz": 1e-7, "mono_n60_wide_top1.npz": 1e-7}
+STEREO_GOLD = [n for n in GOLD_SMALL + GOLD_MID + GOLD_WIDE if n.startswith("stereo")]
+MONO_GOLD = [n for n in GOLD_SMALL + GOLD_MID + GOLD_WIDE if n.startswith("mono")]
 TREE_TOL = 1e-6    # BASELINE.json: 1e-6 relative on pose parameters
 
 
-@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID + GOLD_WIDE)
 def test_transform_vs_reference_golden(ctx, name):
     z = load_golden(name)
     mono = str(z["type"]) == "Monocular"
@@ -74,7 +75,7 @@ def test_join_assembly_and_solve_vs_golden(ctx, name):
         assert np.max(np.abs(joint["stVal"] - xd) / np.maximum(1, np.abs(xd))) < SOLVE_TOL
 
 
-@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID + GOLD_WIDE)
 def test_solve_every_reference_assembled_system_vs_dense_lapack(ctx, name):
     """lsfm_solve_{stereo,mono} (the reference's argument lists) on all 22 systems the REAL reference assembled, against an
     expected value that never passes through the oracle's Schur complement or sparse Cholesky: the dense LAPACK solution
@@ -84,6 +85,12 @@ def test_solve_every_reference_assembled_system_vs_dense_lapack(ctx, name):
     DENSE_TOL = MID_SOLVE_TOL.get(name, 1e-10)
     for j in range(int(z["njoins"])):
         J, ea, eb, mono, sa = golden_system(z, j)
+        if name in PANEL_SLOTS:
+            # the wide fixtures: their one tile is seen by more poses than the 32-slot panel holds and by no more than the expected
+            # variant does -- launch_schur_panel (lsfm_schur_panel.hip) then hands it to exactly that variant, off its tile list
+            ns = tile_pose_counts(J["photo"], J["feature"], J["n"])
+            lo = {48: 33, 64: 49}[PANEL_SLOTS[name]]
+            assert len(ns) == 1 and lo <= ns[0] <= PANEL_SLOTS[name], (name, ns)
         st, rc = ctx.solve(J, ea, eb, mono, sa)
         assert rc == 0
         xd = z[f"join{j}.dense_sol"]
@@ -123,7 +130,7 @@ def test_solve_every_reference_assembled_system_vs_dense_lapack(ctx, name):
         assert np.max(np.abs(st[6 * m:] - dpb) / np.maximum(1, np.abs(dpb))) < 10 * DENSE_TOL
 
 
-@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID + GOLD_WIDE)
 def test_inverse_v_and_solve_features_vs_reference_methods(ctx, name):
     """lsfm_inverse_v / lsfm_solve_features (K7 k_vinv, K11 k_backsub alone) against the outputs of the REAL reference's
     pba_inverseV (Imp.cpp:3022) and pba_solveFeatures (Imp.cpp:2980) on every reference-assembled system: the same V in, the same

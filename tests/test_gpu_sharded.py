@@ -15,6 +15,15 @@ from linearsfm_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+# Sharded against single tree: the two evaluate the sums over features in other groupings (slice by slice; other features in a tile
+# of K9 and of the transform), so they differ by rounding, which the conditioning of the top systems amplifies (Mono: the scale is
+# observable through shared points only).  The bounds are DERIVED from a measurement, not tuned until a run passed:
+# tools/sharded_noise.py -> profiles/r05_sharded_noise.txt (every gloo case of this file, 60-200 runs each) -- largest error seen
+# times >= 10.  (Round 4's 1e-8 / 1e-9 sat on the noise floor: 1.07e-8 was observed on the driver's box.)
+SHARD_TOL_MONO = 3e-7
+SHARD_TOL_STEREO = 3e-8
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,14 +85,15 @@ def _worker(rank, world, port, n_maps, mono, q, top="merge", backend="gloo", pla
 # poses, one exact integer all-reduce of the inter-block separators' accumulators, the separators by everybody); "replicated": by
 # every rank in full (round 3)
 @pytest.mark.parametrize("world,n_maps,mono,top,backend,plans,solve", [
+    # one rank, RCCL, FIRST (a tolerance on the noise floor once hid them behind a red case, review of round 4): the library's sums go
+    # through torch's all_reduce on device pointers under the library's own stream
+    (1, 48, False, "shard", "nccl", True, "owned"), (1, 24, True, "shard", "nccl", False, "owned"),
     (2, 64, False, "merge", "gloo", True, "owned"), (4, 100, False, "merge", "gloo", True, "owned"), (2, 40, True, "merge", "gloo", True, "owned"),
     (3, 21, False, "merge", "gloo", True, "owned"),
     (2, 64, False, "shard", "gloo", True, "owned"), (4, 100, False, "shard", "gloo", True, "owned"), (2, 40, True, "shard", "gloo", True, "owned"),
     (3, 21, False, "shard", "gloo", True, "owned"), (4, 100, False, "shard", "gloo", False, "owned"), (4, 52, True, "shard", "gloo", False, "owned"),
     (4, 3, False, "shard", "gloo", True, "owned"), (4, 200, True, "shard", "gloo", True, "owned"),
-    (2, 64, False, "shard", "gloo", True, "replicated"), (4, 52, True, "shard", "gloo", False, "replicated"),
-    # one rank, RCCL: the library's sums go through torch's all_reduce on device pointers under the library's own stream
-    (1, 48, False, "shard", "nccl", True, "owned"), (1, 24, True, "shard", "nccl", False, "owned")])
+    (2, 64, False, "shard", "gloo", True, "replicated"), (4, 52, True, "shard", "gloo", False, "replicated")])
 def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono, top, backend, plans, solve):
     maps = _make(n_maps, mono)
     single, _, rc = ctx.divide_conquer([dict(m.__dict__) for m in maps], mono)
@@ -105,7 +115,7 @@ def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono, top, backend,
         assert got["Ref"] == single["Ref"] and got["FRef"] == single["FRef"]
         # same tree shape, same joins; the elimination order of a merged system and the summation order of atomics may differ
         # (feature-sharded: the sums over features are taken slice by slice)
-        tol = 1e-8 if mono else 1e-9
+        tol = SHARD_TOL_MONO if mono else SHARD_TOL_STEREO
         assert pose_param_err(got["stVal"], single["stVal"], single["stno"]) < tol
         assert feat_param_err(got["stVal"], single["stVal"], single["stno"]) < tol
 
@@ -169,3 +179,91 @@ def test_comm_buffer_too_small_is_reported(ctx):
     # the context is usable afterwards
     out, _, rc = ctx.divide_conquer([dict(m.__dict__) for m in maps], False)
     assert rc == 0 and out["m"] == 12
+
+
+def _fail_worker(rank, world, port, n_maps, mono, fail_rank, kind, level, plans, q):
+    """One rank of a feature-sharded tree whose rank `fail_rank` fails in its first run (library switch LSFM_TEST_FAIL_*, read in
+    lsfm_tree_run): reports what every run() did on this rank -- ("error", text, seconds) or ("ok", attempts, seconds, state)."""
+    import time
+    os.environ["LSFM_TASK_X"] = "12"
+    os.environ["LSFM_TEST_FAIL_RANK"] = str(fail_rank)
+    os.environ["LSFM_TEST_FAIL_KIND"] = kind
+    os.environ["LSFM_TEST_FAIL_LEVEL"] = str(level)
+    import torch
+    import torch.distributed as dist
+    from linearsfm_amd import api
+    from linearsfm_amd.distributed import ShardedTree, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    maps = _make(n_maps, mono)
+    _, bounds = shard_bounds(n_maps, world)
+    lo, hi = bounds[rank]
+    ctx = api.Context(0)
+    st = ShardedTree(ctx, maps[lo:hi], lo, n_maps, mono, top="shard", comm_bytes=64 << 20, solve="owned")
+    st.set_plans(plans)
+    report = []
+    for _ in range(3):
+        dist.barrier()
+        t0 = time.perf_counter()
+        try:
+            stats, rc = st.run()
+        except api.LsfmError as e:
+            report.append(("error", str(e), time.perf_counter() - t0))
+            continue
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        o = st.download(full=False)
+        report.append(("ok", int(stats["attempts"]), dt, np.asarray(o["stVal"]).copy() if rank == 0 else None))
+    q.put((rank, report))
+    dist.barrier()
+    st.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_maps,mono,fail_rank,kind,level,plans", [
+    (2, 64, False, 1, "throw", 0, True), (4, 100, False, 2, "throw", 1, True), (4, 52, True, 0, "throw", 0, False), (2, 40, True, 1, "throw", 0, True),
+    (2, 64, False, 0, "undone", 0, True), (4, 100, False, 3, "undone", 0, False)])
+def test_one_rank_failing_is_everybodys_verdict(ctx, world, n_maps, mono, fail_rank, kind, level, plans):
+    """Failure paths of the feature-sharded run with more than one rank (advisor, round 3 / review of round 4).  ONE rank's first
+    run fails inside its pass -- `throw`: an error in the middle of a level, between two of the sums that cross the ranks; `undone`:
+    a system reported above its bound.  throw: EVERY rank's run() must end with an error (the failed rank its own, the others "another
+    rank ... failed"), none may hang in a sum the failed rank never joins (60 s); undone: every rank repeats the tree (the same
+    `attempts` everywhere).  The runs after it go through and give the single tree's map."""
+    maps = _make(n_maps, mono)
+    single, _, rc = ctx.divide_conquer([dict(m.__dict__) for m in maps], mono)
+    assert rc == 0
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_fail_worker, args=(r, world, port, n_maps, mono, fail_rank, kind, level, plans, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        reports = dict(q.get(timeout=300) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0
+    for r in range(world):
+        first = reports[r][0]
+        assert first[2] < 60.0, (r, first[2])
+        if kind == "throw":
+            assert first[0] == "error", (r, first)
+            assert ("injected failure" in first[1]) == (r == fail_rank), (r, first[1])
+            if r != fail_rank:
+                assert "another rank" in first[1], first[1]
+        else:
+            assert first[0] == "ok" and first[1] == 2, (r, first[:2])  # the tree was joined twice, on every rank
+        for later in reports[r][1:]:
+            assert later[0] == "ok" and later[1] == 1, (r, later[:2])
+    tol = SHARD_TOL_MONO if mono else SHARD_TOL_STEREO
+    for rep in reports[0]:
+        if rep[0] == "ok":
+            assert pose_param_err(rep[3], single["stVal"], single["stno"]) < tol
+            assert feat_param_err(rep[3], single["stVal"], single["stno"]) < tol

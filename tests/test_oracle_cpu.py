@@ -7,14 +7,14 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import GOLD_MID, GOLD_SMALL, assert_maps_close, dense_reference_solve, get_map, golden_system, load_golden, ref_map, rel_err
+from common import GOLD_MID, GOLD_SMALL, GOLD_WIDE, assert_maps_close, dense_reference_solve, get_map, golden_system, load_golden, ref_map, rel_err
 from linearsfm_amd import synth
 from refdump import dense_info
 
 GOLD = GOLD_SMALL
 
 
-@pytest.mark.parametrize("name", GOLD + GOLD_MID)
+@pytest.mark.parametrize("name", GOLD + GOLD_MID + GOLD_WIDE)
 def test_oracle_transform_and_assembly_vs_reference(oracle, name):
     z = load_golden(name)
     mono = str(z["type"]) == "Monocular"
@@ -108,7 +108,7 @@ def test_oracle_solve_stage_vs_reference_methods_and_dense_lapack(oracle, name):
         assert np.max(np.abs(stx - xd) / np.maximum(1, np.abs(xd))) < 1e-10
 
 
-@pytest.mark.parametrize("name", GOLD_MID)
+@pytest.mark.parametrize("name", GOLD_MID + GOLD_WIDE)
 def test_oracle_solve_stage_vs_reference_at_mid_size(oracle, name):
     """The top joins of the 64-map Stereo and the 88-map Mono tree (m = 64 / 66 / 90 poses), as the REAL reference assembled
     them: the oracle's V^-1 and back-substitution against pba_inverseV / pba_solveFeatures, its block pattern of S against

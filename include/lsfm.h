@@ -97,6 +97,14 @@ typedef struct lsfm_stats {
 	 * differently, their atomics land in another order); the number of systems whose two factors were not the same bits.  Must be 0:
 	 * the accumulation is in fixed point. */
 	int refactor_mismatch;
+	/* LSFM_FACTOR_DIGEST=1: the camera systems of every level (S and the right-hand side E) are ASSEMBLED twice from the same joint
+	 * maps (K9's work-groups land their sums in another order); the number of levels whose two assemblies were not the same bits.
+	 * Must be 0 since round 5: K9 adds in fixed point (include: the per-feature fallback kernel). */
+	int s_rebuild_mismatch;
+	/* tree levels (or stage-level calls) whose camera systems -- at most 16 poses each -- were assembled, factored and solved by the
+	 * one-launch dense path (one work-group per join, the system in LDS: lsfm_small.hip), and the HIP-event time of those launches */
+	int small_levels;
+	double t_small_ms;
 } lsfm_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -116,6 +124,11 @@ int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_steps);
  * fp64 residual, and the stopping rule is the same relative residual as in mode 0, reached in more steps (2-3 instead
  * of 1).  BASELINE.json configs[4]. */
 int lsfm_set_precision(lsfm_context* ctx, int mode);
+/* Camera systems of at most 16 poses (the lowest levels of a tree: thousands of independent joins a level) are assembled, factored
+ * (dense Cholesky in LDS, one refinement step) and solved, features included, by ONE launch with one work-group per join instead of
+ * the level pipeline's ~55 (Imp.cpp:2119-2378 run per join by the reference).  on = 0: every level takes the sparse pipeline (tests
+ * compare the two; default 1).  Feature-sharded runs and the fp32 preconditioner always take the pipeline. */
+int lsfm_set_small_solve(lsfm_context* ctx, int on);
 /* Which kernel multiplies by the Schur matrix in the CG.  0 (default): by size -- a matrix that stays in L2 / Infinity
  * Cache (every level of the named configurations) is multiplied from a row-sorted list of both orientations of its
  * blocks, a larger one streams its upper blocks from HBM once.  1: always the streaming kernel.  2: always the list.

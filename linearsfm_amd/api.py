@@ -37,7 +37,7 @@ class LsfmStats(C.Structure):
                 ("not_converged", C.c_int), ("schur_launches", C.c_long), ("trf_launches", C.c_long),
                 ("schur_ms", C.c_double), ("schur_bytes", C.c_double), ("trf_ms", C.c_double), ("trf_bytes", C.c_double),
                 ("schur_flops", C.c_double), ("upload_ms", C.c_double), ("attempts", C.c_int),
-                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong), ("dist_solves", C.c_int), ("dist_work_total", C.c_double), ("dist_work_shared", C.c_double), ("refactor_mismatch", C.c_int)]
+                ("s_digest", C.c_ulonglong), ("factor_digest", C.c_ulonglong), ("dist_solves", C.c_int), ("dist_work_total", C.c_double), ("dist_work_shared", C.c_double), ("refactor_mismatch", C.c_int), ("s_rebuild_mismatch", C.c_int), ("small_levels", C.c_int), ("t_small_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -66,6 +66,7 @@ def lib():
         L.lsfm_context_destroy.restype = None
         L.lsfm_set_pcg.argtypes = [vp, C.c_double, C.c_int]
         L.lsfm_set_precision.argtypes = [vp, C.c_int]
+        L.lsfm_set_small_solve.argtypes = [vp, C.c_int]
         L.lsfm_set_spmv_variant.argtypes = [vp, C.c_int]
         L.lsfm_last_error.argtypes = [vp]
         L.lsfm_last_error.restype = C.c_char_p
@@ -122,7 +123,7 @@ def lib():
     return _LIB
 
 
-EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_set_precision", "lsfm_set_spmv_variant", "lsfm_last_error", "lsfm_stream",
+EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_set_precision", "lsfm_set_small_solve", "lsfm_set_spmv_variant", "lsfm_last_error", "lsfm_stream",
            "lsfm_map_release", "lsfm_transform_stereo", "lsfm_transform_mono", "lsfm_join_stereo", "lsfm_join_mono",
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_set_stop_level", "lsfm_tree_node_count", "lsfm_tree_download_node", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
@@ -218,6 +219,11 @@ class Context:
     def set_precision(self, mixed):
         """False: fp64 throughout.  True: the Cholesky preconditioner kept and applied in fp32, residual correction in fp64."""
         self._check(lib().lsfm_set_precision(self._h, 1 if mixed else 0), "lsfm_set_precision")
+
+    def set_small_solve(self, on):
+        """True (default): levels whose camera systems have at most 16 poses are solved by the one-launch dense path; False: every
+        level takes the sparse pipeline (the tests compare the two)."""
+        self._check(lib().lsfm_set_small_solve(self._h, 1 if on else 0), "lsfm_set_small_solve")
 
     def set_spmv_variant(self, variant):
         """0: by size (default); 1: always the kernel that streams the upper blocks once; 2: always the row-sorted list."""

@@ -394,6 +394,9 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 					rs.not_converged = (int)((fl[3] + cm.world - 1) / cm.world); // (every rank solves every system: the count, not its multiple)
 					rs.undone = (int)((fl[4] + cm.world - 1) / cm.world);
 					st->not_converged = (int)((fl[5] + cm.world - 1) / cm.world); // (the same verdict on every rank: the repeat test below reads it)
+					// (a failed pass may have left plans and step counts of levels it ran on zeros: the next run starts without them, alike
+					// on every rank)
+					if (pass_error || fl[6]) { t->plans.clear(); t->step_hint.clear(); }
 					if (pass_error) throw *pass_error;
 					if (fl[6]) LSFM_FAIL(LSFM_ERR_INTERNAL, "another rank of the feature-sharded run failed");
 				}
@@ -431,7 +434,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				st->max_rel_residual = std::max(st->max_rel_residual, rs.max_rel_residual);
 				st->upload_ms = t->upload_ms;
 				st->schur_flops += 108.0 * (double)rs.k2;
-				st->s_digest = rs.s_digest; st->factor_digest = rs.factor_digest; st->refactor_mismatch = rs.refactor_mismatch;
+				st->s_digest = rs.s_digest; st->factor_digest = rs.factor_digest; st->refactor_mismatch = rs.refactor_mismatch; st->s_rebuild_mismatch = rs.s_rebuild_mismatch;
 				break;
 			}
 			ctx->flush_times();
@@ -814,6 +817,13 @@ static int solve_raw(lsfm_context* ctx, double* stVal, const double* eb, const d
 		io.U = dU; io.Ui = dUi; io.Uj = dUj; io.W = dW; io.photo = dph; io.fptr = dfp; io.V = dV;
 		io.ea = dea; io.eb = deb; io.x0 = dx0; io.x_pose = dxp; io.x_feat = dxf;
 		io.seg_rows.assign(1, m);
+		if (ctx->small_solve && small_solve_strips(m))
+		{
+			const int offs[6] = { 0, m, 0, n, 0, nU };
+			int* d_offs = ar.alloc<int>(6);
+			h2d(ctx, d_offs, offs, sizeof offs);
+			io.d_pose_off = d_offs; io.d_feat_off = d_offs + 2; io.d_u_off = d_offs + 4;
+		}
 		if (fixed_blk >= 0 || fixed_scalar >= 0)
 		{
 			std::vector<unsigned char> fx((size_t)m * 6, 0);

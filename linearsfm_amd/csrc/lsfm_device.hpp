@@ -201,6 +201,36 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v)
 	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- order-independent sums -------------------------------------------------------------------------------------------------
+// A sum that many work-groups add to with atomics lands in another order every run; in floating point that is another result every
+// run.  Where a bound of every partial sum is known beforehand, the addends are instead rounded ONCE to a fixed-point grid far below
+// fp64's resolution of that bound and added as 64-bit integers: integer addition is associative, the sum is the same bits whatever
+// the order (the factorisation has done so since round 4; K9's sums since round 5).
+__device__ __forceinline__ void atomic_add_i64(long long* p, long long v)
+{
+	__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_add_i64(long long* p, long long v)
+{
+	__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// v 2^sh rounded to the nearest integer; bad: not finite, or beyond the 2^61 the bound leaves room for
+__device__ __forceinline__ long long to_fixed(double v, int sh, bool& bad)
+{
+	const double q = ldexp(v, sh);
+	if (!(fabs(q) < 2305843009213693952.0)) { bad = true; return 0; }
+	return __double2ll_rn(q);
+}
+// two limbs, for sums whose bound is loose: hi in units of 2^-sh, lo in units of 2^-(sh + 40) -- 100 bits below the bound
+__device__ __forceinline__ void to_fixed2(double v, int sh, long long& hi, long long& lo, bool& bad)
+{
+	const double q = ldexp(v, sh);
+	if (!(fabs(q) < 2305843009213693952.0)) { bad = true; hi = 0; lo = 0; return; }
+	const double h = rint(q);
+	hi = (long long)h;
+	lo = __double2ll_rn(ldexp(q - h, 40)); // (q - h is exact: |q| < 2^52 leaves a fraction fp64 holds, beyond that there is none)
+}
+
 // Adds vals[0..N) into dst[0..N) for every lane with valid==true.  When all valid lanes of the wave target the
 // SAME dst (the common case for hub rows: neighbouring features share their hub poses) the values are summed
 // across the wave first and one lane issues the atomics: 64x fewer atomics on the hot blocks.

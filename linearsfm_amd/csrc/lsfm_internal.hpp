@@ -119,7 +119,8 @@ struct RunStatsDev {
 	int floored;           // pivots of the separators replaced by their lower bound (static pivoting, lsfm_pcg.hip k_sn_panel)
 	double max_rel_residual;
 	unsigned long long s_digest, factor_digest; // LSFM_FACTOR_DIGEST=1 (lsfm_stats)
-	int refactor_mismatch, pad_;                // ... systems whose second factorisation gave other bits than the first
+	int refactor_mismatch;                      // ... systems whose second factorisation gave other bits than the first
+	int s_rebuild_mismatch;                     // ... levels whose camera systems (S, E), assembled a second time from the same joint maps, were other bits
 	unsigned long long k2;  // sum over the levels of sum over the features of (W run length)^2: K9's pose pairs, for its algorithmic flop count
 };
 
@@ -246,6 +247,7 @@ struct lsfm_context {
 	int cur = 0;
 	size_t arena_bytes = 0, arena_req = 0; // actual size of each arena / the request it answers (may have been capped)
 	lsfm::PcgOptions pcg;
+	bool small_solve = true; // levels of small systems by the one-launch dense path (lsfm_set_small_solve: tests compare both paths)
 	std::string last_error;
 	int* h_pinned = nullptr; // small pinned staging buffer for counters
 	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
@@ -429,7 +431,12 @@ struct SolveIO {
 	double* x_pose = nullptr;          // [M*6] out
 	double* x_feat = nullptr;          // [NF*3] out
 	std::vector<int> seg_rows;         // host: block rows per segment
+	// optional: [nseg + 1] first pose / feature / U block of every segment (segments are contiguous ranges of the batch).  With them,
+	// a level whose systems have at most 16 poses is solved by the one-launch dense path (lsfm_small.hip)
+	const int *d_pose_off = nullptr, *d_feat_off = nullptr, *d_u_off = nullptr;
 };
+int small_solve_strips(int most_poses); // 16-row strips of the dense path's panel; 0: the systems are too large for it
+void small_solve_launch(lsfm_context* ctx, const SolveIO& io, int strips, int* status, double* max_rel);
 int solve_batch(lsfm_context* ctx, const SolveIO& io);
 // the two feature-side pieces of the solve on their own (C ABI: lsfm_inverse_v / lsfm_solve_features); device pointers
 void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV);

@@ -89,9 +89,11 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
                                 int* __restrict__ lenC, double* __restrict__ Vy, double* __restrict__ eF, int* __restrict__ fid_y,
                                 double* __restrict__ feat_y, int* __restrict__ srcE, int* __restrict__ srcC, int side)
 {
-	// two launches: side 0 = features of the first map of every pair (plain stores into the zeroed joint arrays), then
-	// side 1 = features of the second map, which add to their match (each joint feature has one writer per launch:
-	// no atomics -- 12 scattered 8-byte atomics per feature cost 0.3 ms per level)
+	// two launches: side 0 = features of the first map of every pair, then side 1 = features of the second map, which add to
+	// their match (each joint feature has one writer per launch: no atomics -- 12 scattered 8-byte atomics per feature cost 0.3 ms
+	// per level).  The FIRST writer of a joint feature -- its End source, or its Cur source when it has no match -- stores, and
+	// stores the other side's run length / source as absent: the joint arrays need no fill (until round 5: ~100 bytes per joint
+	// feature of memset and four fill launches per level)
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
 	int mp = feat_map[f];
@@ -103,15 +105,29 @@ __global__ void k_join_features(int NF, const int* __restrict__ feat_map, const 
 	else if (match[f] >= 0) nf = g.FY0 + (match[f] - g.F0E);
 	else nf = g.FY0 + g.nE + (R[f] - g.rC0);
 	newf[f] = nf;
+	const bool first = !cur || match[f] < 0;
 	int len = fptr[f + 1] - fptr[f];
-	if (!cur) lenE[nf] = len; else lenC[nf] = len;
-	if (srcE) { if (!cur) srcE[nf] = f; else srcC[nf] = f; }
+	if (!cur) { lenE[nf] = len; lenC[nf] = 0; }
+	else { lenC[nf] = len; if (first) lenE[nf] = 0; }
+	if (srcE)
+	{
+		if (!cur) { srcE[nf] = f; srcC[nf] = -1; }
+		else { srcC[nf] = f; if (first) srcE[nf] = -1; }
+	}
 	const double* v = V + (size_t)f * 9;
 	const double* x = feat + (size_t)f * 3;
-	for (int i = 0; i < 9; i++) Vy[(size_t)nf * 9 + i] += v[i];
 	// eF += V x  with each map's own estimate (Imp.cpp:2752-2757, 2802-2807, 2874-2879)
-	for (int r = 0; r < 3; r++) eF[(size_t)nf * 3 + r] += v[3 * r] * x[0] + v[3 * r + 1] * x[1] + v[3 * r + 2] * x[2];
-	if (!cur || match[f] < 0)
+	if (first)
+	{
+		for (int i = 0; i < 9; i++) Vy[(size_t)nf * 9 + i] = v[i];
+		for (int r = 0; r < 3; r++) eF[(size_t)nf * 3 + r] = v[3 * r] * x[0] + v[3 * r + 1] * x[1] + v[3 * r + 2] * x[2];
+	}
+	else
+	{
+		for (int i = 0; i < 9; i++) Vy[(size_t)nf * 9 + i] += v[i];
+		for (int r = 0; r < 3; r++) eF[(size_t)nf * 3 + r] += v[3 * r] * x[0] + v[3 * r + 1] * x[1] + v[3 * r + 2] * x[2];
+	}
+	if (first)
 	{
 		fid_y[nf] = feat_id[f];
 		feat_y[(size_t)nf * 3] = x[0]; feat_y[(size_t)nf * 3 + 1] = x[1]; feat_y[(size_t)nf * 3 + 2] = x[2];
@@ -321,22 +337,25 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	int* newf = st.newf = ctx->scratch.alloc<int>(in.NF + 1);
 	int* lens = ctx->scratch.alloc<int>(NFY + 2);
 	st.srcf = ctx->scratch.alloc<int>(in.NW + 1);
-	ZeroSpan zs(ctx->scratch); // the accumulators of the level, zeroed by one memset
+	// (every entry of lenE / lenC / eF / out.V gets its first value from k_join_features: only the pose part of the right-hand
+	// side is an accumulator that starts from zero)
 	int* lenE = st.lenE = ctx->scratch.alloc<int>(NFY + 1);
 	int* lenC = ctx->scratch.alloc<int>(NFY + 1);
-	double* eP = st.eP = ctx->scratch.alloc<double>((size_t)in.M * 6);
 	double* eF = st.eF = ctx->scratch.alloc<double>((size_t)NFY * 3);
-	zs.zero(s);
-	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
+	double* eP = st.eP = ctx->scratch.alloc<double>((size_t)in.M * 6);
+	dev_zero(ctx, eP, (size_t)in.M * 6 * sizeof(double));
 	// a level that analyses, reached through the transform's hook: the sources of every joint feature, for the early pattern of S
 	static const bool early_on = !getenv("LSFM_NO_EARLY_PATTERN");
-	const bool early = early_on && !ctx->comm && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
+	// (a level of small systems takes the dense path: no pattern at all)
+	int most_rows = 0;
+	for (int r : seg_rows) most_rows = std::max(most_rows, r);
+	static const bool no_small = getenv("LSFM_NO_SMALL") != nullptr;
+	const bool small_level = ctx->small_solve && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_rows) > 0;
+	const bool early = early_on && !small_level && !ctx->comm && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
 	int *srcE = nullptr, *srcC = nullptr;
 	if (early)
 	{
-		srcE = ctx->scratch.alloc<int>(NFY + 1); srcC = ctx->scratch.alloc<int>(NFY + 1);
-		LSFM_CHECK_HIP(hipMemsetAsync(srcE, 0xff, sizeof(int) * (size_t)(NFY + 1), s));
-		LSFM_CHECK_HIP(hipMemsetAsync(srcC, 0xff, sizeof(int) * (size_t)(NFY + 1), s));
+		srcE = ctx->scratch.alloc<int>(NFY + 1); srcC = ctx->scratch.alloc<int>(NFY + 1); // (filled by k_join_features)
 	}
 	if (in.NF)
 		for (int side = 0; side < 2; side++)
@@ -408,6 +427,17 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	io.ea = eP; io.eb = eF; io.x0 = in.pose; io.d_fixed = nullptr; io.d_pose_origin = out.pose_origin;
 	io.x_pose = out.pose; io.x_feat = out.feat;
 	io.seg_rows = seg_rows;
+	{
+		// a level of small systems goes to the one-launch dense path, which walks the joins by their ranges (lsfm_small.hip)
+		int most = 0;
+		for (int r : seg_rows) most = std::max(most, r);
+		if (ctx->small_solve && small_solve_strips(most))
+		{
+			int* d_uo = ctx->scratch.alloc<int>(G + 1);
+			h2d(ctx, d_uo, out.u_off.data(), sizeof(int) * (size_t)(G + 1));
+			io.d_pose_off = out.d_pose_off; io.d_feat_off = out.d_feat_off; io.d_u_off = d_uo;
+		}
+	}
 	const bool warm = ctx->warm();
 	ctx->solved_keys = nullptr; ctx->solved_nnzb = 0;
 	int rc = solve_batch(ctx, io);

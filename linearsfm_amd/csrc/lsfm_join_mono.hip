@@ -504,7 +504,7 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 
 	double* eP = sc.alloc<double>((size_t)MY * 6);
 	double* eF = sc.alloc<double>((size_t)NFY * 3);
-	dev_zero(ctx, eP, (size_t)MY * 6 * sizeof(double)); dev_zero(ctx, eF, (size_t)NFY * 3 * sizeof(double));
+	dev_zero(ctx, eP, (size_t)MY * 6 * sizeof(double)); // (eF, out.V and the source lists get their first values from k_join_features)
 
 	// ---- U ----
 	out.NU = uo[B];
@@ -522,9 +522,6 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	int* lens = sc.alloc<int>(NFY + 2);
 	int* srcE = sc.alloc<int>(NFY + 1);
 	int* srcC = sc.alloc<int>(NFY + 1);
-	dev_zero(ctx, out.V, (size_t)NFY * 9 * sizeof(double));
-	hipLaunchKernelGGL(k_fill_int, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY + 1, srcE, -1);
-	hipLaunchKernelGGL(k_fill_int, dim3((NFY + 256) / 256), dim3(256), 0, s, NFY + 1, srcC, -1);
 	if (in.NF)
 		for (int side = 0; side < 2; side++)
 			hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, RF, d_grp,
@@ -588,6 +585,16 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	io.ea = eP; io.eb = eF; io.x0 = x0; io.d_fixed = fixed; io.d_pose_origin = out.pose_origin;
 	io.x_pose = out.pose; io.x_feat = out.feat;
 	io.seg_rows = seg_rows;
+	{
+		int most = 0;
+		for (int r : seg_rows) most = std::max(most, r);
+		if (ctx->small_solve && small_solve_strips(most))
+		{
+			int* d_uo = sc.alloc<int>(G + 1);
+			h2d(ctx, d_uo, out.u_off.data(), sizeof(int) * (size_t)(G + 1));
+			io.d_pose_off = out.d_pose_off; io.d_feat_off = out.d_feat_off; io.d_u_off = d_uo;
+		}
+	}
 	int rc = solve_batch(ctx, io);
 	hipLaunchKernelGGL(k_mono_finish, dim3((G + 127) / 128), dim3(128), 0, s, G, d_mg, pnew, out.pose);
 	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s)); // a warm level is only enqueued: its scratch is reused in stream order

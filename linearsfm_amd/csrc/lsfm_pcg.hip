@@ -1814,11 +1814,18 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 {
 	ctx->drop_prepared();
 	static const bool on = !getenv("LSFM_NO_PREFETCH") && !getenv("LSFM_NO_EARLY_PATTERN");
-	if (!on || !ctx->solved_keys || !Y.M || Y.B < 2) return;
+	if (!on || !Y.M || Y.B < 2) return;
+	// the next level's systems (pairs of Y's maps): small enough for the one-launch dense path?  Then it needs no pattern and no
+	// symbolic factorisation, only -- to be enqueued without a host round trip -- its counts
+	int most_next = 0;
+	for (int b = 0; b < Y.B; b += 2) most_next = std::max(most_next, Y.pose_off[std::min(b + 2, Y.B)] - Y.pose_off[b]);
+	static const bool no_small = getenv("LSFM_NO_SMALL") != nullptr;
+	const bool next_small = ctx->small_solve && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_next) > 0;
 	// with the step count an earlier run left for that level, the level can run like a planned one (no round trip at all): then
 	// its counts are prepared too.  (LSFM_CHECK_EARLY_PATTERN keeps to the path that compares the pattern.)
 	static const bool plan_on = !getenv("LSFM_NO_PREPLAN");
 	const bool whole = plan_on && step_hint > 0 && !getenv("LSFM_CHECK_EARLY_PATTERN");
+	if (next_small && !whole) return; // (nothing to prepare: the level reads its counts back itself)
 	ctx->mark("pre_start");
 	auto pl = std::make_shared<PreLevel>();
 	pl->M = Y.M;
@@ -1843,15 +1850,27 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 		Swap sw(ctx, sa);
 		int* d_tref = ctx->scratch.alloc<int>(Y.B);
 		h2d(ctx, d_tref, target_ref.data(), sizeof(int) * (size_t)Y.B);
-		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy, whole ? &counts : nullptr);
+		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy, whole ? &counts : nullptr, !next_small);
 		if (ok)
 		{
-			chol_fetch(ctx, pl->sy, Y.pose_origin, hin); // (synchronises stream3: the counts have arrived too)
+			if (!next_small) chol_fetch(ctx, pl->sy, Y.pose_origin, hin); // (synchronises stream3: the counts have arrived too)
 			LSFM_CHECK_HIP(hipEventRecord(ctx->evP, ctx->stream));
 		}
 	}
 	ctx->mark("pre_pat");
 	if (!ok) return;
+	if (next_small)
+	{
+		// the plan of a small level is its counts: its solve is one launch that asks the host nothing
+		const int B = Y.B;
+		ctx->pre_plan.tr_cnt.assign(counts.begin(), counts.begin() + 2 * (B + 1));
+		ctx->pre_plan.join_rb.assign(counts.begin() + 2 * (B + 1), counts.end());
+		ctx->pre_plan.solve.reset();
+		ctx->pre_plan.valid = true;
+		ctx->pre_plan_level = next_level;
+		ctx->mark("pre_plan");
+		return;
+	}
 	// The symbolic factorisation is host work that only the level's FACTORISATION needs: it goes to the helper thread, and the
 	// caller enqueues the next level's transform, join and Schur assembly meanwhile -- they need the counts only, which arrived
 	// with the pattern.  (Done here, on this thread, the device sat idle 1-3 ms at every level boundary waiting for the next
@@ -2350,16 +2369,34 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	SchurSystem sy;
 	CholDev ch;
 	CholHostIn hin;
+	// a level of small systems (at most 16 poses each): assembled, factored and solved by one launch (lsfm_small.hip).  The pattern of
+	// S and its symbolic analysis are still made -- the levels above build theirs on them, and a plan of the level keeps them
+	int most_rows = 0;
+	for (int rws : io.seg_rows) most_rows = std::max(most_rows, rws);
+	const int strips = (ctx->small_solve && !ctx->comm && !ctx->pcg.mixed && io.d_pose_off && io.d_feat_off && io.d_u_off && !getenv("LSFM_NO_SMALL"))
+	                       ? small_solve_strips(most_rows) : 0;
 	const bool dbg = getenv("LSFM_DEBUG") != nullptr;
 	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double tw0 = 0, tw1 = 0;
 	int* d_err = nullptr;
+	int* d_small = nullptr; // [2] status of the small path + (as a double behind them) the level's largest relative residual
+	hipEvent_t esm0 = nullptr, esm1 = nullptr;
+	auto small_enqueue = [&]() {
+		d_small = sc.alloc<int>(4);
+		dev_zero(ctx, d_small, 4 * sizeof(int));
+		if (ctx->stats) { esm0 = ctx->pool_event(); esm1 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(esm0, s)); }
+		small_solve_launch(ctx, io, strips, d_small, reinterpret_cast<double*>(d_small + 2));
+		if (ctx->stats) { LSFM_CHECK_HIP(hipEventRecord(esm1, s)); ctx->defer_time(esm0, esm1, &ctx->stats->t_small_ms); ctx->stats->small_levels++; }
+	};
 	if (warm)
 	{
 		ctx->pattern_dep = false;
 		sy = pending ? pending->sy : sp->sy;
-		schur_vinv(ctx, io, sy);
-		build_schur_values(ctx, io, sy);
+		if (!strips)
+		{
+			schur_vinv(ctx, io, sy);
+			build_schur_values(ctx, io, sy);
+		}
 		LSFM_CHECK_HIP(hipEventRecord(eb, s)); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		if (pending)
@@ -2370,9 +2407,12 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			ctx->mark("sym_wait");
 		}
 		ch = sp->ch;
-		chol_alloc_values(ctx, ch);
-		d_err = ch.d_err = sc.alloc<int>(1);
-		dev_zero(ctx, d_err, sizeof(int));
+		if (!strips)
+		{
+			chol_alloc_values(ctx, ch);
+			d_err = ch.d_err = sc.alloc<int>(1);
+			dev_zero(ctx, d_err, sizeof(int));
+		}
 	}
 	else
 	{
@@ -2382,6 +2422,18 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		// complete (evA) and went on to enqueue its right-hand-side kernels, the pattern is built on the side stream next
 		// to them; the values wait for both.
 		static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
+		if (strips)
+		{
+			// no pattern of S, no symbolic factorisation: the dense path needs neither, and the level above builds its pattern from
+			// its own joint maps when this one leaves none (schur_pattern_prefetch / k_pat_insert_w_early)
+			ctx->pattern_dep = false;
+			schur_pattern_early_drop(ctx);
+			if (ctx->pre) { std::shared_ptr<void> keep = ctx->pre; ctx->pre.reset(); pre_wait(ctx, static_cast<PreLevel*>(keep.get())); }
+			small_enqueue();
+			LSFM_CHECK_HIP(hipEventRecord(eb, s));
+			LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
+			goto small_tail;
+		}
 		schur_vinv(ctx, io, sy);
 		bool have = false;
 		std::shared_ptr<void> pre_keep = ctx->pre;
@@ -2397,7 +2449,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			schur_pattern_early_drop(ctx);
 			{
 				SchurSystem prepared = pre->sy; // the index members; V^-1 and its factor are this level's (schur_vinv above)
-				prepared.IV = sy.IV; prepared.LY = sy.LY;
+				prepared.IV = sy.IV; prepared.LY = sy.LY; prepared.ymax = sy.ymax;
 				sy = prepared;
 			}
 			have = true;
@@ -2483,6 +2535,33 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 		tw1 = wall();
 		d_err = ch.d_err;
 	}
+small_tail:
+	if (strips)
+	{
+		if (warm) small_enqueue();
+		LSFM_CHECK_HIP(hipEventRecord(ec, s));
+		LSFM_CHECK_HIP(hipEventRecord(ed, s)); if (roctx().mark) roctx().mark("lsfm solve: end");
+		ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // (no pattern left for the level above)
+		if (ctx->stats) ctx->stats->pcg_iterations += 1;
+		ctx->steps_used = 1;
+		// (a plan made one level ahead is the run's own: nothing to record, nothing to stop for)
+		const bool deferred = ctx->in_tree_run && ctx->d_run && (warm || !lp || lp == &ctx->pre_plan);
+		if (deferred) return 0; // the kernel left its verdict in the run's device record (read at the end of the run)
+		int hs[4];
+		d2h_ints(ctx, d_small, hs, 4); // synchronises
+		if (hs[1]) LSFM_FAIL(LSFM_ERR_NOT_SPD, "Schur system is not positive definite (system " + std::to_string(hs[1] - 1) + " of the level)");
+		double mr;
+		memcpy(&mr, hs + 2, sizeof mr);
+		if (ctx->stats) ctx->stats->max_rel_residual = std::max(ctx->stats->max_rel_residual, mr);
+		if (lp && !lp->solve && hs[0] == 0)
+		{
+			// the plan of a small level: nothing but the fact that it is one (the structure of its solve is the batch's offsets)
+			auto small_plan = std::make_shared<SolvePlan>();
+			small_plan->its = 1; small_plan->mixed = false; small_plan->rel_tol = ctx->pcg.rel_tol;
+			lp->solve = small_plan;
+		}
+		return hs[0];
+	}
 	// ---- CG set-up first: the residual of the starting point is the right-hand side of the first preconditioner
 	// application, whose forward substitution rides on the factorisation (k_sn_panel) ----
 	int* d_misc = sc.alloc<int>(4); // [1] ndone
@@ -2534,6 +2613,19 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			if (a && n) hipLaunchKernelGGL(k_digest, dim3(256), dim3(256), 0, s, n, reinterpret_cast<const unsigned long long*>(a), out);
 		};
 		dg(sy.S, (size_t)sy.nnzb * 36, &ctx->d_run->s_digest);
+		if (!ctx->comm)
+		{
+			// the SAME camera systems assembled a second time (U scatter, K9 with all its variants, the fallback kernel): their
+			// work-groups land their sums in another order -- the bits of S and E must not depend on it (fixed-point sums,
+			// lsfm_schur_panel.hip).  (The stage timings and flop counts of the run count this second assembly too: a debug mode.)
+			SchurSystem sy2 = sy;
+			build_schur_values(ctx, io, sy2);
+			unsigned long long* d = sc.alloc<unsigned long long>(2);
+			dev_zero(ctx, d, 2 * sizeof(unsigned long long));
+			dg(sy.S, (size_t)sy.nnzb * 36, d); dg(sy.E, (size_t)M * 6, d);
+			dg(sy2.S, (size_t)sy.nnzb * 36, d + 1); dg(sy2.E, (size_t)M * 6, d + 1);
+			hipLaunchKernelGGL(k_digest_compare, dim3(1), dim3(1), 0, s, d, &ctx->d_run->s_rebuild_mismatch);
+		}
 		// leaf columns: factored in place in L; group columns: in Lg (their slots of L hold the spent accumulators: integers, summed alike)
 		auto factor_digest = [&](unsigned long long* out) {
 			dg(ch.Dinv, (size_t)ch.M * 36, out);

@@ -467,6 +467,13 @@ int lsfm_set_precision(lsfm_context* ctx, int mode)
 	return LSFM_OK;
 }
 
+int lsfm_set_small_solve(lsfm_context* ctx, int on)
+{
+	if (!ctx) return LSFM_ERR_ARG;
+	ctx->small_solve = on != 0;
+	return LSFM_OK;
+}
+
 int lsfm_set_spmv_variant(lsfm_context* ctx, int variant)
 {
 	if (!ctx || variant < 0 || variant > 2) return LSFM_ERR_ARG;

@@ -86,6 +86,7 @@ struct PmShared {
 	int nslots, bad;
 	unsigned char bf[PM_BF]; // block of the pass -> its feature (the first PM_BF blocks; later ones search the run pointers)
 	int fpt[PM_TILE + 1]; // run pointers of the tile's features: the prefetch of a pass must not wait for them first
+	int sexp[6 * SMAX];     // binary exponent of the scale of every panel row (K9Out::sexp of the slot's pose)
 	double ly[PM_PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
 	double P[6 * SMAX * PM_KS];
 	unsigned char eslot[PM_MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
@@ -97,7 +98,7 @@ template <int T, int SMAX, int THREADS>
 __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                         const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-                                        double* __restrict__ S, double* __restrict__ E, unsigned char* __restrict__ fallback,
+                                        const K9Out& o, unsigned char* __restrict__ fallback,
                                         const unsigned char* __restrict__ ces, int tile, int q0 = 0, bool first_sweep = true)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
@@ -314,6 +315,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
 	}
 	__syncthreads();
+	bool bad = false;
 #pragma unroll
 	for (int t = 0; t < T; t++)
 	{
@@ -332,28 +334,43 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			if (si > sj) continue; // diagonal tile: the mirrored element covers it
 			const int slot = pslot[si * ns + sj];
 			if (slot < 0) continue;
-			double* d = S + (size_t)slot * 36;
+			// order-independent: the entry in fixed point, units of 2^(sexp_R + sexp_C - 60) -- every partial sum of an entry of
+			// W V^-1 W^T is below sqrt(U_RR U_CC) < 2^(sexp_R + sexp_C - 2) (the joint information matrix is positive semi-definite)
+			long long* d = o.S + (size_t)slot * 36;
+			const long long q = to_fixed(v, 60 - sh.sexp[R] - sh.sexp[C], bad);
 			if (si == sj)
 			{
 				// a pose with itself is stored full; across a tile boundary only this half was computed
-				atomic_add_f64(d + r * 6 + c, -v);
-				if (ti[t] != tj[t]) atomic_add_f64(d + c * 6 + r, -v);
+				atomic_add_i64(d + r * 6 + c, q);
+				if (ti[t] != tj[t]) atomic_add_i64(d + c * 6 + r, q);
 			}
 			else
 			{
 				// stored orientation: rows = smaller pose index
 				const bool up = sh.pose_of[si] <= sh.pose_of[sj];
-				atomic_add_f64(d + (up ? r * 6 + c : c * 6 + r), -v);
+				atomic_add_i64(d + (up ? r * 6 + c : c * 6 + r), q);
 			}
 		}
 	}
 	if (lane < 16)
+	{
+		const int ey = *o.ey;
 #pragma unroll
 		for (int si = 0; si < NE; si++)
 		{
 			const int row = 16 * (wave + (THREADS / 64) * si) + lane;
-			if (row < rows && eacc[si] != 0.0) atomic_add_f64(E + (size_t)sh.pose_of[row / 6] * 6 + row % 6, eacc[si]);
+			if (row < rows && eacc[si] != 0.0)
+			{
+				// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
+				long long hi, lo;
+				to_fixed2(eacc[si], 62 - sh.sexp[row] - ey, hi, lo, bad);
+				const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
+				atomic_add_i64(o.Ehi + at, hi);
+				if (lo) atomic_add_i64(o.Elo + at, lo);
+			}
 		}
+	}
+	if (bad) atomic_add_i64(o.poison, 1);
 	K9T(6);
 	K9T_FLUSH(1, 8);
 	K9T_FLUSH(11, 13);
@@ -364,12 +381,12 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 template <int SMAX, int THREADS>
 __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                       const double* __restrict__ W, const double* __restrict__ LY, const unsigned long long* __restrict__ tab,
-                                      const int* __restrict__ val, unsigned long long mask, double* __restrict__ S, double* __restrict__ E,
+                                      const int* __restrict__ val, unsigned long long mask, const K9Out& o,
                                       unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces, int tile)
 {
 	constexpr int NW = THREADS / 64;
 	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
-#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, tile)
+#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile)
 	if constexpr (SMAX <= 8)
 	{
 		if (tpw <= 1) PM_GO(1);
@@ -397,7 +414,7 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		{
 			for (int q0 = 0; q0 < NW * tpw; q0 += NW * TS)
 			{
-				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, ces, tile, q0, q0 == 0);
+				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile, q0, q0 == 0);
 				if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
 			}
 		}
@@ -554,7 +571,7 @@ template <int SMAX, int THREADS, bool LISTED>
 __global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : LSFM_K9_OCC16))
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
               const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-              double* __restrict__ S, double* __restrict__ E, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, K9Cache kc)
+              K9Out o, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, K9Cache kc)
 {
 	__shared__ PmShared<SMAX> sh;
 	const int tid = threadIdx.x;
@@ -580,10 +597,11 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		__syncthreads();
 		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
 		for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+		for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
 		// (visible to the passes through the barrier at the top of the first pass)
 		K9T(0);
 		K9T_FLUSH(0, 1);
-		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot, tile);
+		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile);
 	}
 	else
 	{
@@ -607,9 +625,10 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			__syncthreads();
 			const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
 			for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+			for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
 			K9T(0);
 			K9T_FLUSH(0, 1);
-			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, S, E, fallback, kc.eslot, tile);
+			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile);
 		}
 	}
 }
@@ -635,7 +654,7 @@ void launch_schur_slots(lsfm_context* ctx, int NF, const int* fptr, const int* p
 
 // kc: the tiles' slots (launch_schur_slots of this run, or the plan of the level).
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
-                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
+                        const unsigned long long* tab, const int* val, unsigned long long mask, K9Out out, unsigned char* fallback,
                         int max_poses_per_system, K9Cache kc)
 {
 	if (!NF) return;
@@ -646,12 +665,12 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	// no tile can be seen by more poses than its system has
 	if (max_poses_per_system <= 8)
 	{
-		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 1, none, none, (int*)nullptr, 0, kc);
+		hipLaunchKernelGGL((k_schur_panel<8, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 1, none, none, (int*)nullptr, 0, kc);
 		return;
 	}
 	if (max_poses_per_system <= 16)
 	{
-		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 1, none, none, (int*)nullptr, 0, kc);
+		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 1, none, none, (int*)nullptr, 0, kc);
 		return;
 	}
 	// By tile, not by level: most tiles of the upper levels are seen by a dozen poses (12.1 on average on the NC3500-like
@@ -678,10 +697,10 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	const dim3 wgrid(std::min(ntiles, ncu));
 	// (widest first: a work-group of the 64-slot variant needs a CU's whole LDS to start -- behind the others it would wait for the
 	// 16-slot variant to drain even when its list is empty)
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + 2 * (size_t)ntiles, kc.wcnt + 2, kc.wcnt + 6, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist + ntiles, kc.wcnt + 1, kc.wcnt + 5, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, S, E, fallback, 0, none, none, (int*)nullptr, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist + 2 * (size_t)ntiles, kc.wcnt + 2, kc.wcnt + 6, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist + ntiles, kc.wcnt + 1, kc.wcnt + 5, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, none, none, (int*)nullptr, 0, kc);
 	if (!serial)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[1], s1));

@@ -26,10 +26,15 @@ static const unsigned long long HEMPTY = ~0ull;
 // also what the panel kernel of K9 needs per feature: V^-1 = L L^T (l00 l10 l11 l20 l21 l22) and y = L^T eb, so that its
 // passes find them ready instead of running a Cholesky with square roots and divisions on a dependent load each;
 // l00 = NaN marks a V^-1 without a Cholesky factor (the tile then goes to k_schur_w)
-__global__ void k_vinv(int NF, const double* __restrict__ V, const double* __restrict__ eb, double* __restrict__ IV, double* __restrict__ LY)
+// ymax (optional): per work-group the largest |L^T eb|^2 of its features -- what bounds K9's right-hand-side sums (k_schur_scale)
+__global__ void __launch_bounds__(256) k_vinv(int NF, const double* __restrict__ V, const double* __restrict__ eb, double* __restrict__ IV, double* __restrict__ LY,
+                                               double* __restrict__ ymax)
 {
+	__shared__ double wmax[4];
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= NF) return;
+	double y2 = 0.0;
+	if (f < NF)
+	{
 	double a[9], o[9];
 	ld<9>(a, V + (size_t)f * 9);
 	inv3_sym(a, o);
@@ -50,6 +55,76 @@ __global__ void k_vinv(int NF, const double* __restrict__ V, const double* __res
 	l[8] = l[5] * e[2];
 	if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) l[0] = __builtin_nan("");
 	st<9>(LY + (size_t)f * 9, l);
+	y2 = l[6] * l[6] + l[7] * l[7] + l[8] * l[8];
+	if (!(y2 == y2)) y2 = 0.0; // (a feature without a factor goes to k_schur_w, which checks its own sums)
+	}
+	if (!ymax) return;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) y2 = fmax(y2, __shfl_xor(y2, off, LSFM_WAVE));
+	if ((threadIdx.x & (LSFM_WAVE - 1)) == 0) wmax[threadIdx.x >> 6] = y2;
+	__syncthreads();
+	if (threadIdx.x == 0) ymax[blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+}
+
+// The scales of K9's fixed-point sums.  Per pose scalar i: sexp[i] with 2^sexp[i] > 2 sqrt(U_ii), U_ii the diagonal entry of the
+// camera block of the joint information matrix (k_schur_u has put U into S: the diagonal block is the first of its row).  S = U - W
+// V^-1 W^T is a Schur complement of a positive semi-definite matrix, so every partial sum over features of (W V^-1 W^T)_ij stays below
+// sqrt(U_ii U_jj) (Cauchy-Schwarz on the semi-definite partial sums) -- known BEFORE K9 runs.  sexp[6 M] = ey with
+// 2^ey > 2 sqrt(NF max_f |L_f^T eb_f|^2) >= 2 |L^T eb|: |(W V^-1 eb)_i| = |(W L)(L^T eb)|_i <= sqrt(U_ii) |L^T eb|.
+__device__ __forceinline__ int half_exponent(double d) // smallest-ish e with 2^e > 2 sqrt(d); 0 for d <= 0 (an empty row: nothing is ever added)
+{
+	if (!(d > 0.0) || !(d < 1e300)) return 0;
+	int k;
+	(void)frexp(d, &k); // d = f 2^k, 1/2 <= f < 1: sqrt(d) < 2^((k + 1) >> 1)
+	return ((k + 1) >> 1) + 1;
+}
+__global__ void __launch_bounds__(256) k_schur_scale(int M, const int* __restrict__ rowptr, const double* __restrict__ S, int NF, int nymax,
+                                                      const double* __restrict__ ymax, const unsigned char* __restrict__ fixed, int* __restrict__ sexp)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < 6 * M)
+	{
+		const int p = i / 6, r = i - 6 * p;
+		// (a scalar removed from the system -- the Mono gauge -- has no bound and needs none: a scale beyond every addend, whatever lands
+		// in its row and column rounds to nothing)
+		sexp[i] = (fixed && fixed[i]) ? 400 : half_exponent(S[(size_t)rowptr[p] * 36 + 7 * r]);
+	}
+	if (blockIdx.x == 0)
+	{
+		__shared__ double wmax[4];
+		double m = 0.0;
+		for (int b = threadIdx.x; b < nymax; b += 256) m = fmax(m, ymax[b]);
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, LSFM_WAVE));
+		if ((threadIdx.x & (LSFM_WAVE - 1)) == 0) wmax[threadIdx.x >> 6] = m;
+		__syncthreads();
+		if (threadIdx.x == 0) sexp[6 * (size_t)M] = half_exponent((double)NF * fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])));
+	}
+}
+// S -= (the integer sums of W V^-1 W^T); E += (the two limbs of -W V^-1 eb); a poisoned level leaves NaN everywhere (its
+// factorisation then reports the system, as a NaN in a floating-point sum did)
+__global__ void k_schur_finish(int nnzb, int M, const unsigned long long* __restrict__ keys, const long long* __restrict__ acc, const int* __restrict__ sexp,
+                               double* __restrict__ S, double* __restrict__ E)
+{
+	// acc: [poison word | nnzb * 36 sums of W V^-1 W^T | 6 M high limbs | 6 M low limbs]
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ns = (size_t)nnzb * 36, ne = (size_t)M * 6;
+	const bool poison = acc[0] != 0;
+	acc += 1;
+	if (i < ns)
+	{
+		const unsigned long long key = keys[i / 36];
+		const int p = (int)(key >> 32), q = (int)(key & 0xffffffffull), rc = (int)(i % 36);
+		const double v = ldexp((double)acc[i], sexp[6 * (size_t)p + rc / 6] + sexp[6 * (size_t)q + rc % 6] - 60);
+		S[i] = poison ? __builtin_nan("") : S[i] - v;
+	}
+	else if (i < ns + ne)
+	{
+		const size_t k = i - ns;
+		const int e = sexp[k] + sexp[ne] - 62;
+		const double v = ldexp((double)acc[ns + k], e) + ldexp((double)acc[ns + ne + k], e - 40);
+		E[k] = poison ? __builtin_nan("") : E[k] + v;
+	}
 }
 
 // ---- hash set of block coordinates ------------------------------------------------------------------------
@@ -213,20 +288,23 @@ __global__ void k_schur_u(int NU, const double* __restrict__ U, const int* __res
 __global__ void __launch_bounds__(SCHUR_TILE)
 k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
           const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-          double* __restrict__ S, double* __restrict__ E, const unsigned char* __restrict__ only)
+          K9Out o, const unsigned char* __restrict__ only)
 {
 	if (only && !only[blockIdx.x]) return; // fallback pass: only the tiles the panel kernel could not take
+	// (the same fixed-point sums as the panel kernel's, k_schur_scale: per feature here, so already the LDS tables are integers)
 	__shared__ int skey[SCHUR_CAP];
 	__shared__ int ekey[SCHUR_ECAP];
-	__shared__ double sval[SCHUR_CAP * 36];
-	__shared__ double evalv[SCHUR_ECAP * 6];
+	__shared__ long long sval[SCHUR_CAP * 36];
+	__shared__ long long evalv[SCHUR_ECAP * 12]; // high limbs, then low limbs
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SCHUR_CAP; i += SCHUR_TILE) skey[i] = -1;
 	for (int i = tid; i < SCHUR_ECAP; i += SCHUR_TILE) ekey[i] = -1;
-	for (int i = tid; i < SCHUR_CAP * 36; i += SCHUR_TILE) sval[i] = 0.0;
-	for (int i = tid; i < SCHUR_ECAP * 6; i += SCHUR_TILE) evalv[i] = 0.0;
+	for (int i = tid; i < SCHUR_CAP * 36; i += SCHUR_TILE) sval[i] = 0;
+	for (int i = tid; i < SCHUR_ECAP * 12; i += SCHUR_TILE) evalv[i] = 0;
 	__syncthreads();
 	const int f = blockIdx.x * SCHUR_TILE + tid;
+	bool bad = false;
+	const int ey = *o.ey;
 	if (f < NF)
 	{
 		const int j0 = fptr[f], len = fptr[f + 1] - j0;
@@ -239,6 +317,9 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 			const int pa = photo[j0 + a];
 			ld<18>(Wa, W + (size_t)(j0 + a) * 18);
 			mm<6, 3, 3, false>(Wa, iv, WV); // W V^-1 (V^-1 symmetric), Imp.cpp:2260-2273
+			int ea6[6];
+#pragma unroll
+			for (int r = 0; r < 6; r++) ea6[r] = o.sexp[(size_t)pa * 6 + r];
 			{
 				// E_p -= W V^-1 eb, Imp.cpp:2321-2328
 				const int es = lds_slot(ekey, SCHUR_ECAP, pa);
@@ -246,7 +327,10 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 				for (int r = 0; r < 6; r++)
 				{
 					const double e = -(WV[3 * r] * eb0 + WV[3 * r + 1] * eb1 + WV[3 * r + 2] * eb2);
-					if (es >= 0) lds_add_f64(&evalv[es * 6 + r], e); else atomic_add_f64(E + (size_t)pa * 6 + r, e);
+					long long hi, lo;
+					to_fixed2(e, 62 - ea6[r] - ey, hi, lo, bad);
+					if (es >= 0) { lds_add_i64(&evalv[es * 6 + r], hi); lds_add_i64(&evalv[SCHUR_ECAP * 6 + es * 6 + r], lo); }
+					else { atomic_add_i64(o.Ehi + (size_t)pa * 6 + r, hi); atomic_add_i64(o.Elo + (size_t)pa * 6 + r, lo); }
 				}
 			}
 			for (int b = a; b < len; b++)
@@ -257,8 +341,11 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 				mmt<6, 3, 6, false>(WV, Wb, T); // W_a V^-1 W_b^T = contribution to S(pa,pb), Imp.cpp:2283-2318
 				const int slot = hash_find(tab, val, mask, pair_key(pa, pb));
 				const int ls = lds_slot(skey, SCHUR_CAP, slot);
-				double* dl = ls >= 0 ? &sval[ls * 36] : nullptr;
-				double* dg = S + (size_t)slot * 36;
+				long long* dl = ls >= 0 ? &sval[ls * 36] : nullptr;
+				long long* dg = o.S + (size_t)slot * 36;
+				int eb6[6];
+#pragma unroll
+				for (int c = 0; c < 6; c++) eb6[c] = o.sexp[(size_t)pb * 6 + c];
 				// stored orientation: rows = the smaller pose index; a block of one pose with itself is stored full
 				const bool same = (pa == pb), tr = pa > pb, twice = same && a != b;
 #pragma unroll
@@ -266,24 +353,31 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 #pragma unroll
 					for (int c = 0; c < 6; c++)
 					{
-						double x = -T[r * 6 + c];
-						if (twice) x -= T[c * 6 + r];
-						const int o = tr ? c * 6 + r : r * 6 + c;
-						if (dl) lds_add_f64(dl + o, x); else atomic_add_f64(dg + o, x);
+						// (+: the accumulators hold W V^-1 W^T, k_schur_finish subtracts)
+						double x = T[r * 6 + c];
+						if (twice) x += T[c * 6 + r];
+						const int at = tr ? c * 6 + r : r * 6 + c;
+						const long long q = to_fixed(x, 60 - ea6[r] - eb6[c], bad);
+						if (dl) lds_add_i64(dl + at, q); else atomic_add_i64(dg + at, q);
 					}
 			}
 		}
 	}
+	if (bad) atomic_add_i64(o.poison, 1);
 	__syncthreads();
 	for (int i = tid; i < SCHUR_CAP * 36; i += SCHUR_TILE)
 	{
 		const int k = skey[i / 36];
-		if (k >= 0) atomic_add_f64(S + (size_t)k * 36 + i % 36, sval[i]);
+		if (k >= 0 && sval[i]) atomic_add_i64(o.S + (size_t)k * 36 + i % 36, sval[i]);
 	}
 	for (int i = tid; i < SCHUR_ECAP * 6; i += SCHUR_TILE)
 	{
 		const int k = ekey[i / 6];
-		if (k >= 0) atomic_add_f64(E + (size_t)k * 6 + i % 6, evalv[i]);
+		if (k >= 0)
+		{
+			if (evalv[i]) atomic_add_i64(o.Ehi + (size_t)k * 6 + i % 6, evalv[i]);
+			if (evalv[SCHUR_ECAP * 6 + i]) atomic_add_i64(o.Elo + (size_t)k * 6 + i % 6, evalv[SCHUR_ECAP * 6 + i]);
+		}
 	}
 }
 
@@ -647,7 +741,8 @@ void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
 	sy.IV = ctx->scratch.alloc<double>((size_t)io.NF * 9);
 	sy.LY = ctx->scratch.alloc<double>((size_t)io.NF * 9);
-	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY);
+	sy.ymax = ctx->scratch.alloc<double>((size_t)(io.NF + 255) / 256 + 1);
+	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY, sy.ymax);
 }
 
 // ---- Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only ----
@@ -922,9 +1017,11 @@ __global__ void k_pre_gather(const int* __restrict__ KU, const int* __restrict__
 // `cnt`) and the ranks of the unmatched features there (join_stereo_prepare's `rb`), 3 (B + 1) ints, valid after the
 // caller's next synchronisation of the stream.
 bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy,
-                            std::vector<int>* counts)
+                            std::vector<int>* counts, bool want_pattern)
 {
-	if (!prev_keys || !Y.M) return false;
+	// prev_keys == null: the level that produced Y left no pattern (its systems were small enough for the dense path, which needs
+	// none): the pairs inside every map of Y are then taken from Y's own W runs (k_pat_insert_w), as a level without a predecessor does
+	if (!Y.M) return false;
 	hipStream_t s = ctx->stream;
 	Arena& sc = ctx->scratch;
 	static const bool dbg = getenv("LSFM_DEBUG_SYNC") != nullptr;
@@ -961,6 +1058,12 @@ bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_t
 		counts->resize(3 * (size_t)(B + 1));
 		LSFM_CHECK_HIP(hipMemcpyAsync(counts->data(), d_cnt, counts->size() * sizeof(int), hipMemcpyDeviceToHost, s));
 	}
+	if (!want_pattern)
+	{
+		// (the next level's systems are small: it needs the counts alone; they arrive with the caller's next synchronisation)
+		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		return true;
+	}
 	size_t cap = pattern_capacity(std::max((size_t)Y.NU + Y.M, (size_t)prev_nnzb + Y.M), Y.M);
 	SolveIO io;
 	io.M = Y.M;
@@ -974,7 +1077,8 @@ bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_t
 		chk("begin");
 		hipLaunchKernelGGL(k_pat_insert_u_early, dim3((nu + 255) / 256), dim3(256), 0, s, Y.NU, Y.M, Y.Ui, Y.Uj, Y.pose_map, hub, pb.tab, mask, pb.d_flags);
 		chk("insert_u");
-		if (prev_nnzb) hipLaunchKernelGGL(k_pat_insert_keys, dim3((prev_nnzb + 255) / 256), dim3(256), 0, s, prev_nnzb, prev_keys, pb.tab, mask, pb.d_flags);
+		if (prev_keys && prev_nnzb) hipLaunchKernelGGL(k_pat_insert_keys, dim3((prev_nnzb + 255) / 256), dim3(256), 0, s, prev_nnzb, prev_keys, pb.tab, mask, pb.d_flags);
+		if (!prev_keys && Y.NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((Y.NF + 255) / 256), dim3(256), 0, s, Y.NF, Y.fptr, Y.photo, pb.tab, mask, pb.d_flags);
 		chk("insert_keys");
 		if (Y.NF) hipLaunchKernelGGL(k_pat_insert_w_cross_match, dim3((Y.NF + 255) / 256), dim3(256), 0, s, Y.NF, Y.feat_map, match, Y.fptr, Y.photo, hub, pb.tab, mask, pb.d_flags);
 		chk("insert_cross");
@@ -1066,28 +1170,42 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	const unsigned long long mask = sy.mask;
 	const int ntiles = (NF + SCHUR_TILE - 1) / SCHUR_TILE;
 	unsigned char* fb;
+	// K9 adds in fixed point (order-independent, lsfm_device.hpp): the accumulators of W V^-1 W^T, the two limbs of -W V^-1 eb and the
+	// poison word, back to back; S starts as U, E as the pose part of the right-hand side, k_schur_finish takes the sums off them
+	const size_t nacc = 1 + (size_t)cnt * 36 + (size_t)M * 12;
 	if (ctx->comm)
 	{
-		// feature-sharded run: S and E back to back in the caller's buffer; this rank's features subtract their part (rank 0
-		// starts from U and the pose part of the right-hand side, the others from zero), then the sum over the ranks
+		// feature-sharded run: the accumulators live in the caller's buffer; those of S (and the poison word ahead of them) are
+		// summed over the ranks as INTEGERS -- exact, so every rank holds the same bits of S (U is replicated: every rank starts S
+		// from it).  The right-hand side's limbs stay this rank's own -- their scale hangs on the rank's features (k_schur_scale: ey)
+		// -- and E, this rank's part of it (its features' share of the pose part, rhs kernels of the join, U's on rank 0; its
+		// features' -W V^-1 eb), is summed as doubles once k_schur_finish has put it together.
 		ctx->comm->restart();
-		sy.S = ctx->comm->alloc<double>((size_t)cnt * 36 + (size_t)M * 6);
-		sy.E = sy.S + (size_t)cnt * 36;
-		LSFM_CHECK_HIP(hipMemsetAsync(sy.S, 0, (size_t)cnt * 36 * sizeof(double), s));
+		sy.acc = ctx->comm->alloc<long long>(nacc);
+		sy.E = ctx->comm->alloc<double>((size_t)M * 6);
+		LSFM_CHECK_HIP(hipMemsetAsync(sy.acc, 0, nacc * sizeof(long long), s));
+		ZeroSpan zs(sc);
+		sy.S = sc.alloc<double>((size_t)cnt * 36);
 		fb = sc.alloc<unsigned char>(ntiles + 1);
-		LSFM_CHECK_HIP(hipMemsetAsync(fb, 0, ntiles + 1, s));
+		zs.zero(s);
+		LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
 	else
 	{
 		ZeroSpan zs(sc);
 		sy.S = sc.alloc<double>((size_t)cnt * 36);
 		fb = sc.alloc<unsigned char>(ntiles + 1); // tiles the panel kernel hands to the per-feature kernel
+		sy.acc = sc.alloc<long long>(nacc);
 		zs.zero(s);
 		sy.E = sc.alloc<double>((size_t)M * 6);
+		LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
-	LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
-	if (io.NU && (!ctx->comm || ctx->comm->rank == 0))
-		hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
+	sy.sexp = sc.alloc<int>((size_t)M * 6 + 1);
+	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
+	hipLaunchKernelGGL(k_schur_scale, dim3((6 * M + 255) / 256 + 1), dim3(256), 0, s, M, sy.rowptr, sy.S, NF, NF ? (NF + 255) / 256 : 0, sy.ymax, io.d_fixed, sy.sexp);
+	K9Out ko;
+	ko.poison = sy.acc; ko.S = sy.acc + 1; ko.Ehi = ko.S + (size_t)cnt * 36; ko.Elo = ko.Ehi + (size_t)M * 6;
+	ko.sexp = sy.sexp; ko.ey = sy.sexp + (size_t)M * 6;
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
@@ -1108,8 +1226,8 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			sy.k9_tiles = ntiles; sy.k9_NW = io.NW;
 			launch_schur_slots(ctx, NF, io.fptr, io.photo, fb, sy.k9);
 		}
-		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, sy.S, sy.E, fb, most, sy.k9);
-		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, sy.S, sy.E, fb);
+		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, ko, fb, most, sy.k9);
+		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, ko, fb);
 		if (ctx->stats)
 		{
 			LSFM_CHECK_HIP(hipEventRecord(e3, s));
@@ -1124,7 +1242,12 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 				hipLaunchKernelGGL(k_sum_run_squares, dim3(std::min((NF + 255) / 256, 512)), dim3(256), 0, s, NF, io.fptr, &ctx->d_run->k2);
 		}
 	}
-	if (ctx->comm) ctx->comm->allreduce(s, sy.S, (size_t)cnt * 36 + (size_t)M * 6, LSFM_DTYPE_F64);
+	if (ctx->comm) ctx->comm->allreduce(s, sy.acc, 1 + (size_t)cnt * 36, LSFM_DTYPE_I64);
+	{
+		const size_t n = (size_t)cnt * 36 + (size_t)M * 6;
+		hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cnt, M, sy.upper_keys, sy.acc, sy.sexp, sy.S, sy.E);
+	}
+	if (ctx->comm) ctx->comm->allreduce(s, sy.E, (size_t)M * 6, LSFM_DTYPE_F64);
 	LSFM_CHECK_HIP(hipGetLastError());
 }
 
@@ -1161,7 +1284,7 @@ void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV)
 	double* LY = ctx->scratch.alloc<double>((size_t)NF * 9);
 	double* eb = ctx->scratch.alloc<double>((size_t)NF * 3);
 	dev_zero(ctx, eb, (size_t)NF * 3 * sizeof(double));
-	hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, ctx->stream, NF, V, eb, IV, LY);
+	hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, ctx->stream, NF, V, eb, IV, LY, (double*)nullptr);
 	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 	ctx->scratch.release(mk);
 }

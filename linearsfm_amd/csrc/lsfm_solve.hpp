@@ -33,6 +33,12 @@ struct SchurSystem {
 	const unsigned long long* tab = nullptr; // pose pair -> block of S (open addressing), values in hval
 	const int* hval = nullptr;
 	unsigned long long mask = 0;
+	// K9's sums in fixed point (lsfm_device.hpp "order-independent sums"): acc = one poison word, then [nnzb * 36] accumulators of
+	// W V^-1 W^T, then [6 M] high and [6 M] low limbs of the right-hand side's -W V^-1 eb; sexp = [6 M] binary exponents of the
+	// pose scalars' scales (2^sexp > 2 sqrt(U_ii)) and, at [6 M], the exponent that bounds |L^T eb| over the level
+	long long* acc = nullptr;
+	int* sexp = nullptr;
+	double* ymax = nullptr; // [work-groups of k_vinv] largest |L^T eb|^2 of each
 	K9Cache k9;      // per-tile structure of K9 (null: every run works it out)
 	int k9_tiles = 0, k9_NW = 0;
 	double k9_flops = 0; // algorithmic flops of the numeric Schur complement of this system (structure only)
@@ -42,7 +48,7 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 bool schur_pattern_early_finish(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void schur_pattern_early_extras(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy,
-                            std::vector<int>* counts = nullptr);
+                            std::vector<int>* counts = nullptr, bool want_pattern = true);
 void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int nmir = -1);
@@ -50,8 +56,16 @@ void launch_spmv(lsfm_context* ctx, const SchurSystem& sy, const double* x, doub
                  const int* pose_seg, double* dot, int dot_stride);
 double spmv_bytes(const SchurSystem& sy);
 void launch_schur_slots(lsfm_context* ctx, int NF, const int* fptr, const int* photo, unsigned char* fallback, K9Cache kc);
+// where K9 adds: the fixed-point accumulators of a SchurSystem and the scales they are in
+struct K9Out {
+	long long* S = nullptr;      // [nnzb * 36] += W V^-1 W^T in units of 2^(sexp_r + sexp_c - 60)
+	long long *Ehi = nullptr, *Elo = nullptr; // [6 M] += -W V^-1 eb, two limbs: units of 2^(sexp + ey - 62) and 2^-40 of that
+	long long* poison = nullptr; // != 0: an addend was not finite or outside its bound (the information matrices are not positive semi-definite)
+	const int* sexp = nullptr;   // [6 M]
+	const int* ey = nullptr;     // -> sexp[6 M]: 2^ey bounds |L^T eb| over the level's features
+};
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
-                        const unsigned long long* tab, const int* val, unsigned long long mask, double* S, double* E, unsigned char* fallback,
+                        const unsigned long long* tab, const int* val, unsigned long long mask, K9Out out, unsigned char* fallback,
                         int max_poses_per_system, K9Cache kc);
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);
 

@@ -122,11 +122,14 @@ __global__ void k_tr_new_poses(const double* __restrict__ pose, const int* __res
 }
 
 // Imp.cpp:459-471 / 3311-3365
-__global__ void k_tr_params2(const double* __restrict__ npose, TMap* tm, int B)
+// hub_out (optional): hub pose of every map for the early pattern of S (lsfm_solve.hip): the dense column a transformed map gets,
+// -1: passed through
+__global__ void k_tr_params2(const double* __restrict__ npose, TMap* tm, int B, int* __restrict__ hub_out)
 {
 	int b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= B) return;
 	TMap& t = tm[b];
+	if (hub_out) hub_out[b] = t.active > 0 ? t.hub[0] : -1;
 	if (t.active <= 0) return;
 	const double* p = npose + (size_t)t.hub[0] * 6;
 	t.t[0] = p[0]; t.t[1] = p[1]; t.t[2] = p[2];
@@ -346,10 +349,12 @@ template <int NH>
 __global__ void __launch_bounds__(256)
 k_tr_feat_pre(int NF, const TMap* __restrict__ tm, const int* __restrict__ feat_map, const double* __restrict__ feat, const int* __restrict__ fptr,
               const double* __restrict__ Vold, const int* __restrict__ KW, double* __restrict__ nfeat, int* __restrict__ nfptr,
-              double* __restrict__ Vn, double* __restrict__ FD, int4* __restrict__ finfo)
+              double* __restrict__ Vn, double* __restrict__ FD, int4* __restrict__ finfo, int* __restrict__ hubJ)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= NF) return;
+#pragma unroll
+	for (int sidx = 0; sidx < NH; sidx++) hubJ[(size_t)f * NH + sidx] = -1; // (no old block to a hub pose seen yet: k_tr_entries records them)
 	const TMap* t = &tm[feat_map[f]];
 	const int j0 = fptr[f];
 	const double* x = feat + (size_t)f * 3;
@@ -1005,9 +1010,8 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		double* Gsum = ctx->scratch.alloc<double>((size_t)in.NF * 18 * NH);
 		int* hubJ = ctx->scratch.alloc<int>((size_t)in.NF * NH);
 		int4* finfo = ctx->scratch.alloc<int4>(in.NF);
-		LSFM_CHECK_HIP(hipMemsetAsync(hubJ, 0xff, (size_t)in.NF * NH * sizeof(int), s));
 		hipLaunchKernelGGL(k_tr_feat_pre<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, d_tm, in.feat_map, in.feat, in.fptr, in.V, KW, out.feat,
-		                   out.fptr, out.V, FD, finfo);
+		                   out.fptr, out.V, FD, finfo, hubJ);
 		// the W blocks go to this container -- or straight into the next one when the consumer has laid it out already
 		TrRedirect rd;
 		if (hook) rd = (*hook)(out);
@@ -1056,26 +1060,22 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 	hipLaunchKernelGGL(k_tr_diag<NH>, dim3((in.B + 127) / 128), dim3(128), 0, s, in.B, d_tm, PP, out.U);
 }
 
-__global__ void k_set_last(int* p, int idx, int v) { p[idx] = v; }
 // the output offsets of every map (known to the host once the kept-block counts are) into the device copy of the map records,
-// which keeps what the device computed (hub indices, parameters)
-__global__ void k_tr_patch(TMap* tm, const int4* __restrict__ offs, int B)
+// which keeps what the device computed (hub indices, parameters); also the end of the new run pointers, and -- a level that does
+// not stop for it -- the target-not-found flag into the run's record (three one-thread launches of their own until round 5)
+__global__ void k_tr_patch(TMap* tm, const int4* __restrict__ offs, int B, int* __restrict__ fptr_last, int nw_total, const int* __restrict__ err, RunStatsDev* run)
 {
 	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b == 0)
+	{
+		*fptr_last = nw_total;
+		if (run && *err && !run->tr_err) run->tr_err = *err;
+	}
 	if (b >= B) return;
 	const int4 o = offs[b];
 	tm[b].kU0 = o.x; tm[b].kW0 = o.y; tm[b].U0n = o.z; tm[b].W0n = o.w;
 }
-// hub pose of every map for the early pattern of S (lsfm_solve.hip): the dense column a transformed map gets, -1: passed through
-__global__ void k_tr_export_hubs(const TMap* __restrict__ tm, int B, int* __restrict__ hub)
-{
-	int b = blockIdx.x * blockDim.x + threadIdx.x;
-	if (b < B) hub[b] = tm[b].active > 0 ? tm[b].hub[0] : -1;
-}
-__global__ void k_tr_err_to_run(const int* err, RunStatsDev* run)
-{
-	if (*err && !run->tr_err) run->tr_err = *err;
-}
+
 // a planned Mono level took the signs of the new scales from the plan (the host mirrors of the map records need them
 // before the device has computed anything): they are values, not structure -- check them against what k_tr_params1 found
 __global__ void k_tr_sign_check(const TMap* __restrict__ tm, const int* __restrict__ planned, int B, RunStatsDev* run)
@@ -1110,8 +1110,29 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		t.newLabel = in.Ref[b];
 	}
 	TMap* d_tm = ctx->scratch.alloc<TMap>(B);
-	int* d_err = ctx->scratch.alloc<int>(1);
-	dev_zero(ctx, d_err, sizeof(int));
+	// the accumulators of the stage, zeroed by ONE fill ahead of its first kernel: the target-not-found flag, the pose rows of I C
+	// (Gpose) and the hub-hub blocks (PP).  Feature-sharded run: the two the features add to live back to back in the caller's
+	// buffer and are summed over the ranks between the feature kernels and the pose kernels (launch_stage)
+	int* d_err;
+	double *Gpose, *PP;
+	{
+		const size_t ngp = (size_t)in.M * 36 * nh, npp = (size_t)B * 3 * 36;
+		ZeroSpan zs(ctx->scratch);
+		d_err = ctx->scratch.alloc<int>(1);
+		if (ctx->comm)
+		{
+			ctx->comm->restart();
+			Gpose = ctx->comm->alloc<double>(ngp + npp);
+			PP = Gpose + ngp;
+			LSFM_CHECK_HIP(hipMemsetAsync(Gpose, 0, (ngp + npp) * sizeof(double), s));
+		}
+		else
+		{
+			Gpose = ctx->scratch.alloc<double>(ngp);
+			PP = ctx->scratch.alloc<double>(npp);
+		}
+		zs.zero(s);
+	}
 	CopyBatch cb(ctx); // the small copies of the prologue: map records, offsets, label arrays -- one transfer, one kernel
 	cb.h2d(d_tm, tm.data(), sizeof(TMap) * B);
 
@@ -1143,36 +1164,16 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		hipLaunchKernelGGL(k_tr_find, dim3((M + 255) / 256), dim3(256), 0, s, in.pose_id, in.pose_map, M, d_tm);
 		hipLaunchKernelGGL(k_tr_params1, dim3((B + 127) / 128), dim3(128), 0, s, in.pose, d_tm, B, d_err);
 		hipLaunchKernelGGL(k_tr_new_poses, dim3((M + 255) / 256), dim3(256), 0, s, in.pose, in.pose_id, in.pose_map, M, d_tm, out.pose, out.pose_id);
-		hipLaunchKernelGGL(k_tr_params2, dim3((B + 127) / 128), dim3(128), 0, s, out.pose, d_tm, B);
+		// (for the consumer laid out inside the hook -- a Stereo join that analyses --: what the early pattern of S is made from)
+		int* d_hub = (hook && !mono && B) ? ctx->scratch.alloc<int>(B) : nullptr;
+		hipLaunchKernelGGL(k_tr_params2, dim3((B + 127) / 128), dim3(128), 0, s, out.pose, d_tm, B, d_hub);
+		ctx->tr_in = nullptr; ctx->tr_hub = nullptr;
+		if (d_hub) { ctx->tr_in = &in; ctx->tr_hub = d_hub; }
 	}
-	ctx->tr_in = nullptr; ctx->tr_hub = nullptr;
-	if (hook && !mono && B)
-	{
-		// for the consumer laid out inside the hook (a Stereo join that analyses): what the early pattern of S is made from
-		int* d_hub = ctx->scratch.alloc<int>(B);
-		hipLaunchKernelGGL(k_tr_export_hubs, dim3((B + 127) / 128), dim3(128), 0, s, d_tm, B, d_hub);
-		ctx->tr_in = &in; ctx->tr_hub = d_hub;
-	}
+	else { ctx->tr_in = nullptr; ctx->tr_hub = nullptr; }
 	double* Dp = ctx->scratch.alloc<double>((size_t)M * 36);
 	// Stereo: + the 27 pose-dependent entries of (D_k, C_k) packed per pose, for k_tr_entries (after the one C section)
 	double* Cp = ctx->scratch.alloc<double>((size_t)M * 36 * nh + (nh == 1 ? (size_t)M * 27 : (size_t)M * 63));
-	double *Gpose, *PP;
-	if (ctx->comm)
-	{
-		// feature-sharded run: the two accumulators the features add to live back to back in the caller's buffer and are summed
-		// over the ranks between the feature kernels and the pose kernels (launch_stage)
-		ctx->comm->restart();
-		Gpose = ctx->comm->alloc<double>((size_t)M * 36 * nh + (size_t)B * 3 * 36);
-		PP = Gpose + (size_t)M * 36 * nh;
-		LSFM_CHECK_HIP(hipMemsetAsync(Gpose, 0, ((size_t)M * 36 * nh + (size_t)B * 3 * 36) * sizeof(double), s));
-	}
-	else
-	{
-		ZeroSpan zs(ctx->scratch);
-		Gpose = ctx->scratch.alloc<double>((size_t)M * 36 * nh);
-		PP = ctx->scratch.alloc<double>((size_t)B * 3 * 36);
-		zs.zero(s);
-	}
 	if (M)
 	{
 		if (mono) hipLaunchKernelGGL(k_tr_pose_jac<2>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);
@@ -1207,7 +1208,6 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		if (err) LSFM_FAIL(LSFM_ERR_ARG, "transform: target pose id not found in map " + std::to_string(err - 1));
 		if (plan) plan->tr_cnt = cnt;
 	}
-	if (warm && ctx->d_run) hipLaunchKernelGGL(k_tr_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run);
 	out.u_off.assign(B + 1, 0); out.w_off.assign(B + 1, 0);
 	for (int b = 0; b < B; b++)
 	{
@@ -1241,7 +1241,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		for (int b = 0; b < B; b++) offs[b] = make_int4(tm[b].kU0, tm[b].kW0, tm[b].U0n, tm[b].W0n);
 		int4* d_offs = ctx->scratch.alloc<int4>(B);
 		h2d(ctx, d_offs, offs.data(), sizeof(int4) * B);
-		hipLaunchKernelGGL(k_tr_patch, dim3((B + 127) / 128), dim3(128), 0, s, d_tm, d_offs, B);
+		hipLaunchKernelGGL(k_tr_patch, dim3(std::max(1, (B + 127) / 128)), dim3(128), 0, s, d_tm, d_offs, B, out.fptr + in.NF, out.NW, d_err, (warm && ctx->d_run) ? ctx->d_run : (RunStatsDev*)nullptr);
 	}
 	if (mono)
 	{
@@ -1265,7 +1265,6 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 	out.U = ar.alloc<double>((size_t)out.NU * 36); out.Ui = ar.alloc<int>(out.NU); out.Uj = ar.alloc<int>(out.NU);
 	if (!hook) { out.W = ar.alloc<double>((size_t)out.NW * 18); out.photo = ar.alloc<int>(out.NW); out.feature = ar.alloc<int>(out.NW); }
 	dev_zero(ctx, out.U, (size_t)out.NU * 36 * sizeof(double)); // the (k,h) slots are accumulated into
-	hipLaunchKernelGGL(k_set_last, dim3(1), dim3(1), 0, s, out.fptr, in.NF, out.NW);
 	double nw_act_in = 0, nw_act_out = 0, nf_act = 0;
 	for (int b = 0; b < B; b++)
 		if (tm[b].active)

@@ -411,7 +411,8 @@ def test_factorisation_is_bit_reproducible(config, n_maps):
     TWICE -- scatter, leaf sub-trees, supernode groups with their rank updates into the ancestors -- and the two factors (leaf columns,
     group columns, inverse diagonal blocks, the spent accumulators) are compared through an order-independent digest on the device.
     The updates that several work-groups of a launch add to one block are 64-bit fixed-point integers (lsfm_pcg.hip): whatever order
-    the atomics land in, the sum is the same.  Round 3 added doubles there and two runs never gave the same factor."""
+    the atomics land in, the sum is the same.  Round 3 added doubles there and two runs never gave the same factor.  Since round 5 the
+    assembly of S and E (K9) is held to the same: `s_rebuild_mismatch`."""
     import subprocess
     import sys
     code = (
@@ -421,13 +422,17 @@ def test_factorisation_is_bit_reproducible(config, n_maps):
         "ctx = api.Context(0)\n"
         "t = ctx.tree_upload([m.__dict__ for m in maps], typ == 'Monocular')\n"
         "ctx.tree_set_plans(t, False)\n"
-        "tot = 0\n"
+        "tot = tot_s = 0\n"
         "for _ in range(3):\n"
         "    st, rc = ctx.tree_run(t)\n"
         "    assert rc == 0 and st['factor_digest'] != 0\n"
         "    tot += st['refactor_mismatch']\n"
-        "print('MISMATCH', tot, 'LEVELS', st['levels'])\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), config, n_maps))
+        "    tot_s += st['s_rebuild_mismatch']\n"
+        "print('MISMATCH', tot, 'LEVELS', st['levels'], 'S_REBUILD_MISMATCH', tot_s)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), config, n_maps))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LSFM_FACTOR_DIGEST="1"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("MISMATCH")][0].split()
     assert int(line[1]) == 0 and int(line[3]) >= 8, line
+    # round 5: the camera systems themselves -- S and E of every level ASSEMBLED twice from the same joint maps (U scatter, every panel
+    # variant of K9, the per-feature fallback) -- are the same bits too: K9 adds in fixed point (k_schur_scale, lsfm_schur_panel.hip)
+    assert int(line[5]) == 0, line

@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 # observable through shared points only).  The bounds are DERIVED from a measurement, not tuned until a run passed:
 # tools/sharded_noise.py -> profiles/r05_sharded_noise.txt (every gloo case of this file, 60-200 runs each) -- largest error seen
 # times >= 10.  (Round 4's 1e-8 / 1e-9 sat on the noise floor: 1.07e-8 was observed on the driver's box.)
-SHARD_TOL_MONO = 3e-7
-SHARD_TOL_STEREO = 3e-8
+SHARD_TOL_MONO = 2e-7     # largest of 200 runs of the 4-rank 200-map case: 1.34e-8 (features), 7.99e-9 (poses)
+SHARD_TOL_STEREO = 1e-9   # largest over all Stereo cases, 60 runs each: 1.31e-12
 
 
 def _free_port():
@@ -260,8 +260,10 @@ def test_one_rank_failing_is_everybodys_verdict(ctx, world, n_maps, mono, fail_r
                 assert "another rank" in first[1], first[1]
         else:
             assert first[0] == "ok" and first[1] == 2, (r, first[:2])  # the tree was joined twice, on every rank
-        for later in reports[r][1:]:
-            assert later[0] == "ok" and later[1] == 1, (r, later[:2])
+        for k, later in enumerate(reports[r][1:]):
+            # (the run after a failed one starts without plans and step counts -- the library drops them on every rank -- and may repeat
+            # a level's refinement once; whatever it does, every rank does the same)
+            assert later[0] == "ok" and later[1] <= 2 and later[1] == reports[0][1 + k][1], (r, later[:2])
     tol = SHARD_TOL_MONO if mono else SHARD_TOL_STEREO
     for rep in reports[0]:
         if rep[0] == "ok":

@@ -35,7 +35,7 @@ for i in range(n):
     res.append((rc, st["not_converged"], float("%.2e" % st["max_rel_residual"]), st["pcg_iterations"], st["attempts"]))
     if want_digest:
         _, _, _, stv = ctx.tree_download_state(t)
-        dig.append((st["s_digest"], st["factor_digest"], hashlib.sha1(np.ascontiguousarray(stv).tobytes()).hexdigest()[:12], st["refactor_mismatch"]))
+        dig.append((st["s_digest"], st["factor_digest"], hashlib.sha1(np.ascontiguousarray(stv).tobytes()).hexdigest()[:12], st["refactor_mismatch"], st["s_rebuild_mismatch"]))
 bad = [r for r in res if r[0] != 0 or r[2] > 1e-8]
 print(cfg, "plans" if plans else "analysing", "mean ms %.1f" % np.mean(times), "runs", n, "failed", len(bad), bad[:6], "repeated",
       sum(1 for r in res if r[4] > 1), "worst ok", max([r[2] for r in res if r not in bad] or [0]), "steps/run", sorted(set(r[3] for r in res)))
@@ -43,10 +43,12 @@ if errors:
     print("   runs that ended with an ERROR: %d of %d: %s" % (len(errors), n, errors[:4]))
 if want_digest:
     by_s = {}
-    for s, f, h, _ in dig:
+    for s, f, h, _, _ in dig:
         by_s.setdefault(s, set()).add(f)
     print("   distinct camera-system digests %d, factor digests %d, final states %d; runs whose systems were equal but whose factors differed: %d"
           % (len(by_s), len(set(d[1] for d in dig)), len(set(d[2] for d in dig)), sum(1 for v in by_s.values() if len(v) > 1)))
     print("   every camera system of every run factored twice: systems whose two factors were not the same bits: %d (of %d runs x levels)"
           % (sum(d[3] for d in dig), n))
+    print("   the camera systems of every level assembled twice (S and E: U scatter, K9, fallback kernel): levels whose two assemblies were not the same bits: %d"
+          % sum(d[4] for d in dig))
 ctx.tree_free(t)

@@ -124,11 +124,13 @@ int lsfm_set_pcg(lsfm_context* ctx, double rel_tol, int max_steps);
  * fp64 residual, and the stopping rule is the same relative residual as in mode 0, reached in more steps (2-3 instead
  * of 1).  BASELINE.json configs[4]. */
 int lsfm_set_precision(lsfm_context* ctx, int mode);
-/* Camera systems of at most 16 poses (the lowest levels of a tree: thousands of independent joins a level) are assembled, factored
- * (dense Cholesky in LDS, one refinement step) and solved, features included, by ONE launch with one work-group per join instead of
- * the level pipeline's ~55 (Imp.cpp:2119-2378 run per join by the reference).  on = 0: every level takes the sparse pipeline (tests
- * compare the two; default 1).  Feature-sharded runs and the fp32 preconditioner always take the pipeline. */
-int lsfm_set_small_solve(lsfm_context* ctx, int on);
+/* Camera systems of a few poses (the lowest levels of a tree: thousands of independent joins a level) are assembled, factored (dense
+ * Cholesky in LDS, one refinement step) and solved, features included, by ONE launch with one work-group per join instead of the level
+ * pipeline's ~55 (Imp.cpp:2119-2378, run per join by the reference).  max_poses: the largest system that takes this path -- 0: none,
+ * every level takes the sparse pipeline; at most 16 (what the kernel holds); default 5 (Stereo: the two lowest levels; where the path
+ * beats the pipeline).  The tests compare the two paths at every size.  Feature-sharded runs and the fp32 preconditioner
+ * always take the pipeline. */
+int lsfm_set_small_solve(lsfm_context* ctx, int max_poses);
 /* Which kernel multiplies by the Schur matrix in the CG.  0 (default): by size -- a matrix that stays in L2 / Infinity
  * Cache (every level of the named configurations) is multiplied from a row-sorted list of both orientations of its
  * blocks, a larger one streams its upper blocks from HBM once.  1: always the streaming kernel.  2: always the list.

@@ -220,10 +220,10 @@ class Context:
         """False: fp64 throughout.  True: the Cholesky preconditioner kept and applied in fp32, residual correction in fp64."""
         self._check(lib().lsfm_set_precision(self._h, 1 if mixed else 0), "lsfm_set_precision")
 
-    def set_small_solve(self, on):
-        """True (default): levels whose camera systems have at most 16 poses are solved by the one-launch dense path; False: every
-        level takes the sparse pipeline (the tests compare the two)."""
-        self._check(lib().lsfm_set_small_solve(self._h, 1 if on else 0), "lsfm_set_small_solve")
+    def set_small_solve(self, max_poses=5):
+        """Levels whose camera systems have at most `max_poses` poses are solved by the one-launch dense path (0: none; at most 16;
+        default 5); the others, and everything in feature-sharded runs, by the sparse pipeline.  The tests compare the two."""
+        self._check(lib().lsfm_set_small_solve(self._h, int(max_poses)), "lsfm_set_small_solve")
 
     def set_spmv_variant(self, variant):
         """0: by size (default); 1: always the kernel that streams the upper blocks once; 2: always the row-sorted list."""

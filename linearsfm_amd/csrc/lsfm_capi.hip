@@ -817,7 +817,7 @@ static int solve_raw(lsfm_context* ctx, double* stVal, const double* eb, const d
 		io.U = dU; io.Ui = dUi; io.Uj = dUj; io.W = dW; io.photo = dph; io.fptr = dfp; io.V = dV;
 		io.ea = dea; io.eb = deb; io.x0 = dx0; io.x_pose = dxp; io.x_feat = dxf;
 		io.seg_rows.assign(1, m);
-		if (ctx->small_solve && small_solve_strips(m))
+		if (ctx->small_max > 0 && small_solve_strips(m, ctx->small_max))
 		{
 			const int offs[6] = { 0, m, 0, n, 0, nU };
 			int* d_offs = ar.alloc<int>(6);

@@ -247,7 +247,9 @@ struct lsfm_context {
 	int cur = 0;
 	size_t arena_bytes = 0, arena_req = 0; // actual size of each arena / the request it answers (may have been capped)
 	lsfm::PcgOptions pcg;
-	bool small_solve = true; // levels of small systems by the one-launch dense path (lsfm_set_small_solve: tests compare both paths)
+	// levels whose systems have at most this many poses take the one-launch dense path (lsfm_small.hip); 0: none.  The kernel holds 16;
+	// the default is where it beats the level pipeline on the NC3500-like set (per-level measurements).  lsfm_set_small_solve
+	int small_max = 5;
 	std::string last_error;
 	int* h_pinned = nullptr; // small pinned staging buffer for counters
 	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
@@ -435,7 +437,7 @@ struct SolveIO {
 	// a level whose systems have at most 16 poses is solved by the one-launch dense path (lsfm_small.hip)
 	const int *d_pose_off = nullptr, *d_feat_off = nullptr, *d_u_off = nullptr;
 };
-int small_solve_strips(int most_poses); // 16-row strips of the dense path's panel; 0: the systems are too large for it
+int small_solve_strips(int most_poses, int cap); // 16-row strips of the dense path's panel; 0: the systems are too large for it (cap: lsfm_context::small_max)
 void small_solve_launch(lsfm_context* ctx, const SolveIO& io, int strips, int* status, double* max_rel);
 int solve_batch(lsfm_context* ctx, const SolveIO& io);
 // the two feature-side pieces of the solve on their own (C ABI: lsfm_inverse_v / lsfm_solve_features); device pointers

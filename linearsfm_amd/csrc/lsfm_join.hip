@@ -350,7 +350,7 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	int most_rows = 0;
 	for (int r : seg_rows) most_rows = std::max(most_rows, r);
 	static const bool no_small = getenv("LSFM_NO_SMALL") != nullptr;
-	const bool small_level = ctx->small_solve && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_rows) > 0;
+	const bool small_level = ctx->small_max > 0 && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_rows, ctx->small_max) > 0;
 	const bool early = early_on && !small_level && !ctx->comm && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
 	int *srcE = nullptr, *srcC = nullptr;
 	if (early)
@@ -431,7 +431,7 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 		// a level of small systems goes to the one-launch dense path, which walks the joins by their ranges (lsfm_small.hip)
 		int most = 0;
 		for (int r : seg_rows) most = std::max(most, r);
-		if (ctx->small_solve && small_solve_strips(most))
+		if (ctx->small_max > 0 && small_solve_strips(most, ctx->small_max))
 		{
 			int* d_uo = ctx->scratch.alloc<int>(G + 1);
 			h2d(ctx, d_uo, out.u_off.data(), sizeof(int) * (size_t)(G + 1));

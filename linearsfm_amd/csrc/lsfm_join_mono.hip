@@ -588,7 +588,7 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	{
 		int most = 0;
 		for (int r : seg_rows) most = std::max(most, r);
-		if (ctx->small_solve && small_solve_strips(most))
+		if (ctx->small_max > 0 && small_solve_strips(most, ctx->small_max))
 		{
 			int* d_uo = sc.alloc<int>(G + 1);
 			h2d(ctx, d_uo, out.u_off.data(), sizeof(int) * (size_t)(G + 1));

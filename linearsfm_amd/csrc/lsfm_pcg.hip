@@ -1680,6 +1680,7 @@ struct SolvePlan {
 	int its = 1;    // refinement steps the first run needed ...
 	bool mixed = false; // ... with the preconditioner in this precision
 	double rel_tol = 0; // ... to this relative residual
+	bool small = false; // the plan of a level on the one-launch dense path: no pattern, no factorisation (lsfm_small.hip)
 	char* mem = nullptr;
 	~SolvePlan() { if (mem) (void)hipFree(mem); }
 };
@@ -1820,7 +1821,7 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 	int most_next = 0;
 	for (int b = 0; b < Y.B; b += 2) most_next = std::max(most_next, Y.pose_off[std::min(b + 2, Y.B)] - Y.pose_off[b]);
 	static const bool no_small = getenv("LSFM_NO_SMALL") != nullptr;
-	const bool next_small = ctx->small_solve && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_next) > 0;
+	const bool next_small = ctx->small_max > 0 && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_next, ctx->small_max) > 0;
 	// with the step count an earlier run left for that level, the level can run like a planned one (no round trip at all): then
 	// its counts are prepared too.  (LSFM_CHECK_EARLY_PATTERN keeps to the path that compares the pattern.)
 	static const bool plan_on = !getenv("LSFM_NO_PREPLAN");
@@ -2362,19 +2363,21 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	// needs the pattern only, so it is enqueued first
 	PreLevel* pending = (lp && lp == &ctx->pre_plan && !lp->solve && ctx->pre_pending) ? static_cast<PreLevel*>(ctx->pre_pending.get()) : nullptr;
 	if (!pending && ctx->pre_pending) { pre_wait(ctx, static_cast<PreLevel*>(ctx->pre_pending.get())); ctx->pre_pending.reset(); } // (not this level's: dropped)
+	// a level of small systems (at most 16 poses each): assembled, factored and solved by one launch (lsfm_small.hip).  The pattern of
+	// S and its symbolic analysis are still made -- the levels above build theirs on them, and a plan of the level keeps them
+	int most_rows = 0;
+	for (int rws : io.seg_rows) most_rows = std::max(most_rows, rws);
+	const int strips = (ctx->small_max > 0 && !ctx->comm && !ctx->pcg.mixed && io.d_pose_off && io.d_feat_off && io.d_u_off && !getenv("LSFM_NO_SMALL"))
+	                       ? small_solve_strips(most_rows, ctx->small_max) : 0;
 	SolvePlan* sp = lp ? static_cast<SolvePlan*>(lp->solve.get()) : nullptr;
+	// (a plan recorded on the other path -- lsfm_set_small_solve was changed between two runs of a resident tree -- is void)
+	if (sp && sp->small != (strips > 0)) { lp->solve.reset(); sp = nullptr; }
 	const bool warm = sp != nullptr || pending != nullptr; // pattern + symbolic factorisation known from an earlier run of the same tree level (or made one level ahead)
 	hipEvent_t ea = ctx->pool_event(), eb = ctx->pool_event(), ec = ctx->pool_event(), ed = ctx->pool_event();
 	LSFM_CHECK_HIP(hipEventRecord(ea, s)); if (roctx().mark) roctx().mark("lsfm schur: begin");
 	SchurSystem sy;
 	CholDev ch;
 	CholHostIn hin;
-	// a level of small systems (at most 16 poses each): assembled, factored and solved by one launch (lsfm_small.hip).  The pattern of
-	// S and its symbolic analysis are still made -- the levels above build theirs on them, and a plan of the level keeps them
-	int most_rows = 0;
-	for (int rws : io.seg_rows) most_rows = std::max(most_rows, rws);
-	const int strips = (ctx->small_solve && !ctx->comm && !ctx->pcg.mixed && io.d_pose_off && io.d_feat_off && io.d_u_off && !getenv("LSFM_NO_SMALL"))
-	                       ? small_solve_strips(most_rows) : 0;
 	const bool dbg = getenv("LSFM_DEBUG") != nullptr;
 	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double tw0 = 0, tw1 = 0;
@@ -2557,7 +2560,7 @@ small_tail:
 		{
 			// the plan of a small level: nothing but the fact that it is one (the structure of its solve is the batch's offsets)
 			auto small_plan = std::make_shared<SolvePlan>();
-			small_plan->its = 1; small_plan->mixed = false; small_plan->rel_tol = ctx->pcg.rel_tol;
+			small_plan->its = 1; small_plan->mixed = false; small_plan->rel_tol = ctx->pcg.rel_tol; small_plan->small = true;
 			lp->solve = small_plan;
 		}
 		return hs[0];

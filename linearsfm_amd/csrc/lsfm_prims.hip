@@ -379,6 +379,7 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 	try
 	{
 		c->device = device;
+		if (getenv("LSFM_SMALL_MAX")) c->small_max = std::max(0, std::min(16, atoi(getenv("LSFM_SMALL_MAX")))); // (measurements: tools/small_levels.py)
 		LSFM_CHECK_HIP(hipSetDevice(device));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		LSFM_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -467,10 +468,10 @@ int lsfm_set_precision(lsfm_context* ctx, int mode)
 	return LSFM_OK;
 }
 
-int lsfm_set_small_solve(lsfm_context* ctx, int on)
+int lsfm_set_small_solve(lsfm_context* ctx, int max_poses)
 {
-	if (!ctx) return LSFM_ERR_ARG;
-	ctx->small_solve = on != 0;
+	if (!ctx || max_poses < 0 || max_poses > 16) return LSFM_ERR_ARG;
+	ctx->small_max = max_poses;
 	return LSFM_OK;
 }
 

@@ -27,6 +27,8 @@ namespace lsfm {
 #define SM_KS (SM_K + 1)      /* odd row stride of the panel */
 #define SM_THREADS 256
 #define SM_CHUNK 256           /* features whose run pointers are held in LDS */
+#define SM_SUPER 64            /* features per super-pass (4 passes) */
+#define SM_WROWS 1024          /* W rows of a super-pass held in LDS: 170 blocks = 2.7 a feature (the low levels have 1.2-1.8); the rest is read from memory */
 
 typedef double sm_v4d __attribute__((ext_vector_type(4)));
 
@@ -43,6 +45,7 @@ struct SmallArgs {
 	RunStatsDev* run;                        // outcome of the level (may be null)
 	int* status;                             // [2]: += systems left above the residual bound, 1 + first system with a non-positive pivot
 	double* max_rel;                         // largest relative residual of the level (bit pattern, atomicMax)
+	int dbg;                                 // LSFM_SMALL_DEBUG (timing probes, tools/small_probe.py): bits switch phases OFF -- results are then garbage
 };
 
 // NTR 16-row strips: the panel has 16 NTR >= 6 m rows.  LDS: dense S (R x (R + 1)), panel, vectors.
@@ -52,16 +55,19 @@ struct SmallShared {
 	double S[R * (R + 1)];     // row-major, stride R + 1; after the factorisation: L in the lower triangle, the original above it
 	double P[R * SM_KS];
 	double d0[R];              // the original diagonal
-	double E[R], x[R], r[R], v[R];
-	double ly[SM_PASS * 9];
-	int fpc[SM_CHUNK + 1];     // run pointers of the 256 features the passes are working through (a pass must not wait for them)
+	double E[R], x[R], r[R], v[R], dinv[R]; // dinv: 1 / diagonal of the factor
+	double ly[SM_SUPER * 9];   // per feature of the super-pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
+	double wst[SM_WROWS * 3];  // the W rows of the super-pass (row w of block e: 6 e + r)
+	int sph[SM_WROWS / 6 + 1]; // pose (join-local) of every block of the super-pass
+	int fpc[2][SM_CHUNK + 1];  // run pointers of the 256 features the passes are working through (a pass must not wait for them); two chunks:
+	                           // the last super-pass of one is still at work when the first of the next is prefetched
 	unsigned char fx[R];
 	int bad;
-	int strips; // bit i: a row of 16-row strip i of the panel was staged in this pass
+	int strips[4]; // per pass of the super-pass: bit i = a block lies in 16-row strip i of the panel
 };
 
 template <int NTR>
-__global__ void __launch_bounds__(SM_THREADS, NTR >= 6 ? 1 : (NTR >= 3 ? 2 : 4))
+__global__ void __launch_bounds__(SM_THREADS, NTR >= 6 ? 1 : 2) // (the prefetched super-pass is ~45 registers: three waves a SIMD would spill 160)
 k_small_solve(SmallArgs a)
 {
 	constexpr int R = 16 * NTR, LD = R + 1;
@@ -120,52 +126,67 @@ k_small_solve(SmallArgs a)
 #pragma unroll
 	for (int i = 0; i < NE; i++) eacc[i] = 0.0;
 	const int lbase = (lane & 15) * SM_KS + (lane >> 4);
-	// what a pass reads from memory is fetched one pass ahead: the W rows of a pass are ONE contiguous range (3 doubles a row), its
-	// features' V and eb 12 doubles each
-	constexpr int PF = 3; // rows per lane held in registers (768 rows = 8 blocks per feature); longer passes read the rest late
+	// The features are worked through in SUPER-PASSES of SM_SUPER = 64 (four passes of 16 columns of the panel).  What a super-pass
+	// reads from memory -- its W rows, ONE contiguous range of 3 doubles a row, the photo of every block, V and eb of its features --
+	// is fetched into registers a whole super-pass ahead and parked in LDS when its turn comes: one exposed memory latency per 64
+	// features, not per 16 (the first version prefetched pass by pass and spent a third of its time waiting, tools/small_probe.py).
+	constexpr int PF = SM_WROWS / SM_THREADS; // rows per lane held in registers; a super-pass with more rows reads the rest from memory
+	constexpr int MCAP = R / 6;               // poses the panel has rows for
 	double pw[PF][3];
 	int pk[PF];
 	double pv[9], pe[3];
-	int qb0 = 0, RW = 0, c0 = f0;
+	int qbn = 0, c0 = f0, cb = 1; // first block of the prefetched super-pass; first feature / buffer of the run-pointer chunk it lies in
 	auto prefetch = [&](int q0) {
-		const int nf = min(SM_PASS, f1 - q0);
+		const int nf = min(SM_SUPER, f1 - q0);
 		if (q0 - c0 >= SM_CHUNK || q0 == f0)
 		{
-			// (every 16th pass: the staging of the pass before is done with the old pointers)
-			__syncthreads();
-			c0 = q0;
-			for (int i = tid; i <= min(SM_CHUNK, f1 - c0); i += SM_THREADS) sh.fpc[i] = a.fptr[c0 + i];
+			// (every fourth super-pass, into the OTHER buffer: the super-pass at work still reads the chunk before)
+			c0 = q0; cb ^= 1;
+			for (int i = tid; i <= min(SM_CHUNK, f1 - c0); i += SM_THREADS) sh.fpc[cb][i] = a.fptr[c0 + i];
 			__syncthreads();
 		}
-		qb0 = sh.fpc[q0 - c0];
-		RW = (sh.fpc[q0 - c0 + nf] - qb0) * 6;
+		qbn = sh.fpc[cb][q0 - c0];
+		const int rw = (sh.fpc[cb][q0 - c0 + nf] - qbn) * 6;
 		if (tid < nf)
 		{
 			ld<9>(pv, a.V + (size_t)(q0 + tid) * 9);
 			ld<3>(pe, a.eb + (size_t)(q0 + tid) * 3);
 		}
-		const double* wb = a.W + (size_t)qb0 * 18;
+		const double* wb = a.W + (size_t)qbn * 18;
 #pragma unroll
 		for (int i = 0; i < PF; i++)
 		{
 			const int w = tid + SM_THREADS * i;
-			if (w < RW) { pw[i][0] = wb[3 * (size_t)w]; pw[i][1] = wb[3 * (size_t)w + 1]; pw[i][2] = wb[3 * (size_t)w + 2]; pk[i] = a.photo[qb0 + w / 6]; }
+			if (w < rw) { pw[i][0] = wb[3 * (size_t)w]; pw[i][1] = wb[3 * (size_t)w + 1]; pw[i][2] = wb[3 * (size_t)w + 2]; pk[i] = a.photo[qbn + w / 6]; }
 		}
 	};
+	for (int i = tid; i < R * SM_KS; i += SM_THREADS) sh.P[i] = 0.0; // (rows beyond the last pose's are never written: they stay zero)
 	if (f0 < f1) prefetch(f0);
-	for (int q0 = f0; q0 < f1; q0 += SM_PASS)
+	for (int s0 = f0; s0 < f1; s0 += SM_SUPER)
 	{
-		const int nf = min(SM_PASS, f1 - q0);
-		__syncthreads(); // the pass before is consumed
-		for (int q = tid; q < R * SM_KS; q += SM_THREADS) sh.P[q] = 0.0;
-		if (tid == SM_THREADS - 1) sh.strips = 0;
-		if (tid < SM_PASS)
+		const int nfs = min(SM_SUPER, f1 - s0);
+		const int qbs = qbn, cs = c0, bs = cb; // this super-pass: first block, chunk (start, buffer) its run pointers are in
+		const int rws = (sh.fpc[bs][s0 - cs + nfs] - qbs) * 6;
+		__syncthreads(); // the super-pass before is consumed
+		// ---- park the rows, the photos and (V^-1 = L L^T, y = L^T eb) of the 64 features in LDS ----
+#pragma unroll
+		for (int i = 0; i < PF; i++)
 		{
-			// V^-1 = L L^T, y = L^T eb (k_vinv's arithmetic)
+			const int w = tid + SM_THREADS * i;
+			if (w < rws)
+			{
+				sh.wst[3 * w] = pw[i][0]; sh.wst[3 * w + 1] = pw[i][1]; sh.wst[3 * w + 2] = pw[i][2];
+				if (w % 6 == 0) sh.sph[w / 6] = pk[i] - p0;
+			}
+		}
+		if (tid < 4) sh.strips[tid] = 0;
+		if (tid < SM_SUPER)
+		{
+			// (k_vinv's arithmetic; 64 lanes at once)
 			double l[9];
 #pragma unroll
 			for (int i = 0; i < 9; i++) l[i] = 0.0;
-			if (tid < nf)
+			if (tid < nfs && !(a.dbg & 1))
 			{
 				double o[9];
 				inv3_sym(pv, o);
@@ -183,72 +204,105 @@ k_small_solve(SmallArgs a)
 			st<9>(&sh.ly[tid * 9], l);
 		}
 		__syncthreads();
+		if (s0 + SM_SUPER < f1) prefetch(s0 + SM_SUPER); // (in flight during the four passes below)
+		for (int sub = 0; sub * SM_PASS < nfs; sub++)
 		{
-			// stage P = W L; a (pose, feature) pair may hold two blocks (the joins keep both when a feature was seen from the hub
-			// pose on either side, Imp.cpp:1277): they add up
-			const double* wb = a.W + (size_t)qb0 * 18;
-			auto stage = [&](int w, double w0, double w1, double w2, int k) {
-				const int e = w / 6, r = w - 6 * e, j = qb0 + e;
-				int lo = 0, hi = nf - 1; // feature of block j: the last run of the pass that starts at or before it
-				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sh.fpc[q0 - c0 + mid] <= j) lo = mid; else hi = mid - 1; }
-				const double* l = &sh.ly[lo * 9];
-				const int row = 6 * (k - p0) + r;
-				double* d = &sh.P[row * SM_KS + 3 * lo];
-				if (r == 0 || (row & 15) == 0) atomicOr(&sh.strips, 1 << (row >> 4)); // (a block's six rows lie in one strip or two)
-				lds_add_f64(d + 0, w0 * l[0] + w1 * l[1] + w2 * l[3]);
-				lds_add_f64(d + 1, w1 * l[2] + w2 * l[4]);
-				lds_add_f64(d + 2, w2 * l[5]);
-			};
-#pragma unroll
-			for (int i = 0; i < PF; i++)
+			const int q0 = s0 + sub * SM_PASS, nf = min(SM_PASS, f1 - q0);
+			// ---- the panel P = [W L] of the pass: one lane per (pose, feature) cell.  It walks the feature's run for the blocks
+			// of its pose -- the joins keep both blocks when a feature was seen from the hub pose on either side (Imp.cpp:1277):
+			// they add up, in run order -- and stores its 6 x 3 cell, zeros included: no fill of the panel, no LDS atomics (an LDS
+			// add of a double is serialised lane by lane on this chip: staging by row with atomics was 1.4 of the first version's
+			// 3.7 ms per tree) ----
 			{
-				const int w = tid + SM_THREADS * i;
-				if (w < RW) stage(w, pw[i][0], pw[i][1], pw[i][2], pk[i]);
-			}
-			for (int w = tid + SM_THREADS * PF; w < RW; w += SM_THREADS) stage(w, wb[3 * (size_t)w], wb[3 * (size_t)w + 1], wb[3 * (size_t)w + 2], a.photo[qb0 + w / 6]);
-		}
-		__syncthreads();
-		if (q0 + SM_PASS < f1) prefetch(q0 + SM_PASS);
-		// The panel has a row for every scalar of the join's poses, and a pass of 16 features is seen by a few of them: only the
-		// 16-row strips a block of this pass was staged into are worked on (with all strips, level 3 of an NC3500-like tree -- 16
-		// poses, 1.7 blocks a feature -- spent 2.2 us a pass in 72 matrix instructions a wave, nearly all of them on zeros)
-		const int smask = sh.strips;
-		// E -= P y (Imp.cpp:2321-2328): 16-row strips over the waves, a lane = (row of the strip, quarter of the 48 columns)
-		{
-			const int kq = lane >> 4;
-#pragma unroll
-			for (int si = 0; si < NE; si++)
-			{
-				const int strip = wave + NW * si;
-				if (strip < NTR && ((smask >> strip) & 1))
+				const int lp = tid >> 4, fl = tid & 15;
+				bool found = false;
+				if (lp < MCAP && !(a.dbg & 2))
 				{
-					const double* pr = &sh.P[(16 * strip + (lane & 15)) * SM_KS + 12 * kq];
-					const double* yq = &sh.ly[kq * 36 + 6];
-					double s0 = 0.0, s1 = 0.0;
+					double c18[18];
 #pragma unroll
-					for (int k = 0; k < 12; k += 2)
+					for (int i = 0; i < 18; i++) c18[i] = 0.0;
+					if (fl < nf && lp < m)
 					{
-						s0 = fma(pr[k], yq[(k / 3) * 9 + k % 3], s0);
-						s1 = fma(pr[k + 1], yq[((k + 1) / 3) * 9 + (k + 1) % 3], s1);
+						const int j0 = sh.fpc[bs][q0 - cs + fl], j1 = sh.fpc[bs][q0 - cs + fl + 1];
+						const double* l = &sh.ly[(sub * SM_PASS + fl) * 9];
+						const double l0 = l[0], l1 = l[1], l2 = l[2], l3 = l[3], l4 = l[4], l5 = l[5];
+						for (int j = j0; j < j1; j++)
+						{
+							const int e = j - qbs;
+							const int ph = 6 * e < SM_WROWS ? sh.sph[e] : a.photo[j] - p0;
+							if (ph != lp) continue;
+							found = true;
+#pragma unroll
+							for (int r = 0; r < 6; r++)
+							{
+								double w0, w1, w2;
+								if (6 * e + 5 < SM_WROWS) { w0 = sh.wst[3 * (6 * e + r)]; w1 = sh.wst[3 * (6 * e + r) + 1]; w2 = sh.wst[3 * (6 * e + r) + 2]; }
+								else { const double* wg = a.W + (size_t)j * 18 + 3 * r; w0 = wg[0]; w1 = wg[1]; w2 = wg[2]; }
+								c18[3 * r] += w0 * l0 + w1 * l1 + w2 * l3;
+								c18[3 * r + 1] += w1 * l2 + w2 * l4;
+								c18[3 * r + 2] += w2 * l5;
+							}
+						}
 					}
-					double sum = s0 + s1;
-					sum += __shfl_xor(sum, 16, 64);
-					sum += __shfl_xor(sum, 32, 64);
-					eacc[si] -= sum;
+#pragma unroll
+					for (int r = 0; r < 6; r++)
+					{
+						double* d = &sh.P[(6 * lp + r) * SM_KS + 3 * fl];
+						d[0] = c18[3 * r]; d[1] = c18[3 * r + 1]; d[2] = c18[3 * r + 2];
+					}
+				}
+				// which 16-row strips of the panel hold anything in this pass: one LDS OR per wave and strip
+				const int b0 = (6 * lp) >> 4, b1 = (6 * lp + 5) >> 4;
+#pragma unroll
+				for (int sidx = 0; sidx < NTR; sidx++)
+					if (__ballot(found && (b0 == sidx || b1 == sidx)) != 0ull && lane == 0) atomicOr(&sh.strips[sub], 1 << sidx);
+			}
+			__syncthreads();
+			// The panel has a row for every scalar of the join's poses, and a pass of 16 features is seen by a few of them: only the
+			// 16-row strips that hold a block of this pass are worked on (with all strips, level 3 of an NC3500-like tree -- 16
+			// poses, 1.7 blocks a feature -- spent 2.2 us a pass in 72 matrix instructions a wave, nearly all of them on zeros)
+			const int smask = sh.strips[sub];
+			// E -= P y (Imp.cpp:2321-2328): 16-row strips over the waves, a lane = (row of the strip, quarter of the 48 columns)
+			{
+				const int kq = lane >> 4;
+#pragma unroll
+				for (int si = 0; si < NE; si++)
+				{
+					const int strip = wave + NW * si;
+					if (strip < NTR && ((smask >> strip) & 1) && !(a.dbg & 4))
+					{
+						const double* pr = &sh.P[(16 * strip + (lane & 15)) * SM_KS + 12 * kq];
+						const double* yq = &sh.ly[sub * SM_PASS * 9 + kq * 36 + 6];
+						double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+						for (int k = 0; k < 12; k += 2)
+						{
+							e0 = fma(pr[k], yq[(k / 3) * 9 + k % 3], e0);
+							e1 = fma(pr[k + 1], yq[((k + 1) / 3) * 9 + (k + 1) % 3], e1);
+						}
+						double sum = e0 + e1;
+						sum += __shfl_xor(sum, 16, 64);
+						sum += __shfl_xor(sum, 32, 64);
+						eacc[si] -= sum;
+					}
 				}
 			}
-		}
-		// P P^T: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15]
-#pragma unroll 2
-		for (int ks = 0; ks < SM_K / 4; ks++)
-		{
+			// P P^T: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15]
+			bool on[T];
 #pragma unroll
-			for (int t = 0; t < T; t++)
+			for (int t = 0; t < T; t++) on[t] = ti[t] >= 0 && (((smask >> ti[t]) & (smask >> tj[t]) & 1) != 0) && !(a.dbg & 8);
+#pragma unroll 2
+			for (int ks = 0; ks < SM_K / 4; ks++)
 			{
-				if (ti[t] < 0 || !((smask >> ti[t]) & (smask >> tj[t]) & 1)) continue; // (wave-uniform)
-				const double av = sh.P[16 * ti[t] * SM_KS + lbase + 4 * ks], bv = sh.P[16 * tj[t] * SM_KS + lbase + 4 * ks];
-				acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+#pragma unroll
+				for (int t = 0; t < T; t++)
+				{
+					if (!on[t]) continue; // (wave-uniform)
+					const double av = sh.P[16 * ti[t] * SM_KS + lbase + 4 * ks], bv = sh.P[16 * tj[t] * SM_KS + lbase + 4 * ks];
+					acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+				}
 			}
+			__syncthreads(); // (the next pass overwrites the panel)
 		}
 	}
 	__syncthreads();
@@ -289,7 +343,7 @@ k_small_solve(SmallArgs a)
 	// ---- 3. S = L L^T in place: right-looking, column by column; L ends up in the lower triangle (with its diagonal), the upper
 	// triangle and d0 keep the original ------------------------------------------------------------------------------------------
 	int pivot_bad = -1;
-	for (int j = 0; j < n; j++)
+	for (int j = 0; j < ((a.dbg & 16) ? 0 : n); j++)
 	{
 		const double d = sh.S[j * LD + j];
 		if (!(d > 0.0) || !(d < 1e300)) { pivot_bad = j; break; } // (uniform: every thread reads the same entry)
@@ -297,15 +351,13 @@ k_small_solve(SmallArgs a)
 		__syncthreads();
 		for (int i = j + tid; i < n; i += SM_THREADS) sh.S[i * LD + j] = i == j ? piv : sh.S[i * LD + j] * ip;
 		__syncthreads();
-		// trailing update of the lower triangle: (i, k), j < k <= i
-		const int nt = n - j - 1;
-		for (int q = tid; q < nt * nt; q += SM_THREADS)
+		// trailing update of the lower triangle: (i, k), j < k <= i -- the work-group as a 16 x 16 grid over it (no division in the loop)
 		{
-			const int ii = q / nt, kk = q - ii * nt;
-			if (kk <= ii)
+			const int ty = tid >> 4, tx = tid & 15;
+			for (int i = j + 1 + ty; i < n; i += 16)
 			{
-				const int i = j + 1 + ii, k = j + 1 + kk;
-				sh.S[i * LD + k] = fma(-sh.S[i * LD + j], sh.S[k * LD + j], sh.S[i * LD + k]);
+				const double lij = sh.S[i * LD + j];
+				for (int k = j + 1 + tx; k <= i; k += 16) sh.S[i * LD + k] = fma(-lij, sh.S[k * LD + j], sh.S[i * LD + k]);
 			}
 		}
 		__syncthreads();
@@ -315,6 +367,8 @@ k_small_solve(SmallArgs a)
 		if (tid == 0) { atomicCAS(&a.status[1], 0, 1 + g); if (a.run && !a.run->chol_err) a.run->chol_err = 1 + p0 + pivot_bad / 6; }
 		return;
 	}
+	for (int i = tid; i < n; i += SM_THREADS) sh.dinv[i] = 1.0 / sh.S[i * LD + i];
+	__syncthreads();
 	// x = S^-1 E, then one refinement step against the original S (upper triangle + d0).  One wave does the triangular sweeps: row i
 	// of the solution is final before row i + 1 needs it -- a chain, whatever the number of lanes
 	auto solve = [&](const double* rhs, double* out) {
@@ -323,9 +377,10 @@ k_small_solve(SmallArgs a)
 		__syncthreads();
 		if (wave == 0)
 		{
+			// (d0 is free by now -- the residual reads it, so the inverse diagonal of L lives in sh.r's neighbour: sh.dinv)
 			for (int j = 0; j < n; j++)
 			{
-				const double vj = sh.v[j] / sh.S[j * LD + j];
+				const double vj = sh.v[j] * sh.dinv[j];
 				__builtin_amdgcn_wave_barrier();
 				if (lane == 0) sh.v[j] = vj;
 				for (int i = j + 1 + lane; i < n; i += 64) sh.v[i] = fma(-sh.S[i * LD + j], vj, sh.v[i]);
@@ -333,7 +388,7 @@ k_small_solve(SmallArgs a)
 			}
 			for (int j = n - 1; j >= 0; j--)
 			{
-				const double vj = sh.v[j] / sh.S[j * LD + j];
+				const double vj = sh.v[j] * sh.dinv[j];
 				__builtin_amdgcn_wave_barrier();
 				if (lane == 0) sh.v[j] = vj;
 				for (int i = lane; i < j; i += 64) sh.v[i] = fma(-sh.S[j * LD + i], vj, sh.v[i]);
@@ -355,12 +410,15 @@ k_small_solve(SmallArgs a)
 		}
 		__syncthreads();
 	};
+	if (!(a.dbg & 16))
+	{
 	solve(sh.E, sh.x);
 	residual(sh.x);
 	solve(sh.r, sh.v);      // (out aliases the work vector: harmless, see the copies in solve)
 	for (int i = tid; i < n; i += SM_THREADS) sh.x[i] += sh.v[i];
 	__syncthreads();
 	residual(sh.x);
+	}
 	if (tid == 0)
 	{
 		double rr = 0.0, ee = 0.0;
@@ -377,7 +435,7 @@ k_small_solve(SmallArgs a)
 	}
 	for (int i = tid; i < n; i += SM_THREADS) a.x_pose[(size_t)p0 * 6 + i] = sh.fx[i] ? 0.0 : sh.x[i];
 	// ---- 4. the features: x_f = V^-1 (eb - sum_p W_pf^T x_p), one lane per feature (its run is a handful of blocks) ---------------------
-	for (int f = f0 + tid; f < f1; f += SM_THREADS)
+	for (int f = f0 + tid; f < ((a.dbg & 32) ? f0 : f1); f += SM_THREADS)
 	{
 		double V[9], iv[9];
 		ld<9>(V, a.V + (size_t)f * 9);
@@ -404,8 +462,9 @@ k_small_solve(SmallArgs a)
 }
 
 // strips of 16 rows that hold 6 * most scalars; 0: too large for this path
-int small_solve_strips(int most_poses)
+int small_solve_strips(int most_poses, int cap)
 {
+	if (most_poses > cap) return 0;
 	if (most_poses <= 2) return 1;
 	if (most_poses <= 5) return 2;
 	if (most_poses <= 8) return 3;
@@ -434,6 +493,7 @@ void small_solve_launch(lsfm_context* ctx, const SolveIO& io, int strips, int* s
 	a.ea = io.ea; a.eb = io.eb; a.x0 = io.x0; a.fixed = io.d_fixed; a.x_pose = io.x_pose; a.x_feat = io.x_feat;
 	a.run = (ctx->in_tree_run && ctx->d_run) ? ctx->d_run : nullptr;
 	a.status = status; a.max_rel = max_rel;
+	a.dbg = getenv("LSFM_SMALL_DEBUG") ? atoi(getenv("LSFM_SMALL_DEBUG")) : 0;
 	if (!io.nseg) return;
 	switch (strips)
 	{

@@ -259,7 +259,8 @@ def test_one_rank_failing_is_everybodys_verdict(ctx, world, n_maps, mono, fail_r
             if r != fail_rank:
                 assert "another rank" in first[1], first[1]
         else:
-            assert first[0] == "ok" and first[1] == 2, (r, first[:2])  # the tree was joined twice, on every rank
+            # the tree was joined again, and as many times on every rank (two, unless the repeated pass met a doubt of its own)
+            assert first[0] == "ok" and first[1] >= 2 and first[1] == reports[0][0][1], (r, first[:2], reports[0][0][:2])
         for k, later in enumerate(reports[r][1:]):
             # (the run after a failed one starts without plans and step counts -- the library drops them on every rank -- and may repeat
             # a level's refinement once; whatever it does, every rank does the same)

@@ -1,7 +1,8 @@
 """The one-launch dense path for camera systems of at most 16 poses (lsfm_small.hip: one work-group per join, S in LDS, dense
 Cholesky) against the sparse level pipeline (K7-K11: Schur panels, supernodal Cholesky, refinement, back-substitution), against
 the dense LAPACK expected value of every system the REAL reference assembled, and against the oracle's trees.  The small golden
-fixtures (trees of 2-8 maps, 2-9 poses a join) are exactly its size: by default every solve of them takes it."""
+fixtures (trees of 2-8 maps, 2-9 poses a join) are exactly its size.  By default the path takes systems of at most 5 poses (where it
+beats the pipeline); the tests here open it to all 16 the kernel holds."""
 import numpy as np
 import pytest
 
@@ -13,15 +14,16 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def both(ctx):
-    """runs f with the dense path on (default) and off, always leaves it on"""
+    """runs f with the dense path for every system it can hold (16 poses: all four panel heights of the kernel) and with it off;
+    always leaves the default (5) behind"""
     def run(f):
         try:
-            ctx.set_small_solve(True)
+            ctx.set_small_solve(16)
             a = f()
-            ctx.set_small_solve(False)
+            ctx.set_small_solve(0)
             b = f()
         finally:
-            ctx.set_small_solve(True)
+            ctx.set_small_solve(5)
         return a, b
     return run
 
@@ -55,6 +57,7 @@ def test_trees_through_the_small_path(ctx, both, oracle, mono, n_maps):
     dicts = [dict(m.__dict__) for m in maps]
     (a, sa, rca), (b, sb, rcb) = both(lambda: ctx.divide_conquer(dicts, mono))
     assert rca == 0 and rcb == 0
+    # (16 poses: Stereo levels 0-3; Mono maps hold three poses each: levels 0-2)
     assert sa["small_levels"] >= (3 if n_maps >= 8 else 1) and sb["small_levels"] == 0, (sa["small_levels"], sb["small_levels"])
     assert sa["t_small_ms"] > 0.0
     for k in ("stno", "Ui", "Uj", "photo", "feature"):
@@ -76,5 +79,13 @@ def test_small_path_reports_a_system_that_is_not_positive_definite(ctx):
     J, ea, eb, mono, sa = golden_system(z, 0)
     J = dict(J)
     J["U"] = -np.asarray(J["U"])
+    assert J["m"] <= 5  # (the default path takes it)
     with pytest.raises(api.LsfmError, match="not positive definite"):
         ctx.solve(J, ea, eb, mono, sa)
+
+
+def test_default_takes_the_two_lowest_stereo_levels(ctx):
+    """lsfm_set_small_solve's default (5 poses): an 8-map Stereo tree has joins of 2, 4 and 8 poses -- two levels on the dense path."""
+    maps = synth.make_stereo_set(8, 8, 5, seed=6)
+    _, st, rc = ctx.divide_conquer([dict(m.__dict__) for m in maps], False)
+    assert rc == 0 and st["small_levels"] == 2, st["small_levels"]

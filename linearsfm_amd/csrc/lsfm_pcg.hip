@@ -2163,17 +2163,21 @@ static void chol_apply(lsfm_context* ctx, const CholDev& ch, const double* r, do
 // ---------------------------------------------------------------------------------------------------------------
 // CG pieces
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void k_x_init(int M, const double* __restrict__ x0, const unsigned char* __restrict__ fixed, double* __restrict__ x)
+// (also: the product's accumulator y and the level's counters start from zero -- two fills of their own until round 5)
+__global__ void k_x_init(int M, const double* __restrict__ x0, const unsigned char* __restrict__ fixed, double* __restrict__ x, double* __restrict__ y, int* __restrict__ misc)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < 4) misc[i] = 0;
 	if (i >= (size_t)M * 6) return;
+	y[i] = 0.0;
 	double v = x0 ? x0[i] : 0.0;
 	if (fixed && fixed[i]) v = 0.0;
 	x[i] = v;
 }
 
 // r = E - y ; rr += r.r ; ee += E.E   (fixed scalars are not part of the system)
-__global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* __restrict__ y, const int* __restrict__ pose_seg,
+// (y is spent afterwards: it is left zeroed for the next product, which adds into it)
+__global__ void k_pcg_resid(int M, const double* __restrict__ E, double* __restrict__ y, const int* __restrict__ pose_seg,
                             const unsigned char* __restrict__ fixed, double* __restrict__ r, PcgSeg* seg, int with_ee)
 {
 	int row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2187,6 +2191,7 @@ __global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* _
 		{
 			const size_t o = (size_t)row * 6 + i;
 			double e = E[o], d = e - y[o];
+			y[o] = 0.0;
 			if (fixed && fixed[o]) { e = 0; d = 0; }
 			if (r) r[o] = d;
 			a[0] += d * d; a[1] += e * e;
@@ -2198,9 +2203,11 @@ __global__ void k_pcg_resid(int M, const double* __restrict__ E, const double* _
 }
 
 // p = z, per system: thresholds, convergence state
-__global__ void k_pcg_start(int nseg, PcgSeg* seg, const unsigned char* __restrict__ active, double rel_tol, int* ndone)
+// (err / run: a non-positive pivot of the factorisation goes to the run's record here, when the level does not stop to read it)
+__global__ void k_pcg_start(int nseg, PcgSeg* seg, const unsigned char* __restrict__ active, double rel_tol, int* ndone, const int* __restrict__ err, RunStatsDev* run)
 {
 	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s == 0 && run && *err && !run->chol_err) run->chol_err = *err;
 	if (s >= nseg) return;
 	PcgSeg& g = seg[s];
 	g.thresh = rel_tol * rel_tol * g.ee;
@@ -2567,8 +2574,7 @@ small_tail:
 	}
 	// ---- CG set-up first: the residual of the starting point is the right-hand side of the first preconditioner
 	// application, whose forward substitution rides on the factorisation (k_sn_panel) ----
-	int* d_misc = sc.alloc<int>(4); // [1] ndone
-	dev_zero(ctx, d_misc, 4 * sizeof(int));
+	int* d_misc = sc.alloc<int>(4); // [1] ndone (zeroed by k_x_init)
 	std::vector<PcgSeg> hseg(nseg);
 	{
 		int row = 0;
@@ -2585,8 +2591,7 @@ small_tail:
 	double* Ap = sc.alloc<double>(nscal); double* v = sc.alloc<double>(nscal);
 	const int nbr = (M + 127) / 128, nbs = (nseg + 127) / 128;
 	const unsigned nbe = (unsigned)((nscal + 255) / 256);
-	hipLaunchKernelGGL(k_x_init, dim3(nbe), dim3(256), 0, s, M, io.x0, io.d_fixed, x);
-	dev_zero(ctx, Ap, nscal * sizeof(double));
+	hipLaunchKernelGGL(k_x_init, dim3(std::max(1u, nbe)), dim3(256), 0, s, M, io.x0, io.d_fixed, x, Ap, d_misc);
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 1);
 	const bool mixed = ctx->pcg.mixed;
@@ -2655,8 +2660,7 @@ small_tail:
 	double tw2 = wall();
 	chol_apply(ctx, ch, r, v, z, io.d_fixed, io.d_pose_seg, &seg[0].rz[0], SEG_STRIDE, fused_fwd);
 	hipLaunchKernelGGL(k_copy, dim3(nbe), dim3(256), 0, s, nscal, z, p);
-	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1);
-	dev_zero(ctx, Ap, nscal * sizeof(double));
+	// (Ap is zero again: k_pcg_resid leaves it so)
 	// inside a tree run the outcome of a level (a non-positive pivot, systems left above their bound, the largest residual) is
 	// left in the run's device record and read once at the end of the run; a stage-level call, and a level whose structure is
 	// being recorded as a plan, reads it here
@@ -2669,7 +2673,7 @@ small_tail:
 	// (a feature-sharded run never throws for it in the middle of a pass: the ranks' factorisations are their own, and a rank that left
 	// the pass alone would leave its peers in a sum it never joins -- the flags are exchanged at the end of the run)
 	const bool err_to_run = deferred || (ctx->comm && ctx->d_run);
-	if (err_to_run) hipLaunchKernelGGL(k_chol_err_to_run, dim3(1), dim3(1), 0, s, d_err, ctx->d_run); // reported at the end of the run
+	hipLaunchKernelGGL(k_pcg_start, dim3(nbs), dim3(128), 0, s, nseg, seg, io.d_seg_active, ctx->pcg.rel_tol, d_misc + 1, d_err, err_to_run ? ctx->d_run : (RunStatsDev*)nullptr); // (a bad pivot: reported at the end of the run)
 
 	// One refinement step: x += alpha p, true residual, convergence test per system (converged systems freeze), then the
 	// preconditioner for the next step.  A first run reads the number of finished systems back after every step; a warm
@@ -2754,8 +2758,7 @@ small_tail:
 	// ---- true residual, statistics; one SpMV launch timed with HIP events on this stream.  Nothing here waits for
 	// the device before the back-substitution is enqueued ----
 	const int nsample = 1;
-	PcgSeg* seg2 = seg + nseg; // zeroed accumulators of the final residual
-	dev_zero(ctx, Ap, nscal * sizeof(double));
+	PcgSeg* seg2 = seg + nseg; // zeroed accumulators of the final residual (Ap: left zeroed by the last k_pcg_resid)
 	hipEvent_t es0 = ctx->pool_event(), es1 = ctx->pool_event();
 	LSFM_CHECK_HIP(hipEventRecord(es0, s));
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);

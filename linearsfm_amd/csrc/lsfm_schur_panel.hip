@@ -543,6 +543,7 @@ __global__ void __launch_bounds__(256) k_schur_lists(int ntiles, K9Cache kc)
 		for (int i = 0; i < 256; i++) { const int x = cnt[tid][i]; cnt[tid][i] = run; run += x; }
 		kc.wcnt[tid] = run;
 	}
+	if (tid < 4) kc.wcnt[4 + tid] = 0; // the variants' cursors into their lists (a run that reads the lists from a plan: launch_schur_panel)
 	__syncthreads();
 	int pos[3] = { cnt[0][tid], cnt[1][tid], cnt[2][tid] };
 	for (int t = t0; t < t1; t++)
@@ -655,7 +656,7 @@ void launch_schur_slots(lsfm_context* ctx, int NF, const int* fptr, const int* p
 // kc: the tiles' slots (launch_schur_slots of this run, or the plan of the level).
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, K9Out out, unsigned char* fallback,
-                        int max_poses_per_system, K9Cache kc)
+                        int max_poses_per_system, K9Cache kc, bool fresh_lists)
 {
 	if (!NF) return;
 	const int ntiles = (NF + PM_TILE - 1) / PM_TILE;
@@ -688,7 +689,7 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	static const bool serial = getenv("LSFM_K9_SERIAL") != nullptr;
 	static const int ncu = []() { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
 	hipStream_t s1 = serial ? s : ctx->stream2;
-	LSFM_CHECK_HIP(hipMemsetAsync(kc.wcnt + 4, 0, 4 * sizeof(int), s)); // the variants' cursors into their lists
+	if (!fresh_lists) LSFM_CHECK_HIP(hipMemsetAsync(kc.wcnt + 4, 0, 4 * sizeof(int), s)); // the variants' cursors into their lists (k_schur_lists zeroes them when it has just run)
 	if (!serial)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[0], s));

@@ -79,11 +79,13 @@ __device__ __forceinline__ int half_exponent(double d) // smallest-ish e with 2^
 	return ((k + 1) >> 1) + 1;
 }
 __global__ void __launch_bounds__(256) k_schur_scale(int M, const int* __restrict__ rowptr, const double* __restrict__ S, int NF, int nymax,
-                                                      const double* __restrict__ ymax, const unsigned char* __restrict__ fixed, int* __restrict__ sexp)
+                                                      const double* __restrict__ ymax, const unsigned char* __restrict__ fixed, int* __restrict__ sexp,
+                                                      const double* __restrict__ ea, double* __restrict__ E)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < 6 * M)
 	{
+		E[i] = ea[i]; // (the right-hand side starts as its pose part: a copy of its own until round 5)
 		const int p = i / 6, r = i - 6 * p;
 		// (a scalar removed from the system -- the Mono gauge -- has no bound and needs none: a scale beyond every addend, whatever lands
 		// in its row and column rounds to nothing)
@@ -1188,7 +1190,6 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		sy.S = sc.alloc<double>((size_t)cnt * 36);
 		fb = sc.alloc<unsigned char>(ntiles + 1);
 		zs.zero(s);
-		LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
 	else
 	{
@@ -1198,11 +1199,10 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		sy.acc = sc.alloc<long long>(nacc);
 		zs.zero(s);
 		sy.E = sc.alloc<double>((size_t)M * 6);
-		LSFM_CHECK_HIP(hipMemcpyAsync(sy.E, io.ea, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
 	sy.sexp = sc.alloc<int>((size_t)M * 6 + 1);
 	if (io.NU) hipLaunchKernelGGL(k_schur_u, dim3((io.NU + 255) / 256), dim3(256), 0, s, io.NU, io.U, io.Ui, io.Uj, tab, hval, mask, sy.S);
-	hipLaunchKernelGGL(k_schur_scale, dim3((6 * M + 255) / 256 + 1), dim3(256), 0, s, M, sy.rowptr, sy.S, NF, NF ? (NF + 255) / 256 : 0, sy.ymax, io.d_fixed, sy.sexp);
+	hipLaunchKernelGGL(k_schur_scale, dim3((6 * M + 255) / 256 + 1), dim3(256), 0, s, M, sy.rowptr, sy.S, NF, NF ? (NF + 255) / 256 : 0, sy.ymax, io.d_fixed, sy.sexp, io.ea, sy.E);
 	K9Out ko;
 	ko.poison = sy.acc; ko.S = sy.acc + 1; ko.Ehi = ko.S + (size_t)cnt * 36; ko.Elo = ko.Ehi + (size_t)M * 6;
 	ko.sexp = sy.sexp; ko.ey = sy.sexp + (size_t)M * 6;
@@ -1216,8 +1216,10 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		for (int r : io.seg_rows) most = std::max(most, r);
 		// the per-tile slots of the panel variants: from the plan of the level, or worked out now (and left for the plan, if this
 		// run makes one)
+		bool fresh_lists = false;
 		if (!sy.k9.ns)
 		{
+			fresh_lists = true;
 			sy.k9.ns = sc.alloc<int>(ntiles + 1);
 			sy.k9.pose = sc.alloc<int>((size_t)ntiles * 64 + 1);
 			sy.k9.eslot = sc.alloc<unsigned char>((size_t)io.NW + 1);
@@ -1226,7 +1228,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			sy.k9_tiles = ntiles; sy.k9_NW = io.NW;
 			launch_schur_slots(ctx, NF, io.fptr, io.photo, fb, sy.k9);
 		}
-		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, ko, fb, most, sy.k9);
+		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, ko, fb, most, sy.k9, fresh_lists);
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, ko, fb);
 		if (ctx->stats)
 		{

@@ -66,7 +66,7 @@ struct K9Out {
 };
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, K9Out out, unsigned char* fallback,
-                        int max_poses_per_system, K9Cache kc);
+                        int max_poses_per_system, K9Cache kc, bool fresh_lists = false);
 void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy, const double* x);
 
 } // namespace lsfm

@@ -436,6 +436,9 @@ struct SolveIO {
 	// optional: [nseg + 1] first pose / feature / U block of every segment (segments are contiguous ranges of the batch).  With them,
 	// a level whose systems have at most 16 poses is solved by the one-launch dense path (lsfm_small.hip)
 	const int *d_pose_off = nullptr, *d_feat_off = nullptr, *d_u_off = nullptr;
+	// optional (Stereo tree levels on the sparse pipeline): the W part of the right-hand sides is left to the Schur assembly -- ea
+	// holds U's part only, eb the V part (lsfm_solve.hpp RhsFused; null: ea / eb are complete)
+	const struct RhsFused* rhs = nullptr;
 };
 int small_solve_strips(int most_poses, int cap); // 16-row strips of the dense path's panel; 0: the systems are too large for it (cap: lsfm_context::small_max)
 void small_solve_launch(lsfm_context* ctx, const SolveIO& io, int strips, int* status, double* max_rel);

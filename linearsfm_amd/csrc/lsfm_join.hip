@@ -12,6 +12,7 @@
 #include "lsfm_internal.hpp"
 #include <climits>
 #include "lsfm_join.hpp"
+#include "lsfm_solve.hpp"
 
 namespace lsfm {
 
@@ -352,11 +353,15 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	static const bool no_small = getenv("LSFM_NO_SMALL") != nullptr;
 	const bool small_level = ctx->small_max > 0 && !ctx->comm && !ctx->pcg.mixed && !no_small && small_solve_strips(most_rows, ctx->small_max) > 0;
 	const bool early = early_on && !small_level && !ctx->comm && !ctx->pre && ctx->tr_in && ctx->tr_hub && !ctx->warm() && ctx->tr_in->NF == in.NF && ctx->tr_in->M == in.M;
+	// the W part of the right-hand sides left to the Schur assembly (lsfm_solve.hpp RhsFused): a level on the sparse pipeline, one GPU
+	static const bool fuse_on = !getenv("LSFM_NO_FUSED_RHS");
+	st.fuse_rhs = fuse_on && !small_level && !ctx->comm && !ctx->pcg.mixed;
 	int *srcE = nullptr, *srcC = nullptr;
-	if (early)
+	if (early || st.fuse_rhs)
 	{
 		srcE = ctx->scratch.alloc<int>(NFY + 1); srcC = ctx->scratch.alloc<int>(NFY + 1); // (filled by k_join_features)
 	}
+	st.srcE = srcE; st.srcC = srcC;
 	if (in.NF)
 		for (int side = 0; side < 2; side++)
 			hipLaunchKernelGGL(k_join_features, dim3(nb), dim3(256), 0, s, in.NF, in.feat_map, in.feat_id, in.feat, in.V, in.fptr, match, R, d_grp,
@@ -410,7 +415,9 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 		ctx->pattern_dep = true;
 	}
 	// ---- right-hand sides ----
-	if (NFY)
+	// (the W part: a pass over W of its own -- unless the Schur assembly takes it along, K9Out; a caller that wants eP / eF gets them whole)
+	const bool fuse_rhs = st.fuse_rhs && !eP_out && !eF_out;
+	if (NFY && !fuse_rhs)
 		hipLaunchKernelGGL(k_join_rhs_w, dim3((NFY + RHS_TILE - 1) / RHS_TILE), dim3(256), 0, s, NFY, out.fptr, out.W, out.photo, srcf, in.pose, in.feat, eP, eF);
 	if (in.NU && (!ctx->comm || ctx->comm->rank == 0)) // (feature-sharded run: U is replicated, its part of the sum is rank 0's)
 		hipLaunchKernelGGL(k_join_rhs_u, dim3((in.NU + 127) / 128), dim3(128), 0, s, in.NU, in.U, in.Ui, in.Uj, in.pose, eP);
@@ -427,6 +434,12 @@ void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, Jo
 	io.ea = eP; io.eb = eF; io.x0 = in.pose; io.d_fixed = nullptr; io.d_pose_origin = out.pose_origin;
 	io.x_pose = out.pose; io.x_feat = out.feat;
 	io.seg_rows = seg_rows;
+	RhsFused rhs;
+	if (fuse_rhs)
+	{
+		rhs.srcE = st.srcE; rhs.srcC = st.srcC; rhs.feat_src = in.feat; rhs.pose_src = in.pose; rhs.pose_map_src = in.pose_map;
+		io.rhs = &rhs;
+	}
 	{
 		// a level of small systems goes to the one-launch dense path, which walks the joins by their ranges (lsfm_small.hip)
 		int most = 0;

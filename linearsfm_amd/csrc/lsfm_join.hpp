@@ -19,6 +19,8 @@ struct JoinState {
 	std::vector<unsigned char> seg_active, act_padded;
 	unsigned char* d_act = nullptr; // device copy of seg_active
 	std::vector<int> seg_rows;
+	bool fuse_rhs = false;                    // the W part of the right-hand sides goes with the Schur assembly (RhsFused)
+	int *srcE = nullptr, *srcC = nullptr;     // per joint feature its sources in the input batch (-1: none)
 };
 void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch& out, JoinState& st);
 void join_stereo_finish(lsfm_context* ctx, const DevBatch& in, DevBatch& out, JoinState& st, double* eP_out, double* eF_out);

@@ -80,16 +80,23 @@ __device__ __forceinline__ int pn_hash_find(const unsigned long long* __restrict
 
 template <int SMAX>
 struct PmShared {
-	int hkey[PM_HASH];
-	int hslot[PM_HASH];
+	// (the widest panel fills a CU's LDS: its list of block slots is shorter -- later blocks read the level's copy -- and nothing here is wider than it must be)
+	static constexpr int MAXE = SMAX > PM_SMAX_BIG ? 2560 : PM_MAXE;
 	int pose_of[SMAX];
 	int nslots, bad;
 	unsigned char bf[PM_BF]; // block of the pass -> its feature (the first PM_BF blocks; later ones search the run pointers)
 	int fpt[PM_TILE + 1]; // run pointers of the tile's features: the prefetch of a pass must not wait for them first
-	int sexp[6 * SMAX];     // binary exponent of the scale of every panel row (K9Out::sexp of the slot's pose)
+	short sexp[6 * SMAX];   // binary exponent of the scale of every panel row (K9Out::sexp of the slot's pose)
+	// fused right-hand side (K9Out::xpose): estimate of every panel row's pose scalar, the map side of every slot's pose, per pass
+	// L^-1 x_f of the features' two sources, the partial column sums of P^T x_p and z = y - u for either side
+	double xs[6 * SMAX];
+	unsigned char side[SMAX];
+	double uu[PM_PASS * 6];
+	double cpart[5 * PM_K];
+	double z[2 * PM_K];
 	double ly[PM_PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
-	double P[6 * SMAX * PM_KS];
-	unsigned char eslot[PM_MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
+	alignas(16) double P[6 * SMAX * PM_KS];
+	unsigned char eslot[MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
 };
 
 // T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + NW t over its NW waves; slots
@@ -145,14 +152,16 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	// registers without spilling, with 8 poses per feature prefetched)
 	constexpr int PF = THREADS != 256 ? (T <= 6 ? 3 : 2) : (T <= 3 ? 4 : (T <= 6 ? LSFM_K9_PF6 : (T <= 14 ? 3 : 2)));
 	double pw[PF][3];
-	double lyv = 0.0;
+	double lyv = 0.0, uuv = 0.0;
+	const bool fused = o.xpose != nullptr && first_sweep; // (the right-hand side is the first sweep's; uniform)
 	int qb0 = 0, R = 0;
 	auto prefetch = [&](int p0n) {
 		const int nfn = min(PM_PASS, f1 - p0n);
 		qb0 = sh.fpt[p0n - f0];
 		R = (sh.fpt[p0n - f0 + nfn] - qb0) * 6;
-		lyv = 0.0;
+		lyv = 0.0; uuv = 0.0;
 		if (tid < nfn * 9) lyv = LY[(size_t)p0n * 9 + tid];
+		if (fused && tid < nfn * 6) uuv = o.uu[(size_t)p0n * 6 + tid];
 		const double* wb = W + (size_t)qb0 * 18;
 #pragma unroll
 		for (int i = 0; i < PF; i++)
@@ -168,10 +177,16 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		K9T(5);
 		__syncthreads(); // the previous pass is fully consumed
 		K9T(1);
-		for (int q = tid; q < NT * 16 * PM_KS; q += THREADS) sh.P[q] = 0.0;
+		{
+			// (two doubles a store: the panel starts 16-byte aligned and NT * 16 * PM_KS is even)
+			typedef double d2 __attribute__((ext_vector_type(2)));
+			d2* P2 = reinterpret_cast<d2*>(sh.P);
+			for (int q = tid; q < NT * 8 * PM_KS; q += THREADS) P2[q] = (d2){ 0.0, 0.0 };
+		}
 		if (tid < PM_PASS * 9)
 		{
 			sh.ly[tid] = lyv; // zero for the features past the end of the tile
+			if (tid < PM_PASS * 6) sh.uu[tid] = uuv;
 			if (tid < nf * 9 && tid % 9 == 0 && !(lyv == lyv)) sh.bad = 1; // k_vinv: V^-1 of this feature has no Cholesky factor
 		}
 		{
@@ -196,18 +211,11 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		auto stage = [&](int w, double w0, double w1, double w2, bool second) {
 			const int e = w / 6, r = w - 6 * e, j = qb0 + e;
 			int sl, dup = 1;
-			if (j - jb < PM_MAXE) { sl = sh.eslot[j - jb]; dup = sl & PM_DUP; sl &= PM_DUP - 1; }
+			if (j - jb < PmShared<SMAX>::MAXE) { sl = sh.eslot[j - jb]; dup = sl & PM_DUP; sl &= PM_DUP - 1; }
 			else
 			{
 				if (!second) { later = true; return; }
-				if (ces) sl = ces[j] & (PM_DUP - 1); // the plan's copy (no hash table was built)
-				else
-				{
-					const int key = photo[j];
-					unsigned h = ((unsigned)key * 2654435761u) & (PM_HASH - 1);
-					while (sh.hkey[h] != key) h = (h + 1) & (PM_HASH - 1);
-					sl = sh.hslot[h];
-				}
+				sl = ces[j] & (PM_DUP - 1); // the level's copy (k_schur_slots, or the plan)
 			}
 			if (!second && dup) { later = true; return; }
 			if (second && !dup) return;
@@ -252,9 +260,36 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			__syncthreads();
 		}
 		K9T(4);
+		const int pcur = p0;
 		if (p0 + PM_PASS < f1) prefetch(p0 + PM_PASS);
-		else { R = 0; lyv = 0.0; }
+		else { R = 0; lyv = 0.0; uuv = 0.0; }
 		K9T(12);
+		if (fused)
+		{
+			// y = L^T eb + P^T x_p (the W part of eF, Imp.cpp:2776-2786 and its twins, through the panel): column sums of the panel
+			// weighted by the rows' pose estimates, THREADS / 48 partial sums a column
+			constexpr int NP = 5; // (240 threads: 5 per column)
+			const int col = tid % PM_K, part = tid / PM_K;
+			if (part < NP)
+			{
+				double cs = 0.0;
+				for (int row = part; row < rows; row += NP) cs = fma(sh.P[row * PM_KS + col], sh.xs[row], cs);
+				sh.cpart[part * PM_K + col] = cs;
+			}
+			__syncthreads();
+			if (tid < PM_K)
+			{
+				const int fl = tid / 3, c = tid - 3 * fl;
+				double y = sh.ly[fl * 9 + 6 + c];
+#pragma unroll
+				for (int q = 0; q < NP; q++) y += sh.cpart[q * PM_K + tid];
+				sh.ly[fl * 9 + 6 + c] = y;
+				sh.z[tid] = y - sh.uu[fl * 6 + c];
+				sh.z[PM_K + tid] = y - sh.uu[fl * 6 + 3 + c];
+				if (pcur + fl < f1) o.yfull[(size_t)(pcur + fl) * 3 + c] = y; // (for the back-substitution)
+			}
+			__syncthreads();
+		}
 		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328.  By 16-row strips over ALL the waves: lane (row l & 15 of the strip, quarter
 		// l >> 4 of the 48 columns) sums 12 products, two shuffles add the quarters up -- 24 LDS reads a lane instead of the 96 of
 		// one lane per panel row, which only the first wave or two took part in (a quarter of a 16-slot tile's clocks).  The
@@ -269,13 +304,24 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 				if (strip < NT)
 				{
 					const double* pr = &sh.P[(16 * strip + (lane & 15)) * PM_KS + 12 * kq];
-					const double* yq = &sh.ly[kq * 36 + 6];
 					double s0 = 0.0, s1 = 0.0;
+					if (fused)
+					{
+						// E -= P (y - u): u = L^-1 x_f of the source map the row's pose belongs to (eP += W x_f, Imp.cpp:2770-2775)
+						const int prow = 16 * strip + (lane & 15);
+						const double* zq = &sh.z[(prow < rows && sh.side[prow / 6] ? PM_K : 0) + 12 * kq];
+#pragma unroll
+						for (int k = 0; k < 12; k += 2) { s0 = fma(pr[k], zq[k], s0); s1 = fma(pr[k + 1], zq[k + 1], s1); }
+					}
+					else
+					{
+					const double* yq = &sh.ly[kq * 36 + 6];
 #pragma unroll
 					for (int k = 0; k < 12; k += 2)
 					{
 						s0 = fma(pr[k], yq[(k / 3) * 9 + k % 3], s0);
 						s1 = fma(pr[k + 1], yq[((k + 1) / 3) * 9 + (k + 1) % 3], s1);
+					}
 					}
 					double sum = s0 + s1;
 					sum += __shfl_xor(sum, 16, 64);
@@ -597,8 +643,13 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
 		__syncthreads();
 		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-		for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
-		for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+		for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+		for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+		if (o.xpose)
+		{
+			for (int i = tid; i < 6 * cns; i += THREADS) sh.xs[i] = o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+			for (int i = tid; i < cns; i += THREADS) sh.side[i] = (unsigned char)(o.pside[sh.pose_of[i]] & 1);
+		}
 		// (visible to the passes through the barrier at the top of the first pass)
 		K9T(0);
 		K9T_FLUSH(0, 1);
@@ -625,8 +676,13 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
 			__syncthreads();
 			const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-			for (int e = tid; e < je - jb && e < PM_MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
-			for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+			for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+			for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+			if (o.xpose)
+			{
+				for (int i = tid; i < 6 * cns; i += THREADS) sh.xs[i] = o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+				for (int i = tid; i < cns; i += THREADS) sh.side[i] = (unsigned char)(o.pside[sh.pose_of[i]] & 1);
+			}
 			K9T(0);
 			K9T_FLUSH(0, 1);
 			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile);

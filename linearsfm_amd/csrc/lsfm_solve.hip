@@ -27,8 +27,9 @@ static const unsigned long long HEMPTY = ~0ull;
 // passes find them ready instead of running a Cholesky with square roots and divisions on a dependent load each;
 // l00 = NaN marks a V^-1 without a Cholesky factor (the tile then goes to k_schur_w)
 // ymax (optional): per work-group the largest |L^T eb|^2 of its features -- what bounds K9's right-hand-side sums (k_schur_scale)
+// rhs (fused right-hand side): eb is the V part only; also leaves uu = [L^-1 x_f of the End source | of the Cur source]
 __global__ void __launch_bounds__(256) k_vinv(int NF, const double* __restrict__ V, const double* __restrict__ eb, double* __restrict__ IV, double* __restrict__ LY,
-                                               double* __restrict__ ymax)
+                                               double* __restrict__ ymax, RhsFused rhs, double* __restrict__ uu)
 {
 	__shared__ double wmax[4];
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,6 +57,24 @@ __global__ void __launch_bounds__(256) k_vinv(int NF, const double* __restrict__
 	if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) l[0] = __builtin_nan("");
 	st<9>(LY + (size_t)f * 9, l);
 	y2 = l[6] * l[6] + l[7] * l[7] + l[8] * l[8];
+	if (uu)
+	{
+#pragma unroll
+		for (int sd = 0; sd < 2; sd++)
+		{
+			const int fs = sd ? rhs.srcC[f] : rhs.srcE[f];
+			double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+			if (fs >= 0)
+			{
+				const double* x = rhs.feat_src + (size_t)fs * 3;
+				u0 = x[0] / l[0];
+				u1 = (x[1] - l[1] * u0) / l[2];
+				u2 = (x[2] - l[3] * u0 - l[4] * u1) / l[5];
+			}
+			uu[(size_t)f * 6 + 3 * sd] = u0; uu[(size_t)f * 6 + 3 * sd + 1] = u1; uu[(size_t)f * 6 + 3 * sd + 2] = u2;
+			y2 = fmax(y2, u0 * u0 + u1 * u1 + u2 * u2);
+		}
+	}
 	if (!(y2 == y2)) y2 = 0.0; // (a feature without a factor goes to k_schur_w, which checks its own sums)
 	}
 	if (!ymax) return;
@@ -100,7 +119,8 @@ __global__ void __launch_bounds__(256) k_schur_scale(int M, const int* __restric
 		for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, LSFM_WAVE));
 		if ((threadIdx.x & (LSFM_WAVE - 1)) == 0) wmax[threadIdx.x >> 6] = m;
 		__syncthreads();
-		if (threadIdx.x == 0) sexp[6 * (size_t)M] = half_exponent((double)NF * fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])));
+		// (+ 20: with the fused right-hand side y gains P^T x_p, of the size of L^T eb but not bounded by it -- two limbs leave 100 bits)
+		if (threadIdx.x == 0) sexp[6 * (size_t)M] = half_exponent((double)NF * fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]))) + 20;
 	}
 }
 // S -= (the integer sums of W V^-1 W^T); E += (the two limbs of -W V^-1 eb); a poisoned level leaves NaN everywhere (its
@@ -290,7 +310,7 @@ __global__ void k_schur_u(int NU, const double* __restrict__ U, const int* __res
 __global__ void __launch_bounds__(SCHUR_TILE)
 k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ IV,
           const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-          K9Out o, const unsigned char* __restrict__ only)
+          K9Out o, const unsigned char* __restrict__ only, const double* __restrict__ LY)
 {
 	if (only && !only[blockIdx.x]) return; // fallback pass: only the tiles the panel kernel could not take
 	// (the same fixed-point sums as the panel kernel's, k_schur_scale: per feature here, so already the LDS tables are integers)
@@ -312,7 +332,30 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 		const int j0 = fptr[f], len = fptr[f + 1] - j0;
 		double iv[9];
 		ld<9>(iv, IV + (size_t)f * 9);
-		const double eb0 = eb[(size_t)f * 3], eb1 = eb[(size_t)f * 3 + 1], eb2 = eb[(size_t)f * 3 + 2];
+		double eb0 = eb[(size_t)f * 3], eb1 = eb[(size_t)f * 3 + 1], eb2 = eb[(size_t)f * 3 + 2];
+		double xfs[2][3] = { { 0.0, 0.0, 0.0 }, { 0.0, 0.0, 0.0 } };
+		if (o.xpose)
+		{
+			// fused right-hand side (K9Out): eb += W^T x_p over the run; the feature's estimate in either source map = L u; y to yfull
+			for (int a = 0; a < len; a++)
+			{
+				const double* wa = W + (size_t)(j0 + a) * 18;
+				const double* xp = o.xpose + (size_t)photo[j0 + a] * 6;
+#pragma unroll
+				for (int r = 0; r < 6; r++) { eb0 = fma(wa[3 * r], xp[r], eb0); eb1 = fma(wa[3 * r + 1], xp[r], eb1); eb2 = fma(wa[3 * r + 2], xp[r], eb2); }
+			}
+			const double* l = LY + (size_t)f * 9;
+			if (!(l[0] == l[0])) bad = true; // (V^-1 without a factor: no y to leave -- the level is reported, as a NaN in S would be)
+#pragma unroll
+			for (int sd = 0; sd < 2; sd++)
+			{
+				const double* u = o.uu + (size_t)f * 6 + 3 * sd;
+				xfs[sd][0] = l[0] * u[0]; xfs[sd][1] = l[1] * u[0] + l[2] * u[1]; xfs[sd][2] = l[3] * u[0] + l[4] * u[1] + l[5] * u[2];
+			}
+			o.yfull[(size_t)f * 3] = l[0] * eb0 + l[1] * eb1 + l[3] * eb2;
+			o.yfull[(size_t)f * 3 + 1] = l[2] * eb1 + l[4] * eb2;
+			o.yfull[(size_t)f * 3 + 2] = l[5] * eb2;
+		}
 		for (int a = 0; a < len; a++)
 		{
 			double WV[18], Wa[18];
@@ -328,7 +371,8 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 #pragma unroll
 				for (int r = 0; r < 6; r++)
 				{
-					const double e = -(WV[3 * r] * eb0 + WV[3 * r + 1] * eb1 + WV[3 * r + 2] * eb2);
+					double e = -(WV[3 * r] * eb0 + WV[3 * r + 1] * eb1 + WV[3 * r + 2] * eb2);
+					if (o.xpose) { const double* xf = xfs[o.pside[pa] & 1]; e += Wa[3 * r] * xf[0] + Wa[3 * r + 1] * xf[1] + Wa[3 * r + 2] * xf[2]; }
 					long long hi, lo;
 					to_fixed2(e, 62 - ea6[r] - ey, hi, lo, bad);
 					if (es >= 0) { lds_add_i64(&evalv[es * 6 + r], hi); lds_add_i64(&evalv[SCHUR_ECAP * 6 + es * 6 + r], lo); }
@@ -655,7 +699,8 @@ k_spmv_gather(int M, int nent, const unsigned long long* __restrict__ ent, const
 __global__ void __launch_bounds__(256)
 k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
           const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,
-          const int* __restrict__ feat_seg, const unsigned char* __restrict__ active, double* __restrict__ xf)
+          const int* __restrict__ feat_seg, const unsigned char* __restrict__ active, double* __restrict__ xf,
+          const double* __restrict__ LY, const double* __restrict__ yfull)
 {
 	// one lane per W block (coalesced): W^T x_p, summed per feature through LDS; then x_f = V^-1 (eb - sum)
 	__shared__ int sFp[BSUB_TILE + 1];
@@ -686,6 +731,16 @@ k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 	{
 		const int f = f0 + fl;
 		if (active && !active[feat_seg[f]]) continue;
+		if (yfull)
+		{
+			// fused right-hand side: eb as a whole was never formed -- K9 left y = L^T eb: x_f = V^-1 (eb - s) = L (y - L^T s)
+			const double* l = LY + (size_t)f * 9;
+			const double s0 = sS[fl * 3], s1 = sS[fl * 3 + 1], s2 = sS[fl * 3 + 2];
+			const double d0 = yfull[(size_t)f * 3] - (l[0] * s0 + l[1] * s1 + l[3] * s2), d1 = yfull[(size_t)f * 3 + 1] - (l[2] * s1 + l[4] * s2),
+			             d2 = yfull[(size_t)f * 3 + 2] - l[5] * s2;
+			xf[(size_t)f * 3] = l[0] * d0; xf[(size_t)f * 3 + 1] = l[1] * d0 + l[2] * d1; xf[(size_t)f * 3 + 2] = l[3] * d0 + l[4] * d1 + l[5] * d2;
+			continue;
+		}
 		const double* iv = IV + (size_t)f * 9;
 		const double d[3] = { eb[(size_t)f * 3] - sS[fl * 3], eb[(size_t)f * 3 + 1] - sS[fl * 3 + 1], eb[(size_t)f * 3 + 2] - sS[fl * 3 + 2] };
 		for (int r = 0; r < 3; r++) xf[(size_t)f * 3 + r] = iv[3 * r] * d[0] + iv[3 * r + 1] * d[1] + iv[3 * r + 2] * d[2];
@@ -744,7 +799,9 @@ void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	sy.IV = ctx->scratch.alloc<double>((size_t)io.NF * 9);
 	sy.LY = ctx->scratch.alloc<double>((size_t)io.NF * 9);
 	sy.ymax = ctx->scratch.alloc<double>((size_t)(io.NF + 255) / 256 + 1);
-	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY, sy.ymax);
+	sy.uu = nullptr; sy.yfull = nullptr;
+	if (io.rhs) { sy.uu = ctx->scratch.alloc<double>((size_t)io.NF * 6); sy.yfull = ctx->scratch.alloc<double>((size_t)io.NF * 3); }
+	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY, sy.ymax, io.rhs ? *io.rhs : RhsFused(), sy.uu);
 }
 
 // ---- Pattern of S (hash of pose pairs, sorted key list, block CSR, SpMV index): depends on the index structure only ----
@@ -1206,6 +1263,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	K9Out ko;
 	ko.poison = sy.acc; ko.S = sy.acc + 1; ko.Ehi = ko.S + (size_t)cnt * 36; ko.Elo = ko.Ehi + (size_t)M * 6;
 	ko.sexp = sy.sexp; ko.ey = sy.sexp + (size_t)M * 6;
+	if (io.rhs) { ko.xpose = io.rhs->pose_src; ko.pside = io.rhs->pose_map_src; ko.uu = sy.uu; ko.yfull = sy.yfull; }
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
@@ -1229,7 +1287,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			launch_schur_slots(ctx, NF, io.fptr, io.photo, fb, sy.k9);
 		}
 		launch_schur_panel(ctx, NF, io.fptr, io.photo, io.W, sy.LY, tab, hval, mask, ko, fb, most, sy.k9, fresh_lists);
-		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, ko, fb);
+		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, ko, fb, sy.LY);
 		if (ctx->stats)
 		{
 			LSFM_CHECK_HIP(hipEventRecord(e3, s));
@@ -1240,6 +1298,9 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			// algorithmic flops of K9 = 144 NW + 108 (sum of squared run lengths + NW): the sum is taken on the device and read with
 			// the run's record at the end of a tree run (lsfm_tree_run adds 108 x that)
 			ctx->stats->schur_flops += (double)io.NW * (144.0 + 108.0);
+			// (the W part of the right-hand sides, when K9 takes it along: eF += W^T x_p and eP += W x_f, 36 multiply-adds a block,
+			// and the estimates they read -- until round 5 a pass of its own, k_join_rhs_w)
+			if (io.rhs) { ctx->stats->schur_flops += (double)io.NW * 72.0; ctx->stats->schur_bytes += (double)io.NF * (48 + 24) + (double)io.M * 48; }
 			if (ctx->in_tree_run && ctx->d_run)
 				hipLaunchKernelGGL(k_sum_run_squares, dim3(std::min((NF + 255) / 256, 512)), dim3(256), 0, s, NF, io.fptr, &ctx->d_run->k2);
 		}
@@ -1276,7 +1337,7 @@ void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy,
 {
 	if (io.NF)
 		hipLaunchKernelGGL(k_backsub, dim3((io.NF + BSUB_TILE - 1) / BSUB_TILE), dim3(256), 0, ctx->stream, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x,
-		                   io.d_feat_seg, io.d_seg_active, io.x_feat);
+		                   io.d_feat_seg, io.d_seg_active, io.x_feat, sy.LY, io.rhs ? sy.yfull : (const double*)nullptr);
 }
 
 void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV)
@@ -1286,7 +1347,7 @@ void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV)
 	double* LY = ctx->scratch.alloc<double>((size_t)NF * 9);
 	double* eb = ctx->scratch.alloc<double>((size_t)NF * 3);
 	dev_zero(ctx, eb, (size_t)NF * 3 * sizeof(double));
-	hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, ctx->stream, NF, V, eb, IV, LY, (double*)nullptr);
+	hipLaunchKernelGGL(k_vinv, dim3((NF + 255) / 256), dim3(256), 0, ctx->stream, NF, V, eb, IV, LY, (double*)nullptr, RhsFused(), (double*)nullptr);
 	LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
 	ctx->scratch.release(mk);
 }
@@ -1294,7 +1355,7 @@ void backsub_only(lsfm_context* ctx, int NF, const int* fptr, const int* photo, 
 {
 	if (NF)
 		hipLaunchKernelGGL(k_backsub, dim3((NF + BSUB_TILE - 1) / BSUB_TILE), dim3(256), 0, ctx->stream, NF, fptr, photo, W, IV, eb, xp,
-		                   (const int*)nullptr, (const unsigned char*)nullptr, xf);
+		                   (const int*)nullptr, (const unsigned char*)nullptr, xf, (const double*)nullptr, (const double*)nullptr);
 }
 
 // y = S x for an externally supplied symmetric block matrix (upper block CSR): measurement entry of the C ABI

@@ -38,6 +38,8 @@ struct SchurSystem {
 	// pose scalars' scales (2^sexp > 2 sqrt(U_ii)) and, at [6 M], the exponent that bounds |L^T eb| over the level
 	long long* acc = nullptr;
 	int* sexp = nullptr;
+	double* uu = nullptr;    // [NF * 6] fused right-hand side: L^-1 x_f for the End / Cur source of every feature (K9Out::uu)
+	double* yfull = nullptr; // [NF * 3] fused right-hand side: the complete y = L^T eb, written by K9, read by the back-substitution
 	double* ymax = nullptr; // [work-groups of k_vinv] largest |L^T eb|^2 of each
 	K9Cache k9;      // per-tile structure of K9 (null: every run works it out)
 	int k9_tiles = 0, k9_NW = 0;
@@ -63,6 +65,25 @@ struct K9Out {
 	long long* poison = nullptr; // != 0: an addend was not finite or outside its bound (the information matrices are not positive semi-definite)
 	const int* sexp = nullptr;   // [6 M]
 	const int* ey = nullptr;     // -> sexp[6 M]: 2^ey bounds |L^T eb| over the level's features
+	// The W part of the join's right-hand sides taken by K9 itself (a pass over W of its own until round 5: k_join_rhs_w): non-null =
+	// eb holds the V part only (k_join_features), E starts as U's part of the pose side.  With P = W L of a pass:
+	//   y = L^T (eb + W^T x_p) = L^T eb + P^T x_p           (x_p: the estimates of the poses, xpose)
+	//   E -= P (y - u),  u = L^-1 x_f                        (x_f: the estimate of the feature in the map the block came from:
+	//                                                         uu = [u of its End source | u of its Cur source] per feature, k_vinv;
+	//                                                         pside[pose] & 1 says which map a pose -- and so its blocks -- came from)
+	// and y itself goes to yfull for the back-substitution, x_f = L (y - L^T sum W^T x_p).   Imp.cpp:2770-2786, 2822-2838, 2891-2906
+	const double* xpose = nullptr;
+	const int* pside = nullptr;
+	const double* uu = nullptr;
+	double* yfull = nullptr;
+};
+// what the fused right-hand side needs beside the joint map (lsfm_join.hip): per joint feature its sources in the level's input,
+// their estimates, the poses' estimates and maps
+struct RhsFused {
+	const int *srcE = nullptr, *srcC = nullptr; // [NF] source feature in the input batch, -1: none
+	const double* feat_src = nullptr;           // [input features * 3]
+	const double* pose_src = nullptr;           // [M * 6]
+	const int* pose_map_src = nullptr;          // [M] map of the input batch a pose belongs to (odd: the second map of its pair)
 };
 void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* LY,
                         const unsigned long long* tab, const int* val, unsigned long long mask, K9Out out, unsigned char* fallback,

@@ -62,8 +62,11 @@ def test_trees_through_the_small_path(ctx, both, oracle, mono, n_maps):
     assert sa["t_small_ms"] > 0.0
     for k in ("stno", "Ui", "Uj", "photo", "feature"):
         assert np.array_equal(a[k], b[k]), k
-    assert pose_param_err(a["stVal"], b["stVal"], b["stno"]) < 1e-9
-    assert feat_param_err(a["stVal"], b["stVal"], b["stno"]) < 1e-9
+    # (Mono: two runs of the SAME path differ by up to 7e-9 on sets of this kind -- profiles/r05_sharded_noise.txt, "single tree vs
+    # itself" -- the monocular scale is observable through shared points only; Stereo: 1e-12)
+    tol = 1e-7 if mono else 1e-9
+    assert pose_param_err(a["stVal"], b["stVal"], b["stno"]) < tol
+    assert feat_param_err(a["stVal"], b["stVal"], b["stno"]) < tol
     exp, _, rc = oracle.divide_conquer(dicts, mono)
     assert rc == 0
     assert np.array_equal(a["stno"], exp["stno"])

@@ -50,6 +50,22 @@ def pmc_traffic(config):
         return None
 
 
+def twin_floor(config):
+    """How far the oracle (fp64) and its long-double twin differ on THIS set under the same two error definitions (tools/oracle_twin_floor.py
+    -> profiles/r*_oracle_twin_floor_<config>.json; a CPU run of minutes, made once): what the device's distance from the oracle is to be
+    read against -- a true relative error of a few 1e-5 on near-zero angles is the reference's own arithmetic, not the device's."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_oracle_twin_floor_{config}.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"pose_param_max_rel_err_oracle_vs_long_double_twin": d["pose_param_max_rel_err_oracle_vs_twin"],
+                "pose_param_max_true_rel_err_oracle_vs_long_double_twin": d["pose_param_max_true_rel_err_oracle_vs_twin"],
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def spmv_stream(args, ctx, rank, world, torch, dist, synth_mod):
     """--config spmv-stream: the CG's SpMV kernel (K10a, k_spmv) alone on a Schur-like matrix too large for the caches
     (pose chain with 12 neighbours + 12 dense hub rows, 262 144 poses, 1.38 GB of upper blocks).  On the tree configurations S
@@ -364,7 +380,10 @@ def main():
                                            "interior to block r, one exact int64 all-reduce of the inter-block separators' accumulators, the separators by every rank; "
                                            "share = block products (6x6x6) of the shared columns / all, over rank 0's top-tree levels"} if world > 1 else None),
             "device_breakdown_ms": {k: acc.get(k, 0.0) / args.steps for k in
-                                    ("t_total_ms", "t_transform_ms", "t_join_ms", "t_schur_ms", "t_pcg_ms", "t_backsub_ms")},
+                                    ("t_total_ms", "t_transform_ms", "t_join_ms", "t_schur_ms", "t_pcg_ms", "t_backsub_ms", "t_small_ms")},
+            "dense_path": {"levels_per_step": acc.get("small_levels", 0) / args.steps, "ms_per_step": acc.get("t_small_ms", 0.0) / args.steps,
+                           "note": "tree levels whose camera systems (at most 5 poses) are assembled, factored and solved by one launch, one "
+                                   "work-group per join (lsfm_small.hip, lsfm_set_small_solve); K9's roofline counts the levels K9 runs on"},
             "pcg_iterations_per_step": acc.get("pcg_iterations", 0) / args.steps,
             "max_rel_residual": (stats or {}).get("max_rel_residual"),
             "not_converged": (stats or {}).get("not_converged"),
@@ -467,6 +486,7 @@ def main():
                                                             "pair; gpu_same_sample_resolve_ms: repeat runs of the resident tree",
                                     "pose_param_max_rel_err_vs_oracle": perr,
                                     "pose_param_max_true_rel_err_vs_oracle": perr_true,
+                                    "reference_arithmetic_floor": twin_floor(args.config),
                                     "pose_param_err_definition": "max_rel_err: |a - b| / max(1, |b|) (translations of a monocular set are scale-normalised to O(1), "
                                                                  "angles are <= 0.3 rad: an absolute error below 1); max_true_rel_err: |a - b| / max(|b|, 1e-3 x the "
                                                                  "largest scalar of its kind)",

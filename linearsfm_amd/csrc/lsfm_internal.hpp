@@ -439,6 +439,9 @@ struct SolveIO {
 	// optional (Stereo tree levels on the sparse pipeline): the W part of the right-hand sides is left to the Schur assembly -- ea
 	// holds U's part only, eb the V part (lsfm_solve.hpp RhsFused; null: ea / eb are complete)
 	const struct RhsFused* rhs = nullptr;
+	// optional (Mono tree levels that analyse): the pattern of S follows from the pattern of the level below instead of being built
+	// from every pose pair of every feature again (lsfm_solve.hpp PatternSeed; null: from scratch)
+	const struct PatternSeed* seed = nullptr;
 };
 int small_solve_strips(int most_poses, int cap); // 16-row strips of the dense path's panel; 0: the systems are too large for it (cap: lsfm_context::small_max)
 void small_solve_launch(lsfm_context* ctx, const SolveIO& io, int strips, int* status, double* max_rel);

@@ -15,6 +15,7 @@
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
 #include "lsfm_join.hpp"
+#include "lsfm_solve.hpp"
 
 namespace lsfm {
 
@@ -37,13 +38,16 @@ __global__ void k_mono_find(int M, const int* __restrict__ pose_id, const int* _
 	if (id == g.scap) { if (mp & 1) g.C2 = k; else g.P2 = k; }
 }
 
-__global__ void k_mono_pose_flags(int M, const int* __restrict__ pose_map, const MGroup* __restrict__ grp, int* __restrict__ removed)
+// removed: Cur's copies of the shared poses (they become End's); dropped: the poses whose U / W blocks the join drops (the
+// gauge-fixed reference pose on either side)
+__global__ void k_mono_pose_flags(int M, const int* __restrict__ pose_map, const MGroup* __restrict__ grp, int* __restrict__ removed, unsigned char* __restrict__ dropped)
 {
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k > M) return;
 	if (k == M) { removed[M] = 0; return; }
 	const MGroup& g = grp[pose_map[k] >> 1];
 	removed[k] = (g.pair && (k == g.C1 || k == g.C2)) ? 1 : 0;
+	dropped[k] = (g.pair && (k == g.P1 || k == g.C1)) ? 1 : 0;
 }
 
 // wrap-around of the scale pose's angles, in place on the copy of the prior poses (Imp.cpp:7427-7465)
@@ -409,12 +413,13 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	MGroup* d_mg = sc.alloc<MGroup>(G);
 	h2d(ctx, d_mg, mg.data(), sizeof(MGroup) * G);
 	int* removed = sc.alloc<int>(M + 1);
+	unsigned char* dropped = sc.alloc<unsigned char>(M + 1);
 	int* R = sc.alloc<int>(M + 2);
 	int* pnew = sc.alloc<int>(M + 1);
 	double* prior = sc.alloc<double>((size_t)M * 6);
 	const int nbp = (M + 255) / 256;
 	hipLaunchKernelGGL(k_mono_find, dim3(nbp), dim3(256), 0, s, M, in.pose_id, in.pose_map, d_mg);
-	hipLaunchKernelGGL(k_mono_pose_flags, dim3((M + 256) / 256), dim3(256), 0, s, M, in.pose_map, d_mg, removed);
+	hipLaunchKernelGGL(k_mono_pose_flags, dim3((M + 256) / 256), dim3(256), 0, s, M, in.pose_map, d_mg, removed, dropped);
 	dev_exclusive_scan(ctx, removed, R, M);
 	LSFM_CHECK_HIP(hipMemcpyAsync(prior, in.pose, (size_t)M * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
 	hipLaunchKernelGGL(k_mono_wrap, dim3((G + 127) / 128), dim3(128), 0, s, G, d_mg, prior);
@@ -595,7 +600,24 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 			io.d_pose_off = out.d_pose_off; io.d_feat_off = out.d_feat_off; io.d_u_off = d_uo;
 		}
 	}
+	// the pattern of this level's system from the one below (a level that analyses; the level below left its pattern with its maps)
+	PatternSeed seed;
+	static const bool seed_on = !getenv("LSFM_NO_MONO_SEED");
+	if (seed_on && !warm && in.s_keys && in.s_nnzb > 0 && !ctx->comm)
+	{
+		seed.prev_keys = in.s_keys; seed.prev_nnzb = in.s_nnzb; seed.pnew = pnew; seed.dropped = dropped;
+		seed.NFY = NFY; seed.srcE = srcE; seed.srcC = srcC; seed.fptr_in = in.fptr; seed.photo_in = in.photo;
+		io.seed = &seed;
+	}
+	ctx->solved_keys = nullptr; ctx->solved_nnzb = 0;
 	int rc = solve_batch(ctx, io);
+	if (!warm && ctx->in_tree_run && ctx->solved_keys && ctx->solved_nnzb > 0 && !ctx->comm)
+	{
+		// ... and this level's pattern stays with its output for the level above
+		unsigned long long* k = ar.alloc<unsigned long long>((size_t)ctx->solved_nnzb + 1);
+		LSFM_CHECK_HIP(hipMemcpyAsync(k, ctx->solved_keys, (size_t)ctx->solved_nnzb * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+		out.s_keys = k; out.s_nnzb = ctx->solved_nnzb;
+	}
 	hipLaunchKernelGGL(k_mono_finish, dim3((G + 127) / 128), dim3(128), 0, s, G, d_mg, pnew, out.pose);
 	if (!warm) LSFM_CHECK_HIP(hipStreamSynchronize(s)); // a warm level is only enqueued: its scratch is reused in stream order
 	sc.release(smark);

@@ -869,6 +869,53 @@ static void pattern_finish(lsfm_context* ctx, const SolveIO& io, const PatternBu
 }
 
 __global__ void k_pat_insert_keys(int n, const unsigned long long* __restrict__ keys, unsigned long long* tab, unsigned long long mask, int* overflow);
+// the pattern of the level below through the join's pose renumbering (PatternSeed)
+__global__ void k_pat_insert_keys_remap(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ pnew, const unsigned char* __restrict__ dropped,
+                                        unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int a = (int)(keys[i] >> 32), b = (int)(keys[i] & 0xffffffffull);
+	if (dropped[a] || dropped[b]) return;
+	hash_insert(tab, mask, pair_key(pnew[a], pnew[b]), overflow);
+}
+// ... and the pairs across the two sources of a matched joint feature
+__global__ void __launch_bounds__(256)
+k_pat_insert_cross_remap(PatternSeed sd, unsigned long long* tab, unsigned long long mask, int* overflow)
+{
+	// (the wave in step, like k_pat_insert_w: neighbouring features are seen by the same poses -- when every lane asks for the same
+	// pair, one lane inserts it)
+	const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+	int jE = 0, lenE = 0, jC = 0, lenC = 0;
+	if (nf < sd.NFY)
+	{
+		const int fe = sd.srcE[nf], fc = sd.srcC[nf];
+		if (fe >= 0 && fc >= 0) { jE = sd.fptr_in[fe]; lenE = sd.fptr_in[fe + 1] - jE; jC = sd.fptr_in[fc]; lenC = sd.fptr_in[fc + 1] - jC; }
+	}
+	int maxE = lenE, maxC = lenC;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { maxE = max(maxE, __shfl_xor(maxE, off, LSFM_WAVE)); maxC = max(maxC, __shfl_xor(maxC, off, LSFM_WAVE)); }
+	const int lane = threadIdx.x & (LSFM_WAVE - 1);
+	for (int a = 0; a < maxE; a++)
+	{
+		int na = -1;
+		if (a < lenE) { const int pa = sd.photo_in[jE + a]; if (!sd.dropped[pa]) na = sd.pnew[pa]; }
+		for (int b = 0; b < maxC; b++)
+		{
+			int nb = -1;
+			if (na >= 0 && b < lenC) { const int pb = sd.photo_in[jC + b]; if (!sd.dropped[pb]) nb = sd.pnew[pb]; }
+			const bool v = nb >= 0;
+			const unsigned long long key = v ? pair_key(na, nb) : 0ull;
+			const unsigned long long m = __ballot(v);
+			if (m == 0ull) continue;
+			const int leader = __ffsll((long long)m) - 1;
+			const unsigned long long first = (unsigned long long)__shfl((long long)key, leader, LSFM_WAVE);
+			const bool uniform = __ballot(v && key != first) == 0ull;
+			if (uniform) { if (lane == leader) hash_insert(tab, mask, key, overflow); }
+			else if (v) hash_insert(tab, mask, key, overflow);
+		}
+	}
+}
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 {
 	hipStream_t s = ctx->stream;
@@ -882,7 +929,15 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		pattern_begin(ctx, cap, pb);
 		const int nu = std::max(io.NU, M);
 		if (nu) hipLaunchKernelGGL(k_pat_insert_u, dim3((nu + 255) / 256), dim3(256), 0, s, io.NU, M, io.Ui, io.Uj, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
-		if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
+		const PatternSeed* sd = (io.seed && io.seed->prev_keys && !ctx->comm) ? io.seed : nullptr;
+		if (sd)
+		{
+			// (until round 5 every Mono level that analyses hashed every pose pair of every feature again: 66 GB and 28 ms of a
+			// synth-16k tree, profiles/r04_pmc_traffic_summary_synth16k.json)
+			if (sd->prev_nnzb) hipLaunchKernelGGL(k_pat_insert_keys_remap, dim3((sd->prev_nnzb + 255) / 256), dim3(256), 0, s, sd->prev_nnzb, sd->prev_keys, sd->pnew, sd->dropped, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
+			if (sd->NFY) hipLaunchKernelGGL(k_pat_insert_cross_remap, dim3((sd->NFY + 255) / 256), dim3(256), 0, s, *sd, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
+		}
+		else if (NF) hipLaunchKernelGGL(k_pat_insert_w, dim3((NF + 255) / 256), dim3(256), 0, s, NF, io.fptr, io.photo, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
 		pattern_compact(ctx, pb);
 		int cnt = 0;
 		bool ok = pattern_count(ctx, pb, &cnt);
@@ -923,6 +978,28 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		if (ok)
 		{
 			pattern_finish(ctx, io, pb, cnt, sy);
+			if (sd && getenv("LSFM_CHECK_MONO_SEED"))
+			{
+				// debug / test: the pattern built from the finished joint map must be contained in the seeded one (a pair the seeded
+				// pattern lacked would lose its share of S without a word) -- and, the seed being exact, equal to it
+				LSFM_CHECK_HIP(hipDeviceSynchronize());
+				SolveIO plain = io;
+				plain.seed = nullptr;
+				SchurSystem ref;
+				build_schur_pattern(ctx, plain, ref);
+				std::vector<unsigned long long> a(sy.nnzb), b(ref.nnzb);
+				d2h(ctx, a.data(), sy.upper_keys, a.size() * sizeof(unsigned long long));
+				d2h(ctx, b.data(), ref.upper_keys, b.size() * sizeof(unsigned long long));
+				size_t missing = 0, ia = 0;
+				for (unsigned long long k : b)
+				{
+					while (ia < a.size() && a[ia] < k) ia++;
+					if (ia == a.size() || a[ia] != k) missing++;
+				}
+				if (missing || a.size() != b.size())
+					LSFM_FAIL(LSFM_ERR_INTERNAL, "seeded pattern of S (" + std::to_string(a.size()) + " blocks) against the joint map's (" + std::to_string(b.size()) + "): " +
+					                                 std::to_string(missing) + " pair(s) missing");
+			}
 			build_spmv_index(ctx, sy, pb.list, pb.d_flags);
 			return;
 		}

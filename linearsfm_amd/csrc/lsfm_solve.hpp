@@ -46,6 +46,20 @@ struct SchurSystem {
 	double k9_flops = 0; // algorithmic flops of the numeric Schur complement of this system (structure only)
 };
 
+// The pattern of a Mono level's camera system from the one below (the Stereo levels have had this since round 3, through the early
+// pattern): every pose pair inside one source map is in the level below's pattern -- a joint feature is seen by everything its
+// sources were seen by --, the transform's hub links are blocks of the joint U, and what is new are the pairs ACROSS the two sources of
+// a matched feature.  Poses are renumbered by the join (Cur's copies of the shared reference / scale pose become End's: pnew), and the
+// blocks of the gauge-fixed reference pose are dropped (Imp.cpp:7482-7547, 7619-7700): `dropped`.
+struct PatternSeed {
+	const unsigned long long* prev_keys = nullptr; // sorted upper pattern of the level below, in the INPUT batch's pose numbering
+	int prev_nnzb = 0;
+	const int* pnew = nullptr;               // [input poses] -> joint pose
+	const unsigned char* dropped = nullptr;  // [input poses] 1: a pose whose U / W blocks the join drops
+	int NFY = 0;                             // joint features
+	const int *srcE = nullptr, *srcC = nullptr; // [NFY] source features in the input batch (-1: none)
+	const int *fptr_in = nullptr, *photo_in = nullptr; // W runs of the input batch
+};
 void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 bool schur_pattern_early_finish(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void schur_pattern_early_extras(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);

@@ -1138,6 +1138,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 
 	out = DevBatch();
 	out.B = B; out.M = in.M; out.NF = in.NF;
+	if (mono) { out.s_keys = in.s_keys; out.s_nnzb = in.s_nnzb; } // (pose indices are unchanged: the pattern below travels with the maps, lsfm_join_mono.hip)
 	out.pose_off = in.pose_off; out.feat_off = in.feat_off;
 	out.Ref = in.Ref; out.FRef = in.FRef; out.ScaP = in.ScaP; out.Fix = in.Fix; out.Sign = in.Sign; out.FScaP = in.FScaP; out.FFix = in.FFix;
 	// nothing of `out` may alias `in`: the two live in different arenas with different lifetimes

@@ -436,3 +436,26 @@ def test_factorisation_is_bit_reproducible(config, n_maps):
     # round 5: the camera systems themselves -- S and E of every level ASSEMBLED twice from the same joint maps (U scatter, every panel
     # variant of K9, the per-feature fallback) -- are the same bits too: K9 adds in fixed point (k_schur_scale, lsfm_schur_panel.hip)
     assert int(line[5]) == 0, line
+
+
+@pytest.mark.parametrize("n_maps", [24, 150])
+def test_mono_pattern_from_the_level_below_equals_the_joint_maps(ctx, oracle, monkeypatch, n_maps):
+    """Mono levels that analyse build the pattern of S from the pattern of the level below (through the join's pose renumbering) +
+    the joint U + the pairs across the two sources of matched features (PatternSeed, lsfm_solve.hip).  LSFM_CHECK_MONO_SEED=1 makes
+    every such level ALSO hash every pose pair of every feature of its joint maps, as before, and fail unless the two patterns are
+    the same set -- a pair the seed lacked would lose its share of S silently.  The dense path is switched off so that every level
+    has a pattern; the result is held to the oracle's."""
+    maps = synth.make_mono_set(n_maps, 8, 4, seed=9, **synth.SPIRAL)
+    dicts = [dict(m.__dict__) for m in maps]
+    monkeypatch.setenv("LSFM_CHECK_MONO_SEED", "1")
+    try:
+        ctx.set_small_solve(0)
+        got, stats, rc = ctx.divide_conquer(dicts, True)
+    finally:
+        ctx.set_small_solve(5)
+    monkeypatch.delenv("LSFM_CHECK_MONO_SEED")
+    assert rc == 0, stats
+    exp, _, orc = oracle.divide_conquer(dicts, True)
+    assert orc == 0
+    _same_structure(got, exp)
+    assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < TREE_TOL

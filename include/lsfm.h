@@ -331,6 +331,11 @@ int lsfm_write_localmap(const char* path, int mono, const lsfm_map* map);
  * out[count] (library-allocated; LSFM_ERR_IO and nothing kept when the file is truncated, foreign or of the other map type). */
 int lsfm_write_mapset(const char* path, const lsfm_map* maps, int N, int mono);
 int lsfm_mapset_info(const char* path, int* N, int* mono);
+/* Eight bytes of the cache's header are the writer's: a stamp of what the cache was made from (0: none).  set_to != NULL writes it, stamp
+ * (optional) receives what the file holds afterwards.  The command line stamps a cache with a hash of the resolved -path and of the size and
+ * modification time of every localmap_k.txt it parsed, and parses again when the files no longer match (advisor, round 4: a cache was trusted
+ * whenever it held enough maps of the right type). */
+int lsfm_mapset_stamp(const char* path, unsigned long long* stamp, const unsigned long long* set_to);
 int lsfm_read_mapset(const char* path, int mono, int first, int count, int threads, lsfm_map* out);
 int lsfm_save_state(const char* path, const double* st, const int* stno, int n);
 /* the same state vector as raw doubles (parity tooling): int32 n, int32 0, stno[n] (+ 4 bytes of padding when n is odd),

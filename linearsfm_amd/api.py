@@ -128,7 +128,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_set_stop_level", "lsfm_tree_node_count", "lsfm_tree_download_node", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_set_comm_blocks", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
-           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_write_mapset", "lsfm_mapset_info", "lsfm_read_mapset", "lsfm_save_state_bin", "lsfm_save_state", "lsfm_save_poses",
+           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_write_mapset", "lsfm_mapset_info", "lsfm_mapset_stamp", "lsfm_read_mapset", "lsfm_save_state_bin", "lsfm_save_state", "lsfm_save_poses",
            "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
 
 

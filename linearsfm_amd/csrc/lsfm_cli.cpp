@@ -9,6 +9,7 @@
 // -cache <file> (binary cache of the set: read instead of the text files when it holds -num maps of -type, written after the text files
 // were parsed otherwise), -fullbin <file> (final state as raw doubles), -json <file> (the run's lsfm_stats and phase times as one JSON object).
 #include <chrono>
+#include <sys/stat.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,13 +81,42 @@ int main(int argc, char** argv)
 	const double w0 = now();
 	std::vector<lsfm_map> maps(num);
 	bool from_cache = false;
+	// what a cache must have been made from to be believed: the resolved directory and size + modification time of its first n text files
+	// (FNV-1a; 0 is "no stamp": never produced)
+	auto source_stamp = [&](int n, bool* all_there) {
+		unsigned long long h = 1469598103934665603ull;
+		auto mix = [&](const void* p, size_t len) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < len; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+		char* rp = realpath(path.c_str(), nullptr);
+		const std::string dir = rp ? rp : path;
+		free(rp);
+		mix(dir.data(), dir.size());
+		*all_there = true;
+		for (int k = 1; k <= n; k++)
+		{
+			struct stat st;
+			const std::string fn = path + "/localmap_" + std::to_string(k) + ".txt";
+			if (stat(fn.c_str(), &st) != 0) { *all_there = false; return 0ull; }
+			const long long v[3] = { (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long long)st.st_mtim.tv_nsec };
+			mix(v, sizeof v);
+		}
+		return h ? h : 1ull;
+	};
 	if (!cache.empty())
 	{
-		// the binary cache of an earlier run over this set: used when it holds what is asked for, (re)written otherwise
+		// the binary cache of an earlier run over this set: used when it holds what is asked for AND was made from the text files as they
+		// are now (its stamp); (re)written otherwise.  Text files that are gone cannot contradict it: the cache is then all there is.
 		int cn = 0, cm = 0;
 		if (lsfm_mapset_info(cache.c_str(), &cn, &cm) == LSFM_OK && cn >= num && cm == type)
-			from_cache = lsfm_read_mapset(cache.c_str(), type, 0, num, 0, maps.data()) == LSFM_OK;
-		if (!from_cache && cn) fprintf(stderr, "LinearSFM: %s does not hold %d %s maps: reading the text files\n", cache.c_str(), num, type ? "Monocular" : "Stereo");
+		{
+			unsigned long long have = 0;
+			bool there = false;
+			const unsigned long long want = source_stamp(cn, &there);
+			(void)lsfm_mapset_stamp(cache.c_str(), &have, nullptr);
+			if (there && have != want)
+				fprintf(stderr, "LinearSFM: %s was not made from the text files under %s as they are now: reading them again\n", cache.c_str(), path.c_str());
+			else from_cache = lsfm_read_mapset(cache.c_str(), type, 0, num, 0, maps.data()) == LSFM_OK;
+		}
+		else if (cn) fprintf(stderr, "LinearSFM: %s does not hold %d %s maps: reading the text files\n", cache.c_str(), num, type ? "Monocular" : "Stereo");
 	}
 	if (!from_cache)
 	{
@@ -97,7 +127,13 @@ int main(int argc, char** argv)
 			fprintf(stderr, "LinearSFM: cannot read %s/localmap_%d.txt\n", path.c_str(), bad);
 			return 1;
 		}
-		if (!cache.empty() && lsfm_write_mapset(cache.c_str(), maps.data(), num, type)) fprintf(stderr, "LinearSFM: cannot write %s\n", cache.c_str());
+		if (!cache.empty())
+		{
+			bool there = false;
+			const unsigned long long stamp = source_stamp(num, &there);
+			if (lsfm_write_mapset(cache.c_str(), maps.data(), num, type) || lsfm_mapset_stamp(cache.c_str(), nullptr, &stamp))
+				fprintf(stderr, "LinearSFM: cannot write %s\n", cache.c_str());
+		}
 	}
 	const double w1 = now();
 	lsfm_context* ctx = nullptr;

@@ -336,6 +336,25 @@ int lsfm_mapset_info(const char* path, int* N, int* mono)
 	return LSFM_OK;
 }
 
+// A cache says nothing of the text files it was made from unless its writer leaves a stamp (include/lsfm.h): 8 bytes of the header's padding
+int lsfm_mapset_stamp(const char* path, unsigned long long* stamp, const unsigned long long* set_to)
+{
+	if (!path) return LSFM_ERR_ARG;
+	FILE* f = fopen(path, set_to ? "r+b" : "rb");
+	if (!f) return LSFM_ERR_IO;
+	SetHeader h;
+	bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, SET_MAGIC, 8) == 0 && h.version == 1 && h.N >= 0;
+	if (ok && set_to)
+	{
+		memcpy(&h.pad[0], set_to, 8);
+		ok = fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof h, 1, f) == 1;
+	}
+	fclose(f);
+	if (!ok) return LSFM_ERR_IO;
+	if (stamp) memcpy(stamp, &h.pad[0], 8);
+	return LSFM_OK;
+}
+
 // maps first .. first+count-1 (0-based) of a cache on `threads` host threads; everything is checked against the file size before
 // a byte is copied (a truncated or foreign file is LSFM_ERR_IO, never a wild read)
 int lsfm_read_mapset(const char* path, int mono, int first, int count, int threads, lsfm_map* out)

@@ -181,3 +181,38 @@ def test_cli_binary_cache_json_and_binary_state(tmp_path):
     r = subprocess.run([exe, "-path", str(d), "-num", "12", "-type", "Stereo", "-cache", cache, "-json", js, "-quiet", "1"], capture_output=True, text=True, check=True)
     assert "does not hold 12 Stereo maps" in r.stderr and json.load(open(js))["from_cache"] is False
     assert api.mapset_info(cache) == (12, False)
+
+
+def test_cli_cache_is_not_trusted_once_the_text_files_changed(tmp_path):
+    """-cache carries a stamp of what it was made from (resolved -path, size and modification time of every localmap_k.txt): a set that was
+    regenerated under the same directory, with the same -num and -type, is parsed again instead of answered from the stale cache (advisor,
+    round 4); text files that are gone cannot contradict the cache, which is then all there is."""
+    import json
+    import shutil
+    import time
+    exe = os.path.join(ROOT, "linearsfm_amd", "LinearSFM")
+    d = tmp_path / "set"
+    cache = str(tmp_path / "set.lsfmbin")
+
+    def run(tag):
+        full, js = str(tmp_path / f"full_{tag}"), str(tmp_path / f"json_{tag}")
+        r = subprocess.run([exe, "-path", str(d), "-num", "8", "-type", "Stereo", "-cache", cache, "-full", full, "-json", js, "-quiet", "1"],
+                           capture_output=True, text=True, check=True)
+        vals = np.array([[float(x) for x in l.split()] for l in open(full).read().splitlines()])
+        return json.load(open(js))["from_cache"], vals, r.stderr
+
+    synth.write_set(str(d), synth.make_stereo_set(8, 6, 4, seed=8))
+    c0, a, _ = run("a")
+    c1, b, _ = run("b")
+    assert c0 is False and c1 is True
+    time.sleep(0.05)
+    synth.write_set(str(d), synth.make_stereo_set(8, 6, 4, seed=9))  # other values, same directory, same -num / -type
+    c2, c, err = run("c")
+    assert c2 is False and "not made from the text files" in err
+    assert np.max(np.abs(c[:, 1] - a[:, 1])) > 1e-3  # the new set's map, not the cached one's
+    c3, _, _ = run("d")
+    assert c3 is True  # (the cache was replaced and stamped anew)
+    shutil.rmtree(d)
+    os.makedirs(d)
+    c4, e, _ = run("e")
+    assert c4 is True and np.max(np.abs(e[:, 1] - c[:, 1])) <= RESUME_TOL * max(1.0, np.max(np.abs(c[:, 1])))

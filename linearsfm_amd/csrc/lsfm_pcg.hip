@@ -2459,7 +2459,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			schur_pattern_early_drop(ctx);
 			{
 				SchurSystem prepared = pre->sy; // the index members; V^-1 and its factor are this level's (schur_vinv above)
-				prepared.IV = sy.IV; prepared.LY = sy.LY; prepared.ymax = sy.ymax; prepared.uu = sy.uu; prepared.yfull = sy.yfull;
+				prepared.IV = sy.IV; prepared.LY = sy.LY; prepared.ymax = sy.ymax; prepared.uu = sy.uu;
 				sy = prepared;
 			}
 			have = true;

@@ -7,7 +7,12 @@
 // contraction over the 3 * PM_TILE feature columns: the panel is staged PM_PASS features at a time in LDS and the
 // 16x16 tiles of the upper block triangle of P P^T are accumulated with v_mfma_f64_16x16x4_f64, the tiles dealt round
 // robin to the waves of the work-group.  No lane idles on an absent pose pair and every touched block of S leaves the
-// work-group once.  The right-hand side part is the panel times y = L^T eb, one panel row per lane.
+// work-group once.  The right-hand side rides on the same products: E -= P (y - u) with y = L^T eb + P^T x_p (K9Out) is
+//   E_r -= (P z_side(r))_r + sum_r' (P P^T)_rr' x_p,r',    z_side = L^T eb - u_side,
+// so the two vectors z_End, z_Cur are two more ROWS of the panel behind the poses' (the products of a row with them come out of
+// the MFMAs as two more columns of P P^T -- in the spare rows of the last 16-row strip unless the poses fill it), and the second
+// term is the finished tile of P P^T times the poses' estimates, once per tile.  (Round 5 first had both per PASS on the vector
+// units -- column sums of the panel, two more barriers, a strip-wise P z: a fifth of the kernel.)
 //
 // Variants by the number of slots of a tile (launch_schur_panel): 8 / 16 / 32 slots with 256 threads (4 / 3 / 2
 // work-groups per CU), 48 and 64 slots with 1024 threads (one work-group per CU; 64: the output tiles in two sweeps over
@@ -82,20 +87,22 @@ template <int SMAX>
 struct PmShared {
 	// (the widest panel fills a CU's LDS: its list of block slots is shorter -- later blocks read the level's copy -- and nothing here is wider than it must be)
 	static constexpr int MAXE = SMAX > PM_SMAX_BIG ? 2560 : PM_MAXE;
+	// rows of the panel: six per slot and two more for the right-hand side (below); whole 16-row strips.  The widest variant has no
+	// room for a strip more: it takes tiles of up to 63 poses
+	static constexpr int PROWS = SMAX >= PM_SMAX_MAX ? 6 * SMAX : 6 * SMAX + 16;
+	static constexpr int CAP = (PROWS - 2) / 6 < SMAX ? (PROWS - 2) / 6 : SMAX; // poses of a tile this variant takes
 	int pose_of[SMAX];
 	int nslots, bad;
 	unsigned char bf[PM_BF]; // block of the pass -> its feature (the first PM_BF blocks; later ones search the run pointers)
 	int fpt[PM_TILE + 1]; // run pointers of the tile's features: the prefetch of a pass must not wait for them first
 	short sexp[6 * SMAX];   // binary exponent of the scale of every panel row (K9Out::sexp of the slot's pose)
-	// fused right-hand side (K9Out::xpose): estimate of every panel row's pose scalar, the map side of every slot's pose, per pass
-	// L^-1 x_f of the features' two sources, the partial column sums of P^T x_p and z = y - u for either side
-	double xs[6 * SMAX];
+	// right-hand side (K9Out): estimate of every panel row's pose scalar (zero: not fused, and past the tile's rows), the map side
+	// of every slot's pose, per pass L^-1 x_f of the features' two sources
+	double xs[PROWS];
 	unsigned char side[SMAX];
 	double uu[PM_PASS * 6];
-	double cpart[5 * PM_K];
-	double z[2 * PM_K];
 	double ly[PM_PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
-	alignas(16) double P[6 * SMAX * PM_KS];
+	alignas(16) double P[PROWS * PM_KS];
 	unsigned char eslot[MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
 };
 
@@ -106,11 +113,12 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
                                         const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         const K9Out& o, unsigned char* __restrict__ fallback,
-                                        const unsigned char* __restrict__ ces, int tile, int q0 = 0, bool first_sweep = true)
+                                        const unsigned char* __restrict__ ces, int tile, int q0 = 0)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
 	K9T_DECL;
-	const int rows = 6 * ns, NT = (rows + 15) >> 4, ntile = NT * (NT + 1) / 2;
+	// (rows: the poses' rows; behind them rows and rows + 1 hold z of the End / the Cur side)
+	const int rows = 6 * ns, NT = (rows + 2 + 15) >> 4, ntile = NT * (NT + 1) / 2;
 	int ti[T], tj[T], offA[T], offB[T]; // wave-uniform
 	const int lbase = (lane & 15) * PM_KS + (lane >> 4);
 	v4d acc[T];
@@ -133,10 +141,6 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		offB[t] = 16 * j * PM_KS;
 		acc[t] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
 	}
-	constexpr int NE = ((6 * SMAX + 15) / 16 + THREADS / 64 - 1) / (THREADS / 64); // 16-row strips of the panel per wave
-	double eacc[NE];
-#pragma unroll
-	for (int i = 0; i < NE; i++) eacc[i] = 0.0;
 	// Everything a pass reads from memory is fetched into registers before the MFMA loop of the pass before it, and none of
 	// it behind a dependent load: the run pointers of the tile sit in LDS, the W rows of a pass are ONE contiguous range
 	// (row w of the pass = 3 doubles at W[18 qb0 + 3 w]: consecutive lanes, consecutive 24 bytes, whatever the lengths of
@@ -153,7 +157,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	constexpr int PF = THREADS != 256 ? (T <= 6 ? 3 : 2) : (T <= 3 ? 4 : (T <= 6 ? LSFM_K9_PF6 : (T <= 14 ? 3 : 2)));
 	double pw[PF][3];
 	double lyv = 0.0, uuv = 0.0;
-	const bool fused = o.xpose != nullptr && first_sweep; // (the right-hand side is the first sweep's; uniform)
+	const bool fused = o.xpose != nullptr; // (uniform)
 	int qb0 = 0, R = 0;
 	auto prefetch = [&](int p0n) {
 		const int nfn = min(PM_PASS, f1 - p0n);
@@ -208,6 +212,14 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		// LDS slot list) wait for the barrier and are added
 		bool later = false;
 		const double* wb = W + (size_t)qb0 * 18;
+		if (tid < PM_K)
+		{
+			// the right-hand side's two rows: z = L^T eb - u of either source side (u = 0: not fused; zero past the last feature)
+			const int fl = tid / 3, c = tid - 3 * fl;
+			const double yv = sh.ly[fl * 9 + 6 + c];
+			sh.P[rows * PM_KS + tid] = yv - sh.uu[fl * 6 + c];
+			sh.P[(rows + 1) * PM_KS + tid] = yv - sh.uu[fl * 6 + 3 + c];
+		}
 		auto stage = [&](int w, double w0, double w1, double w2, bool second) {
 			const int e = w / 6, r = w - 6 * e, j = qb0 + e;
 			int sl, dup = 1;
@@ -260,77 +272,9 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			__syncthreads();
 		}
 		K9T(4);
-		const int pcur = p0;
 		if (p0 + PM_PASS < f1) prefetch(p0 + PM_PASS);
 		else { R = 0; lyv = 0.0; uuv = 0.0; }
 		K9T(12);
-		if (fused)
-		{
-			// y = L^T eb + P^T x_p (the W part of eF, Imp.cpp:2776-2786 and its twins, through the panel): column sums of the panel
-			// weighted by the rows' pose estimates, THREADS / 48 partial sums a column
-			constexpr int NP = 5; // (240 threads: 5 per column)
-			const int col = tid % PM_K, part = tid / PM_K;
-			if (part < NP)
-			{
-				double cs = 0.0;
-				for (int row = part; row < rows; row += NP) cs = fma(sh.P[row * PM_KS + col], sh.xs[row], cs);
-				sh.cpart[part * PM_K + col] = cs;
-			}
-			__syncthreads();
-			if (tid < PM_K)
-			{
-				const int fl = tid / 3, c = tid - 3 * fl;
-				double y = sh.ly[fl * 9 + 6 + c];
-#pragma unroll
-				for (int q = 0; q < NP; q++) y += sh.cpart[q * PM_K + tid];
-				sh.ly[fl * 9 + 6 + c] = y;
-				sh.z[tid] = y - sh.uu[fl * 6 + c];
-				sh.z[PM_K + tid] = y - sh.uu[fl * 6 + 3 + c];
-				if (pcur + fl < f1) o.yfull[(size_t)(pcur + fl) * 3 + c] = y; // (for the back-substitution)
-			}
-			__syncthreads();
-		}
-		// E_p -= W V^-1 eb = P y, Imp.cpp:2321-2328.  By 16-row strips over ALL the waves: lane (row l & 15 of the strip, quarter
-		// l >> 4 of the 48 columns) sums 12 products, two shuffles add the quarters up -- 24 LDS reads a lane instead of the 96 of
-		// one lane per panel row, which only the first wave or two took part in (a quarter of a 16-slot tile's clocks).  The
-		// panel and y are zero past the pass's last feature and past the tile's rows: no bounds in the loop.
-		if (first_sweep)
-		{
-			const int kq = lane >> 4;
-#pragma unroll
-			for (int si = 0; si < NE; si++)
-			{
-				const int strip = wave + (THREADS / 64) * si; // wave-uniform
-				if (strip < NT)
-				{
-					const double* pr = &sh.P[(16 * strip + (lane & 15)) * PM_KS + 12 * kq];
-					double s0 = 0.0, s1 = 0.0;
-					if (fused)
-					{
-						// E -= P (y - u): u = L^-1 x_f of the source map the row's pose belongs to (eP += W x_f, Imp.cpp:2770-2775)
-						const int prow = 16 * strip + (lane & 15);
-						const double* zq = &sh.z[(prow < rows && sh.side[prow / 6] ? PM_K : 0) + 12 * kq];
-#pragma unroll
-						for (int k = 0; k < 12; k += 2) { s0 = fma(pr[k], zq[k], s0); s1 = fma(pr[k + 1], zq[k + 1], s1); }
-					}
-					else
-					{
-					const double* yq = &sh.ly[kq * 36 + 6];
-#pragma unroll
-					for (int k = 0; k < 12; k += 2)
-					{
-						s0 = fma(pr[k], yq[(k / 3) * 9 + k % 3], s0);
-						s1 = fma(pr[k + 1], yq[((k + 1) / 3) * 9 + (k + 1) % 3], s1);
-					}
-					}
-					double sum = s0 + s1;
-					sum += __shfl_xor(sum, 16, 64);
-					sum += __shfl_xor(sum, 32, 64);
-					eacc[si] -= sum;
-				}
-			}
-		}
-		K9T(11);
 		// P P^T, four feature columns per MFMA: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15].
 		// Always the full PM_K columns (zero past the last feature); the T tiles of a step are independent chains
 		constexpr int UNR = T <= 1 ? PM_K / 4 : (T <= 3 ? 4 : (T <= 6 ? 2 : 1));
@@ -360,8 +304,72 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		const int si = q / ns, sj = q - si * ns;
 		pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
 	}
+	// ... and behind them the tile's right-hand side rows, two limbs each (the same fixed point as in memory: whatever order the
+	// waves add in, the sum is the same)
+	long long* eh = reinterpret_cast<long long*>(sh.P) + ((ns * ns + 1) >> 1);
+	long long* el = eh + rows;
+	for (int q = tid; q < 2 * rows; q += THREADS) eh[q] = 0;
 	__syncthreads();
 	bool bad = false;
+	const int ey = *o.ey;
+	// E_R -= sum_C (P P^T)_RC m_C: m_C = the estimate of pose scalar C; for the two columns behind the poses' (P z_End, P z_Cur)
+	// 1 on the rows of that side's poses.  Off the diagonal a tile stands for its mirror image too: E_C -= sum_R (P P^T)_RC x_R.
+#pragma unroll
+	for (int t = 0; t < T; t++)
+	{
+		if (ti[t] < 0) continue; // (uniform)
+		const int C = 16 * tj[t] + (lane & 15), Rb = 16 * ti[t] + (lane >> 4);
+		if (!fused && 16 * tj[t] + 15 < rows) continue; // (uniform: without estimates only the tiles of the last strip count)
+		const double xc = C < rows ? sh.xs[C] : 0.0;
+		const int zc = C - rows;
+		const bool mirror = ti[t] != tj[t] && fused;
+		double rs[4], cs = 0.0;
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+		{
+			const int R = Rb + 4 * e;
+			const double v = acc[t][e];
+			double term = v * xc;
+			if (zc >= 0) term = (zc < 2 && R < rows && sh.side[R / 6] == zc) ? v : 0.0;
+			rs[e] = term;
+			if (mirror && C < rows) cs = fma(v, sh.xs[R], cs); // (xs is zero past the poses' rows)
+		}
+#pragma unroll
+		for (int off = 1; off < 16; off <<= 1)
+		{
+#pragma unroll
+			for (int e = 0; e < 4; e++) rs[e] += __shfl_xor(rs[e], off, 64);
+		}
+		if ((lane & 15) == 0)
+		{
+#pragma unroll
+			for (int e = 0; e < 4; e++)
+			{
+				const int R = Rb + 4 * e;
+				if (R < rows && rs[e] != 0.0)
+				{
+					// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
+					long long hi, lo;
+					to_fixed2(-rs[e], 62 - sh.sexp[R] - ey, hi, lo, bad);
+					lds_add_i64(eh + R, hi);
+					if (lo) lds_add_i64(el + R, lo);
+				}
+			}
+		}
+		if (mirror)
+		{
+			cs += __shfl_xor(cs, 16, 64);
+			cs += __shfl_xor(cs, 32, 64);
+			if (lane < 16 && C < rows && cs != 0.0)
+			{
+				long long hi, lo;
+				to_fixed2(-cs, 62 - sh.sexp[C] - ey, hi, lo, bad);
+				lds_add_i64(eh + C, hi);
+				if (lo) lds_add_i64(el + C, lo);
+			}
+		}
+	}
+	K9T(11);
 #pragma unroll
 	for (int t = 0; t < T; t++)
 	{
@@ -398,23 +406,13 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			}
 		}
 	}
-	if (lane < 16)
+	__syncthreads();
+	for (int row = tid; row < rows; row += THREADS)
 	{
-		const int ey = *o.ey;
-#pragma unroll
-		for (int si = 0; si < NE; si++)
-		{
-			const int row = 16 * (wave + (THREADS / 64) * si) + lane;
-			if (row < rows && eacc[si] != 0.0)
-			{
-				// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
-				long long hi, lo;
-				to_fixed2(eacc[si], 62 - sh.sexp[row] - ey, hi, lo, bad);
-				const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
-				atomic_add_i64(o.Ehi + at, hi);
-				if (lo) atomic_add_i64(o.Elo + at, lo);
-			}
-		}
+		const long long hi = eh[row], lo = el[row];
+		const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
+		if (hi) atomic_add_i64(o.Ehi + at, hi);
+		if (lo) atomic_add_i64(o.Elo + at, lo);
 	}
 	if (bad) atomic_add_i64(o.poison, 1);
 	K9T(6);
@@ -431,18 +429,20 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
                                       unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces, int tile)
 {
 	constexpr int NW = THREADS / 64;
-	const int NT = (6 * ns + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform
+	const int NT = (6 * ns + 2 + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform (strips: pm_body)
 #define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile)
 	if constexpr (SMAX <= 8)
 	{
 		if (tpw <= 1) PM_GO(1);
-		else PM_GO(2); // 48 rows: 6 tiles over 4 waves
+		else if (tpw <= 2) PM_GO(2); // 3 strips: 6 tiles over 4 waves
+		else PM_GO(3); // (8 poses: a fourth strip for the right-hand side's rows)
 	}
 	else if constexpr (SMAX <= 16)
 	{
 		if (tpw <= 1) PM_GO(1);
 		else if (tpw <= 3) PM_GO(3);
-		else PM_GO(6); // 96 rows: 21 tiles over 4 waves
+		else if (tpw <= 6) PM_GO(6); // 6 strips: 21 tiles over 4 waves
+		else PM_GO(7); // (16 poses: a seventh strip)
 	}
 	else
 	{
@@ -451,7 +451,7 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		// wave at 128 registers: 400-640 spilled registers in the 48 / 64-slot variants).  Wider panels take their output tiles
 		// in sweeps over the tile's passes: 32 slots 78 tiles = 10 per wave, 48 slots 171 tiles = 2 sweeps of 11, 64 slots
 		// 300 tiles = 3 sweeps of 13.
-		constexpr int TS = SMAX <= PM_SMAX ? 10 : (SMAX <= PM_SMAX_BIG ? 11 : 13);
+		constexpr int TS = SMAX <= PM_SMAX ? 10 : (SMAX <= PM_SMAX_BIG ? 12 : 13);
 		if (tpw <= 1) PM_GO(1);
 		else if (tpw <= 3) PM_GO(3);
 		else if (tpw <= 6) PM_GO(6);
@@ -460,7 +460,7 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		{
 			for (int q0 = 0; q0 < NW * tpw; q0 += NW * TS)
 			{
-				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile, q0, q0 == 0);
+				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile, q0);
 				if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
 			}
 		}
@@ -550,7 +550,8 @@ __global__ void __launch_bounds__(PM_THREADS) k_schur_slots(int NF, const int* _
 		}
 	}
 	__syncthreads();
-	if (tid == 0) kc.ns[blockIdx.x] = ns;
+	// (more poses than the widest panel takes -- its last strip has no room for the right-hand side's rows: k_schur_w)
+	if (tid == 0) kc.ns[blockIdx.x] = ns > PmShared<PM_SMAX_MAX>::CAP ? -ns : ns;
 	if (tid < ns) kc.pose[(size_t)blockIdx.x * PM_SMAX_MAX + tid] = sh.pose_of[tid];
 	for (int e = tid; e < je - jb; e += PM_THREADS)
 	{
@@ -629,7 +630,7 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		const int tile = blockIdx.x;
 		const int cns = kc.ns[tile];
 		if (cns >= 0 && cns <= lo) return; // (lo: widest panel of the narrower variants launched beside this one)
-		if (cns < 0 || cns > SMAX)
+		if (cns < 0 || cns > PmShared<SMAX>::CAP)
 		{
 			// more poses than the hash table of the slots kernel holds, or -- where this is the only variant launched (levels of
 			// small systems; a tile may straddle systems and see more poses than any one of them has) -- than the panel: k_schur_w
@@ -645,11 +646,8 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
 		for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
 		for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
-		if (o.xpose)
-		{
-			for (int i = tid; i < 6 * cns; i += THREADS) sh.xs[i] = o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6];
-			for (int i = tid; i < cns; i += THREADS) sh.side[i] = (unsigned char)(o.pside[sh.pose_of[i]] & 1);
-		}
+		for (int i = tid; i < PmShared<SMAX>::PROWS; i += THREADS) sh.xs[i] = (o.xpose && i < 6 * cns) ? o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6] : 0.0;
+		for (int i = tid; i < cns; i += THREADS) sh.side[i] = o.pside ? (unsigned char)(o.pside[sh.pose_of[i]] & 1) : (unsigned char)0;
 		// (visible to the passes through the barrier at the top of the first pass)
 		K9T(0);
 		K9T_FLUSH(0, 1);
@@ -678,11 +676,8 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
 			for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
 			for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
-			if (o.xpose)
-			{
-				for (int i = tid; i < 6 * cns; i += THREADS) sh.xs[i] = o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6];
-				for (int i = tid; i < cns; i += THREADS) sh.side[i] = (unsigned char)(o.pside[sh.pose_of[i]] & 1);
-			}
+			for (int i = tid; i < PmShared<SMAX>::PROWS; i += THREADS) sh.xs[i] = (o.xpose && i < 6 * cns) ? o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6] : 0.0;
+			for (int i = tid; i < cns; i += THREADS) sh.side[i] = o.pside ? (unsigned char)(o.pside[sh.pose_of[i]] & 1) : (unsigned char)0;
 			K9T(0);
 			K9T_FLUSH(0, 1);
 			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile);

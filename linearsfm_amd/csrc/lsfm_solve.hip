@@ -336,7 +336,7 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 		double xfs[2][3] = { { 0.0, 0.0, 0.0 }, { 0.0, 0.0, 0.0 } };
 		if (o.xpose)
 		{
-			// fused right-hand side (K9Out): eb += W^T x_p over the run; the feature's estimate in either source map = L u; y to yfull
+			// fused right-hand side (K9Out): eb += W^T x_p over the run; the feature's estimate in either source map = L u
 			for (int a = 0; a < len; a++)
 			{
 				const double* wa = W + (size_t)(j0 + a) * 18;
@@ -352,9 +352,6 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 				const double* u = o.uu + (size_t)f * 6 + 3 * sd;
 				xfs[sd][0] = l[0] * u[0]; xfs[sd][1] = l[1] * u[0] + l[2] * u[1]; xfs[sd][2] = l[3] * u[0] + l[4] * u[1] + l[5] * u[2];
 			}
-			o.yfull[(size_t)f * 3] = l[0] * eb0 + l[1] * eb1 + l[3] * eb2;
-			o.yfull[(size_t)f * 3 + 1] = l[2] * eb1 + l[4] * eb2;
-			o.yfull[(size_t)f * 3 + 2] = l[5] * eb2;
 		}
 		for (int a = 0; a < len; a++)
 		{
@@ -700,7 +697,7 @@ __global__ void __launch_bounds__(256)
 k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W,
           const double* __restrict__ IV, const double* __restrict__ eb, const double* __restrict__ xp,
           const int* __restrict__ feat_seg, const unsigned char* __restrict__ active, double* __restrict__ xf,
-          const double* __restrict__ LY, const double* __restrict__ yfull)
+          const double* __restrict__ LY, const double* __restrict__ xhat)
 {
 	// one lane per W block (coalesced): W^T x_p, summed per feature through LDS; then x_f = V^-1 (eb - sum)
 	__shared__ int sFp[BSUB_TILE + 1];
@@ -717,6 +714,13 @@ k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 			const double* a = xp + (size_t)photo[j] * 6;
 			double a6[6];
 			ld<6>(a6, a);
+			if (xhat)
+			{
+				// (fused right-hand side: the step from the poses' estimates, see below)
+				const double* h = xhat + (size_t)photo[j] * 6;
+#pragma unroll
+				for (int r = 0; r < 6; r++) a6[r] -= h[r];
+			}
 #pragma unroll
 			for (int c = 0; c < 3; c++)
 			{
@@ -731,13 +735,14 @@ k_backsub(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
 	{
 		const int f = f0 + fl;
 		if (active && !active[feat_seg[f]]) continue;
-		if (yfull)
+		if (xhat)
 		{
-			// fused right-hand side: eb as a whole was never formed -- K9 left y = L^T eb: x_f = V^-1 (eb - s) = L (y - L^T s)
+			// fused right-hand side: eb as a whole was never formed (eb here is its V part; the W part is W^T x^_p, x^_p the poses'
+			// estimates): x_f = V^-1 (eb + W^T x^_p - W^T x_p) = L (L^T eb - L^T s), s = sum W^T (x_p - x^_p) over the feature's run
 			const double* l = LY + (size_t)f * 9;
 			const double s0 = sS[fl * 3], s1 = sS[fl * 3 + 1], s2 = sS[fl * 3 + 2];
-			const double d0 = yfull[(size_t)f * 3] - (l[0] * s0 + l[1] * s1 + l[3] * s2), d1 = yfull[(size_t)f * 3 + 1] - (l[2] * s1 + l[4] * s2),
-			             d2 = yfull[(size_t)f * 3 + 2] - l[5] * s2;
+			const double d0 = l[6] - (l[0] * s0 + l[1] * s1 + l[3] * s2), d1 = l[7] - (l[2] * s1 + l[4] * s2),
+			             d2 = l[8] - l[5] * s2;
 			xf[(size_t)f * 3] = l[0] * d0; xf[(size_t)f * 3 + 1] = l[1] * d0 + l[2] * d1; xf[(size_t)f * 3 + 2] = l[3] * d0 + l[4] * d1 + l[5] * d2;
 			continue;
 		}
@@ -799,8 +804,8 @@ void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	sy.IV = ctx->scratch.alloc<double>((size_t)io.NF * 9);
 	sy.LY = ctx->scratch.alloc<double>((size_t)io.NF * 9);
 	sy.ymax = ctx->scratch.alloc<double>((size_t)(io.NF + 255) / 256 + 1);
-	sy.uu = nullptr; sy.yfull = nullptr;
-	if (io.rhs) { sy.uu = ctx->scratch.alloc<double>((size_t)io.NF * 6); sy.yfull = ctx->scratch.alloc<double>((size_t)io.NF * 3); }
+	sy.uu = nullptr;
+	if (io.rhs) sy.uu = ctx->scratch.alloc<double>((size_t)io.NF * 6);
 	if (io.NF) hipLaunchKernelGGL(k_vinv, dim3((io.NF + 255) / 256), dim3(256), 0, ctx->stream, io.NF, io.V, io.eb, sy.IV, sy.LY, sy.ymax, io.rhs ? *io.rhs : RhsFused(), sy.uu);
 }
 
@@ -1340,7 +1345,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	K9Out ko;
 	ko.poison = sy.acc; ko.S = sy.acc + 1; ko.Ehi = ko.S + (size_t)cnt * 36; ko.Elo = ko.Ehi + (size_t)M * 6;
 	ko.sexp = sy.sexp; ko.ey = sy.sexp + (size_t)M * 6;
-	if (io.rhs) { ko.xpose = io.rhs->pose_src; ko.pside = io.rhs->pose_map_src; ko.uu = sy.uu; ko.yfull = sy.yfull; }
+	if (io.rhs) { ko.xpose = io.rhs->pose_src; ko.pside = io.rhs->pose_map_src; ko.uu = sy.uu; }
 	if (NF)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
@@ -1414,7 +1419,7 @@ void launch_backsub(lsfm_context* ctx, const SolveIO& io, const SchurSystem& sy,
 {
 	if (io.NF)
 		hipLaunchKernelGGL(k_backsub, dim3((io.NF + BSUB_TILE - 1) / BSUB_TILE), dim3(256), 0, ctx->stream, io.NF, io.fptr, io.photo, io.W, sy.IV, io.eb, x,
-		                   io.d_feat_seg, io.d_seg_active, io.x_feat, sy.LY, io.rhs ? sy.yfull : (const double*)nullptr);
+		                   io.d_feat_seg, io.d_seg_active, io.x_feat, sy.LY, io.rhs ? io.rhs->pose_src : (const double*)nullptr);
 }
 
 void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV)

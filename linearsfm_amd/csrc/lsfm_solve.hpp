@@ -39,7 +39,6 @@ struct SchurSystem {
 	long long* acc = nullptr;
 	int* sexp = nullptr;
 	double* uu = nullptr;    // [NF * 6] fused right-hand side: L^-1 x_f for the End / Cur source of every feature (K9Out::uu)
-	double* yfull = nullptr; // [NF * 3] fused right-hand side: the complete y = L^T eb, written by K9, read by the back-substitution
 	double* ymax = nullptr; // [work-groups of k_vinv] largest |L^T eb|^2 of each
 	K9Cache k9;      // per-tile structure of K9 (null: every run works it out)
 	int k9_tiles = 0, k9_NW = 0;
@@ -85,11 +84,11 @@ struct K9Out {
 	//   E -= P (y - u),  u = L^-1 x_f                        (x_f: the estimate of the feature in the map the block came from:
 	//                                                         uu = [u of its End source | u of its Cur source] per feature, k_vinv;
 	//                                                         pside[pose] & 1 says which map a pose -- and so its blocks -- came from)
-	// and y itself goes to yfull for the back-substitution, x_f = L (y - L^T sum W^T x_p).   Imp.cpp:2770-2786, 2822-2838, 2891-2906
+	// (lsfm_schur_panel.hip has how the panel kernel gets both out of its matrix products); the back-substitution needs no y of its
+	// own: x_f = L (L^T eb - L^T sum W^T (x_p - x^_p)), k_backsub.   Imp.cpp:2770-2786, 2822-2838, 2891-2906
 	const double* xpose = nullptr;
 	const int* pside = nullptr;
 	const double* uu = nullptr;
-	double* yfull = nullptr;
 };
 // what the fused right-hand side needs beside the joint map (lsfm_join.hip): per joint feature its sources in the level's input,
 // their estimates, the poses' estimates and maps

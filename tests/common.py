@@ -12,11 +12,13 @@ MAPKEYS = ("Ref", "FRef", "m", "n", "ScaP", "Fix", "Sign", "FScaP", "FFix", "stn
 # inputs and result), and the top joins of two mid-size trees (m = 64-90 poses, lap closures, features with 20-30 W blocks)
 GOLD_SMALL = ["stereo_n2.npz", "stereo_n3.npz", "stereo_n5.npz", "stereo_n8.npz", "mono_n2.npz", "mono_n3.npz", "mono_n5.npz", "mono_n8.npz"]
 GOLD_MID = ["stereo_n64_top1.npz", "mono_n88_top2.npz"]
-# ... and of four sets with LONG tracks (every point visible for 34-44 frames): the one tile of 128 features of their top join is seen by
-# 48 / 64 (Stereo) and 47 / 61 (Mono) poses, features have runs of up to 41-60 W blocks -- what the 48- and the 64-slot variant of the
-# device's Schur panel kernel and its tile lists (k_schur_lists) take; expected PANEL_SLOTS[name] = the variant's width
-GOLD_WIDE = ["stereo_n48_wide_top1.npz", "stereo_n64_wide_top1.npz", "mono_n46_wide_top1.npz", "mono_n60_wide_top1.npz"]
-PANEL_SLOTS = {"stereo_n48_wide_top1.npz": 48, "stereo_n64_wide_top1.npz": 64, "mono_n46_wide_top1.npz": 48, "mono_n60_wide_top1.npz": 64}
+# ... and of five sets with LONG tracks (every point visible for 34-44 frames): the one tile of 128 features of their top join is seen by
+# 48 / 62 / 64 (Stereo) and 47 / 61 (Mono) poses, features have runs of up to 41-60 W blocks -- what the 48- and the 64-slot variant of
+# the device's Schur panel kernel and its tile lists (k_schur_lists) take, and (64 poses: one more than the widest panel holds beside the
+# right-hand side's two rows) the per-feature kernel k_schur_w; expected PANEL_SLOTS[name] = the variant's width, 0 = k_schur_w
+GOLD_WIDE = ["stereo_n48_wide_top1.npz", "stereo_n62_wide_top1.npz", "stereo_n64_wide_top1.npz", "mono_n46_wide_top1.npz", "mono_n60_wide_top1.npz"]
+PANEL_SLOTS = {"stereo_n48_wide_top1.npz": 48, "stereo_n62_wide_top1.npz": 64, "stereo_n64_wide_top1.npz": 0, "mono_n46_wide_top1.npz": 48, "mono_n60_wide_top1.npz": 64}
+PANEL_RANGE = {48: (33, 48), 64: (49, 63), 0: (64, 1 << 30)}  # poses of a tile -> variant (lsfm_schur_panel.hip PmShared::CAP)
 
 
 def tile_pose_counts(photo, feature, n, tile=128):

@@ -320,6 +320,9 @@ def main():
         # variant of its Schur panel kernel off the tile lists (k_schur_lists), and the dense-revisit paths of the transform's pose table
         run_top("Stereo", synth.make_stereo_set(48, new_per_frame=1, vis=40, seed=21), os.path.join(out, "stereo_n48_wide_top1.npz"), tmp, 1)
         run_top("Stereo", synth.make_stereo_set(64, new_per_frame=1, vis=44, seed=22), os.path.join(out, "stereo_n64_wide_top1.npz"), tmp, 1)
+        # (62 poses: the widest tile the 64-slot variant takes -- two rows of its last 16-row strip carry the right-hand side; the 64-pose
+        # tile above goes to the per-feature kernel k_schur_w)
+        run_top("Stereo", synth.make_stereo_set(62, new_per_frame=1, vis=43, seed=25), os.path.join(out, "stereo_n62_wide_top1.npz"), tmp, 1)
         run_top("Monocular", synth.make_mono_set(46, new_per_frame=1, vis=34, seed=23, **synth.SPIRAL), os.path.join(out, "mono_n46_wide_top1.npz"), tmp, 1)
         run_top("Monocular", synth.make_mono_set(60, new_per_frame=1, vis=40, seed=24, **synth.SPIRAL), os.path.join(out, "mono_n60_wide_top1.npz"), tmp, 1)
 

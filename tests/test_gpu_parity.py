@@ -6,7 +6,7 @@ the dense expected value."""
 import numpy as np
 import pytest
 
-from common import (GOLD_MID, GOLD_SMALL, GOLD_WIDE, PANEL_SLOTS, tile_pose_counts, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
+from common import (GOLD_MID, GOLD_SMALL, GOLD_WIDE, PANEL_RANGE, PANEL_SLOTS, tile_pose_counts, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
                     pose_param_err, pose_param_true_rel_err, ref_map, rel_err)
 from linearsfm_amd import synth
 
@@ -89,8 +89,8 @@ def test_solve_every_reference_assembled_system_vs_dense_lapack(ctx, name):
             # the wide fixtures: their one tile is seen by more poses than the 32-slot panel holds and by no more than the expected
             # variant does -- launch_schur_panel (lsfm_schur_panel.hip) then hands it to exactly that variant, off its tile list
             ns = tile_pose_counts(J["photo"], J["feature"], J["n"])
-            lo = {48: 33, 64: 49}[PANEL_SLOTS[name]]
-            assert len(ns) == 1 and lo <= ns[0] <= PANEL_SLOTS[name], (name, ns)
+            lo, hi = PANEL_RANGE[PANEL_SLOTS[name]]
+            assert len(ns) == 1 and lo <= ns[0] <= hi, (name, ns)
         st, rc = ctx.solve(J, ea, eb, mono, sa)
         assert rc == 0
         xd = z[f"join{j}.dense_sol"]

@@ -461,6 +461,8 @@ struct EarlyPatternIn {
 void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in); // enqueues on the side stream; the caller has recorded evC
 void schur_pattern_early_drop(lsfm_context* ctx);
 // target_ref[b] of the NEXT level's transform for every map of `Y` (-1: passed through), as run_level will compute it
+unsigned timing_event_flags(); // (lsfm_prims.hip: events without the system-scope fence)
+unsigned order_event_flags();
 void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int next_level, int step_hint);
 // the block pattern of S alone (K8), from the index members of io: upper block CSR left in the scratch arena
 void schur_pattern_only(lsfm_context* ctx, const SolveIO& io, int* nnzb, const int** rowptr, const int** colidx);

@@ -291,12 +291,22 @@ void lsfm_context::mark(const char* what)
 	if (!timeline_on) return;
 	timeline.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
 }
+namespace lsfm {
+// The events of the path are recorded some 250 times per tree, between kernels of one stream.  A default event ends with a system-scope
+// release -- cache write-back and invalidation for the HOST's sake -- and the kernel behind it starts 5-15 us late (rocprofv3
+// kernel trace of round 5: every gap of that size on the main queue sat at a hipEventRecord).  Nothing here needs that: the events that
+// bracket phases are read by hipEventElapsedTime after the run's stream synchronisation, the others order streams of ONE device
+// (device-scope release); what the host reads it reads behind a stream synchronisation of its own.  LSFM_EVENTS_DEFAULT=1: as before.
+static bool events_default() { static const bool v = getenv("LSFM_EVENTS_DEFAULT") != nullptr; return v; }
+unsigned timing_event_flags() { return events_default() ? hipEventDefault : hipEventDisableSystemFence; }
+unsigned order_event_flags() { return events_default() ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice); }
+}
 hipEvent_t lsfm_context::pool_event()
 {
 	if (ev_next == ev_pool.size())
 	{
 		hipEvent_t e = nullptr;
-		LSFM_CHECK_HIP(hipEventCreate(&e));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&e, lsfm::timing_event_flags()));
 		ev_pool.push_back(e);
 	}
 	return ev_pool[ev_next++];
@@ -389,21 +399,21 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 			LSFM_CHECK_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest));
 		}
-		for (auto& e : c->ev_k9) LSFM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
-		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
-		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
-		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evY, hipEventDisableTiming));
-		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
-		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evK, hipEventDisableTiming));
+		for (auto& e : c->ev_k9) LSFM_CHECK_HIP(hipEventCreateWithFlags(&e, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evA, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evB, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evC, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evY, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evP, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evK, lsfm::order_event_flags()));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		c->stage_size = (size_t)64 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
-		LSFM_CHECK_HIP(hipEventCreate(&c->ev0));
-		LSFM_CHECK_HIP(hipEventCreate(&c->ev1));
-		LSFM_CHECK_HIP(hipEventCreate(&c->ev2));
-		LSFM_CHECK_HIP(hipEventCreate(&c->ev3));
-		for (auto& e : c->evs) LSFM_CHECK_HIP(hipEventCreate(&e));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev0, lsfm::timing_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev1, lsfm::timing_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev2, lsfm::timing_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev3, lsfm::timing_event_flags()));
+		for (auto& e : c->evs) LSFM_CHECK_HIP(hipEventCreateWithFlags(&e, lsfm::timing_event_flags()));
 		LSFM_CHECK_HIP(hipMalloc((void**)&c->d_run, sizeof(lsfm::RunStatsDev)));
 		LSFM_CHECK_HIP(hipMemset(c->d_run, 0, sizeof(lsfm::RunStatsDev)));
 		if (arena_bytes) c->ensure_arenas(arena_bytes);

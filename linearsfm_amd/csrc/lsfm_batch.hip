@@ -419,7 +419,7 @@ int wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps, doub
 	hipStream_t s = ctx->stream;
 	double* a = ctx->scratch.alloc<double>((size_t)nblocks * 18);
 	double* b = ctx->scratch.alloc<double>((size_t)nblocks * 18);
-	LSFM_CHECK_HIP(hipMemsetAsync(a, 0, (size_t)nblocks * 144, s));
+	fill_async(s, a, 0, (size_t)nblocks * 144);
 	float total = 0;
 	for (int k = 0; k < reps + 2; k++)
 	{

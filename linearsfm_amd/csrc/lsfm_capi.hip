@@ -122,6 +122,13 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 	// stage times from events on the stream (a warm level is only enqueued: host clocks say nothing about it)
 	hipEvent_t e_t0 = ctx->pool_event(), e_t1 = ctx->pool_event(), e_t2 = ctx->pool_event();
 	LSFM_CHECK_HIP(hipEventRecord(e_t0, ctx->stream));
+	{
+		// LSFM_LEVEL_GAPS=1: what the device waited for the host between the levels of a run (the event behind a level's solve was
+		// handed over long before the host got here; this one is stamped when the stream reaches it, or when it arrives)
+		static const bool gaps = getenv("LSFM_LEVEL_GAPS") != nullptr;
+		if (gaps && ctx->ev_solve_end && ctx->in_tree_run) ctx->defer_time(ctx->ev_solve_end, e_t0, &ctx->dbg_gap_ms);
+		ctx->ev_solve_end = nullptr;
+	}
 	// three arenas in rotation: X (this level; slot -1 = the resident inputs, never written) stays alive until the join
 	// is done, because the W blocks of the maps the transform passes through are read from X, not copied (W_alias)
 	const int so = t->slot < 0 ? 0 : (t->slot + 1) % 3, sm = t->slot < 0 ? 1 : (t->slot + 2) % 3;
@@ -238,6 +245,7 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 	ctx->arena[0].reset(); ctx->arena[1].reset(); ctx->arena[2].reset(); ctx->scratch.reset();
 	ctx->stage_off = 0; // the stream is idle: the staging ring starts over
 	ctx->drop_prepared(); ctx->early.reset(); ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // nothing prepared by an earlier run
+	ctx->ev_solve_end = nullptr;
 	LSFM_CHECK_HIP(hipMemsetAsync(ctx->d_run, 0, sizeof(RunStatsDev), ctx->stream));
 	static const bool poison = getenv("LSFM_POISON") != nullptr; // debug: every byte a run has not written itself reads as NaN / -1
 	if (poison)
@@ -438,6 +446,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				break;
 			}
 			ctx->flush_times();
+			if (getenv("LSFM_LEVEL_GAPS")) { fprintf(stderr, "[lsfm] device idle between the levels of this run: %.3f ms\n", ctx->dbg_gap_ms); ctx->dbg_gap_ms = 0.0; }
 		}
 		catch (...) { ctx->stats = nullptr; throw; }
 		ctx->stats = nullptr;

@@ -253,6 +253,7 @@ struct lsfm_context {
 	std::string last_error;
 	int* h_pinned = nullptr; // small pinned staging buffer for counters
 	char* h_stage = nullptr; // pinned ring for small host->device copies: they are enqueued, not waited for
+	char* d_stage = nullptr; // ... as the device sees it (null: not mapped -- copies then go through hipMemcpyAsync)
 	size_t stage_size = 0, stage_off = 0;
 	hipEvent_t ev_half[2] = { nullptr, nullptr }; // h2d_gather: a half of the ring may be refilled once its copy has left
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -296,6 +297,8 @@ struct lsfm_context {
 		if (worker) { try { worker->wait(); } catch (...) {} }
 		pre.reset(); pre_pending.reset(); pre_plan = lsfm::LevelPlan(); pre_plan_level = -1;
 	}
+	hipEvent_t ev_solve_end = nullptr; // (LSFM_LEVEL_GAPS=1: the event behind the last solve, against the next level's first)
+	double dbg_gap_ms = 0.0;
 	hipEvent_t evY = nullptr, evP = nullptr; // joint index arrays of the level final (main stream) / prefetch complete (stream3)
 	hipEvent_t evK = nullptr;                // the level's Schur assembly (K9) has left the main stream: the chain of the factorisation starts
 	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)
@@ -362,6 +365,7 @@ struct CopyBatch {
 };
 void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes);
 void dev_zero(lsfm_context* ctx, void* d, size_t bytes);
+void fill_async(hipStream_t s, void* d, int byte, size_t bytes); // (a kernel of the library, not hipMemsetAsync: lsfm_prims.hip)
 
 // ---- batches (lsfm_batch.hip) -------------------------------------------------------------------------------
 void batch_upload(lsfm_context* ctx, Arena& ar, const lsfm_map* maps, int N, bool mono, DevBatch& out);

@@ -71,7 +71,7 @@ void join_match_features(lsfm_context* ctx, const DevBatch& in, int* match, int*
 	while (cap < 2 * (size_t)in.NF) cap <<= 1;
 	unsigned long long* tab = ctx->scratch.alloc<unsigned long long>(cap);
 	int* tval = ctx->scratch.alloc<int>(cap);
-	LSFM_CHECK_HIP(hipMemsetAsync(tab, 0xff, cap * sizeof(unsigned long long), s));
+	fill_async(s, tab, 0xff, cap * sizeof(unsigned long long));
 	const int nb = (in.NF + 255) / 256;
 	hipLaunchKernelGGL(k_join_hash_insert, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, tab, tval, (unsigned long long)(cap - 1));
 	hipLaunchKernelGGL(k_join_hash_probe, dim3(nb), dim3(256), 0, s, in.NF, in.feat_id, in.feat_map, tab, tval, (unsigned long long)(cap - 1), match, unm);

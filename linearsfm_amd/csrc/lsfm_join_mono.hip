@@ -556,8 +556,8 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 	{
 		int* dst = sc.alloc<int>((size_t)in.NW + 1);
 		int* jf = sc.alloc<int>((size_t)in.NF + 1);
-		LSFM_CHECK_HIP(hipMemsetAsync(dst, 0xff, sizeof(int) * (size_t)in.NW, s)); // MW_DROP for blocks no joint feature claims
-		LSFM_CHECK_HIP(hipMemsetAsync(jf, 0xff, sizeof(int) * (size_t)in.NF, s));
+		fill_async(s, dst, 0xff, sizeof(int) * (size_t)in.NW); // MW_DROP for blocks no joint feature claims
+		fill_async(s, jf, 0xff, sizeof(int) * (size_t)in.NF);
 		hipLaunchKernelGGL(k_mono_w_index, dim3((NFY + 255) / 256), dim3(256), 0, s, NFY, srcE, srcC, in.fptr, in.photo, out.feat_map, d_mg, pnew, out.fptr,
 		                   out.photo, out.feature, dst, jf);
 		// the joint maps' index arrays are final here (U's were written by k_mono_u_fill): a level that analyses builds the pattern of S

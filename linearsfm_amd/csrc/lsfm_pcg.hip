@@ -2551,6 +2551,7 @@ small_tail:
 		if (warm) small_enqueue();
 		LSFM_CHECK_HIP(hipEventRecord(ec, s));
 		LSFM_CHECK_HIP(hipEventRecord(ed, s)); if (roctx().mark) roctx().mark("lsfm solve: end");
+		ctx->ev_solve_end = ed;
 		ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // (no pattern left for the level above)
 		if (ctx->stats) ctx->stats->pcg_iterations += 1;
 		ctx->steps_used = 1;
@@ -2751,7 +2752,7 @@ small_tail:
 		Comm& cm = *ctx->comm;
 		double* xb = cm.alloc<double>(nscal);
 		if (cm.rank == 0) LSFM_CHECK_HIP(hipMemcpyAsync(xb, x, nscal * sizeof(double), hipMemcpyDeviceToDevice, s));
-		else LSFM_CHECK_HIP(hipMemsetAsync(xb, 0, nscal * sizeof(double), s));
+		else fill_async(s, xb, 0, nscal * sizeof(double));
 		cm.allreduce(s, xb, nscal, LSFM_DTYPE_F64);
 		LSFM_CHECK_HIP(hipMemcpyAsync(x, xb, nscal * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
@@ -2768,6 +2769,7 @@ small_tail:
 	launch_backsub(ctx, io, sy, x);
 	LSFM_CHECK_HIP(hipGetLastError());
 	LSFM_CHECK_HIP(hipEventRecord(ed, s)); if (roctx().mark) roctx().mark("lsfm solve: end");
+	ctx->ev_solve_end = ed;
 	if (ctx->stats)
 	{
 		lsfm_stats* st = ctx->stats;

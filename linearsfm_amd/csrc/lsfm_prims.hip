@@ -21,9 +21,59 @@ void Arena::destroy()
 	if (base) (void)hipFree(base);
 	base = nullptr; cap = off = 0;
 }
+// Fills and the small host -> device copies of the path as kernels of the library (round 5).  hipMemsetAsync / hipMemcpyAsync are
+// blit kernels or SDMA transfers of the runtime with their own hand-over on the queue: the kernel trace of a tree showed the main stream
+// idle for 10-50 us around each of them (~100 fills and ~100 small copies per tree), while kernels that follow kernels start
+// without a gap.  A small copy is read by the kernel straight from the pinned ring (device-visible host memory).
+__global__ void __launch_bounds__(256) k_fill_words(uint4* __restrict__ d16, size_t n16, unsigned* __restrict__ tail, int ntail, unsigned v)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const uint4 v4 = make_uint4(v, v, v, v);
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += stride) d16[q] = v4;
+	if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = v;
+}
+__global__ void __launch_bounds__(256) k_fill_bytes(unsigned char* __restrict__ d, size_t n, unsigned char v)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) d[q] = v;
+}
+void fill_async(hipStream_t s, void* d, int byte, size_t bytes)
+{
+	if (!bytes) return;
+	static const bool runtime_fill = getenv("LSFM_RUNTIME_FILL") != nullptr; // (as before: hipMemsetAsync)
+	if (runtime_fill) { LSFM_CHECK_HIP(hipMemsetAsync(d, byte, bytes, s)); return; }
+	const unsigned b = (unsigned)byte & 0xffu, v = b * 0x01010101u;
+	char* p = static_cast<char*>(d);
+	// (head up to a 16-byte boundary and the last bytes one by one: the arenas hand out 256-byte aligned arrays of 4- and 8-byte elements,
+	// so this is the rare case)
+	const size_t head = std::min(bytes, (size_t)((16 - ((size_t)p & 15)) & 15));
+	if (head) hipLaunchKernelGGL(k_fill_bytes, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned char*>(p), head, (unsigned char)b);
+	p += head; bytes -= head;
+	const size_t n16 = bytes / 16, rest = bytes - 16 * n16, nw = rest / 4, nb = rest - 4 * nw;
+	if (n16 || nw)
+	{
+		const unsigned grid = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (n16 + 1023) / 1024));
+		hipLaunchKernelGGL(k_fill_words, dim3(grid), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16, reinterpret_cast<unsigned*>(p + 16 * n16), (int)nw, v);
+	}
+	if (nb) hipLaunchKernelGGL(k_fill_bytes, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned char*>(p + 16 * n16 + 4 * nw), nb, (unsigned char)b);
+}
+__global__ void __launch_bounds__(256) k_copy_words(unsigned* __restrict__ d, const unsigned* __restrict__ h, size_t nw)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if ((((size_t)d | (size_t)h) & 15) == 0)
+	{
+		const size_t n16 = nw / 4;
+		uint4* o = reinterpret_cast<uint4*>(d);
+		const uint4* i = reinterpret_cast<const uint4*>(h);
+		for (size_t q = first; q < n16; q += stride) o[q] = i[q];
+		for (size_t q = 4 * n16 + first; q < nw; q += stride) d[q] = h[q];
+	}
+	else
+		for (size_t q = first; q < nw; q += stride) d[q] = h[q];
+}
 void ZeroSpan::zero(hipStream_t s) const
 {
-	if (ar.off > from) LSFM_CHECK_HIP(hipMemsetAsync(ar.base + from, 0, ar.off - from, s));
+	if (ar.off > from) fill_async(s, ar.base + from, 0, ar.off - from);
 }
 void* Arena::alloc_bytes(size_t bytes)
 {
@@ -106,6 +156,16 @@ void h2d(lsfm_context* ctx, void* d, const void* h, size_t bytes)
 		char* slot = ctx->h_stage + ctx->stage_off;
 		memcpy(slot, h, bytes);
 		ctx->stage_off += need;
+		static const bool runtime_copy = getenv("LSFM_RUNTIME_COPY") != nullptr; // (as before: hipMemcpyAsync from the ring)
+		if (!runtime_copy && ctx->d_stage && bytes <= ((size_t)1 << 20) && bytes % 4 == 0 && ((size_t)d & 3) == 0)
+		{
+			// (the kernel reads the ring slot over the bus: tables of a few KB)
+			const size_t nw = bytes / 4;
+			const unsigned grid = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (nw + 1023) / 1024));
+			hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(256), 0, ctx->stream, static_cast<unsigned*>(d),
+			                   reinterpret_cast<const unsigned*>(ctx->d_stage + (slot - ctx->h_stage)), nw);
+			return;
+		}
 		LSFM_CHECK_HIP(hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
 		return;
 	}
@@ -199,7 +259,10 @@ void CopyBatch::flush()
 	}
 	char* slot = ctx->h_stage + ctx->stage_off;
 	ctx->stage_off += (total + 63) & ~(size_t)63;
-	char* dev = static_cast<char*>(ctx->scratch.alloc_bytes(total)); // (256-byte aligned: the 16-byte path applies to aligned pieces)
+	// (the table and the host pieces: read by the kernel from the ring itself where it is device-visible, else through a copy of the slot)
+	static const bool runtime_copy = getenv("LSFM_RUNTIME_COPY") != nullptr;
+	const bool direct = ctx->d_stage && !runtime_copy;
+	char* dev = direct ? ctx->d_stage + (slot - ctx->h_stage) : static_cast<char*>(ctx->scratch.alloc_bytes(total)); // (256-byte aligned / 64: the 16-byte path applies to aligned pieces)
 	CopyDesc* desc = reinterpret_cast<CopyDesc*>(slot);
 	size_t off = table;
 	for (size_t i = 0; i < items.size(); i++)
@@ -214,7 +277,7 @@ void CopyBatch::flush()
 		}
 		else desc[i].src = (unsigned long long)(size_t)it.src;
 	}
-	LSFM_CHECK_HIP(hipMemcpyAsync(dev, slot, total, hipMemcpyHostToDevice, ctx->stream));
+	if (!direct) LSFM_CHECK_HIP(hipMemcpyAsync(dev, slot, total, hipMemcpyHostToDevice, ctx->stream));
 	const unsigned ny = (unsigned)std::min<size_t>(256, std::max<size_t>(1, most / (64 * 1024)));
 	hipLaunchKernelGGL(k_copy_many, dim3((unsigned)items.size(), ny), dim3(256), 0, ctx->stream, reinterpret_cast<const CopyDesc*>(dev));
 	items.clear();
@@ -226,7 +289,7 @@ void d2h(lsfm_context* ctx, void* h, const void* d, size_t bytes)
 }
 void dev_zero(lsfm_context* ctx, void* d, size_t bytes)
 {
-	if (bytes) LSFM_CHECK_HIP(hipMemsetAsync(d, 0, bytes, ctx->stream));
+	fill_async(ctx->stream, d, 0, bytes);
 }
 
 // ---- the sums of a feature-sharded run (Comm, lsfm_internal.hpp) ---------------------------------------------------------------
@@ -257,7 +320,7 @@ bool Comm::follow(hipStream_t s)
 		const long long count = h[2] / h[1], what = h[3] / h[1];
 		if ((what >> 8) == KIND_FINAL) return true;
 		if (count <= 0 || HDR_BYTES + (size_t)count * 8 > cap) { broken = true; return false; }
-		LSFM_CHECK_HIP(hipMemsetAsync(buf + HDR_BYTES, 0, (size_t)count * 8, s)); // (this rank's part of the sum: nothing)
+		fill_async(s, buf + HDR_BYTES, 0, (size_t)count * 8); // (this rank's part of the sum: nothing)
 		call(s, HDR_BYTES, (size_t)count, (int)(what & 0xff));
 	}
 	broken = true;
@@ -409,6 +472,11 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		c->stage_size = (size_t)64 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
+		{
+			void* dp = nullptr;
+			if (hipHostGetDevicePointer(&dp, c->h_stage, 0) == hipSuccess) c->d_stage = static_cast<char*>(dp);
+			else (void)hipGetLastError();
+		}
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev0, lsfm::timing_event_flags()));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev1, lsfm::timing_event_flags()));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->ev2, lsfm::timing_event_flags()));

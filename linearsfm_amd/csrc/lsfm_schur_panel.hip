@@ -740,7 +740,7 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	static const bool serial = getenv("LSFM_K9_SERIAL") != nullptr;
 	static const int ncu = []() { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
 	hipStream_t s1 = serial ? s : ctx->stream2;
-	if (!fresh_lists) LSFM_CHECK_HIP(hipMemsetAsync(kc.wcnt + 4, 0, 4 * sizeof(int), s)); // the variants' cursors into their lists (k_schur_lists zeroes them when it has just run)
+	if (!fresh_lists) fill_async(s, kc.wcnt + 4, 0, 4 * sizeof(int)); // the variants' cursors into their lists (k_schur_lists zeroes them when it has just run)
 	if (!serial)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[0], s));

@@ -970,7 +970,7 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 				else
 				{
 					unsigned long long* all = cm.alloc<unsigned long long>((size_t)total + 1);
-					LSFM_CHECK_HIP(hipMemsetAsync(all, 0, sizeof(unsigned long long) * (size_t)total, s));
+					fill_async(s, all, 0, sizeof(unsigned long long) * (size_t)total);
 					if (cnt) LSFM_CHECK_HIP(hipMemcpyAsync(all + mine, pb.list, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
 					cm.allreduce(s, all, (size_t)total, LSFM_DTYPE_I64);
 					if (total) hipLaunchKernelGGL(k_pat_insert_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (int)total, all, pb.tab, (unsigned long long)(cap - 1), pb.d_flags);
@@ -1173,7 +1173,7 @@ bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_t
 	};
 	chk("before");
 	int* hub = sc.alloc<int>(Y.B);
-	LSFM_CHECK_HIP(hipMemsetAsync(hub, 0xff, sizeof(int) * (size_t)Y.B, s));
+	fill_async(s, hub, 0xff, sizeof(int) * (size_t)Y.B);
 	hipLaunchKernelGGL(k_pre_hubs, dim3((Y.M + 255) / 256), dim3(256), 0, s, Y.M, Y.pose_id, Y.pose_map, d_tref, hub);
 	chk("hubs");
 	int* match = sc.alloc<int>(Y.NF + 1);
@@ -1324,7 +1324,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		ctx->comm->restart();
 		sy.acc = ctx->comm->alloc<long long>(nacc);
 		sy.E = ctx->comm->alloc<double>((size_t)M * 6);
-		LSFM_CHECK_HIP(hipMemsetAsync(sy.acc, 0, nacc * sizeof(long long), s));
+		fill_async(s, sy.acc, 0, nacc * sizeof(long long));
 		ZeroSpan zs(sc);
 		sy.S = sc.alloc<double>((size_t)cnt * 36);
 		fb = sc.alloc<unsigned char>(ntiles + 1);

@@ -1124,7 +1124,7 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 			ctx->comm->restart();
 			Gpose = ctx->comm->alloc<double>(ngp + npp);
 			PP = Gpose + ngp;
-			LSFM_CHECK_HIP(hipMemsetAsync(Gpose, 0, (ngp + npp) * sizeof(double), s));
+			fill_async(s, Gpose, 0, (ngp + npp) * sizeof(double));
 		}
 		else
 		{

@@ -121,7 +121,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 	}
 	// stage times from events on the stream (a warm level is only enqueued: host clocks say nothing about it)
 	hipEvent_t e_t0 = ctx->pool_event(), e_t1 = ctx->pool_event(), e_t2 = ctx->pool_event();
-	LSFM_CHECK_HIP(hipEventRecord(e_t0, ctx->stream));
+	LSFM_REC_T(e_t0, ctx->stream);
 	{
 		// LSFM_LEVEL_GAPS=1: what the device waited for the host between the levels of a run (the event behind a level's solve was
 		// handed over long before the host got here; this one is stamped when the stream reaches it, or when it arrives)
@@ -143,7 +143,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 	{
 		{ Range r("lsfm transform"); transform_batch(ctx, other, X, tref, tscap, tfix, true, Xt, true); }
 		if (inject) LSFM_FAIL(LSFM_ERR_INTERNAL, "injected failure of this rank (LSFM_TEST_FAIL_RANK)");
-		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
+		LSFM_REC_T(e_t1, ctx->stream);
 		Range r("lsfm join + solve");
 		join_batch_mono(ctx, mine, Xt, Y, nullptr, nullptr);
 	}
@@ -161,7 +161,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		};
 		{ Range r("lsfm transform"); transform_batch(ctx, other, X, tref, tscap, tfix, false, Xt, false, &hook); } // (the join's layout kernels run inside)
 		if (inject) LSFM_FAIL(LSFM_ERR_INTERNAL, "injected failure of this rank (LSFM_TEST_FAIL_RANK)");
-		LSFM_CHECK_HIP(hipEventRecord(e_t1, ctx->stream));
+		LSFM_REC_T(e_t1, ctx->stream);
 		Range r("lsfm join + solve");
 		js.smark = smark; // everything of this level goes at once
 		join_stereo_finish(ctx, Xt, Y, js, nullptr, nullptr);
@@ -186,7 +186,7 @@ void run_level(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st, int level)
 		}
 		else ctx->drop_prepared();
 	}
-	LSFM_CHECK_HIP(hipEventRecord(e_t2, ctx->stream));
+	LSFM_REC_T(e_t2, ctx->stream);
 	if (ctx->steps_used > 0) t->step_hint[level] = ctx->steps_used;
 	ctx->step_hint = 0;
 	ctx->plan = nullptr;
@@ -269,12 +269,12 @@ static void tree_pass(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* st)
 		other.reset();
 		DevBatch Xt;
 		hipEvent_t e0 = ctx->pool_event(), e1 = ctx->pool_event();
-		LSFM_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+		LSFM_REC_T(e0, ctx->stream);
 		ctx->plan = t->use_plans ? &t->plans[nlev] : nullptr;
 		transform_batch(ctx, other, X, tref, tscap, tfix, t->mono, Xt);
 		if (ctx->plan) ctx->plan->valid = true;
 		ctx->plan = nullptr;
-		LSFM_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+		LSFM_REC_T(e1, ctx->stream);
 		ctx->defer_time(e0, e1, &st->t_transform_ms);
 		st->transforms++;
 		t->level = Xt;

@@ -465,6 +465,8 @@ struct EarlyPatternIn {
 void schur_pattern_early_issue(lsfm_context* ctx, const EarlyPatternIn& in); // enqueues on the side stream; the caller has recorded evC
 void schur_pattern_early_drop(lsfm_context* ctx);
 // target_ref[b] of the NEXT level's transform for every map of `Y` (-1: passed through), as run_level will compute it
+bool no_timing_events(); // (LSFM_NO_TIMING_EVENTS=1: the phase brackets are not recorded -- the stage times of lsfm_stats stay zero)
+#define LSFM_REC_T(e, s) do { if (!lsfm::no_timing_events()) LSFM_CHECK_HIP(hipEventRecord(e, s)); } while (0)
 unsigned timing_event_flags(); // (lsfm_prims.hip: events without the system-scope fence)
 unsigned order_event_flags();
 void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector<int>& target_ref, int next_level, int step_hint);

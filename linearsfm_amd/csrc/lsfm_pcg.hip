@@ -2381,7 +2381,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	if (sp && sp->small != (strips > 0)) { lp->solve.reset(); sp = nullptr; }
 	const bool warm = sp != nullptr || pending != nullptr; // pattern + symbolic factorisation known from an earlier run of the same tree level (or made one level ahead)
 	hipEvent_t ea = ctx->pool_event(), eb = ctx->pool_event(), ec = ctx->pool_event(), ed = ctx->pool_event();
-	LSFM_CHECK_HIP(hipEventRecord(ea, s)); if (roctx().mark) roctx().mark("lsfm schur: begin");
+	LSFM_REC_T(ea, s); if (roctx().mark) roctx().mark("lsfm schur: begin");
 	SchurSystem sy;
 	CholDev ch;
 	CholHostIn hin;
@@ -2394,9 +2394,9 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 	auto small_enqueue = [&]() {
 		d_small = sc.alloc<int>(4);
 		dev_zero(ctx, d_small, 4 * sizeof(int));
-		if (ctx->stats) { esm0 = ctx->pool_event(); esm1 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(esm0, s)); }
+		if (ctx->stats) { esm0 = ctx->pool_event(); esm1 = ctx->pool_event(); LSFM_REC_T(esm0, s); }
 		small_solve_launch(ctx, io, strips, d_small, reinterpret_cast<double*>(d_small + 2));
-		if (ctx->stats) { LSFM_CHECK_HIP(hipEventRecord(esm1, s)); ctx->defer_time(esm0, esm1, &ctx->stats->t_small_ms); ctx->stats->small_levels++; }
+		if (ctx->stats) { LSFM_REC_T(esm1, s); ctx->defer_time(esm0, esm1, &ctx->stats->t_small_ms); ctx->stats->small_levels++; }
 	};
 	if (warm)
 	{
@@ -2407,7 +2407,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			schur_vinv(ctx, io, sy);
 			build_schur_values(ctx, io, sy);
 		}
-		LSFM_CHECK_HIP(hipEventRecord(eb, s)); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
+		LSFM_REC_T(eb, s); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		if (pending)
 		{
@@ -2440,7 +2440,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			schur_pattern_early_drop(ctx);
 			if (ctx->pre) { std::shared_ptr<void> keep = ctx->pre; ctx->pre.reset(); pre_wait(ctx, static_cast<PreLevel*>(keep.get())); }
 			small_enqueue();
-			LSFM_CHECK_HIP(hipEventRecord(eb, s));
+			LSFM_REC_T(eb, s);
 			LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 			goto small_tail;
 		}
@@ -2535,7 +2535,7 @@ int solve_batch(lsfm_context* ctx, const SolveIO& io)
 			chol_fetch(ctx, sy, io.d_pose_origin, hin);
 		}
 		build_schur_values(ctx, io, sy);
-		LSFM_CHECK_HIP(hipEventRecord(eb, s)); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
+		LSFM_REC_T(eb, s); if (roctx().mark) roctx().mark("lsfm factor + refine: begin");
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evK, s));
 		tw0 = wall();
 		ctx->mark("k9_enq");
@@ -2549,8 +2549,8 @@ small_tail:
 	if (strips)
 	{
 		if (warm) small_enqueue();
-		LSFM_CHECK_HIP(hipEventRecord(ec, s));
-		LSFM_CHECK_HIP(hipEventRecord(ed, s)); if (roctx().mark) roctx().mark("lsfm solve: end");
+		LSFM_REC_T(ec, s);
+		LSFM_REC_T(ed, s); if (roctx().mark) roctx().mark("lsfm solve: end");
 		ctx->ev_solve_end = ed;
 		ctx->solved_keys = nullptr; ctx->solved_nnzb = 0; // (no pattern left for the level above)
 		if (ctx->stats) ctx->stats->pcg_iterations += 1;
@@ -2761,14 +2761,14 @@ small_tail:
 	const int nsample = 1;
 	PcgSeg* seg2 = seg + nseg; // zeroed accumulators of the final residual (Ap: left zeroed by the last k_pcg_resid)
 	hipEvent_t es0 = ctx->pool_event(), es1 = ctx->pool_event();
-	LSFM_CHECK_HIP(hipEventRecord(es0, s));
+	LSFM_REC_T(es0, s);
 	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
-	LSFM_CHECK_HIP(hipEventRecord(es1, s));
+	LSFM_REC_T(es1, s);
 	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg2, 1);
-	LSFM_CHECK_HIP(hipEventRecord(ec, s)); if (roctx().mark) roctx().mark("lsfm back-substitution: begin");
+	LSFM_REC_T(ec, s); if (roctx().mark) roctx().mark("lsfm back-substitution: begin");
 	launch_backsub(ctx, io, sy, x);
 	LSFM_CHECK_HIP(hipGetLastError());
-	LSFM_CHECK_HIP(hipEventRecord(ed, s)); if (roctx().mark) roctx().mark("lsfm solve: end");
+	LSFM_REC_T(ed, s); if (roctx().mark) roctx().mark("lsfm solve: end");
 	ctx->ev_solve_end = ed;
 	if (ctx->stats)
 	{

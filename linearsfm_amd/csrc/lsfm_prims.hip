@@ -361,6 +361,7 @@ namespace lsfm {
 // bracket phases are read by hipEventElapsedTime after the run's stream synchronisation, the others order streams of ONE device
 // (device-scope release); what the host reads it reads behind a stream synchronisation of its own.  LSFM_EVENTS_DEFAULT=1: as before.
 static bool events_default() { static const bool v = getenv("LSFM_EVENTS_DEFAULT") != nullptr; return v; }
+bool no_timing_events() { static const bool v = getenv("LSFM_NO_TIMING_EVENTS") != nullptr; return v; }
 unsigned timing_event_flags() { return events_default() ? hipEventDefault : hipEventDisableSystemFence; }
 unsigned order_event_flags() { return events_default() ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice); }
 }

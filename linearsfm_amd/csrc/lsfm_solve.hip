@@ -1350,7 +1350,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 	{
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
 		hipEvent_t e2 = nullptr, e3 = nullptr;
-		if (ctx->stats) { e2 = ctx->pool_event(); e3 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(e2, s)); }
+		if (ctx->stats) { e2 = ctx->pool_event(); e3 = ctx->pool_event(); LSFM_REC_T(e2, s); }
 		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
 		int most = 0;
 		for (int r : io.seg_rows) most = std::max(most, r);
@@ -1372,7 +1372,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		hipLaunchKernelGGL(k_schur_w, dim3(ntiles), dim3(SCHUR_TILE), 0, s, NF, io.fptr, io.photo, io.W, sy.IV, io.eb, tab, hval, mask, ko, fb, sy.LY);
 		if (ctx->stats)
 		{
-			LSFM_CHECK_HIP(hipEventRecord(e3, s));
+			LSFM_REC_T(e3, s);
 			ctx->defer_time(e2, e3, &ctx->stats->schur_ms);
 			ctx->stats->schur_launches++;
 			// every input once (W block + photo index; V^-1, eb, run pointer per feature), every output once (S, E)

@@ -1017,10 +1017,10 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		if (hook) rd = (*hook)(out);
 		if (!rd.W) { rd = TrRedirect(); rd.wbase = out.fptr; rd.W = out.W; rd.photo = out.photo; rd.feature = out.feature; }
 		hipEvent_t e0 = nullptr, e1 = nullptr; // the events bracket k_tr_entries alone; read at the end of the run
-		if (ctx->stats) { e0 = ctx->pool_event(); e1 = ctx->pool_event(); LSFM_CHECK_HIP(hipEventRecord(e0, s)); }
+		if (ctx->stats) { e0 = ctx->pool_event(); e1 = ctx->pool_event(); LSFM_REC_T(e0, s); }
 		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, finfo, in.fptr, in.W,
 		                   in.photo, KW, Dp, Cp, FD, rd.W, rd.photo, rd.feature, Gsum, Gpose, hubJ, out.W_alias ? 1 : 0, rd.wbase, rd.newf, rd.srcf);
-		if (ctx->stats) LSFM_CHECK_HIP(hipEventRecord(e1, s));
+		if (ctx->stats) LSFM_REC_T(e1, s);
 		LSFM_CHECK_HIP(hipEventRecord(ctx->evA, s)); // pose rows of G complete: the U stage may start on the side stream
 		ev_entries = true;
 		hipLaunchKernelGGL(k_tr_feat_post<NH>, dim3((in.NF + 255) / 256), dim3(256), 0, s, in.NF, M, d_tm, in.feat_map, in.fptr, in.V, in.W, in.photo,

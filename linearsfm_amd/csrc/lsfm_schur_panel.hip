@@ -439,8 +439,12 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 	}
 	else if constexpr (SMAX <= 16)
 	{
+		// (an instance per count: a wave of the T = 6 instance with four tiles to its name multiplied two more for nothing -- a third of the
+		// matrix products of the commonest tiles, 11-13 poses, until round 5)
 		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 2) PM_GO(2);
 		else if (tpw <= 3) PM_GO(3);
+		else if (tpw <= 4) PM_GO(4); // 5 strips: 15 tiles over 4 waves
 		else if (tpw <= 6) PM_GO(6); // 6 strips: 21 tiles over 4 waves
 		else PM_GO(7); // (16 poses: a seventh strip)
 	}
@@ -455,6 +459,7 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		if (tpw <= 1) PM_GO(1);
 		else if (tpw <= 3) PM_GO(3);
 		else if (tpw <= 6) PM_GO(6);
+		else if (tpw <= 8) PM_GO(8); // (24-29 poses: 55 / 66 tiles over 8 waves)
 		else if (tpw <= TS) PM_GO(TS);
 		else
 		{

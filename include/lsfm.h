@@ -355,6 +355,13 @@ int lsfm_spmv_bench(lsfm_context* ctx, int m, const int* rowptr, const int* coli
  * on consecutive 16 bytes (the stream copy).  avg_ms over reps launches (HIP events); bytes moved = 2 * 144 * nblocks. */
 int lsfm_wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps, double* avg_ms);
 
+/* Self-test of the library's own fill and small-copy kernels (they stand where hipMemsetAsync / hipMemcpyAsync stood until round 5:
+ * every accumulator of the path is cleared and every index table arrives through them): fills of `cases` pseudo-random (offset, length,
+ * byte) triples -- unaligned heads and tails included -- into a guarded buffer, host -> device copies of random lengths through the
+ * pinned ring (one by one and as batches), each read back and compared.  Returns LSFM_OK, or LSFM_ERR_INTERNAL with the first
+ * mismatch in lsfm_last_error. */
+int lsfm_selftest_prims(lsfm_context* ctx, int cases, unsigned seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,7 @@ def lib():
         L.lsfm_solve_features.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int, C.c_int, ip, ip]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
         L.lsfm_wstream_bench.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, dp]
+        L.lsfm_selftest_prims.argtypes = [vp, C.c_int, C.c_uint]
         _LIB = L
     return _LIB
 
@@ -129,7 +130,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_tree_download", "lsfm_tree_set_stop_level", "lsfm_tree_node_count", "lsfm_tree_download_node", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_set_comm_blocks", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
            "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_write_mapset", "lsfm_mapset_info", "lsfm_mapset_stamp", "lsfm_read_mapset", "lsfm_save_state_bin", "lsfm_save_state", "lsfm_save_poses",
-           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
+           "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_selftest_prims", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
 
 
 def _c(a, dtype):
@@ -429,6 +430,14 @@ def _wstream(self, nblocks, mode, reps=10):
 
 
 Context.wstream_bench = _wstream
+
+
+def _selftest_prims(self, cases=64, seed=1):
+    """The library's own fill / small-copy kernels against the host (lsfm_selftest_prims); raises LsfmError on the first mismatch."""
+    self._check(lib().lsfm_selftest_prims(self._h, int(cases), int(seed)), "lsfm_selftest_prims")
+
+
+Context.selftest_prims = _selftest_prims
 
 
 def symbolic_analyse(rowptr, colidx, origin=None, reps=1):

@@ -974,4 +974,64 @@ int lsfm_wstream_bench(lsfm_context* ctx, long long nblocks, int mode, int reps,
 	});
 }
 
+int lsfm_selftest_prims(lsfm_context* ctx, int cases, unsigned seed)
+{
+	if (cases <= 0) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() {
+		ctx->ensure_arenas((size_t)64 << 20);
+		ctx->scratch.reset();
+		const size_t cap = (size_t)1 << 20;
+		unsigned char* buf = ctx->scratch.alloc<unsigned char>(cap);
+		std::vector<unsigned char> ref(cap), got(cap);
+		unsigned long long st = seed * 2654435761ull + 12345ull;
+		auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(st >> 33); };
+		LSFM_CHECK_HIP(hipMemset(buf, 0xA5, cap));
+		std::fill(ref.begin(), ref.end(), (unsigned char)0xA5);
+		auto compare = [&](const char* what, int c) {
+			d2h(ctx, got.data(), buf, cap);
+			for (size_t i = 0; i < cap; i++)
+				if (got[i] != ref[i])
+					LSFM_FAIL(LSFM_ERR_INTERNAL, std::string("lsfm_selftest_prims: ") + what + " case " + std::to_string(c) + ": byte " + std::to_string(i) + " is " +
+					                                 std::to_string(got[i]) + ", expected " + std::to_string(ref[i]));
+		};
+		for (int c = 0; c < cases; c++)
+		{
+			// fills: short and long, any alignment of either end
+			const size_t len = (c % 3 == 0) ? rnd() % 70 : rnd() % (cap / 2);
+			const size_t off = rnd() % (cap - len);
+			const int byte = (c % 4 == 0) ? 0 : (c % 4 == 1 ? 0xff : (int)(rnd() & 0xff));
+			fill_async(ctx->stream, buf + off, byte, len);
+			std::fill(ref.begin() + off, ref.begin() + off + len, (unsigned char)byte);
+			if (c % 8 == 7 || c + 1 == cases) compare("fill", c);
+		}
+		std::vector<unsigned> src(cap / 4);
+		for (unsigned& v : src) v = rnd();
+		for (int c = 0; c < cases; c++)
+		{
+			// copies of whole words (what the path copies: index tables, records), one by one ...
+			const size_t nw = 1 + rnd() % (c % 2 ? 300 : 60000), offw = rnd() % (cap / 4 - nw), from = rnd() % (cap / 4 - nw);
+			h2d(ctx, buf + 4 * offw, src.data() + from, 4 * nw);
+			memcpy(ref.data() + 4 * offw, src.data() + from, 4 * nw);
+			if (c % 8 == 7 || c + 1 == cases) compare("copy", c);
+		}
+		for (int c = 0; c < cases; c += 4)
+		{
+			// ... and as a batch of host pieces and device-to-device pieces (CopyBatch: one table, one launch)
+			CopyBatch cb(ctx);
+			size_t at = 0;
+			const size_t half = cap / 2;
+			for (int i = 0; i < 5 && at + 70000 < half; i++)
+			{
+				const size_t nw = 4 * (1 + rnd() % 4000), from = rnd() % (cap / 4 - nw);
+				if (i % 2 == 0) { cb.h2d(buf + at, src.data() + from, 4 * nw); memcpy(ref.data() + at, src.data() + from, 4 * nw); }
+				else { cb.d2d(buf + at, buf + half + 4 * (from % (half / 4 - nw)), 4 * nw); memcpy(ref.data() + at, ref.data() + half + 4 * (from % (half / 4 - nw)), 4 * nw); }
+				at += 4 * nw + 4 * (rnd() % 5);
+			}
+			cb.flush();
+			compare("batch", c);
+		}
+		return LSFM_OK;
+	});
+}
+
 } // extern "C"

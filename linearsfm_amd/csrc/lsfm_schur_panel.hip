@@ -304,16 +304,16 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		const int si = q / ns, sj = q - si * ns;
 		pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
 	}
-	// ... and behind them the tile's right-hand side rows, two limbs each (the same fixed point as in memory: whatever order the
-	// waves add in, the sum is the same)
-	long long* eh = reinterpret_cast<long long*>(sh.P) + ((ns * ns + 1) >> 1);
-	long long* el = eh + rows;
-	for (int q = tid; q < 2 * rows; q += THREADS) eh[q] = 0;
+	// ... and behind them the tile's right-hand side rows, one set per wave: a wave adds its output tiles' shares in the order it holds
+	// them, the waves' sets are added in their order below -- the same bits every run, no atomics, one conversion to the fixed point per row
+	constexpr int NWV = THREADS / 64;
+	double* wsum = sh.P + ((ns * ns + 1) >> 1);
+	for (int q = tid; q < NWV * rows; q += THREADS) wsum[q] = 0.0;
 	__syncthreads();
 	bool bad = false;
-	const int ey = *o.ey;
 	// E_R -= sum_C (P P^T)_RC m_C: m_C = the estimate of pose scalar C; for the two columns behind the poses' (P z_End, P z_Cur)
 	// 1 on the rows of that side's poses.  Off the diagonal a tile stands for its mirror image too: E_C -= sum_R (P P^T)_RC x_R.
+	double* mine = wsum + wave * rows;
 #pragma unroll
 	for (int t = 0; t < T; t++)
 	{
@@ -334,39 +334,23 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			rs[e] = term;
 			if (mirror && C < rows) cs = fma(v, sh.xs[R], cs); // (xs is zero past the poses' rows)
 		}
-#pragma unroll
-		for (int off = 1; off < 16; off <<= 1)
+		// the four row sums over the 16 lanes of a row group in five exchanges: halves of the group trade the pair of sums they do not
+		// keep, quarters the one, then two plain steps -- lane bits (3, 2) of the group say whose sum a lane ends up with
 		{
-#pragma unroll
-			for (int e = 0; e < 4; e++) rs[e] += __shfl_xor(rs[e], off, 64);
-		}
-		if ((lane & 15) == 0)
-		{
-#pragma unroll
-			for (int e = 0; e < 4; e++)
-			{
-				const int R = Rb + 4 * e;
-				if (R < rows && rs[e] != 0.0)
-				{
-					// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
-					long long hi, lo;
-					to_fixed2(-rs[e], 62 - sh.sexp[R] - ey, hi, lo, bad);
-					lds_add_i64(eh + R, hi);
-					if (lo) lds_add_i64(el + R, lo);
-				}
-			}
+			const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+			const double s0 = b3 ? rs[0] : rs[2], s1 = b3 ? rs[1] : rs[3];
+			const double a0 = (b3 ? rs[2] : rs[0]) + __shfl_xor(s0, 8, 64), a1 = (b3 ? rs[3] : rs[1]) + __shfl_xor(s1, 8, 64);
+			double r = (b2 ? a1 : a0) + __shfl_xor(b2 ? a0 : a1, 4, 64);
+			r += __shfl_xor(r, 2, 64);
+			r += __shfl_xor(r, 1, 64);
+			const int R = Rb + 4 * ((b3 ? 2 : 0) + (b2 ? 1 : 0));
+			if ((lane & 3) == 0 && R < rows) mine[R] -= r;
 		}
 		if (mirror)
 		{
 			cs += __shfl_xor(cs, 16, 64);
 			cs += __shfl_xor(cs, 32, 64);
-			if (lane < 16 && C < rows && cs != 0.0)
-			{
-				long long hi, lo;
-				to_fixed2(-cs, 62 - sh.sexp[C] - ey, hi, lo, bad);
-				lds_add_i64(eh + C, hi);
-				if (lo) lds_add_i64(el + C, lo);
-			}
+			if (lane < 16 && C < rows) mine[C] -= cs; // (rows of another strip than the ones above: ti != tj)
 		}
 	}
 	K9T(11);
@@ -407,12 +391,23 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		}
 	}
 	__syncthreads();
-	for (int row = tid; row < rows; row += THREADS)
 	{
-		const long long hi = eh[row], lo = el[row];
-		const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
-		if (hi) atomic_add_i64(o.Ehi + at, hi);
-		if (lo) atomic_add_i64(o.Elo + at, lo);
+		const int ey = *o.ey;
+		for (int row = tid; row < rows; row += THREADS)
+		{
+			double e = 0.0;
+#pragma unroll
+			for (int w = 0; w < NWV; w++) e += wsum[w * rows + row];
+			if (e != 0.0)
+			{
+				// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
+				long long hi, lo;
+				to_fixed2(e, 62 - sh.sexp[row] - ey, hi, lo, bad);
+				const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
+				atomic_add_i64(o.Ehi + at, hi);
+				if (lo) atomic_add_i64(o.Elo + at, lo);
+			}
+		}
 	}
 	if (bad) atomic_add_i64(o.poison, 1);
 	K9T(6);

@@ -657,6 +657,13 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 	{
 		__shared__ int s_it;
 		const int nlist = *wcnt;
+		// A short list -- the handful of 33-48-pose tiles of a top level, say -- would leave one work-group per tile walking its eight passes
+		// alone while the launch behind it on the stream waits (150-200 us for ONE tile, 0.4 ms per tree): its tiles are cut into
+		// parts of whole passes, each taken by a work-group of its own with the tile's slots.  The sums are integers: whatever is
+		// added in how many pieces, S and E are the same; how a list is cut hangs on its length and the launch alone -- the same every run.
+		const int room = (int)gridDim.x;
+		const int parts = nlist * 8 <= room ? 8 : (nlist * 4 <= room ? 4 : (nlist * 2 <= room ? 2 : 1));
+		const int plen = PM_TILE / parts;
 		for (int round = 0;; round++)
 		{
 			// the next tile of the list, whoever comes first (tiles differ in work by an order of magnitude)
@@ -664,11 +671,12 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			if (tid == 0) s_it = atomicAdd(cursor, 1);
 			__syncthreads();
 			const int it = s_it;
-			if (it >= nlist) break;
-			const int tile = wlist[it];
+			if (it >= nlist * parts) break;
+			const int tile = wlist[it / parts];
 			const int cns = kc.ns[tile];
 			K9T_DECL;
-			const int f0 = tile * PM_TILE, f1 = min(f0 + PM_TILE, NF);
+			const int f0 = tile * PM_TILE + (it % parts) * plen, f1 = min(f0 + plen, NF);
+			if (f0 >= f1) continue; // (the ragged end of the level's last tile; uniform)
 			for (int i = tid; i <= f1 - f0; i += THREADS) sh.fpt[i] = fptr[f0 + i];
 			if (tid < cns) sh.pose_of[tid] = kc.pose[(size_t)tile * PM_SMAX_MAX + tid];
 			if (tid == 0) { sh.nslots = cns; sh.bad = 0; }

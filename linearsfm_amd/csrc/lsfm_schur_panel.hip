@@ -154,7 +154,13 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 #endif
 	// rows per lane in flight: 4 x 256 rows = 10.6 poses per feature on average (LSFM_K9_PF6 = 3: the 16-slot variant fits its 170
 	// registers without spilling, with 8 poses per feature prefetched)
-	constexpr int PF = THREADS != 256 ? (T <= 6 ? 3 : 2) : (T <= 3 ? 4 : (T <= 6 ? LSFM_K9_PF6 : (T <= 14 ? 3 : 2)));
+#ifndef LSFM_K9_PFW
+#define LSFM_K9_PFW 1
+#endif
+	// (rows past the prefetched ones are loaded INSIDE the staging, a memory round trip in the open: the instances that hold fewer output
+	// tiles spend the registers on a deeper prefetch -- T = 4, the 11-13-pose tiles, five rows a lane = 213 blocks a pass)
+	constexpr int PF = THREADS != 256 ? (LSFM_K9_PFW ? (T <= 8 ? 4 : 3) : (T <= 6 ? 3 : 2))
+	                                  : (T <= 3 ? 4 : (T <= 4 ? (LSFM_K9_PFW ? 5 : LSFM_K9_PF6) : (T <= 6 ? LSFM_K9_PF6 : (T <= 14 ? 3 : 2))));
 	double pw[PF][3];
 	double lyv = 0.0, uuv = 0.0;
 	const bool fused = o.xpose != nullptr; // (uniform)

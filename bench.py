@@ -321,7 +321,10 @@ def main():
             kern[key]["gbs"] = kern[key]["avg_bytes"] / (kern[key]["avg_ms"] * 1e-3) / 1e9 if kern[key]["avg_ms"] > 0 else 0.0
         kern["schur"]["avg_flops"] = acc.get("schur_flops", 0.0) / max(1, acc.get("schur_launches", 0))
         kern["schur"]["tflops"] = kern["schur"]["avg_flops"] / (kern["schur"]["avg_ms"] * 1e-3) / 1e12 if kern["schur"]["avg_ms"] > 0 else 0.0
-        dom = max(("schur", "trf"), key=lambda k: kern[k]["total_ms"])
+        # (K9's event bracket and k_tr_entries' are within a few per cent of each other since round 5 -- 5.9 vs 5.9-6.0 ms per tree; by the
+        # rocprof sum of its variants, which run beside each other, K9 is still the larger: 8.3 vs 6.0.  The object stays with K9 unless the
+        # transform's kernel leads by more than a tenth, so that the line does not flip from run to run; both are under "kernels".)
+        dom = "trf" if kern["trf"]["total_ms"] > 1.1 * kern["schur"]["total_ms"] else "schur"
         pmc = pmc_traffic(args.config) if (world == 1 and not args.maps) else None
         traffic = None
         whole = None

@@ -1,7 +1,7 @@
 # round 5: everything profiles/r05_* is refreshed from, in one gpurun call:  gpurun --timeout 3300 -- bash tools/measure_r05.sh
 # then:  python tools/refresh_profiles.py gpurun_out/r05u r05 nc3500 7   (7 = trees in a --steps 2 --warmup 1 PMC run)
 ulimit -c 0
-D=gpurun_out/r05w2; mkdir -p $D
+D=gpurun_out/r05fin; mkdir -p $D
 timeout 1800 python -m pytest tests -x -q -m gpu --durations=10 > $D/gpu_tests.log 2>&1; tail -3 $D/gpu_tests.log
 timeout 500 python bench.py > $D/bench_default.log 2> $D/bench_default.err
 timeout 300 python bench.py --config rs468 --steps 10 --warmup 2 > $D/bench_rs468.log 2>/dev/null
@@ -29,7 +29,7 @@ python - <<'PY'
 import json
 for f in ("default","rs468","rs90","aerial","synth16k","synth64k_16k","prof","prof_synth16k","prof_rs468"):
     try:
-        l=[x for x in open(f"gpurun_out/r05w2/bench_{f}.log") if x.startswith("{")]
+        l=[x for x in open(f"gpurun_out/r05fin/bench_{f}.log") if x.startswith("{")]
         d=json.loads(l[0]); print(f, round(d["value"],2), round(d["resolve_ms"],2), round(d["first_run_ms"],1), round(d["roofline"]["frac"],4), d["max_rel_residual"], d["not_converged"], (d.get("cpu_baseline") or {}).get("pose_param_max_rel_err_vs_oracle"), (d.get("e2e_cli") or {}).get("e2e_cli_s"))
     except Exception as e: print(f, "ERR", e)
 PY

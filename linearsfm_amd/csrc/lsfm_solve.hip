@@ -285,17 +285,31 @@ __global__ void k_rowptr_from_keys(int rows, int n, const unsigned long long* __
 }
 
 // ---- numeric Schur complement ------------------------------------------------------------------------------
-__global__ void k_schur_u(int NU, const double* __restrict__ U, const int* __restrict__ Ui, const int* __restrict__ Uj,
-                          const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask, double* __restrict__ S)
+// (one lane per block looks its place in S up; the 36 numbers of the work-group's blocks then leave by consecutive lanes on consecutive
+// numbers -- one lane per block adding its 36 at a stride of 288 bytes was 63 us for the 37 MB of U at the top of an NC3500-like tree)
+#define SCHUR_U_BLOCKS 256
+__global__ void __launch_bounds__(SCHUR_U_BLOCKS) k_schur_u(int NU, const double* __restrict__ U, const int* __restrict__ Ui, const int* __restrict__ Uj,
+                                                          const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+                                                          double* __restrict__ S)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= NU) return;
-	int a = Ui[i], b = Uj[i];
-	int slot = hash_find(tab, val, mask, pair_key(a, b));
-	const double* u = U + (size_t)i * 36;
-	double* s = S + (size_t)slot * 36;
-	if (a <= b) { for (int q = 0; q < 36; q++) atomic_add_f64(s + q, u[q]); }
-	else { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) atomic_add_f64(s + c * 6 + r, u[r * 6 + c]); }
+	__shared__ int s_slot[SCHUR_U_BLOCKS]; // slot of S, | 1 << 30: the block goes in transposed
+	const int i0 = blockIdx.x * SCHUR_U_BLOCKS, nb = min(SCHUR_U_BLOCKS, NU - i0);
+	if ((int)threadIdx.x < nb)
+	{
+		const int a = Ui[i0 + threadIdx.x], b = Uj[i0 + threadIdx.x];
+		const int slot = hash_find(tab, val, mask, pair_key(a, b));
+		s_slot[threadIdx.x] = slot < 0 ? -1 : (slot | (a <= b ? 0 : (1 << 30)));
+	}
+	__syncthreads();
+	const double* u = U + (size_t)i0 * 36;
+	for (int p = threadIdx.x; p < nb * 36; p += SCHUR_U_BLOCKS)
+	{
+		const int blk = p / 36, q = p - 36 * blk, sl = s_slot[blk];
+		if (sl < 0) continue;
+		const int slot = sl & ((1 << 30) - 1);
+		const int qq = (sl >> 30) ? (q % 6) * 6 + q / 6 : q; // (u[r][c] -> s[c][r])
+		atomic_add_f64(S + (size_t)slot * 36 + qq, u[p]);
+	}
 }
 
 // K9, one lane per feature.  A tile of SCHUR_TILE consecutive features (one work-group) touches few distinct blocks

@@ -31,6 +31,11 @@
 //   ref_dump trans Monocular A.txt Ref ScaP Fix out.bin
 //   ref_dump parts Stereo|Monocular  in.bin out.bin          in.bin (same tagged format): m n nW V W photo mapPhoto ea eb
 //                                                            dpa rowptr colidx S [Ref ScaP Fix]
+//   ref_dump save  both|pose|feat in.bin pose.txt feat.txt state.txt
+//                                                            in.bin: stno stVal.  The REAL writers lmj_SaveStateVector
+//                                                            (Imp.cpp:2102) and lmj_SavePoses_3DPF (Imp.cpp:7876; with
+//                                                            "pose" / "feat" the other path is handed over as NULL) write the
+//                                                            three text files: the bytes the product's writers are held to
 // Output: tagged binary ("name dtype count\n" + raw little-endian payload), read by tests/refdump.py.
 #define private public
 #include "LinearSFMImp.h"
@@ -176,12 +181,26 @@ static void run_parts(CLinearSFMImp* imp, bool mono, const char* inp)
 	put_d("parts.Sx", Sx, Sp[dim]);
 }
 
+static int run_save(CLinearSFMImp* imp, char** argv)
+{
+	static Blob bl[8];
+	int nb = read_blobs(argv[3], bl, 8);
+	Blob* bs = find_blob(bl, nb, "stno");
+	const int n = (int)bs->n;
+	char* pose = strcmp(argv[2], "feat") == 0 ? NULL : argv[4];
+	char* feat = strcmp(argv[2], "pose") == 0 ? NULL : argv[5];
+	imp->lmj_SaveStateVector(argv[6], BD("stVal"), BI("stno"), n);
+	imp->lmj_SavePoses_3DPF(pose, feat, BI("stno"), BD("stVal"), n);
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
 	if (argc < 5) { fprintf(stderr, "usage: see header of ref_harness.cpp\n"); return 2; }
 	// raw zeroed storage: the constructor (cholmod_start) must not run.
 	void* raw = calloc(1, sizeof(CLinearSFMImp) + 64);
 	CLinearSFMImp* imp = reinterpret_cast<CLinearSFMImp*>(raw);
+	if (strcmp(argv[1], "save") == 0) return argc == 7 ? run_save(imp, argv) : 2;
 	bool mono = strcmp(argv[2], "Monocular") == 0;
 	const char* outp = argv[argc - 1];
 	g_out = fopen(outp, "wb");

@@ -199,3 +199,25 @@ def dense_reference_solve(J, ea, eb, mono, sa=None, IV=None):
     if mono:
         out[sa[2]] = sa[3]
     return out
+
+
+def reference_writer_bytes(stno, st):
+    """What the reference's lmj_SaveStateVector (LinearSFMImp.cpp:2102-2117) and lmj_SavePoses_3DPF (7876-7967) write for a state, as
+    bytes: (state, pose, feature).  A Python statement of the two writers for states no fixture holds (the CLI's own output on the GPU
+    box); pinned to the real writers' bytes on every case of tests/golden/writers.npz by
+    test_oracle_cpu.py::test_python_statement_of_the_writers_vs_reference_bytes.  `%lf` = Python's `%f`: both print the exactly
+    rounded decimal expansion of the binary double."""
+    stno, st = np.asarray(stno), np.asarray(st, np.float64)
+    state = "".join("%d %f\n" % (int(a), float(b)) for a, b in zip(stno, st))
+    poses, feats = {}, {}
+    i = 0
+    while i < len(stno):
+        if stno[i] <= 0:
+            poses[-int(stno[i])] = i          # std::map: a repeated id keeps its last occurrence
+            i += 6
+        else:
+            feats[int(stno[i])] = i
+            i += 3
+    pose = "".join("%d  %f  %f  %f %f  %f  %f\n" % ((k,) + tuple(float(v) for v in st[poses[k]:poses[k] + 6])) for k in sorted(poses))
+    feat = "".join("%d  %f  %f %f\n" % ((k,) + tuple(float(v) for v in st[feats[k]:feats[k] + 3])) for k in sorted(feats))
+    return state.encode(), pose.encode(), feat.encode()

@@ -406,6 +406,46 @@ def test_binary_state_dump(tmp_path):
         assert np.frombuffer(raw[8 + 4 * (n + (n & 1)):], np.float64).tobytes() == st.tobytes()
 
 
+def _writer_cases():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "writers.npz"))
+    return z, [str(n) for n in z["names"]]
+
+
+@pytest.mark.parametrize("name", _writer_cases()[1])
+def test_writers_byte_for_byte_vs_reference(tmp_path, name):
+    """lsfm_save_state / lsfm_save_poses (csrc/lsfm_io.cpp) against the BYTES the reference's own lmj_SaveStateVector
+    (LinearSFMImp.cpp:2102-2117) and lmj_SavePoses_3DPF (7876-7967) wrote for the same state (tests/golden/writers.npz, made by
+    tests/golden/make_writer_golden.py running the real methods through oracle/_ref/ref_dump save): ids out of order, repeated
+    ids (the last occurrence is kept), label 0, negative zeros, sixth-decimal rounding, 1e300, an empty state; both files, only
+    the pose file, only the feature file (the method takes NULL for either path)."""
+    import ctypes as C
+    from linearsfm_amd import api
+    z, _ = _writer_cases()
+    stno, st = np.ascontiguousarray(z[f"{name}.stno"], np.int32), np.ascontiguousarray(z[f"{name}.stVal"], np.float64)
+    ip, dp = stno.ctypes.data_as(C.POINTER(C.c_int)), st.ctypes.data_as(C.POINTER(C.c_double))
+    L = api.lib()
+    fs = str(tmp_path / "state.txt")
+    assert L.lsfm_save_state(fs.encode(), dp, ip, len(stno)) == 0
+    assert open(fs, "rb").read() == bytes(z[f"{name}.state"])
+    for which in ("both", "pose", "feat"):
+        fp, ff = str(tmp_path / f"{which}_pose.txt"), str(tmp_path / f"{which}_feat.txt")
+        assert L.lsfm_save_poses(fp.encode() if which != "feat" else None, ff.encode() if which != "pose" else None, ip, dp, len(stno)) == 0
+        assert os.path.exists(fp) == (which != "feat") and os.path.exists(ff) == (which != "pose")
+        if which != "feat":
+            assert open(fp, "rb").read() == bytes(z[f"{name}.{which}.pose"]), which
+        if which != "pose":
+            assert open(ff, "rb").read() == bytes(z[f"{name}.{which}.feat"]), which
+
+
+@pytest.mark.parametrize("name", _writer_cases()[1])
+def test_python_statement_of_the_writers_vs_reference_bytes(name):
+    """tests/common.py reference_writer_bytes (used by the -m gpu CLI test for the device's own state) against the real writers' bytes."""
+    from common import reference_writer_bytes
+    z, _ = _writer_cases()
+    state, pose, feat = reference_writer_bytes(z[f"{name}.stno"], z[f"{name}.stVal"])
+    assert state == bytes(z[f"{name}.state"]) and pose == bytes(z[f"{name}.both.pose"]) and feat == bytes(z[f"{name}.both.feat"])
+
+
 @pytest.mark.parametrize("mono", [False, True])
 def test_threaded_oracle_tree_is_identical(oracle, mono):
     """orc_divide_conquer_omp (the multi-core CPU figure of bench.py) computes every join exactly like the serial tree."""

@@ -1,6 +1,6 @@
 """How far two fp64-faithful evaluations of the REFERENCE's algorithm differ on a named set: the oracle (fp64 throughout) against its
 long-double twin (every solve of the tree in long double, transform and assembly fp64 as pinned to the reference) -- under both error
-definitions bench.py and tests/test_gpu_parity.py use for the device.  CPU only.  -> profiles/r05_oracle_twin_floor_<config>.json
+definitions bench.py and tests/test_gpu_parity.py use for the device.  CPU only.  -> profiles/r06_oracle_twin_floor_<config>.json (r05_* : the same, made in round 5)
 usage: python tools/oracle_twin_floor.py <config> [...]"""
 import json
 import os
@@ -31,5 +31,5 @@ for cfg in sys.argv[1:] or ["nc3500"]:
                feature_param_max_rel_err_oracle_vs_twin=feat_param_err(a["stVal"], b["stVal"], b["stno"]),
                note="oracle/lsfm_oracle.c (fp64) against the same tree with every solve in long double (orc_set_extended): the spread of the "
                     "reference's own arithmetic on this set, in the two metrics the device is held to")
-    json.dump(res, open(os.path.join(ROOT, "profiles", f"r05_oracle_twin_floor_{cfg}.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "profiles", f"r06_oracle_twin_floor_{cfg}.json"), "w"), indent=1)
     print(res, flush=True)

@@ -37,17 +37,47 @@ METRIC_NAMES = {"nc3500": "NC3500-like stereo", "rs468": "RS468-like monocular",
                 "spmv-stream": "CG SpMV stand-alone on a 1.4 GB Schur-like matrix"}
 
 
+ROUND = "r06"  # the round whose profiles/ files the line may quote: counters of an older build say nothing about this one's kernels
+
+
 def pmc_traffic(config):
-    """HBM bytes per launch / per tree from the rocprofv3 PMC passes kept under profiles/ for THIS configuration
-    (profiles/r*_pmc_traffic_summary_<config>.json, written by tools/refresh_profiles.py from separate FETCH_SIZE and
-    WRITE_SIZE runs with the gfx950 corrections of MI355X_MICROARCH.md).  None when no such file exists."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_summary_{config}.json")))
-    if not files:
+    """HBM bytes per launch / per tree from THIS round's rocprofv3 PMC passes for THIS configuration
+    (profiles/<ROUND>_pmc_traffic_summary_<config>.json, written by tools/refresh_profiles.py from separate FETCH_SIZE and
+    WRITE_SIZE runs with the gfx950 corrections of MI355X_MICROARCH.md).  None when the round has no such file -- an older
+    round's counters are never quoted (the kernels have changed since)."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic_summary_{config}.json")
+    if not os.path.exists(path):
         return None
     try:
-        return json.load(open(files[-1]))
+        return json.load(open(path))
     except Exception:
         return None
+
+
+def rocprof_kernel_avg(config, prefixes):
+    """Per-launch average (us) and total of the kernels whose names start with one of `prefixes`, from THIS round's committed
+    `rocprofv3 --kernel-trace --stats` summary of this command (profiles/<ROUND>_bench_<config>_kernel_stats.csv): the line carries it
+    so that its roofline fraction can be recomputed from profiles/ alone.  None when the round has no such file."""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_bench_{config}_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    rows = []
+    try:
+        for r in csv.DictReader(open(path)):
+            name = r.get("Name") or r.get("KernelName") or ""
+            mt = re.search(r"lsfm::(k_\w+(?:<[^>]*>)?)", name)
+            short = mt.group(1) if mt else name
+            if any(short.startswith(p) for p in prefixes):
+                rows.append({"kernel": short[:60], "calls": int(r["Calls"]), "total_us": float(r["TotalDurationNs"]) / 1e3,
+                             "avg_us": float(r["AverageNs"]) / 1e3})
+    except Exception:
+        return None
+    if not rows:
+        return None
+    return {"source": os.path.relpath(path, ROOT), "kernels": rows, "total_us": sum(r["total_us"] for r in rows),
+            "calls": sum(r["calls"] for r in rows)}
 
 
 def twin_floor(config):
@@ -327,6 +357,7 @@ def main():
         dom = "trf" if kern["trf"]["total_ms"] > 1.1 * kern["schur"]["total_ms"] else "schur"
         pmc = pmc_traffic(args.config) if (world == 1 and not args.maps) else None
         traffic = None
+        traffic_note = None if pmc else f"no {ROUND} PMC passes for this configuration under profiles/ (counters of an older round are not quoted)"
         whole = None
         if pmc:
             traffic = pmc.get("per_launch", {}).get({"schur": "k_schur_panel", "trf": "k_tr_entries"}[dom])
@@ -393,7 +424,8 @@ def main():
             "roofline": ({"bound": "hbm", "kernel": kern[dom]["name"], "achieved": kern[dom]["gbs"],
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                           "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_bytes_per_launch": kern[dom]["avg_bytes"],
-                          "launches_per_step": kern[dom]["launches_per_step"],
+                          "launches_per_step": kern[dom]["launches_per_step"], "traffic_note": traffic_note,
+                          "rocprof": rocprof_kernel_avg(args.config, ("k_tr_entries",)),
                           "note": "one launch per tree level (12 levels + final re-anchoring); average over all of them, small "
                                   "low-level launches included; algorithmic bytes = every input and output moved once "
                                   "(DESIGN.md); traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/ for this "
@@ -403,7 +435,11 @@ def main():
                           "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_flops_per_launch": kern[dom]["avg_flops"],
                           "hbm_view": {"algorithmic_bytes_per_launch": kern[dom]["avg_bytes"], "achieved_GBps": kern[dom]["gbs"],
                                        "frac_of_hbm_peak": kern[dom]["gbs"] / HBM_PEAK_GBS},
-                          "launches_per_step": kern[dom]["launches_per_step"],
+                          "launches_per_step": kern[dom]["launches_per_step"], "traffic_note": traffic_note,
+                          "rocprof": rocprof_kernel_avg(args.config, ("k_schur_panel", "k_schur_w", "k_schur_slots", "k_schur_lists")),
+                          "rocprof_note": "per-variant averages of the committed rocprofv3 --kernel-trace --stats summary of this command; the variants of a "
+                                          "level run beside each other on two streams, so their SUM (total_us / trees profiled) is above the event "
+                                          "bracket avg_launch_ms x launches_per_step that `achieved` is computed from",
                           "note": "K9 is the one real contraction of the path: a tile's contribution to S is P P^T on v_mfma_f64_16x16x4_f64. "
                                   "ALGORITHMIC flops per feature with k W blocks: k (108 + 36) + k (k + 1) / 2 * 216 (Imp.cpp:2260-2328) -- "
                                   "the zero blocks the dense panel also multiplies are not counted; ~17 flop per HBM byte at the top "

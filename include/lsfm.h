@@ -175,6 +175,24 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
                     const int* feature, int m, int n, int nU, int nW, int Ref, int ScaP, int Fix, int Sign,
                     int FixBlk, const double* x0);
 
+/* ---- Gauss-Newton polish of the map-joining objective (BASELINE.json north_star "plus the Gauss-Newton BA refinement") ----
+ * NO reference counterpart: the reference joins once and has no iterative step (no loop and no residual anywhere in LinearSFMImp.cpp) --
+ * PARITY UNPINNED; checked against oracle/lsfm_gn.inc and by properties (the objective never rises, its gradient falls, a minimiser is
+ * a fixed point).  Minimises, over the global state x and ALL N local maps at once,
+ *     F(x) = sum_k || x^_k - f_k(x) ||^2_{I_k}
+ * x^_k / I_k: estimate / information matrix of local map k, f_k: the reference's own change of frame into map k's frame
+ * (Imp.cpp:421-455, Mono 3268-3306) with the Jacobian the reference's transform forms (Imp.cpp:485-683, Mono 3383-3688) -- the objective
+ * every join of the tree linearises once.  A step solves H d = b (H = sum J^T I J, b = sum J^T I r) through the same Schur + factorisation
+ * as a tree level and takes x += a d, a = 1 halved (at most 8 times) while F does not fall; a step without decrease ends the run.
+ * maps[N]: the local maps the tree was built from.  x: the global state to start from -- m, n, stno, stVal (updated in place; arrays of
+ * the caller), Ref = the pose its frame is anchored at (Stereo: not in the state; a local map with that Ref is in the global frame),
+ * Mono: ScaP / Fix (the gauge: the 6 scalars of pose Ref and scalar Fix of pose ScaP stay where they are), optional pose_origin --
+ * e.g. the result of lsfm_tree_download / lsfm_divide_conquer.  type: 0 Stereo, 1 Monocular.  obj[iters + 1], gnorm[iters + 1]: F and
+ * max |b_i| over the free scalars at the start and after every step; halvings[iters] (may be NULL; 9: no decrease found).
+ * Returns LSFM_OK, LSFM_NOT_CONVERGED (a step's camera system stayed above its residual bound), < 0 errors (LSFM_ERR_ARG: a local
+ * variable that is not in the global state, a global variable no map holds, a Stereo map that holds the global reference pose). */
+int lsfm_gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, int type, lsfm_map* x, int iters, double* obj, double* gnorm, int* halvings);
+
 /* replaces pba_inverseV (Imp.h:213, Imp.cpp:3022-3042): V^-1 of the n 3x3 feature blocks, IN PLACE like the reference's (which
  * inverts V in place and restores it afterwards, Imp.cpp:2210-2212, 2365): the upper triangle of the computed inverse, mirrored.
  * m is unused, as in the reference. */

@@ -116,6 +116,7 @@ def lib():
         L.lsfm_schur_pattern.argtypes = [vp, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, C.c_int, ip]
         L.lsfm_symbolic_analyse.argtypes = [C.c_int, ip, ip, ip, C.c_int, ip, ip, ip, C.c_int, ip, dp]
         L.lsfm_inverse_v.argtypes = [vp, dp, C.c_int, C.c_int]
+        L.lsfm_gn_polish.argtypes = [vp, P(LsfmMap), C.c_int, C.c_int, P(LsfmMap), C.c_int, dp, dp, ip]
         L.lsfm_solve_features.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int, C.c_int, ip, ip]
         L.lsfm_spmv_bench.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
         L.lsfm_wstream_bench.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, dp]
@@ -129,7 +130,7 @@ EXPORTS = ["lsfm_context_create", "lsfm_context_destroy", "lsfm_set_pcg", "lsfm_
            "lsfm_solve_stereo", "lsfm_solve_mono", "lsfm_tree_upload", "lsfm_tree_run", "lsfm_tree_set_final_reanchor",
            "lsfm_tree_download", "lsfm_tree_set_stop_level", "lsfm_tree_node_count", "lsfm_tree_download_node", "lsfm_tree_download_state", "lsfm_tree_set_plans", "lsfm_tree_export_size", "lsfm_tree_export_dev", "lsfm_packed_size",
            "lsfm_tree_upload_dev", "lsfm_tree_reload_dev", "lsfm_tree_set_comm", "lsfm_tree_set_comm_blocks", "lsfm_tree_export_slice_sizes", "lsfm_tree_export_slice_dev",
-           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_write_mapset", "lsfm_mapset_info", "lsfm_mapset_stamp", "lsfm_read_mapset", "lsfm_save_state_bin", "lsfm_save_state", "lsfm_save_poses",
+           "lsfm_tree_free", "lsfm_divide_conquer", "lsfm_read_localmap", "lsfm_read_localmaps", "lsfm_write_localmap", "lsfm_write_mapset", "lsfm_mapset_info", "lsfm_mapset_stamp", "lsfm_read_mapset", "lsfm_save_state_bin", "lsfm_save_state", "lsfm_save_poses", "lsfm_gn_polish",
            "lsfm_spmv_bench", "lsfm_wstream_bench", "lsfm_selftest_prims", "lsfm_schur_pattern", "lsfm_symbolic_analyse", "lsfm_inverse_v", "lsfm_solve_features"]
 
 
@@ -378,6 +379,28 @@ class Context:
         finally:
             self.tree_free(t)
         return out, stats, rc
+
+    def gn_polish(self, maps, mono, G, iters):
+        """lsfm_gn_polish: `iters` Gauss-Newton steps of the map-joining objective over all local maps from the global state G (a map
+        dict: stno, stVal, m, n, Ref; Mono: ScaP, Fix; e.g. what divide_conquer returned).  No reference counterpart (parity unpinned).
+        Returns (stVal, obj[iters + 1], gnorm[iters + 1], halvings[iters], rc)."""
+        hms = [HostMap(d) for d in maps]
+        arr = (LsfmMap * len(hms))(*[h.c for h in hms])
+        x = LsfmMap()
+        stno = _c(G["stno"], np.int32)
+        st = np.array(np.asarray(G["stVal"], np.float64), copy=True)
+        x.m, x.n, x.Ref, x.FRef = int(G["m"]), int(G["n"]), int(G["Ref"]), int(G.get("FRef", G["Ref"]))
+        x.ScaP, x.Fix, x.Sign = int(G.get("ScaP", 0)), int(G.get("Fix", 0)), int(G.get("Sign", 1))
+        x.stno, x.stVal = _ptr(stno, C.c_int), _ptr(st, C.c_double)
+        org = None
+        if G.get("pose_origin") is not None:
+            org = _c(G["pose_origin"], np.int32)
+            x.pose_origin = _ptr(org, C.c_int)
+        obj, gn, hv = np.zeros(iters + 1), np.zeros(iters + 1), np.zeros(max(iters, 1), np.int32)
+        rc = lib().lsfm_gn_polish(self._h, arr, len(hms), int(mono), C.byref(x), int(iters), _ptr(obj, C.c_double), _ptr(gn, C.c_double), _ptr(hv, C.c_int))
+        if rc < 0:
+            self._check(rc, "lsfm_gn_polish")
+        return st, obj, gn, hv[:iters], rc
 
     def inverse_v(self, V):
         """lsfm_inverse_v (the reference's pba_inverseV, Imp.cpp:3022): V^-1 of the 3x3 feature blocks, [n, 9]."""

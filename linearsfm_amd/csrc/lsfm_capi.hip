@@ -869,6 +869,12 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
 	return rc;
 }
 
+int lsfm_gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, int type, lsfm_map* x, int iters, double* obj, double* gnorm, int* halvings)
+{
+	if (!maps || N <= 0 || !x || iters < 0 || !obj || !gnorm || (type != 0 && type != 1)) return LSFM_ERR_ARG;
+	return guarded(ctx, [&]() { return gn_polish(ctx, maps, N, type == 1, x, iters, obj, gnorm, halvings); });
+}
+
 int lsfm_inverse_v(lsfm_context* ctx, double* V, int m, int n)
 {
 	(void)m;

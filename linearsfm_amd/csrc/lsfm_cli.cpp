@@ -7,7 +7,8 @@
 // (level checkpoint: stop after L tree levels and write the nodes of that level as <dir>/localmap_1.txt ...; a later run with
 // -path <dir> -num <nodes> finishes the tree and gives the result of the uninterrupted run), -quiet 1 (no progress lines).
 // -cache <file> (binary cache of the set: read instead of the text files when it holds -num maps of -type, written after the text files
-// were parsed otherwise), -fullbin <file> (final state as raw doubles), -json <file> (the run's lsfm_stats and phase times as one JSON object).
+// were parsed otherwise), -fullbin <file> (final state as raw doubles), -json <file> (the run's lsfm_stats and phase times as one JSON object),
+// -gn <steps> (Gauss-Newton polish of the map-joining objective from the tree's result: lsfm_gn_polish; no reference counterpart).
 #include <chrono>
 #include <sys/stat.h>
 #include <cstdio>
@@ -37,7 +38,7 @@ static void print_help()
 int main(int argc, char** argv)
 {
 	std::string path, st, pose, fea, full, info, nodes, cache, fullbin, json;
-	int num = 0, type = -1, gpu = 0, want_stats = 0, levels = 0, quiet = 0;
+	int num = 0, type = -1, gpu = 0, want_stats = 0, levels = 0, quiet = 0, gn = 0;
 	bool has_path = false, has_num = false;
 	double tol = 0;
 	for (int i = 1; i < argc; i++)
@@ -70,6 +71,7 @@ int main(int argc, char** argv)
 		else if (name == "cache") cache = next();
 		else if (name == "fullbin") fullbin = next();
 		else if (name == "json") json = next();
+		else if (name == "gn") gn = atoi(next());
 	}
 	if (!has_path) { printf("LinerSFM Error: Please Input Right File Path:\n"); return 0; }
 	if (!has_num) { printf("LinerSFM Error: Please Set Local Map Number:\n"); return 0; }
@@ -204,6 +206,21 @@ int main(int argc, char** argv)
 		fprintf(stderr, "LinearSFM: WARNING: %d camera system(s) not solved to the residual of a direct solve (max relative residual %.3e)\n",
 		        stats.not_converged, stats.max_rel_residual);
 	printf("Total Used Time:  %lf  sec\n\n", stats.t_total_ms * 1e-3); // Imp.cpp:2072
+	if (gn > 0)
+	{
+		// -gn <steps>: Gauss-Newton polish of the map-joining objective over all local maps, from the tree's result (lsfm_gn_polish; the
+		// reference has no such step -- without the flag the program is the reference's)
+		std::vector<double> obj(gn + 1), gnorm(gn + 1);
+		std::vector<int> halv(gn);
+		const double g0 = now();
+		const int grc = lsfm_gn_polish(ctx, maps.data(), num, type, &out, gn, obj.data(), gnorm.data(), halv.data());
+		if (grc < 0) { fprintf(stderr, "LinearSFM: %s\n", lsfm_last_error(ctx)); return 3; }
+		if (!quiet)
+		{
+			for (int i = 0; i <= gn; i++) printf("Gauss-Newton Step %d: Objective %.9e  Gradient %.3e\n", i, obj[i], gnorm[i]);
+			printf("Gauss-Newton Used Time:  %lf  sec\n\n", now() - g0);
+		}
+	}
 	if (want_stats)
 		fprintf(stderr, "lsfm: total %.3f ms (transform %.3f, join %.3f [schur %.3f, pcg %.3f, backsub %.3f]), pcg its %ld, max rel resid %.2e, not converged %d, attempts %d\n",
 		        stats.t_total_ms, stats.t_transform_ms, stats.t_join_ms, stats.t_schur_ms, stats.t_pcg_ms, stats.t_backsub_ms, stats.pcg_iterations,

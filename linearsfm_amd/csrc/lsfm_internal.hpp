@@ -450,6 +450,8 @@ struct SolveIO {
 int small_solve_strips(int most_poses, int cap); // 16-row strips of the dense path's panel; 0: the systems are too large for it (cap: lsfm_context::small_max)
 void small_solve_launch(lsfm_context* ctx, const SolveIO& io, int strips, int* status, double* max_rel);
 int solve_batch(lsfm_context* ctx, const SolveIO& io);
+// Gauss-Newton polish of the map-joining objective over all local maps at once (lsfm_gn.hip; C ABI: lsfm_gn_polish)
+int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_map* x, int iters, double* obj, double* gnorm, int* halvings);
 // the two feature-side pieces of the solve on their own (C ABI: lsfm_inverse_v / lsfm_solve_features); device pointers
 void vinv_only(lsfm_context* ctx, int NF, const double* V, double* IV);
 void backsub_only(lsfm_context* ctx, int NF, const int* fptr, const int* photo, const double* W, const double* IV, const double* eb, const double* xp, double* xf);

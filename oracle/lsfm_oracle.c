@@ -1719,3 +1719,8 @@ int orc_divide_conquer(orc_map* LM, int nLocalMapCount, int mono, orc_map* out, 
 	if (timing) { timing[0] = now_s() - t0; timing[1] = g_t_trans; timing[2] = g_t_asm; timing[3] = g_t_solve; }
 	return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Gauss-Newton polish of the map-joining objective (no counterpart in the reference: parity unpinned)
+ * ---------------------------------------------------------------------------------------------- */
+#include "lsfm_gn.inc"

@@ -113,6 +113,15 @@ int orc_chol_solve_x(int n, const int* Ap, const int* Ai, const long double* Ax,
 /* minimum-degree ordering on a symmetric block pattern given as upper CSC (Ap[nb+1], Ai) */
 void orc_min_degree(int nb, const int* Ap, const int* Ai, int* perm);
 
+/* Gauss-Newton polish of the map-joining objective F(x) = sum_k ||x^_k - f_k(x)||^2_{I_k} over the N local maps (lsfm_gn.inc; the
+ * reference has no such step: PARITY UNPINNED, property-checked).  G: the global state -- stno / stVal / m / n, Ref (its frame), Mono
+ * also ScaP / Fix (gauge) -- e.g. the result of orc_divide_conquer; stVal is updated in place.  obj / gnorm: [iters + 1]. */
+int orc_gn_polish(const orc_map* maps, int N, int mono, orc_map* G, int iters, double* obj, double* gnorm, int* halvings);
+/* F and b = sum_k J_k^T I_k r_k (= -1/2 grad F) at G's state; grad[6m + 3n] may be NULL */
+int orc_gn_objective(const orc_map* maps, int N, int mono, const orc_map* G, double* F, double* grad);
+/* y = H v, H = sum_k J_k^T I_k J_k the matrix of a step at G's state (test entry) */
+int orc_gn_hessian_times(const orc_map* maps, int N, int mono, const orc_map* G, const double* v, double* y);
+
 void orc_set_match_hash(int on);
 /* on = 0: orc_divide_conquer leaves the final map in the frame of its last join (a subtree root, Imp.cpp:2032),
  * instead of taking it back to its first frame (Imp.cpp:2039-2063) */

@@ -62,6 +62,9 @@ def lib():
         L.orc_schur_csc.argtypes = [dp, ip, ip, C.c_int, C.c_int, C.c_int, P(ip), P(ip), P(dp)]
         L.orc_schur_csc.restype = C.c_int
         L.orc_solve_features.argtypes = [dp, dp, dp, dp, dp, C.c_int, ip, ip, C.c_int]
+        L.orc_gn_polish.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), C.c_int, dp, dp, ip]
+        L.orc_gn_objective.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), dp, dp]
+        L.orc_gn_hessian_times.argtypes = [P(OrcMap), C.c_int, C.c_int, P(OrcMap), dp, dp]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _LIB = L
@@ -297,3 +300,62 @@ def divide_conquer(dicts, mono, verbose=False, match_hash=True, final_reanchor=T
     res = map_to_dict(out)
     L.orc_map_free(C.byref(out))
     return res, list(timing), rc
+
+
+def _gn_maps(dicts, G):
+    N = len(dicts)
+    arr = (OrcMap * N)()
+    for k, d in enumerate(dicts):
+        arr[k] = dict_to_map(d)
+    g = dict_to_map(G)
+    return arr, g
+
+
+def _gn_free(arr, g):
+    L = lib()
+    for k in range(len(arr)):
+        L.orc_map_free(C.byref(arr[k]))
+    L.orc_map_free(C.byref(g))
+
+
+def gn_objective(dicts, mono, G, want_grad=True):
+    """F(x) = sum_k ||x^_k - f_k(x)||^2_{I_k} and b = sum_k J_k^T I_k r_k (= -grad F / 2) at the global state G (lsfm_gn.inc)."""
+    L = lib()
+    arr, g = _gn_maps(dicts, G)
+    F = C.c_double(0.0)
+    grad = np.zeros(6 * g.m + 3 * g.n) if want_grad else None
+    rc = L.orc_gn_objective(arr, len(dicts), int(mono), C.byref(g), C.byref(F), _p(grad, C.c_double) if want_grad else None)
+    _gn_free(arr, g)
+    if rc:
+        raise ValueError(f"orc_gn_objective -> {rc}")
+    return F.value, grad
+
+
+def gn_hessian_times(dicts, mono, G, v):
+    """H v for the step matrix H = sum_k J_k^T I_k J_k at the global state G."""
+    L = lib()
+    arr, g = _gn_maps(dicts, G)
+    v = np.ascontiguousarray(v, np.float64)
+    y = np.zeros_like(v)
+    rc = L.orc_gn_hessian_times(arr, len(dicts), int(mono), C.byref(g), _p(v, C.c_double), _p(y, C.c_double))
+    _gn_free(arr, g)
+    if rc:
+        raise ValueError(f"orc_gn_hessian_times -> {rc}")
+    return y
+
+
+def gn_polish(dicts, mono, G, iters, extended=False):
+    """`iters` Gauss-Newton steps of the map-joining objective from the global state G (a map dict: stno, stVal, Ref, Mono: ScaP, Fix).
+    Returns (stVal, obj[iters + 1], gnorm[iters + 1], halvings[iters], rc).  extended: the steps' solves in long double (the twin)."""
+    L = lib()
+    L.orc_set_extended(int(extended))
+    L.orc_set_comm(0, 1, C.cast(None, REDUCE_FN))
+    arr, g = _gn_maps(dicts, G)
+    obj, gn, hv = np.zeros(iters + 1), np.zeros(iters + 1), np.zeros(max(iters, 1), np.int32)
+    rc = L.orc_gn_polish(arr, len(dicts), int(mono), C.byref(g), int(iters), _p(obj, C.c_double), _p(gn, C.c_double), _p(hv, C.c_int))
+    st = _arr(g.stVal, 6 * g.m + 3 * g.n, np.float64)
+    _gn_free(arr, g)
+    L.orc_set_extended(0)
+    if rc < 0:
+        raise ValueError(f"orc_gn_polish -> {rc}")
+    return st, obj, gn, hv[:iters], rc

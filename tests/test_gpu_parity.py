@@ -365,12 +365,14 @@ def test_baseline_configuration_at_full_size_vs_oracle(ctx, oracle, config):
           f"{stats['t_total_ms']:.1f} ms" + (f"; the oracle against its long-double twin on the same set: {floor['pose_param_max_rel_err_oracle_vs_twin']:.2e} "
                                              f"(without the unit floor: {floor['pose_param_max_true_rel_err_oracle_vs_twin']:.2e})" if floor else ""))
     assert ep < TREE_TOL and ef < TREE_TOL, (ep, ef)
-    # measured: 2.6e-5 on the NC3500-like set -- the absolute noise of the largest coordinates (1.7e-7 x a path that spans ~150 units)
-    # held against components of size ~1; the oracle's two evaluations differ by 2.5e-5 in that metric (the floor file above)
-    assert et < 1e-4, et
-    if floor:
-        # the device is no further from the oracle than a small multiple of what the reference's own arithmetic leaves open
-        assert et < 4 * max(floor["pose_param_max_true_rel_err_oracle_vs_twin"], 1e-7), (et, floor)
+    # BASELINE.json's 1e-6 read literally -- |a - b| / |b| per pose scalar -- is NOT met by the reference's own arithmetic on these sets: its
+    # fp64 evaluation and the evaluation with every solve in long double differ by 2.5e-5 (nc3500), 9.4e-6 (rs468), 2.4e-7 (rs90) in that
+    # metric (the floor files: the absolute noise of the largest coordinates held against components of size ~1).  The device is held to
+    # TWICE that measured floor (round 5: a flat 1e-4)
+    assert floor is not None, "profiles/r*_oracle_twin_floor_<config>.json is missing"
+    bar = 2.0 * floor["pose_param_max_true_rel_err_oracle_vs_twin"]
+    print(f"{config}: true relative error {et:.3e} against the bar {bar:.3e} (2 x the oracle-vs-long-double-twin floor)")
+    assert et < bar, (et, bar)
 
 
 @pytest.mark.parametrize("mono", [False, True])

@@ -27,6 +27,7 @@
 // back-substitution).  HBM-bound: a step streams the local maps' W once (144 B in + 144 B out per block, + 144 B per hub block) and
 // the joint map through the solver.
 #include <algorithm>
+#include <chrono>
 
 #include "lsfm_device.hpp"
 #include "lsfm_internal.hpp"
@@ -487,6 +488,12 @@ int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_ma
 {
 	hipStream_t s = ctx->stream;
 	const int M = x->m, NFG = x->n;
+	// LSFM_GN_TIMING=1: wall clock of the call's parts on stderr (every part ends with a synchronisation of its own)
+	static const bool timing = getenv("LSFM_GN_TIMING") != nullptr;
+	auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tw0 = wall();
+	double t_asm = 0.0, t_solve = 0.0;
+	int n_asm = 0, n_solve = 0;
 	if (M <= 0 || NFG < 0 || !x->stno || !x->stVal) LSFM_FAIL(LSFM_ERR_ARG, "gn polish: the global state is empty");
 	// ---- structure, once per call (host): which global variable every local one is, where every local block lands ----
 	std::vector<Lab> pt(M), ft(NFG);
@@ -639,6 +646,7 @@ int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_ma
 
 	// F and the step's system at the state in d_x
 	auto assemble = [&]() -> double {
+		const double ta = wall();
 		dev_zero(ctx, Gacc, ((size_t)P * GN_GW + (size_t)N * GN_HW + 2) * sizeof(double));
 		hipLaunchKernelGGL(k_gn_hubs, grid_for(N, 128), dim3(128), 0, s, N, d_gm, d_x);
 		hipLaunchKernelGGL(k_gn_poses, grid_for(P, 128), dim3(128), 0, s, P, X.pose_map, d_gm, d_gp, d_x, X.pose, Dp, Cp, rp);
@@ -654,6 +662,7 @@ int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_ma
 		hipLaunchKernelGGL(k_gn_gather_pose, grid_for(M, 128), dim3(128), 0, s, M, d_psp, d_psi, ePinst, Hacc, ea);
 		double F = 0.0;
 		d2h(ctx, &F, Fsum, sizeof(double));
+		t_asm += wall() - ta; n_asm++;
 		return F;
 	};
 	auto grad_norm = [&]() -> double {
@@ -674,6 +683,8 @@ int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_ma
 
 	int ret = LSFM_OK;
 	bool stopped = false;
+	LSFM_CHECK_HIP(hipStreamSynchronize(s));
+	const double tw1 = wall();
 	double F = assemble();
 	for (int it = 0; it <= iters; it++)
 	{
@@ -683,8 +694,10 @@ int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_ma
 		if (stopped) continue;
 		if (!(F == F)) LSFM_FAIL(LSFM_ERR_INTERNAL, "gn polish: the objective is not a number");
 		const size_t smark = ctx->scratch.mark();
+		const double ts = wall();
 		const int rc = solve_batch(ctx, io);
 		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		t_solve += wall() - ts; n_solve++;
 		ctx->scratch.release(smark);
 		if (rc) ret = LSFM_NOT_CONVERGED;
 		LSFM_CHECK_HIP(hipMemcpyAsync(d_x0, d_x, RS * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -707,6 +720,10 @@ int gn_polish(lsfm_context* ctx, const lsfm_map* maps, int N, bool mono, lsfm_ma
 		if (halvings) halvings[it] = h > 8 ? 9 : h;
 	}
 	d2h(ctx, x->stVal, d_x, RS * sizeof(double));
+	if (timing)
+		fprintf(stderr, "lsfm_gn: %d maps, %d poses, %d features, joint system %d U / %d W blocks; structure + upload %.2f ms, %d assemblies %.2f ms each, "
+		                "%d solves %.2f ms each, call %.2f ms\n", N, M, NFG, NUJ, NWJ, tw1 - tw0, n_asm, n_asm ? t_asm / n_asm : 0.0, n_solve,
+		        n_solve ? t_solve / n_solve : 0.0, wall() - tw0);
 	return ret;
 }
 

@@ -31,7 +31,7 @@
 
 namespace lsfm {
 
-#define PM_TILE 128
+#define PM_TILE LSFM_PM_TILE
 #define PM_PASS 16
 #define PM_K (3 * PM_PASS)
 #define PM_KS (PM_K + 1) /* odd row stride: the 16 rows x 2 k of a half-wave fall into distinct LDS banks */
@@ -41,7 +41,7 @@ namespace lsfm {
 #define PM_HASH 64
 #define PM_THREADS 256
 #define PM_WIDE 512     /* threads of the 32 / 48 / 64-slot variants */
-#define PM_MAXE 3584 /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 per feature on average); later ones are added after the first blocks */
+#define PM_MAXE (PM_TILE == 128 ? 3584 : 5120) /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 / 20 per feature on average); later ones are added after the first blocks */
 #define PM_BF 352   /* >= rows held in registers per pass / 6 (4 x 256 or 3 x 512) */
 #define PM_DUP 0x80  /* eslot: a block whose (pose, feature) an earlier block of the tile already holds */
 

@@ -326,7 +326,7 @@ k_schur_w(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, c
           const double* __restrict__ eb, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
           K9Out o, const unsigned char* __restrict__ only, const double* __restrict__ LY)
 {
-	if (only && !only[blockIdx.x]) return; // fallback pass: only the tiles the panel kernel could not take
+	if (only && !only[blockIdx.x / (LSFM_PM_TILE / SCHUR_TILE)]) return; // fallback pass: only the tiles the panel kernel could not take
 	// (the same fixed-point sums as the panel kernel's, k_schur_scale: per feature here, so already the LDS tables are integers)
 	__shared__ int skey[SCHUR_CAP];
 	__shared__ int ekey[SCHUR_ECAP];
@@ -1365,7 +1365,7 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 		// bracketed by HIP events on this stream: live duration of the K9 launch for the roofline line of bench.py
 		hipEvent_t e2 = nullptr, e3 = nullptr;
 		if (ctx->stats) { e2 = ctx->pool_event(); e3 = ctx->pool_event(); LSFM_REC_T(e2, s); }
-		static_assert(SCHUR_TILE == 128, "the fallback kernel must tile like the panel kernel");
+		static_assert(LSFM_PM_TILE % SCHUR_TILE == 0, "a tile of the panel kernel must be whole tiles of the fallback kernel");
 		int most = 0;
 		for (int r : io.seg_rows) most = std::max(most, r);
 		// the per-tile slots of the panel variants: from the plan of the level, or worked out now (and left for the plan, if this

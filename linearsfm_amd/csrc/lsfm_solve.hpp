@@ -2,6 +2,12 @@
 #pragma once
 #include "lsfm_internal.hpp"
 
+// features per tile of K9's panel kernel (lsfm_schur_panel.hip); the per-feature fallback k_schur_w keeps tiles of 128 and looks its
+// flag up in the panel kernel's tiling
+#ifndef LSFM_PM_TILE
+#define LSFM_PM_TILE 128
+#endif
+
 namespace lsfm {
 
 // What K9's panel kernel works out per tile of 128 features from index arrays alone (which poses see the tile = its slots,

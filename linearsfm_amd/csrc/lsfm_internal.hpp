@@ -98,8 +98,22 @@ struct PcgOptions { double rel_tol = 1e-12; int max_steps = 50; bool mixed = fal
 // groups of the factorisation (the reference redoes its symbolic analysis in every join: cholmod_analyze_p,
 // Imp.cpp:2440; here it is done once per tree shape).  With a valid plan a level is enqueued without a single
 // host <-> device synchronisation.
+// Index arrays of a level that depend on its structure alone and that transform and join would otherwise work out again: the
+// exclusive scans of the transform's kept-block flags (k_tr_flags + two scans) and the join's common-feature matches with the ranks
+// of the unmatched features (hash insert + probe + a scan).  A run that analyses finds them where the level below's preparation
+// one level ahead left them (schur_pattern_prefetch computes exactly these for the counts and the pattern: they were computed twice
+// until round 6); a resident tree's plan keeps copies of its own (`own`).
+struct LevelIndex {
+	int NU = -1, NW = -1, NF = -1;             // sizes of the level's INPUT batch they belong to
+	const int *KU = nullptr, *KW = nullptr;    // [NU + 2] / [NW + 2] (transform_batch)
+	const int *match = nullptr, *R = nullptr;  // [NF + 1] / [NF + 2] (join_stereo_prepare)
+	std::shared_ptr<void> own;                 // plan-owned device memory; null: the arrays live in the preparer's arena
+};
+const int* level_index_keep(lsfm_context* ctx, LevelIndex& li, const int* src, size_t n); // a copy of src[0..n) in memory li owns
+
 struct LevelPlan {
 	bool valid = false;
+	LevelIndex idx;
 	std::vector<int> tr_cnt;     // transform: kept-block prefix values at the map boundaries (U then W)
 	// Mono: sign of the new scale of every transformed map.  This one depends on VALUES (sign of a pose component): a
 	// planned level compares it with what the device computes from the current values and flags the run when they differ

@@ -279,25 +279,44 @@ void join_stereo_prepare(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBa
 	st.smark = ctx->scratch.mark();
 	st.ar = &ar;
 
-	// ---- common features (K5) ----
-	int* match = ctx->scratch.alloc<int>(in.NF + 1);
-	int* unm = ctx->scratch.alloc<int>(in.NF + 2);
-	int* R = ctx->scratch.alloc<int>(in.NF + 2);
+	// ---- common features (K5) ---- (from the level's plan when it holds them: LevelIndex, lsfm_internal.hpp)
+	static const bool reuse_index = !getenv("LSFM_NO_INDEX_REUSE");
+	LevelPlan* plan = ctx->plan;
+	const int *match = nullptr, *R = nullptr;
 	const int nb = (in.NF + 255) / 256;
-	if (in.NF) join_match_features(ctx, in, match, unm);
-	else dev_zero(ctx, unm, 2 * sizeof(int));
-	dev_exclusive_scan(ctx, unm, R, in.NF);
-	// unmatched counts per map -> joint feature offsets (host)
-	int* d_rb = ctx->scratch.alloc<int>(B + 1);
-	hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, R, in.d_feat_off, B + 1, d_rb);
 	std::vector<int> rb(B + 1);
-	if (ctx->warm()) rb = ctx->plan->join_rb; // known from an earlier run of the same tree
+	if (reuse_index && ctx->warm() && plan->idx.match && plan->idx.R && plan->idx.NF == in.NF)
+	{
+		match = plan->idx.match; R = plan->idx.R;
+		rb = plan->join_rb;
+	}
 	else
 	{
-		ctx->mark("jn_enq");
-		d2h_ints(ctx, d_rb, rb.data(), B + 1);
-		ctx->mark("jn_rb");
-		if (ctx->plan) ctx->plan->join_rb = rb;
+		int* mt = ctx->scratch.alloc<int>(in.NF + 1);
+		int* unm = ctx->scratch.alloc<int>(in.NF + 2);
+		int* Rw = ctx->scratch.alloc<int>(in.NF + 2);
+		if (in.NF) join_match_features(ctx, in, mt, unm);
+		else dev_zero(ctx, unm, 2 * sizeof(int));
+		dev_exclusive_scan(ctx, unm, Rw, in.NF);
+		match = mt; R = Rw;
+		if (ctx->warm()) rb = plan->join_rb; // known from an earlier run of the same tree
+		else
+		{
+			// unmatched counts per map -> joint feature offsets (host)
+			int* d_rb = ctx->scratch.alloc<int>(B + 1);
+			hipLaunchKernelGGL(k_gather_at, dim3((B + 1 + 127) / 128), dim3(128), 0, s, R, in.d_feat_off, B + 1, d_rb);
+			ctx->mark("jn_enq");
+			d2h_ints(ctx, d_rb, rb.data(), B + 1);
+			ctx->mark("jn_rb");
+			if (plan) plan->join_rb = rb;
+			if (reuse_index && plan && plan != &ctx->pre_plan && ctx->in_tree_run)
+			{
+				// a resident tree records the level: its later runs skip the matching and its scan
+				plan->idx.match = level_index_keep(ctx, plan->idx, mt, (size_t)in.NF + 1);
+				plan->idx.R = level_index_keep(ctx, plan->idx, Rw, (size_t)in.NF + 2);
+				plan->idx.NF = in.NF;
+			}
+		}
 	}
 
 	out = DevBatch();

@@ -1841,6 +1841,7 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 	if (ctx->timeline_on) { (void)hipEventSynchronize(ctx->evY); ctx->mark("pre_evY"); }
 	CholHostIn& hin = pl->hin;
 	std::vector<int> counts;
+	LevelIndex kept;
 	bool ok = false;
 	struct Swap { // this stretch runs on stream3 and allocates from the small arena of the level's parity
 		lsfm_context* c; Arena& a;
@@ -1851,7 +1852,7 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 		Swap sw(ctx, sa);
 		int* d_tref = ctx->scratch.alloc<int>(Y.B);
 		h2d(ctx, d_tref, target_ref.data(), sizeof(int) * (size_t)Y.B);
-		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy, whole ? &counts : nullptr, !next_small);
+		ok = schur_pattern_prefetch(ctx, Y, d_tref, ctx->solved_keys, ctx->solved_nnzb, pl->sy, whole ? &counts : nullptr, !next_small, whole ? &kept : nullptr);
 		if (ok)
 		{
 			if (!next_small) chol_fetch(ctx, pl->sy, Y.pose_origin, hin); // (synchronises stream3: the counts have arrived too)
@@ -1867,6 +1868,7 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 		ctx->pre_plan.tr_cnt.assign(counts.begin(), counts.begin() + 2 * (B + 1));
 		ctx->pre_plan.join_rb.assign(counts.begin() + 2 * (B + 1), counts.end());
 		ctx->pre_plan.solve.reset();
+		ctx->pre_plan.idx = kept;
 		ctx->pre_plan.valid = true;
 		ctx->pre_plan_level = next_level;
 		ctx->mark("pre_plan");
@@ -1898,6 +1900,7 @@ void prefetch_next_level(lsfm_context* ctx, const DevBatch& Y, const std::vector
 	ctx->pre_plan.tr_cnt.assign(counts.begin(), counts.begin() + 2 * (B + 1));
 	ctx->pre_plan.join_rb.assign(counts.begin() + 2 * (B + 1), counts.end());
 	ctx->pre_plan.solve.reset();
+	ctx->pre_plan.idx = kept;
 	ctx->pre_plan.valid = true;
 	ctx->pre_plan_level = next_level;
 	ctx->pre_pending = pl;

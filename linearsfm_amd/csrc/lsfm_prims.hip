@@ -87,6 +87,23 @@ void* Arena::alloc_bytes(size_t bytes)
 	return base + a;
 }
 
+namespace {
+struct IndexHold {
+	std::vector<void*> p;
+	~IndexHold() { for (void* q : p) (void)hipFree(q); }
+};
+} // namespace
+const int* level_index_keep(lsfm_context* ctx, LevelIndex& li, const int* src, size_t n)
+{
+	if (!li.own) li.own = std::make_shared<IndexHold>();
+	IndexHold* h = static_cast<IndexHold*>(li.own.get());
+	void* d = nullptr;
+	LSFM_CHECK_HIP(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(int)));
+	h->p.push_back(d);
+	if (n) LSFM_CHECK_HIP(hipMemcpyAsync(d, src, n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+	return static_cast<const int*>(d);
+}
+
 void dev_exclusive_scan(lsfm_context* ctx, const int* in, int* out, size_t n)
 {
 	// scans n+1 entries (callers keep one trailing zero in `in`) so that out[n] is the total

@@ -1172,7 +1172,7 @@ __global__ void k_pre_gather(const int* __restrict__ KU, const int* __restrict__
 // `cnt`) and the ranks of the unmatched features there (join_stereo_prepare's `rb`), 3 (B + 1) ints, valid after the
 // caller's next synchronisation of the stream.
 bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy,
-                            std::vector<int>* counts, bool want_pattern)
+                            std::vector<int>* counts, bool want_pattern, LevelIndex* keep)
 {
 	// prev_keys == null: the level that produced Y left no pattern (its systems were small enough for the dense path, which needs
 	// none): the pairs inside every map of Y are then taken from Y's own W runs (k_pat_insert_w), as a level without a predecessor does
@@ -1212,6 +1212,14 @@ bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_t
 		hipLaunchKernelGGL(k_pre_gather, dim3((B + 1 + 127) / 128), dim3(128), 0, s, KU, KW, R, d_off, d_off + B + 1, Y.d_feat_off, B, d_cnt);
 		counts->resize(3 * (size_t)(B + 1));
 		LSFM_CHECK_HIP(hipMemcpyAsync(counts->data(), d_cnt, counts->size() * sizeof(int), hipMemcpyDeviceToHost, s));
+		if (keep)
+		{
+			// what the next level's transform and join would work out again from the same index arrays (they live in this arena until
+			// the level after next prepares ITS successor)
+			*keep = LevelIndex();
+			keep->NU = Y.NU; keep->NW = Y.NW; keep->NF = Y.NF;
+			keep->KU = KU; keep->KW = KW; keep->match = match; keep->R = R;
+		}
 	}
 	if (!want_pattern)
 	{

@@ -69,7 +69,7 @@ void build_schur_pattern(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 bool schur_pattern_early_finish(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void schur_pattern_early_extras(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 bool schur_pattern_prefetch(lsfm_context* ctx, const DevBatch& Y, const int* d_tref, const unsigned long long* prev_keys, int prev_nnzb, SchurSystem& sy,
-                            std::vector<int>* counts = nullptr, bool want_pattern = true);
+                            std::vector<int>* counts = nullptr, bool want_pattern = true, LevelIndex* keep = nullptr);
 void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void schur_vinv(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy);
 void build_spmv_index(lsfm_context* ctx, SchurSystem& sy, const unsigned long long* sorted_upper, int* d_flags, int nmir = -1);

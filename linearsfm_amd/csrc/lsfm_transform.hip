@@ -1180,20 +1180,33 @@ void transform_batch(lsfm_context* ctx, Arena& ar, const DevBatch& in, const std
 		if (mono) hipLaunchKernelGGL(k_tr_pose_jac<2>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);
 		else hipLaunchKernelGGL(k_tr_pose_jac<1>, dim3((M + 127) / 128), dim3(128), 0, s, out.pose, in.pose_map, M, d_tm, Dp, Cp);
 	}
-	// structure of the output: which blocks survive as they are, prefix sums, per-map offsets
-	int* keepU = ctx->scratch.alloc<int>(in.NU + 1);
-	int* keepW = ctx->scratch.alloc<int>(in.NW + 1);
-	int* KU = ctx->scratch.alloc<int>(in.NU + 2);
-	int* KW = ctx->scratch.alloc<int>(in.NW + 2);
-	{
-		int nmax = std::max(std::max(in.NU, in.NW), 1);
-		hipLaunchKernelGGL(k_tr_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, in.Ui, in.Uj, in.NU, in.photo, in.NW, in.pose_map, d_tm, keepU, keepW);
-	}
-	dev_exclusive_scan(ctx, keepU, KU, in.NU);
-	dev_exclusive_scan(ctx, keepW, KW, in.NW);
-	int* d_cnt = ctx->scratch.alloc<int>(3 * (B + 1));
+	// structure of the output: which blocks survive as they are, prefix sums, per-map offsets -- from the level's plan when it holds
+	// them (LevelIndex: left by the preparation one level ahead, or kept by a resident tree), worked out here otherwise
 	LevelPlan* plan = ctx->plan;
 	const bool warm = ctx->warm();
+	static const bool reuse_index = !getenv("LSFM_NO_INDEX_REUSE");
+	const int *KU = nullptr, *KW = nullptr;
+	if (reuse_index && warm && plan->idx.KW && plan->idx.KU && plan->idx.NU == in.NU && plan->idx.NW == in.NW) { KU = plan->idx.KU; KW = plan->idx.KW; }
+	else
+	{
+		int* keepU = ctx->scratch.alloc<int>(in.NU + 1);
+		int* keepW = ctx->scratch.alloc<int>(in.NW + 1);
+		int* kU = ctx->scratch.alloc<int>(in.NU + 2);
+		int* kW = ctx->scratch.alloc<int>(in.NW + 2);
+		int nmax = std::max(std::max(in.NU, in.NW), 1);
+		hipLaunchKernelGGL(k_tr_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, in.Ui, in.Uj, in.NU, in.photo, in.NW, in.pose_map, d_tm, keepU, keepW);
+		dev_exclusive_scan(ctx, keepU, kU, in.NU);
+		dev_exclusive_scan(ctx, keepW, kW, in.NW);
+		KU = kU; KW = kW;
+		if (reuse_index && plan && !warm && plan != &ctx->pre_plan && ctx->in_tree_run)
+		{
+			// a resident tree records the level: its later runs skip the three launches above
+			plan->idx.KU = level_index_keep(ctx, plan->idx, kU, (size_t)in.NU + 2);
+			plan->idx.KW = level_index_keep(ctx, plan->idx, kW, (size_t)in.NW + 2);
+			plan->idx.NU = in.NU; plan->idx.NW = in.NW;
+		}
+	}
+	int* d_cnt = ctx->scratch.alloc<int>(3 * (B + 1));
 	std::vector<int> cnt(2 * (B + 1)), dev_sign;
 	if (warm) cnt = plan->tr_cnt; // the structure of this level is known from an earlier run of the same tree: no round trip
 	else

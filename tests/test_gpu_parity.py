@@ -368,10 +368,11 @@ def test_baseline_configuration_at_full_size_vs_oracle(ctx, oracle, config):
     # BASELINE.json's 1e-6 read literally -- |a - b| / |b| per pose scalar -- is NOT met by the reference's own arithmetic on these sets: its
     # fp64 evaluation and the evaluation with every solve in long double differ by 2.5e-5 (nc3500), 9.4e-6 (rs468), 2.4e-7 (rs90) in that
     # metric (the floor files: the absolute noise of the largest coordinates held against components of size ~1).  The device is held to
-    # TWICE that measured floor (round 5: a flat 1e-4)
+    # TWICE that measured floor (round 5: a flat 1e-4) -- or to BASELINE.json's literal 1e-6 where the floor lies below half of it (rs90:
+    # the device's 5e-7 meets the tolerance as written)
     assert floor is not None, "profiles/r*_oracle_twin_floor_<config>.json is missing"
-    bar = 2.0 * floor["pose_param_max_true_rel_err_oracle_vs_twin"]
-    print(f"{config}: true relative error {et:.3e} against the bar {bar:.3e} (2 x the oracle-vs-long-double-twin floor)")
+    bar = max(1e-6, 2.0 * floor["pose_param_max_true_rel_err_oracle_vs_twin"])
+    print(f"{config}: true relative error {et:.3e} against the bar {bar:.3e} (max of 1e-6 and 2 x the oracle-vs-long-double-twin floor)")
     assert et < bar, (et, bar)
 
 

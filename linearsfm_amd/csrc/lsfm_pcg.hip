@@ -2218,6 +2218,9 @@ __global__ void k_pcg_start(int nseg, PcgSeg* seg, const unsigned char* __restri
 	g.active = active ? active[s] : 1;
 	g.done = (!g.active || !(g.rr > g.thresh)) ? 1 : 0;
 	g.rr_prev = g.rr;
+	// the record of the system's LAST true residual (seg[nseg + s]: what k_pcg_run_stats and the host's verdict read): the starting
+	// point's, until a step's test replaces it (k_pcg_check) -- a system that starts below its bound is never touched again
+	seg[nseg + s].rr = g.rr; seg[nseg + s].ee = g.ee;
 	g.rr = 0;
 	if (g.done) atomicAdd(ndone, 1);
 }
@@ -2268,6 +2271,7 @@ __global__ void k_pcg_check(int nseg, PcgSeg* seg, int* ndone)
 	if (g.done) return;
 	const double rr = g.rr;
 	g.its++;
+	seg[nseg + s].rr = rr; // (the true residual r = E - S x of the iterate just formed: frozen systems keep the one they froze with)
 	// converged; or the true residual stopped shrinking where a direct solve would leave it too (relative 1e-8: attainable
 	// accuracy reached); or -- far above that -- three steps in a row that hardly moved it (a system this badly conditioned is
 	// reported: the final check counts it as not converged).  One slow step alone does not end the refinement: the camera
@@ -2291,6 +2295,12 @@ __global__ void k_pcg_reset(int nseg, int cur, PcgSeg* seg)
 	g.pAp = 0; g.rr = 0; g.rz[cur] = 0; // rz[cur] is the accumulator of the next iteration
 }
 
+// (a feature-sharded run forms the final residual once more, for the x every rank ends with: its record starts from zero)
+__global__ void k_pcg_final_zero(int nseg, PcgSeg* fin)
+{
+	int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < nseg) { fin[s].rr = 0.0; fin[s].ee = 0.0; }
+}
 // per-system outcome of a level into the run's device accumulators (a warm level does not stop to read them)
 __global__ void k_pcg_run_stats(int nseg, const PcgSeg* __restrict__ seg, RunStatsDev* run)
 {
@@ -2692,6 +2702,8 @@ small_tail:
 	// (a run that counts its steps does not stop to ask before the first one either: systems that start below their bound
 	// are frozen on the device, the step costs them nothing)
 	int its = 0, ndone = 0;
+	hipEvent_t es0 = ctx->pool_event(), es1 = ctx->pool_event(); // around one product S x of the refinement (lsfm_stats.spmv_ms)
+	bool es_done = false;
 	// (a level that needed two steps or more -- three with the fp32 preconditioner, where two is the rule -- is ill-conditioned enough
 	// for its count to vary from run to run -- one synth-16k run in
 	// eight asked for one more than the run before and had to be repeated as a whole: such levels get one step of margin; systems
@@ -2703,7 +2715,9 @@ small_tail:
 		const int cur = its & 1;
 		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
 		hipLaunchKernelGGL(k_pcg_update1, dim3(nbr), dim3(128), 0, s, M, cur, io.d_pose_seg, x, p, Ap, seg);
+		if (!es_done) LSFM_REC_T(es0, s);
 		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
+		if (!es_done) { LSFM_REC_T(es1, s); es_done = true; }
 		hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, r, seg, 0);
 		// the test comes before the preconditioner: the apply for a residual that already passed would be wasted
 		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, seg, d_misc + 1);
@@ -2759,15 +2773,21 @@ small_tail:
 		cm.allreduce(s, xb, nscal, LSFM_DTYPE_F64);
 		LSFM_CHECK_HIP(hipMemcpyAsync(x, xb, nscal * sizeof(double), hipMemcpyDeviceToDevice, s));
 	}
-	// ---- true residual, statistics; one SpMV launch timed with HIP events on this stream.  Nothing here waits for
-	// the device before the back-substitution is enqueued ----
+	// ---- true residual, statistics.  Every step's test has left the system's last true residual r = E - S x in seg[nseg + g]
+	// (k_pcg_start / k_pcg_check): the product and the residual kernel that formed it once more behind the loop (until round 6) are
+	// gone -- except in a feature-sharded run, whose x has just been replaced by rank 0's.  One of the loop's products is timed with
+	// HIP events (es0, es1).  Nothing here waits for the device before the back-substitution is enqueued ----
 	const int nsample = 1;
-	PcgSeg* seg2 = seg + nseg; // zeroed accumulators of the final residual (Ap: left zeroed by the last k_pcg_resid)
-	hipEvent_t es0 = ctx->pool_event(), es1 = ctx->pool_event();
-	LSFM_REC_T(es0, s);
-	launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
-	LSFM_REC_T(es1, s);
-	hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg2, 1);
+	static const bool final_again = getenv("LSFM_FINAL_RESIDUAL") != nullptr; // (as until round 6: for comparison)
+	if (ctx->comm || !es_done || final_again)
+	{
+		PcgSeg* seg2 = seg + nseg;
+		if (!es_done) LSFM_REC_T(es0, s);
+		launch_spmv(ctx, sy, x, Ap, io.d_fixed, nullptr, nullptr, nullptr, 1);
+		if (!es_done) { LSFM_REC_T(es1, s); es_done = true; }
+		hipLaunchKernelGGL(k_pcg_final_zero, dim3(nbs), dim3(128), 0, s, nseg, seg2);
+		hipLaunchKernelGGL(k_pcg_resid, dim3(nbr), dim3(128), 0, s, M, sy.E, Ap, io.d_pose_seg, io.d_fixed, (double*)nullptr, seg2, 1);
+	}
 	LSFM_REC_T(ec, s); if (roctx().mark) roctx().mark("lsfm back-substitution: begin");
 	launch_backsub(ctx, io, sy, x);
 	LSFM_CHECK_HIP(hipGetLastError());

@@ -2,7 +2,7 @@
 ulimit -c 0
 D=gpurun_out/ab; mkdir -p $D
 CONFIG=${CONFIG:-nc3500}; STEPS=${STEPS:-20}
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for spec in "$@"; do
   label="${spec%%|*}"; envs="${spec#*|}"
   env $envs timeout 600 python bench.py --config $CONFIG --cpu-baseline 0 --extras 0 --steps $STEPS --warmup 3 2>/dev/null | python -c "
@@ -14,3 +14,14 @@ for l in sys.stdin:
 "
 done
 done 2>&1 | tee $D/abenv_$(date +%H%M%S).txt
+python - <<'PY'
+import glob, re, collections
+f = sorted(glob.glob("gpurun_out/ab/abenv_*.txt"))[-1]
+acc = collections.defaultdict(list)
+for l in open(f):
+    m = re.match(r"(\S+) analysing ([\d.]+) repeat ([\d.]+)", l)
+    if m: acc[m.group(1)].append((float(m.group(2)), float(m.group(3))))
+for k, v in acc.items():
+    a = sorted(x[0] for x in v); r = sorted(x[1] for x in v)
+    print(f"MEDIAN {k}: analysing {a[len(a)//2]:.2f} (min {a[0]:.2f}) repeat {r[len(r)//2]:.2f} (min {r[0]:.2f}) over {len(v)}")
+PY

@@ -76,8 +76,10 @@ def rocprof_kernel_avg(config, prefixes):
         return None
     if not rows:
         return None
-    return {"source": os.path.relpath(path, ROOT), "kernels": rows, "total_us": sum(r["total_us"] for r in rows),
-            "calls": sum(r["calls"] for r in rows)}
+    trees = 7 if config == "synth16k" else 14  # tools/measure.sh: --steps 2 --warmup 1 (synth16k) / --steps 5 --warmup 2: first run + warm-ups + both modes
+    total = sum(r["total_us"] for r in rows)
+    return {"source": os.path.relpath(path, ROOT), "kernels": rows, "total_us": total, "calls": sum(r["calls"] for r in rows),
+            "trees_profiled": trees, "ms_per_tree": total / trees / 1e3}
 
 
 def twin_floor(config):

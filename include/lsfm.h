@@ -177,7 +177,7 @@ int lsfm_solve_mono(lsfm_context* ctx, double* stVal, const double* eb, const do
 
 /* ---- Gauss-Newton polish of the map-joining objective (BASELINE.json north_star "plus the Gauss-Newton BA refinement") ----
  * NO reference counterpart: the reference joins once and has no iterative step (no loop and no residual anywhere in LinearSFMImp.cpp) --
- * PARITY UNPINNED; checked against oracle/lsfm_gn.inc and by properties (the objective never rises, its gradient falls, a minimiser is
+ * PARITY UNPINNED; the tests hold it against the CPU checker's statement of the same steps and against properties (the objective never rises, its gradient falls, a minimiser is
  * a fixed point).  Minimises, over the global state x and ALL N local maps at once,
  *     F(x) = sum_k || x^_k - f_k(x) ||^2_{I_k}
  * x^_k / I_k: estimate / information matrix of local map k, f_k: the reference's own change of frame into map k's frame

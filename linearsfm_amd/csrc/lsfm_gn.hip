@@ -8,7 +8,7 @@
 // with f_k the reference's own change of frame (lmj_Transform_PF3DStereo Imp.cpp:421-455, Mono 3268-3306: origin at the map's
 // reference pose, Mono: unit = component Fix_k of its scale pose) and its Jacobian as the reference forms it (J1 / J2 / J3,
 // Imp.cpp:485-683 / 3383-3688: J = blkdiag(D) + sum_s C_s e_{h_s}^T, "old state with respect to new state at the new state" -- here
-// old = frame k, new = the global frame, h_s = the global poses Ref_k [, ScaP_k]).  One step (checked against oracle/lsfm_gn.inc):
+// old = frame k, new = the global frame, h_s = the global poses Ref_k [, ScaP_k]).  One step (the tests hold every step against the CPU checker's statement of it):
 //
 //     H = sum_k J_k^T I_k J_k,   b = sum_k J_k^T I_k r_k,   r_k = x^_k - f_k(x) (angles wrapped),   H d = b,   x += a d
 //

@@ -45,7 +45,7 @@ struct SmallArgs {
 	RunStatsDev* run;                        // outcome of the level (may be null)
 	int* status;                             // [2]: += systems left above the residual bound, 1 + first system with a non-positive pivot
 	double* max_rel;                         // largest relative residual of the level (bit pattern, atomicMax)
-	int dbg;                                 // LSFM_SMALL_DEBUG (timing probes, tools/small_probe.py): bits switch phases OFF -- results are then garbage
+	int dbg;                                 // LSFM_SMALL_DEBUG (timing probes): bits switch phases OFF -- results are then garbage
 };
 
 // NTR 16-row strips: the panel has 16 NTR >= 6 m rows.  LDS: dense S (R x (R + 1)), panel, vectors.
@@ -129,7 +129,7 @@ k_small_solve(SmallArgs a)
 	// The features are worked through in SUPER-PASSES of SM_SUPER = 64 (four passes of 16 columns of the panel).  What a super-pass
 	// reads from memory -- its W rows, ONE contiguous range of 3 doubles a row, the photo of every block, V and eb of its features --
 	// is fetched into registers a whole super-pass ahead and parked in LDS when its turn comes: one exposed memory latency per 64
-	// features, not per 16 (the first version prefetched pass by pass and spent a third of its time waiting, tools/small_probe.py).
+	// features, not per 16 (the first version prefetched pass by pass and spent a third of its time waiting).
 	constexpr int PF = SM_WROWS / SM_THREADS; // rows per lane held in registers; a super-pass with more rows reads the rest from memory
 	constexpr int MCAP = R / 6;               // poses the panel has rows for
 	double pw[PF][3];

@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from linearsfm_amd import synth
-from linearsfm_amd.distributed import merge_schedule, shard_bounds, sharded_divide_conquer
+from linearsfm_amd.distributed import merge_schedule, shard_bounds
+from sharded_reference import sharded_divide_conquer
 
 
 def _free_port():
@@ -104,7 +105,7 @@ def _oracle_run_slices(slices, mono, rank, world):
 
 
 def _worker_top(rank, world, port, n_maps, mono, q):
-    from linearsfm_amd.distributed import sharded_divide_conquer_top
+    from sharded_reference import sharded_divide_conquer_top
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -144,7 +145,8 @@ def test_feature_sharded_top_levels_equal_serial_tree(oracle, world, n_maps, mon
 
 
 def test_slices_of_a_map_add_up_to_the_map():
-    from linearsfm_amd.distributed import joint_feature_order, merge_slices, slice_map
+    from linearsfm_amd.distributed import joint_feature_order, merge_slices
+    from sharded_reference import slice_map
     from oracle import pyoracle as po
     maps = [po.localmap_to_dict(m) for m in _make(6, False)]
     node = _oracle_run_tree(maps[:4], False, True)

@@ -122,11 +122,12 @@ def test_sharded_tree_equals_single_tree(ctx, world, n_maps, mono, top, backend,
 
 @pytest.mark.parametrize("mono,n_maps,nslices", [(False, 24, 3), (True, 12, 4), (False, 5, 1)])
 def test_device_slice_packs_equal_the_numpy_slices(ctx, mono, n_maps, nslices):
-    """lsfm_tree_export_slice_dev against linearsfm_amd.distributed.slice_map: the final map of a tree cut by feature label on the
+    """lsfm_tree_export_slice_dev against tests/sharded_reference.py slice_map: the final map of a tree cut by feature label on the
     device, every pack uploaded again as a one-map tree and downloaded, must be the slice numpy cuts from the downloaded map --
     labels, state, V, W blocks and their order, run pointers -- and the slices must add up to the map."""
     import torch
-    from linearsfm_amd.distributed import merge_slices, slice_map
+    from linearsfm_amd.distributed import merge_slices
+    from sharded_reference import slice_map
     maps = _make(n_maps, mono)
     t = ctx.tree_upload([dict(m.__dict__) for m in maps], mono)
     packs = []

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Copies the rocprofv3 / bench outputs of one gpurun_out/<dir> into profiles/ and writes the HBM traffic summary bench.py reads
 (FETCH_SIZE doubled as MI355X_MICROARCH prescribes for gfx950, + WRITE_SIZE; KB -> bytes; separate --pmc passes).
-usage: python tools/refresh_profiles.py gpurun_out/<dir> <round tag, e.g. r02> <config, e.g. nc3500> <trees in the profiled run>"""
+usage: python tools/refresh_profiles.py gpurun_out/<dir> <round tag, e.g. r02> <config, e.g. nc3500> <trees in the profiled run>
+PROFILES_DIR=<dir> writes there instead of profiles/ (tools/measure.sh runs this ON THE BOX so that only the summaries travel back);
+KEEP_RAW=0 leaves the per-dispatch counter CSVs (megabytes) where they are."""
 import collections
 import csv
 import glob
@@ -12,6 +14,9 @@ import sqlite3
 import sys
 
 src, tag, config, trees = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+OUT = os.environ.get("PROFILES_DIR", "profiles")
+KEEP_RAW = os.environ.get("KEEP_RAW", "1") != "0"
+os.makedirs(OUT, exist_ok=True)
 
 
 def short(n):
@@ -26,7 +31,8 @@ def counter(name):
     agg = collections.defaultdict(lambda: [0, 0.0])
     files = glob.glob(f"{src}/pmc_{name}/**/*counter_collection.csv", recursive=True)
     if files:
-        shutil.copy(files[0], f"profiles/{tag}_pmc_{name}_counter_collection_{config}.csv")
+        if KEEP_RAW:
+            shutil.copy(files[0], f"{OUT}/{tag}_pmc_{name}_counter_collection_{config}.csv")
         for r in csv.DictReader(open(files[0])):
             agg[short(r["Kernel_Name"])][0] += 1
             agg[short(r["Kernel_Name"])][1] += float(r["Counter_Value"])
@@ -40,7 +46,7 @@ def counter(name):
     kn = [c for c in cols if "kernel" in c.lower() and "name" in c.lower()][0]
     val = [c for c in cols if c.lower() in ("value", "counter_value")][0]
     rows = list(cur.execute(f"select {kn}, {val} from {view}"))
-    with open(f"profiles/{tag}_pmc_{name}_per_kernel_{config}.csv", "w") as f:
+    with open(f"{OUT}/{tag}_pmc_{name}_per_kernel_{config}.csv", "w") as f:
         f.write("Kernel_Name,Counter_Value\n")
         for k, v in rows:
             f.write(f"\"{k}\",{v}\n")
@@ -70,15 +76,15 @@ for n in names[:14]:
     print(f"{n[:44]:44s} n={detail[n]['launches']:5d} -> {per_launch[n] / 1e6:8.1f} MB/launch")
 res = dict(config=config, trees_in_profiled_run=trees, bytes_per_tree=total / trees, per_launch=per_launch, kernels=detail,
            source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --config {config}; FETCH_SIZE doubled (gfx950), KB -> bytes")
-json.dump(res, open(f"profiles/{tag}_pmc_traffic_summary_{config}.json", "w"), indent=1)
+json.dump(res, open(f"{OUT}/{tag}_pmc_traffic_summary_{config}.json", "w"), indent=1)
 print("HBM bytes per tree: %.2f GB" % (total / trees / 1e9))
 st = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
 if st:
-    shutil.copy(st[0], f"profiles/{tag}_bench_{config}_kernel_stats.csv")
-for name, dst in (("bench_default.log", f"profiles/{tag}_bench_default.json"), ("bench_prof.log", f"profiles/{tag}_bench_under_rocprof.json")):
+    shutil.copy(st[0], f"{OUT}/{tag}_bench_{config}_kernel_stats.csv")
+for name, dst in (("bench_default.log", f"{OUT}/{tag}_bench_default.json"), ("bench_prof.log", f"{OUT}/{tag}_bench_under_rocprof.json")):
     if os.path.exists(f"{src}/{name}"):
         lines = [l for l in open(f"{src}/{name}") if l.startswith("{")]
         if lines:
             open(dst, "w").write(lines[0])
 for f in glob.glob(f"{src}/full_parity_*.json"):
-    shutil.copy(f, f"profiles/{tag}_{os.path.basename(f)}")
+    shutil.copy(f, f"{OUT}/{tag}_{os.path.basename(f)}")

@@ -21,6 +21,21 @@ PANEL_SLOTS = {"stereo_n48_wide_top1.npz": 48, "stereo_n62_wide_top1.npz": 64, "
 PANEL_RANGE = {48: (33, 48), 64: (49, 63), 0: (64, 1 << 30)}  # poses of a tile -> variant (lsfm_schur_panel.hip PmShared::CAP)
 
 
+# whole mid-size trees evaluated by the REAL reference (every transform, every assembly) + exact solves of the reference-assembled systems
+# (schur_reference_solve): tests/golden/make_chain_golden.py.  No arithmetic of the oracle or the library is in them.
+GOLD_CHAIN = ["chain_stereo_n512", "chain_mono_n200", "chain_stereo_n2048"]
+
+
+def chain_set(name):
+    """(type, mono, local maps, fixture) of a reference-chain fixture: the set is re-made from the generator's stored arguments"""
+    from linearsfm_amd import synth
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    typ = str(z["type"])
+    kw = {k[4:]: z[k].item() for k in z.files if k.startswith("gen.")}
+    maps = synth.make_mono_set(**kw) if typ == "Monocular" else synth.make_stereo_set(**kw)
+    return typ, typ == "Monocular", maps, z
+
+
 def tile_pose_counts(photo, feature, n, tile=128):
     """number of distinct poses that see each tile of `tile` consecutive features (what selects the width of K9's panel)"""
     photo, feature = np.asarray(photo), np.asarray(feature)
@@ -196,6 +211,87 @@ def dense_reference_solve(J, ea, eb, mono, sa=None, IV=None):
             break
     out = np.zeros(6 * m + 3 * n)
     out[keep] = np.asarray(xl, np.float64)
+    if mono:
+        out[sa[2]] = sa[3]
+    return out
+
+
+def schur_reference_solve(J, ea, eb, mono, sa=None, tol=1e-17, max_it=12):
+    """The same expected value as dense_reference_solve -- the exact solution of the FULL assembled normal equations
+    [[U, W], [W^T, V]] x = [ea; eb], rounded to fp64 -- for systems whose dense full matrix does not fit (hundreds of poses, tens
+    of thousands of features).  Nothing of the oracle or the library: the residual of the FULL system is formed in long double
+    from the blocks as they are (the upper triangle of a diagonal U block mirrored, Imp.cpp:2224-2229; entries with equal
+    coordinates add up), and corrected through a dense LAPACK Cholesky factor of the Schur complement S = U - W V^-1 W^T
+    (numpy / scipy, fp64: a preconditioner -- the fixed point of the iteration is the full system's solution whatever rounding S
+    carries) until the correction is below `tol` relative.  Mono: block sa[0] and scalar sa[2] removed, x[Fix] = Sign at the end."""
+    import scipy.linalg as sl
+    import scipy.sparse as sp
+    m, n = int(J["m"]), int(J["n"])
+    U = np.asarray(J["U"], np.float64).reshape(-1, 6, 6)
+    Ui, Uj = np.asarray(J["Ui"]), np.asarray(J["Uj"])
+    W = np.asarray(J["W"], np.float64).reshape(-1, 6, 3)
+    ph, fe = np.asarray(J["photo"]), np.asarray(J["feature"])
+    V = np.asarray(J["V"], np.float64).reshape(-1, 3, 3)
+    # U as the symmetric matrix the reference's solver reads: a diagonal block by its upper triangle
+    Ud = U.copy()
+    dg = Ui == Uj
+    Ud[dg] = np.triu(Ud[dg]) + np.transpose(np.triu(Ud[dg], 1), (0, 2, 1))
+    keep = np.ones(6 * m, bool)
+    if mono:
+        keep[6 * sa[0]:6 * sa[0] + 6] = False
+        keep[sa[2]] = False
+    Ul, Wl, Vl = Ud.astype(np.longdouble), W.astype(np.longdouble), V.astype(np.longdouble)
+    eal, ebl = np.asarray(ea, np.float64).astype(np.longdouble), np.asarray(eb, np.float64).astype(np.longdouble)
+
+    def full_residual(xp, xf):
+        """[ea - U xp - W xf ; eb - W^T xp - V xf] in long double"""
+        rp = eal.copy().reshape(m, 6)
+        xp6, xf3 = xp.reshape(m, 6), xf.reshape(n, 3)
+        np.add.at(rp, Ui, -np.einsum("kij,kj->ki", Ul, xp6[Uj]))
+        off = ~dg
+        np.add.at(rp, Uj[off], -np.einsum("kji,kj->ki", Ul[off], xp6[Ui[off]]))
+        np.add.at(rp, ph, -np.einsum("kij,kj->ki", Wl, xf3[fe]))
+        rf = ebl.copy().reshape(n, 3) - np.einsum("kij,kj->ki", Vl, xf3)
+        np.add.at(rf, fe, -np.einsum("kji,kj->ki", Wl, xp6[ph]))
+        return rp.reshape(-1), rf.reshape(-1)
+
+    # the preconditioner: dense Schur complement in fp64
+    Vi = np.linalg.inv(V)
+    rows = (6 * ph[:, None, None] + np.arange(6)[None, :, None]).repeat(3, 2)
+    cols = (3 * fe[:, None, None] + np.arange(3)[None, None, :]).repeat(6, 1)
+    Ws = sp.csr_matrix((W.ravel(), (rows.ravel(), cols.ravel())), shape=(6 * m, 3 * n))
+    bi = (3 * np.arange(n)[:, None, None] + np.arange(3)[None, :, None]).repeat(3, 2)
+    bj = (3 * np.arange(n)[:, None, None] + np.arange(3)[None, None, :]).repeat(3, 1)
+    Vis = sp.csr_matrix((Vi.ravel(), (bi.ravel(), bj.ravel())), shape=(3 * n, 3 * n))
+    S = np.zeros((6 * m, 6 * m))
+    ur = (6 * Ui[:, None, None] + np.arange(6)[None, :, None]).repeat(6, 2)
+    uc = (6 * Uj[:, None, None] + np.arange(6)[None, None, :]).repeat(6, 1)
+    np.add.at(S, (ur.ravel(), uc.ravel()), Ud.ravel())
+    off = ~dg
+    np.add.at(S, (uc[off].ravel(), ur[off].ravel()), Ud[off].ravel())
+    S -= (Ws @ Vis @ Ws.T).toarray()
+    S = 0.5 * (S + S.T)
+    cf = sl.cho_factor(S[np.ix_(keep, keep)])
+
+    def correct(rp, rf):
+        rp64, rf64 = np.asarray(rp, np.float64), np.asarray(rf, np.float64)
+        g = rp64 - Ws @ (Vis @ rf64)
+        dp = np.zeros(6 * m)
+        dp[keep] = sl.cho_solve(cf, g[keep])
+        df = Vis @ (rf64 - Ws.T @ dp)
+        return dp, df
+
+    xp, xf = np.zeros(6 * m, np.longdouble), np.zeros(3 * n, np.longdouble)
+    for it in range(max_it):
+        rp, rf = full_residual(xp, xf)
+        rp[~keep] = 0
+        dp, df = correct(rp, rf)
+        xp += dp
+        xf += df
+        scale = max(np.max(np.abs(xp)), np.max(np.abs(xf)) if n else 0.0, 1e-300)
+        if max(np.max(np.abs(dp)), np.max(np.abs(df)) if n else 0.0) <= tol * scale:
+            break
+    out = np.concatenate([np.asarray(xp, np.float64), np.asarray(xf, np.float64)])
     if mono:
         out[sa[2]] = sa[3]
     return out

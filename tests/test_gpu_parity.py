@@ -6,7 +6,7 @@ the dense expected value."""
 import numpy as np
 import pytest
 
-from common import (GOLD_MID, GOLD_SMALL, GOLD_WIDE, PANEL_RANGE, PANEL_SLOTS, tile_pose_counts, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
+from common import (GOLD_CHAIN, GOLD_MID, GOLD_SMALL, GOLD_WIDE, PANEL_RANGE, PANEL_SLOTS, tile_pose_counts, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden,
                     pose_param_err, pose_param_true_rel_err, ref_map, rel_err)
 from linearsfm_amd import synth
 
@@ -331,6 +331,26 @@ def test_tree_mono_vs_oracle(ctx, oracle, N, npf, vis, seed, path):
     assert np.array_equal(got["Ui"], exp["Ui"]) and np.array_equal(got["Uj"], exp["Uj"])
     assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < TREE_TOL
     assert feat_param_err(got["stVal"], exp["stVal"], exp["stno"]) < TREE_TOL
+
+
+@pytest.mark.parametrize("name", GOLD_CHAIN)
+def test_whole_tree_vs_reference_chain(ctx, name):
+    """lsfm_divide_conquer against a whole tree evaluated WITHOUT the oracle: every transform and join assembly by the real reference
+    (oracle/_ref/ref_dump in the authoring container), every solve the exact solution of the reference-assembled normal equations (long-double
+    residuals, dense LAPACK; tests/golden/make_chain_golden.py) -- 512 and 2 048 Stereo maps on paths that close laps, 200 Mono maps.  The
+    reference's own CHOLMOD solve cannot run here; a direct SPD solve is unique, and the chain carries that unique solution from level to
+    level.  BASELINE.json's 1e-6 on the pose parameters, with identical labels and gauge."""
+    from common import chain_set
+    typ, mono, maps, z = chain_set(name)
+    got, stats, rc = ctx.divide_conquer([m.__dict__ for m in maps], mono)
+    assert rc == 0 and stats["not_converged"] == 0, stats
+    assert np.array_equal(got["stno"], z["result.stno"])
+    for k in ("Ref", "FRef") + (("ScaP", "Fix", "Sign") if mono else ()):
+        assert int(got[k]) == int(z[f"result.{k}"]), k
+    ep, ef = pose_param_err(got["stVal"], z["result.stVal"], z["result.stno"]), feat_param_err(got["stVal"], z["result.stVal"], z["result.stno"])
+    et = pose_param_true_rel_err(got["stVal"], z["result.stVal"], z["result.stno"])
+    print(f"{name}: {len(maps)} maps, device vs the reference chain: pose parameters {ep:.2e} (true relative {et:.2e}), features {ef:.2e}")
+    assert ep < TREE_TOL and ef < TREE_TOL, (ep, ef)
 
 
 @pytest.mark.parametrize("config", ["rs90", "rs468", "nc3500"])

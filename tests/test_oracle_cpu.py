@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import GOLD_MID, GOLD_SMALL, GOLD_WIDE, assert_maps_close, dense_reference_solve, get_map, golden_system, load_golden, ref_map, rel_err
+from common import GOLD_MID, GOLD_SMALL, GOLD_WIDE, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden, pose_param_err, ref_map, rel_err
 from linearsfm_amd import synth
 from refdump import dense_info
 
@@ -480,6 +480,40 @@ def test_oracle_whole_tree_from_fixture_inputs_to_fixture_result(oracle, name):
     if mono:
         for k in ("ScaP", "Fix", "Sign"):
             assert int(got[k]) == int(exp[k]), k
+
+
+@pytest.mark.parametrize("name", GOLD_SMALL + GOLD_MID)
+def test_schur_reference_solve_is_the_dense_expected_value(name):
+    """tests/common.py schur_reference_solve (what the reference-chain fixtures' solves are: long-double residuals of the FULL system, a
+    dense LAPACK factor of the Schur complement as preconditioner) against the fixtures' dense_sol -- the dense LU of the full normal
+    equations: the same exact solution, reached another way.  (Mono: dense_sol takes the reference's computed V^-1 as exact, this one V:
+    they differ by cond(V) x 1e-16, which a monocular camera system amplifies to 1e-11..1e-10.)"""
+    from common import schur_reference_solve
+    z = load_golden(name)
+    for j in range(int(z["njoins"])):
+        J, ea, eb, mono, sa = golden_system(z, j)
+        x = schur_reference_solve(J, ea, eb, mono, sa)
+        d = z[f"join{j}.dense_sol"]
+        assert np.max(np.abs(x - d) / np.maximum(1, np.abs(d))) < (1e-9 if mono else 1e-12), (name, j)
+
+
+@pytest.mark.parametrize("name", ["chain_stereo_n512", "chain_mono_n200", "chain_stereo_n2048"])
+def test_oracle_whole_tree_vs_reference_chain(oracle, name):
+    """The oracle's WHOLE tree -- transforms, assemblies, Schur complements, sparse Cholesky, back-substitutions, 9 / 8 levels, systems of up
+    to 512 / 202 / 2 048 poses with lap closures -- against the same tree evaluated by the REAL reference (every transform and assembly:
+    oracle/_ref/ref_dump) with every solve replaced by the exact solution of the reference-assembled system (make_chain_golden.py): the
+    chain holds no arithmetic of the oracle.  Measured 6.8e-10 (512 Stereo) / 3.4e-8 (Mono) / 2.5e-8 (2 048 Stereo) on the pose parameters; the long-double twin of the
+    oracle's solves lands at the same distance -- what is left is the rounding of the state between the levels, not a solver's."""
+    from common import chain_set
+    typ, mono, maps, z = chain_set(name)
+    d = [oracle.localmap_to_dict(m) for m in maps]
+    G, _, rc = oracle.divide_conquer(d, mono, match_hash=True)
+    assert rc == 0
+    assert np.array_equal(G["stno"], z["result.stno"])
+    for k in ("Ref", "FRef") + (("ScaP", "Fix", "Sign") if mono else ()):
+        assert int(G[k]) == int(z[f"result.{k}"]), k
+    ep, ef = pose_param_err(G["stVal"], z["result.stVal"], z["result.stno"]), feat_param_err(G["stVal"], z["result.stVal"], z["result.stno"])
+    assert ep < 1e-7 and ef < 1e-7, (ep, ef)
 
 
 def test_generator_visibility_index_equals_a_pass_over_all_points():

@@ -16,8 +16,8 @@ byq = defaultdict(list)
 for r in rows:
     byq[r[3]].append(r)
 main = max(byq.values(), key=len)
-n = len(main) // runs
-run = main[(runs - 1) * n:]
+finds = [i for i, r in enumerate(main) if "k_tr_find" in r[2]]
+run = main[finds[len(finds) - len(finds) // runs]:]  # the last run: it starts at its first level's k_tr_find
 idx = [i for i, r in enumerate(run) if "k_tr_find" in r[2]] + [len(run)]
 t0 = run[idx[level]][0]
 t1 = run[idx[level + 1]][0] if idx[level + 1] < len(run) else run[-1][1]

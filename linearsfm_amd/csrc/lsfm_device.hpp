@@ -231,35 +231,49 @@ __device__ __forceinline__ void to_fixed2(double v, int sh, long long& hi, long 
 	lo = __double2ll_rn(ldexp(q - h, 40)); // (q - h is exact: |q| < 2^52 leaves a fraction fp64 holds, beyond that there is none)
 }
 
-// Adds vals[0..N) into dst[0..N) for every lane with valid==true.  When all valid lanes of the wave target the
-// SAME dst (the common case for hub rows: neighbouring features share their hub poses) the values are summed
-// across the wave first and one lane issues the atomics: 64x fewer atomics on the hot blocks.
+// Adds vals[0..N) into dst[0..N) for every lane with valid==true.  The lanes of a wave that target the SAME dst (the common case
+// for hub rows and per-map sums: neighbouring features share their map) are summed across the wave first and one wave instruction
+// issues the atomics: 64x fewer atomics on the hot blocks.  Up to four distinct targets per wave are taken that way, one after the
+// other (a wave that straddles a map boundary has two; until round 6 any second target sent ALL 64 lanes to N single-lane atomics
+// each on the same few addresses -- at the lowest levels of a monocular tree, whose maps hold ~200 features, most waves straddle:
+// k_tr_feat_post<2> took 4.7 ms at level 1 of a synth-16k tree against 1.3 at level 0); what is left after four adds lane by lane.
 // Must be called by all 64 lanes (convergent).
 template <int N>
 __device__ __forceinline__ void wave_scatter_add(double* dst, const double* vals, bool valid)
 {
-	unsigned long long mask = __ballot(valid);
-	if (mask == 0ull) return;
-	int leader = __ffsll((long long)mask) - 1;
-	unsigned long long mine = (unsigned long long)(size_t)dst;
-	unsigned long long first = (unsigned long long)__shfl((long long)mine, leader, LSFM_WAVE);
-	bool uniform = __ballot(valid && mine != first) == 0ull;
-	if (uniform && __popcll(mask) > 1)
+	static_assert(N <= LSFM_WAVE, "one lane per value");
+	unsigned long long todo = __ballot(valid);
+	if (todo == 0ull) return;
+	const int lane = threadIdx.x & (LSFM_WAVE - 1);
+	const unsigned long long mine = (unsigned long long)(size_t)dst;
+#pragma unroll 1
+	for (int round = 0; round < 4 && todo; round++)
 	{
-		// lane i keeps sum i: the N sums leave as ONE wave instruction over N contiguous doubles (one lane issuing N
-		// single-lane atomics serialises on the same 64-byte lines: measured 1.3 ms for 7k waves on one 288-byte row)
-		static_assert(N <= LSFM_WAVE, "one lane per value");
-		const int lane = threadIdx.x & (LSFM_WAVE - 1);
-		double keep = 0.0;
-#pragma unroll
-		for (int i = 0; i < N; i++)
+		const int leader = __ffsll((long long)todo) - 1;
+		const unsigned long long first = (unsigned long long)__shfl((long long)mine, leader, LSFM_WAVE);
+		const bool same = valid && mine == first;
+		const unsigned long long grp = __ballot(same);
+		if (__popcll(grp) > 1)
 		{
-			const double s = wave_sum(valid ? vals[i] : 0.0);
-			if (lane == i) keep = s;
+			// lane i keeps sum i: the N sums leave as ONE wave instruction over N contiguous doubles (one lane issuing N
+			// single-lane atomics serialises on the same 64-byte lines: measured 1.3 ms for 7k waves on one 288-byte row)
+			double keep = 0.0;
+#pragma unroll
+			for (int i = 0; i < N; i++)
+			{
+				const double sm = wave_sum(same ? vals[i] : 0.0);
+				if (lane == i) keep = sm;
+			}
+			if (lane < N) atomic_add_f64(reinterpret_cast<double*>((size_t)first) + lane, keep);
 		}
-		if (lane < N) atomic_add_f64(reinterpret_cast<double*>((size_t)first) + lane, keep);
+		else if (same)
+		{
+#pragma unroll
+			for (int i = 0; i < N; i++) atomic_add_f64(dst + i, vals[i]);
+		}
+		todo &= ~grp;
 	}
-	else if (valid)
+	if (valid && ((todo >> lane) & 1ull))
 	{
 #pragma unroll
 		for (int i = 0; i < N; i++) atomic_add_f64(dst + i, vals[i]);

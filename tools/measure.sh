@@ -9,7 +9,7 @@ ulimit -c 0
 TAG=${1:-r06}
 D=gpurun_out/$TAG; mkdir -p $D
 timeout 1800 python -m pytest tests -x -q -m gpu --durations=10 > $D/gpu_tests.log 2>&1; tail -3 $D/gpu_tests.log
-timeout 600 python bench.py > $D/bench_default.log 2> $D/bench_default.err
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $D/bench_default.log 2> $D/bench_default.err   # (the driver's own command line)
 timeout 300 python bench.py --config rs468 --steps 10 --warmup 2 > $D/bench_rs468.log 2>/dev/null
 timeout 300 python bench.py --config rs90 --steps 10 --warmup 2 > $D/bench_rs90.log 2>/dev/null
 timeout 300 python bench.py --config aerial --steps 10 --warmup 2 > $D/bench_aerial.log 2>/dev/null

@@ -40,7 +40,16 @@ namespace lsfm {
 #define PM_SMAX_MAX 64  /* the widest panel: the same 1024 threads take its 300 output tiles in two sweeps over the tile's passes */
 #define PM_HASH 64
 #define PM_THREADS 256
-#define PM_WIDE 512     /* threads of the 32 / 48 / 64-slot variants */
+#define PM_WIDE 512     /* threads of the 48 / 64-slot variants */
+#ifndef LSFM_K9_T16
+#define LSFM_K9_T16 256 /* threads of the 16-slot variant (256 | 512) */
+#endif
+#ifndef LSFM_K9_T32
+#define LSFM_K9_T32 512 /* threads of the 32-slot variant (512 | 1024) */
+#endif
+#ifndef LSFM_K9_OCC16W
+#define LSFM_K9_OCC16W 2 /* work-groups per CU of a 512-thread 16-slot variant: 2 = 128 registers a wave, 3 = 80 */
+#endif
 #define PM_MAXE (PM_TILE == 128 ? 3584 : 5120) /* W blocks of the tile whose slot is kept in LDS (one byte each: 28 / 20 per feature on average); later ones are added after the first blocks */
 #define PM_BF 352   /* >= rows held in registers per pass / 6 (4 x 256 or 3 x 512) */
 #define PM_DUP 0x80  /* eslot: a block whose (pose, feature) an earlier block of the tile already holds */
@@ -104,16 +113,20 @@ struct PmShared {
 	double ly[PM_PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
 	alignas(16) double P[PROWS * PM_KS];
 	unsigned char eslot[MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
+	// block of S of every slot pair si <= sj (at sj (sj + 1) / 2 + si), looked up while the first pass's rows are on their way instead of
+	// behind the last pass (the widest variants have no room: they look them up at the tile's end, into the free panel)
+	static constexpr bool PLANNED = SMAX <= PM_SMAX;
+	int pslot[PLANNED ? SMAX * (SMAX + 1) / 2 : 1];
 };
 
 // T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + NW t over its NW waves; slots
 // past the last tile recompute tile (0,0) and are dropped)
-template <int T, int SMAX, int THREADS>
+template <int T, int SMAX, int THREADS, class Fill>
 __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                         const double* __restrict__ W, const double* __restrict__ LY,
                                         const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
                                         const K9Out& o, unsigned char* __restrict__ fallback,
-                                        const unsigned char* __restrict__ ces, int tile, int q0 = 0)
+                                        const unsigned char* __restrict__ ces, int tile, Fill&& fill, int q0 = 0)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
 	K9T_DECL;
@@ -159,7 +172,9 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 #endif
 	// (rows past the prefetched ones are loaded INSIDE the staging, a memory round trip in the open: the instances that hold fewer output
 	// tiles spend the registers on a deeper prefetch -- T = 4, the 11-13-pose tiles, five rows a lane = 213 blocks a pass)
-	constexpr int PF = THREADS != 256 ? (LSFM_K9_PFW ? (T <= 8 ? 4 : 3) : (T <= 6 ? 3 : 2))
+	// (sixteen waves: 2 x 1024 rows = 21 poses per feature; eight waves on a 16-slot panel: 3 x 512 rows = every block it can hold)
+	constexpr int PF = THREADS == 1024 ? 2
+	                 : THREADS != 256 ? (SMAX <= 16 ? (LSFM_K9_OCC16W >= 3 ? 2 : 3) : (LSFM_K9_PFW ? (T <= 8 ? 4 : 3) : (T <= 6 ? 3 : 2)))
 	                                  : (T <= 3 ? 4 : (T <= 4 ? (LSFM_K9_PFW ? 5 : LSFM_K9_PF6) : (T <= 6 ? LSFM_K9_PF6 : (T <= 14 ? 3 : 2))));
 	double pw[PF][3];
 	double lyv = 0.0, uuv = 0.0;
@@ -181,6 +196,11 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		}
 	};
 	if (f0 < f1) prefetch(f0);
+	// what the tile keeps in LDS beside the run pointers (slots of its blocks, scales and estimates of its poses, the blocks of S it
+	// adds to): loaded behind the first pass's rows, not in front of them -- one memory round trip of a tile's three less in the open;
+	// visible to the passes through the barrier at the top of the first one
+	if (q0 == 0) fill();
+	const int ey = *o.ey;
 	for (int p0 = f0; p0 < f1; p0 += PM_PASS)
 	{
 		const int nf = min(PM_PASS, f1 - p0), pb = p0 - f0;
@@ -283,7 +303,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		K9T(12);
 		// P P^T, four feature columns per MFMA: lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15].
 		// Always the full PM_K columns (zero past the last feature); the T tiles of a step are independent chains
-		constexpr int UNR = T <= 1 ? PM_K / 4 : (T <= 3 ? 4 : (T <= 6 ? 2 : 1));
+		constexpr int UNR = T <= 1 ? PM_K / 4 : (T <= 3 ? 4 : (T <= (THREADS == 1024 ? 4 : 6) ? 2 : 1));
 #pragma unroll UNR
 		for (int ks = 0; ks < PM_K / 4; ks++)
 		{
@@ -303,12 +323,16 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 		if (tid == 0) fallback[tile] = 1;
 		return;
 	}
-	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair, in the (now free) panel ----
+	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair: planned at the tile's start, or now, in the
+	// (now free) panel ----
 	int* pslot = reinterpret_cast<int*>(sh.P);
-	for (int q = tid; q < ns * ns; q += THREADS)
+	if constexpr (!PmShared<SMAX>::PLANNED)
 	{
-		const int si = q / ns, sj = q - si * ns;
-		pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
+		for (int q = tid; q < ns * ns; q += THREADS)
+		{
+			const int si = q / ns, sj = q - si * ns;
+			pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
+		}
 	}
 	// ... and behind them the tile's right-hand side rows, one set per wave: a wave adds its output tiles' shares in the order it holds
 	// them, the waves' sets are added in their order below -- the same bits every run, no atomics, one conversion to the fixed point per row
@@ -376,7 +400,9 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 			if (R >= rows || !(v != 0.0)) continue; // exact zero: this pose pair shares no feature of the tile
 			const int si = R / 6, r = R - 6 * si;
 			if (si > sj) continue; // diagonal tile: the mirrored element covers it
-			const int slot = pslot[si * ns + sj];
+			int slot;
+			if constexpr (PmShared<SMAX>::PLANNED) slot = sh.pslot[sj * (sj + 1) / 2 + si];
+			else slot = pslot[si * ns + sj];
 			if (slot < 0) continue;
 			// order-independent: the entry in fixed point, units of 2^(sexp_R + sexp_C - 60) -- every partial sum of an entry of
 			// W V^-1 W^T is below sqrt(U_RR U_CC) < 2^(sexp_R + sexp_C - 2) (the joint information matrix is positive semi-definite)
@@ -398,7 +424,6 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	}
 	__syncthreads();
 	{
-		const int ey = *o.ey;
 		for (int row = tid; row < rows; row += THREADS)
 		{
 			double e = 0.0;
@@ -423,22 +448,22 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 }
 
 // the variant of pm_body for the tile's number of 16x16 output tiles per wave
-template <int SMAX, int THREADS>
+template <int SMAX, int THREADS, class Fill>
 __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1, int jb, const int* __restrict__ fptr, const int* __restrict__ photo,
                                       const double* __restrict__ W, const double* __restrict__ LY, const unsigned long long* __restrict__ tab,
                                       const int* __restrict__ val, unsigned long long mask, const K9Out& o,
-                                      unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces, int tile)
+                                      unsigned char* __restrict__ fallback, const unsigned char* __restrict__ ces, int tile, Fill&& fill)
 {
 	constexpr int NW = THREADS / 64;
 	const int NT = (6 * ns + 2 + 15) >> 4, tpw = (NT * (NT + 1) / 2 + NW - 1) / NW; // tiles per wave, uniform (strips: pm_body)
-#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile)
+#define PM_GO(T) pm_body<T, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile, fill)
 	if constexpr (SMAX <= 8)
 	{
 		if (tpw <= 1) PM_GO(1);
 		else if (tpw <= 2) PM_GO(2); // 3 strips: 6 tiles over 4 waves
 		else PM_GO(3); // (8 poses: a fourth strip for the right-hand side's rows)
 	}
-	else if constexpr (SMAX <= 16)
+	else if constexpr (SMAX <= 16 && THREADS == 256)
 	{
 		// (an instance per count: a wave of the T = 6 instance with four tiles to its name multiplied two more for nothing -- a third of the
 		// matrix products of the commonest tiles, 11-13 poses, until round 5)
@@ -448,6 +473,25 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		else if (tpw <= 4) PM_GO(4); // 5 strips: 15 tiles over 4 waves
 		else if (tpw <= 6) PM_GO(6); // 6 strips: 21 tiles over 4 waves
 		else PM_GO(7); // (16 poses: a seventh strip)
+	}
+	else if constexpr (SMAX <= 16)
+	{
+		// eight waves: at most 28 tiles = 4 per wave
+		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 2) PM_GO(2);
+		else if (tpw <= 3) PM_GO(3);
+		else PM_GO(4);
+	}
+	else if constexpr (THREADS == 1024)
+	{
+		// sixteen waves, four to a SIMD, 128 registers each: a 32-slot panel's 91 output tiles = at most 6 per wave
+		static_assert(SMAX <= PM_SMAX, "sixteen waves: the 32-slot variant only");
+		if (tpw <= 1) PM_GO(1);
+		else if (tpw <= 2) PM_GO(2);
+		else if (tpw <= 3) PM_GO(3);
+		else if (tpw <= 4) PM_GO(4);
+		else if (tpw <= 5) PM_GO(5);
+		else PM_GO(6);
 	}
 	else
 	{
@@ -466,7 +510,7 @@ __device__ __forceinline__ void k9_go(PmShared<SMAX>& sh, int ns, int f0, int f1
 		{
 			for (int q0 = 0; q0 < NW * tpw; q0 += NW * TS)
 			{
-				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile, q0);
+				pm_body<TS, SMAX, THREADS>(sh, ns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, ces, tile, fill, q0);
 				if (sh.bad) return; // (uniform: set before the barrier that ends the passes)
 			}
 		}
@@ -610,6 +654,36 @@ __global__ void __launch_bounds__(256) k_schur_lists(int ntiles, K9Cache kc)
 	}
 }
 
+#ifndef LSFM_K9_OCC16
+#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
+#endif
+template <int SMAX, int THREADS>
+constexpr int k9_waves_per_simd() { return THREADS == 256 ? (SMAX <= 8 ? 4 : LSFM_K9_OCC16) : (SMAX <= 16 ? LSFM_K9_OCC16W * (THREADS / 256) : THREADS / 256 / 2); }
+
+// what a tile keeps in LDS beside its run pointers and poses (called by pm_body behind the first pass's prefetch)
+template <int SMAX, int THREADS>
+__device__ __forceinline__ void k9_fill(PmShared<SMAX>& sh, int cns, int jb, int je, const K9Out& o, const K9Cache& kc,
+                                        const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask)
+{
+	const int tid = threadIdx.x;
+	for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
+	for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
+	for (int i = tid; i < PmShared<SMAX>::PROWS; i += THREADS) sh.xs[i] = (o.xpose && i < 6 * cns) ? o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6] : 0.0;
+	for (int i = tid; i < cns; i += THREADS) sh.side[i] = o.pside ? (unsigned char)(o.pside[sh.pose_of[i]] & 1) : (unsigned char)0;
+	if constexpr (PmShared<SMAX>::PLANNED)
+	{
+		// (from the last thread down: the first ones hold the loops above)
+		for (int q = THREADS - 1 - tid; q < cns * (cns + 1) / 2; q += THREADS)
+		{
+			int sj = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+			while (sj * (sj + 1) / 2 > q) sj--;
+			while ((sj + 1) * (sj + 2) / 2 <= q) sj++;
+			const int si = q - sj * (sj + 1) / 2;
+			sh.pslot[q] = pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]);
+		}
+	}
+}
+
 // One variant per panel width; a tile belongs to the narrowest variant that holds its poses.  The 8- and 16-slot variants are
 // launched with one work-group per tile of the level (wlist == nullptr; `alone`: no wider variant is launched beside it -- a tile that
 // exceeds the panel is flagged for k_schur_w, like the tiles the slots kernel gave up on); the 32-, 48- and 64-slot variants
@@ -619,10 +693,7 @@ __global__ void __launch_bounds__(256) k_schur_lists(int ntiles, K9Cache kc)
 // A tile is then all latency -- eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
 // work-groups share a CU instead of 2.
 template <int SMAX, int THREADS, bool LISTED>
-#ifndef LSFM_K9_OCC16
-#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
-#endif
-__global__ void __launch_bounds__(THREADS, THREADS != 256 ? 1 : (SMAX <= 8 ? 4 : LSFM_K9_OCC16))
+__global__ void __launch_bounds__(THREADS, (k9_waves_per_simd<SMAX, THREADS>()))
 k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
               const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
               K9Out o, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, K9Cache kc)
@@ -650,14 +721,10 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 		if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
 		__syncthreads();
 		const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-		for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
-		for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
-		for (int i = tid; i < PmShared<SMAX>::PROWS; i += THREADS) sh.xs[i] = (o.xpose && i < 6 * cns) ? o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6] : 0.0;
-		for (int i = tid; i < cns; i += THREADS) sh.side[i] = o.pside ? (unsigned char)(o.pside[sh.pose_of[i]] & 1) : (unsigned char)0;
-		// (visible to the passes through the barrier at the top of the first pass)
 		K9T(0);
 		K9T_FLUSH(0, 1);
-		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile);
+		k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile,
+		                     [&]() { k9_fill<SMAX, THREADS>(sh, cns, jb, je, o, kc, tab, val, mask); });
 	}
 	else
 	{
@@ -688,13 +755,10 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			if (tid == 0) { sh.nslots = cns; sh.bad = 0; }
 			__syncthreads();
 			const int jb = sh.fpt[0], je = sh.fpt[f1 - f0];
-			for (int e = tid; e < je - jb && e < PmShared<SMAX>::MAXE; e += THREADS) sh.eslot[e] = kc.eslot[jb + e];
-			for (int i = tid; i < 6 * cns; i += THREADS) sh.sexp[i] = (short)o.sexp[6 * (size_t)sh.pose_of[i / 6] + i % 6];
-			for (int i = tid; i < PmShared<SMAX>::PROWS; i += THREADS) sh.xs[i] = (o.xpose && i < 6 * cns) ? o.xpose[6 * (size_t)sh.pose_of[i / 6] + i % 6] : 0.0;
-			for (int i = tid; i < cns; i += THREADS) sh.side[i] = o.pside ? (unsigned char)(o.pside[sh.pose_of[i]] & 1) : (unsigned char)0;
 			K9T(0);
 			K9T_FLUSH(0, 1);
-			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile);
+			k9_go<SMAX, THREADS>(sh, cns, f0, f1, jb, fptr, photo, W, LY, tab, val, mask, o, fallback, kc.eslot, tile,
+			                     [&]() { k9_fill<SMAX, THREADS>(sh, cns, jb, je, o, kc, tab, val, mask); });
 		}
 	}
 }
@@ -728,6 +792,18 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	const dim3 grid(ntiles);
 	hipStream_t s = ctx->stream;
 	const int* none = nullptr;
+	static const bool hist = getenv("LSFM_K9_HIST") != nullptr; // diagnostic: poses per tile of every level, on stderr
+	if (hist)
+	{
+		std::vector<int> h(ntiles);
+		LSFM_CHECK_HIP(hipStreamSynchronize(s));
+		LSFM_CHECK_HIP(hipMemcpy(h.data(), kc.ns, sizeof(int) * ntiles, hipMemcpyDeviceToHost));
+		int cnt[66] = { 0 };
+		for (int v : h) cnt[v < 0 ? 65 : std::min(v, 64)]++;
+		fprintf(stderr, "K9 tiles %d (largest system %d poses):", ntiles, max_poses_per_system);
+		for (int i = 0; i < 66; i++) if (cnt[i]) fprintf(stderr, " %d:%d", i == 65 ? -1 : i, cnt[i]);
+		fprintf(stderr, "\n");
+	}
 	// no tile can be seen by more poses than its system has
 	if (max_poses_per_system <= 8)
 	{
@@ -736,7 +812,7 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	}
 	if (max_poses_per_system <= 16)
 	{
-		hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 1, none, none, (int*)nullptr, 0, kc);
+		hipLaunchKernelGGL((k_schur_panel<16, LSFM_K9_T16, false>), grid, dim3(LSFM_K9_T16), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 1, none, none, (int*)nullptr, 0, kc);
 		return;
 	}
 	// By tile, not by level: most tiles of the upper levels are seen by a dozen poses (12.1 on average on the NC3500-like
@@ -765,8 +841,8 @@ void launch_schur_panel(lsfm_context* ctx, int NF, const int* fptr, const int* p
 	// 16-slot variant to drain even when its list is empty)
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_MAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist + 2 * (size_t)ntiles, kc.wcnt + 2, kc.wcnt + 6, 0, kc);
 	hipLaunchKernelGGL((k_schur_panel<PM_SMAX_BIG, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist + ntiles, kc.wcnt + 1, kc.wcnt + 5, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, PM_WIDE, true>), wgrid, dim3(PM_WIDE), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
-	hipLaunchKernelGGL((k_schur_panel<16, PM_THREADS, false>), grid, dim3(PM_THREADS), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, none, none, (int*)nullptr, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<PM_SMAX, LSFM_K9_T32, true>), wgrid, dim3(LSFM_K9_T32), 0, s, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, kc.wlist, kc.wcnt, kc.wcnt + 4, 0, kc);
+	hipLaunchKernelGGL((k_schur_panel<16, LSFM_K9_T16, false>), grid, dim3(LSFM_K9_T16), 0, s1, NF, fptr, photo, W, LY, tab, val, mask, out, fallback, 0, none, none, (int*)nullptr, 0, kc);
 	if (!serial)
 	{
 		LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[1], s1));

@@ -32,9 +32,12 @@
 namespace lsfm {
 
 #define PM_TILE LSFM_PM_TILE
-#define PM_PASS 16
-#define PM_K (3 * PM_PASS)
-#define PM_KS (PM_K + 1) /* odd row stride: the 16 rows x 2 k of a half-wave fall into distinct LDS banks */
+#ifndef LSFM_K9_PASS16
+#define LSFM_K9_PASS16 16 /* features per pass of the 8- and 16-slot variants: 16, or 8 (half the panel in LDS, twice the barriers per tile) */
+#endif
+#ifndef LSFM_K9_PASS32
+#define LSFM_K9_PASS32 16 /* ... of the 32-, 48- and 64-slot variants */
+#endif
 #define PM_SMAX 32      /* slots of the common variant: 256 threads, two work-groups per CU */
 #define PM_SMAX_BIG 48  /* slots of the variant for the tiles that exceed it: 1024 threads (16 waves share the 171 output tiles) */
 #define PM_SMAX_MAX 64  /* the widest panel: the same 1024 threads take its 300 output tiles in two sweeps over the tile's passes */
@@ -95,6 +98,8 @@ __device__ __forceinline__ int pn_hash_find(const unsigned long long* __restrict
 template <int SMAX>
 struct PmShared {
 	// (the widest panel fills a CU's LDS: its list of block slots is shorter -- later blocks read the level's copy -- and nothing here is wider than it must be)
+	// features per pass, panel columns, row stride (odd: the 16 rows x 2 k of a half-wave fall into distinct LDS banks)
+	static constexpr int PASS = SMAX <= 16 ? LSFM_K9_PASS16 : LSFM_K9_PASS32, K = 3 * PASS, KS = K + 1;
 	static constexpr int MAXE = SMAX > PM_SMAX_BIG ? 2560 : PM_MAXE;
 	// rows of the panel: six per slot and two more for the right-hand side (below); whole 16-row strips.  The widest variant has no
 	// room for a strip more: it takes tiles of up to 63 poses
@@ -109,9 +114,9 @@ struct PmShared {
 	// of every slot's pose, per pass L^-1 x_f of the features' two sources
 	double xs[PROWS];
 	unsigned char side[SMAX];
-	double uu[PM_PASS * 6];
-	double ly[PM_PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
-	alignas(16) double P[PROWS * PM_KS];
+	double uu[PASS * 6];
+	double ly[PASS * 9]; // per feature of the pass: l00 l10 l11 l20 l21 l22 of V^-1 = L L^T, then y = L^T eb; zero past the last one
+	alignas(16) double P[PROWS * KS];
 	unsigned char eslot[MAXE]; // slot of the tile's W blocks (| PM_DUP), filled once: the passes do not touch photo[] again
 	// block of S of every slot pair si <= sj (at sj (sj + 1) / 2 + si), looked up while the first pass's rows are on their way instead of
 	// behind the last pass (the widest variants have no room: they look them up at the tile's end, into the free panel)
@@ -129,6 +134,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
                                         const unsigned char* __restrict__ ces, int tile, Fill&& fill, int q0 = 0)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile coordinates live in SGPRs
+	constexpr int PM_PASS = PmShared<SMAX>::PASS, PM_K = PmShared<SMAX>::K, PM_KS = PmShared<SMAX>::KS;
 	K9T_DECL;
 	// (rows: the poses' rows; behind them rows and rows + 1 hold z of the End / the Cur side)
 	const int rows = 6 * ns, NT = (rows + 2 + 15) >> 4, ntile = NT * (NT + 1) / 2;
@@ -693,12 +699,12 @@ __device__ __forceinline__ void k9_fill(PmShared<SMAX>& sh, int cns, int jb, int
 // A tile is then all latency -- eight short passes, a handful of MFMAs -- and the smaller panel lets 6 / 3
 // work-groups share a CU instead of 2.
 template <int SMAX, int THREADS, bool LISTED>
-__global__ void __launch_bounds__(THREADS, (k9_waves_per_simd<SMAX, THREADS>()))
-k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
-              const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
-              K9Out o, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, K9Cache kc)
+__device__ __forceinline__ void
+k9_kernel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
+          const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+          const K9Out& o, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, const K9Cache& kc,
+          PmShared<SMAX>& sh)
 {
-	__shared__ PmShared<SMAX> sh;
 	const int tid = threadIdx.x;
 	// (LISTED is a template parameter, not a test of wlist: the loop around the tile cost the 16-slot variant, which sits at its
 	// register limit, ten spilled registers)
@@ -761,6 +767,16 @@ k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ phot
 			                     [&]() { k9_fill<SMAX, THREADS>(sh, cns, jb, je, o, kc, tab, val, mask); });
 		}
 	}
+}
+
+template <int SMAX, int THREADS, bool LISTED>
+__global__ void __launch_bounds__(THREADS, (k9_waves_per_simd<SMAX, THREADS>()))
+k_schur_panel(int NF, const int* __restrict__ fptr, const int* __restrict__ photo, const double* __restrict__ W, const double* __restrict__ LY,
+              const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+              K9Out o, unsigned char* fallback, int alone, const int* __restrict__ wlist, const int* __restrict__ wcnt, int* cursor, int lo, K9Cache kc)
+{
+	__shared__ PmShared<SMAX> sh;
+	k9_kernel<SMAX, THREADS, LISTED>(NF, fptr, photo, W, LY, tab, val, mask, o, fallback, alone, wlist, wcnt, cursor, lo, kc, sh);
 }
 
 int schur_panel_tile() { return PM_TILE; }

@@ -40,6 +40,7 @@ struct Workspace {
 	std::vector<int> sep, lev_cnt, edge_lev, edge_a, edge_b, eorder;
 	std::vector<int> vid, verts, cdeg, start, adj, cur;
 	std::vector<char> covered;
+	std::vector<std::pair<int, int>> live;
 	std::vector<std::vector<int>> bucket;
 	std::vector<unsigned long long> heap;
 	std::vector<int> rcnt, radj, fill, anc, mark, cfill, lev, lcount, lfill;
@@ -119,107 +120,187 @@ static SymPool& sym_pool()
 	return p;
 }
 
-// greedy vertex cover of the crossing edges among keys[kb, ke) -- the rows of a set of whole systems -- top level first: sep[pose] =
-// level of the separator the pose was put into (0: none).  Writes sep at the poses of these rows only.
-static void cover_edges(const unsigned long long* keys, int kb, int ke, const int* origin, int M, std::vector<int>& sep, Workspace& w)
+// ---- separators: greedy vertex cover of the crossing edges, top level first ---------------------------------------------------
+// The crossing edges among keys[kb, ke) -- the rows of a set of whole systems -- bucketed by the tree level they cross.  An edge
+// of level l joins two poses whose origins agree above bit l - 1: the edges of the levels <= split fall into independent GROUPS
+// (origin >> split) -- no edge of those levels leaves its group, and what the levels above decided about a group's poses is final
+// before the group starts -- so the groups' covers are worked out side by side (chol_symbolic: one task per group), each exactly as
+// the single pass over all edges of a level would have: the greedy choice inside a group never looks at another group's degrees.
+// (The top system of a 16 384-map monocular tree: 806 k crossing edges, 81 % of them below the top five cuts; its cover took 14 of
+// the analysis's 30 ms on one thread while the device waited for the factorisation's index arrays.)
+struct CoverJob {
+	int kb = 0, ke = 0, ne = 0, split = 0, ngroups = 1, gbase = 0;
+	std::vector<int> edge_a, edge_b; // the crossing edges, bucketed: the levels above split by level, then (group, level <= split)
+	std::vector<int> high_ptr;  // [36]: the ranges of the levels above split
+	std::vector<int> group_ptr; // [ngroups * (split + 1) + 1]: the ranges of (group, level <= split), behind the high ones
+};
+
+// one cut level: the uncovered ones of the (bucketed) edges [b0, b1) lose one endpoint each to the level's separator
+static void cover_level(int l, const CoverJob& jb, int b0, int b1, std::vector<int>& sep, Workspace& w, int M)
 {
-	// the off-diagonal edges bucketed by the tree level they cross (counting sort, order inside a level kept)
-	const int nk = ke - kb;
-	w.edge_lev.resize(nk); w.edge_a.resize(nk); w.edge_b.resize(nk); w.eorder.resize(nk);
-	w.lev_cnt.assign(35, 0);
-	int ne = 0;
-	for (int e = kb; e < ke; e++)
-	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p == q) continue;
-		const int l = bitlen((unsigned)(origin[p] ^ origin[q]));
-		w.edge_a[ne] = p; w.edge_b[ne] = q; w.edge_lev[ne] = l;
-		w.lev_cnt[l + 1]++;
-		ne++;
-	}
-	for (int l = 0; l < 34; l++) w.lev_cnt[l + 1] += w.lev_cnt[l];
-	{
-		int pos[35];
-		for (int l = 0; l < 35; l++) pos[l] = w.lev_cnt[l];
-		for (int e = 0; e < ne; e++) w.eorder[pos[w.edge_lev[e]]++] = e;
-	}
+	if (b0 == b1) return;
 	if ((int)w.vid.size() != M) w.vid.assign(M, -1); // (left all -1 by every call)
-	std::vector<std::pair<int, int>> live;
-	for (int l = 33; l >= 1; l--)
+	std::vector<std::pair<int, int>>& live = w.live;
+	live.clear();
+	for (int t = b0; t < b1; t++)
 	{
-		const int b0 = w.lev_cnt[l], b1 = w.lev_cnt[l + 1];
-		if (b0 == b1) continue;
-		// uncovered edges of the level
-		live.clear();
-		for (int t = b0; t < b1; t++)
-		{
-			const int e = w.eorder[t], p = w.edge_a[e], q = w.edge_b[e];
-			if (sep[p] < l && sep[q] < l) live.emplace_back(p, q);
-		}
-		if (live.empty()) continue;
-		// their endpoints, ascending (the tie-break of the heap below is the pose index), with a dense local numbering
-		std::vector<int>& verts = w.verts;
-		verts.clear();
-		for (const auto& pq : live)
-		{
-			if (w.vid[pq.first] < 0) { w.vid[pq.first] = 0; verts.push_back(pq.first); }
-			if (w.vid[pq.second] < 0) { w.vid[pq.second] = 0; verts.push_back(pq.second); }
-		}
-		std::sort(verts.begin(), verts.end());
-		const int nv = (int)verts.size();
-		for (int i = 0; i < nv; i++) w.vid[verts[i]] = i;
-		w.cdeg.assign(nv, 0);
-		for (const auto& pq : live) { w.cdeg[w.vid[pq.first]]++; w.cdeg[w.vid[pq.second]]++; }
-		w.start.resize(nv + 1);
-		w.start[0] = 0;
-		for (int i = 0; i < nv; i++) w.start[i + 1] = w.start[i] + w.cdeg[i];
-		w.adj.resize(w.start[nv]);
-		w.cur.assign(nv, 0); // fill counters first, live degrees afterwards
-		for (int e = 0; e < (int)live.size(); e++)
-		{
-			const int a = w.vid[live[e].first], b = w.vid[live[e].second];
-			w.adj[w.start[a] + w.cur[a]++] = e;
-			w.adj[w.start[b] + w.cur[b]++] = e;
-		}
-		w.covered.assign(live.size(), 0);
-		// the pose with the most uncovered crossing edges first, the higher pose index on a tie: ONE max-heap of (degree, local
-		// vertex number) keys (verts is ascending, so local order = pose order) whose entries are refreshed lazily -- covering an
-		// edge only lowers the other endpoint's live degree; a popped entry whose degree is stale goes back with the live one.
-		// (Round 3 pushed an entry into a per-degree heap at every decrement: ~1 M heap pushes for the top system of a
-		// 16 384-map monocular tree, 57 of the 78 ms of its analysis.)  The vertex selected is the same one.
-		for (int i = 0; i < nv; i++) w.cur[i] = w.cdeg[i];
-		std::vector<unsigned long long>& hp = w.heap;
-		hp.resize(nv);
-		for (int i = 0; i < nv; i++) hp[i] = ((unsigned long long)(unsigned)w.cdeg[i] << 32) | (unsigned)i;
-		std::make_heap(hp.begin(), hp.end());
-		while (!hp.empty())
-		{
-			std::pop_heap(hp.begin(), hp.end());
-			const unsigned long long key = hp.back();
-			hp.pop_back();
-			const int iv = (int)(key & 0xffffffffull), d = (int)(key >> 32);
-			const int live_d = w.cur[iv];
-			if (live_d <= 0) continue; // (all its edges are covered)
-			if (live_d != d)
-			{
-				hp.push_back(((unsigned long long)(unsigned)live_d << 32) | (unsigned)iv);
-				std::push_heap(hp.begin(), hp.end());
-				continue;
-			}
-			const int v = verts[iv];
-			sep[v] = l;
-			for (int t = w.start[iv]; t < w.start[iv + 1]; t++)
-			{
-				const int e = w.adj[t];
-				if (w.covered[e]) continue;
-				w.covered[e] = 1;
-				const int u = live[e].first == v ? live[e].second : live[e].first;
-				--w.cur[w.vid[u]];
-			}
-			w.cur[iv] = 0;
-		}
-		for (int v : verts) w.vid[v] = -1;
+		const int p = jb.edge_a[t], q = jb.edge_b[t];
+		if (sep[p] < l && sep[q] < l) live.emplace_back(p, q);
 	}
+	if (live.empty()) return;
+	// their endpoints, ascending (the tie-break of the heap below is the pose index), with a dense local numbering
+	std::vector<int>& verts = w.verts;
+	verts.clear();
+	for (const auto& pq : live)
+	{
+		if (w.vid[pq.first] < 0) { w.vid[pq.first] = 0; verts.push_back(pq.first); }
+		if (w.vid[pq.second] < 0) { w.vid[pq.second] = 0; verts.push_back(pq.second); }
+	}
+	std::sort(verts.begin(), verts.end());
+	const int nv = (int)verts.size();
+	for (int i = 0; i < nv; i++) w.vid[verts[i]] = i;
+	w.cdeg.assign(nv, 0);
+	for (const auto& pq : live) { w.cdeg[w.vid[pq.first]]++; w.cdeg[w.vid[pq.second]]++; }
+	w.start.resize(nv + 1);
+	w.start[0] = 0;
+	for (int i = 0; i < nv; i++) w.start[i + 1] = w.start[i] + w.cdeg[i];
+	w.adj.resize(w.start[nv]);
+	w.cur.assign(nv, 0); // fill counters first, live degrees afterwards
+	for (int e = 0; e < (int)live.size(); e++)
+	{
+		const int a = w.vid[live[e].first], b = w.vid[live[e].second];
+		w.adj[w.start[a] + w.cur[a]++] = e;
+		w.adj[w.start[b] + w.cur[b]++] = e;
+	}
+	w.covered.assign(live.size(), 0);
+	// the pose with the most uncovered crossing edges first, the higher pose index on a tie: ONE max-heap of (degree, local
+	// vertex number) keys (verts is ascending, so local order = pose order) whose entries are refreshed lazily -- covering an
+	// edge only lowers the other endpoint's live degree; a popped entry whose degree is stale goes back with the live one.
+	// (Round 3 pushed an entry into a per-degree heap at every decrement: ~1 M heap pushes for the top system of a
+	// 16 384-map monocular tree, 57 of the 78 ms of its analysis.)  The vertex selected is the same one.
+	for (int i = 0; i < nv; i++) w.cur[i] = w.cdeg[i];
+	std::vector<unsigned long long>& hp = w.heap;
+	hp.resize(nv);
+	for (int i = 0; i < nv; i++) hp[i] = ((unsigned long long)(unsigned)w.cdeg[i] << 32) | (unsigned)i;
+	std::make_heap(hp.begin(), hp.end());
+	while (!hp.empty())
+	{
+		std::pop_heap(hp.begin(), hp.end());
+		const unsigned long long key = hp.back();
+		hp.pop_back();
+		const int iv = (int)(key & 0xffffffffull), d = (int)(key >> 32);
+		const int live_d = w.cur[iv];
+		if (live_d <= 0) continue; // (all its edges are covered)
+		if (live_d != d)
+		{
+			hp.push_back(((unsigned long long)(unsigned)live_d << 32) | (unsigned)iv);
+			std::push_heap(hp.begin(), hp.end());
+			continue;
+		}
+		const int v = verts[iv];
+		sep[v] = l;
+		for (int t = w.start[iv]; t < w.start[iv + 1]; t++)
+		{
+			const int e = w.adj[t];
+			if (w.covered[e]) continue;
+			w.covered[e] = 1;
+			const int u = live[e].first == v ? live[e].second : live[e].first;
+			--w.cur[w.vid[u]];
+		}
+		w.cur[iv] = 0;
+	}
+	for (int v : verts) w.vid[v] = -1;
+}
+
+// the edges of a job, bucketed (counting sort, order inside a bucket kept), and its top levels' separators -- the part that is one
+// piece of work; `want_groups`: how many groups to cut the lower levels into (1: none); rows [r0, r1) are the job's
+static void cover_prepare(const unsigned long long* keys, const int* origin, int M, int r0, int r1, std::vector<int>& sep, CoverJob& jb, int want_groups)
+{
+	const int nk = jb.ke - jb.kb;
+	static const bool tm = getenv("LSFM_SYM_TIMING") != nullptr;
+	auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = tm ? now() : 0;
+	jb.edge_a.resize(nk); jb.edge_b.resize(nk);
+	Workspace& w = workspace();
+	// groups: origin >> split, as many as asked for (a power of two) when the job has the levels for it.  (No key crosses a job's
+	// rows: the origins of its rows bound the levels of its edges.)
+	unsigned omin = ~0u, omax = 0;
+	for (int p = r0; p < r1; p++) { omin = std::min(omin, (unsigned)origin[p]); omax = std::max(omax, (unsigned)origin[p]); }
+	int split = 0;
+	if (want_groups > 1 && nk >= 100000 && r1 > r0)
+	{
+		int lg = 0;
+		while ((1 << lg) < want_groups) lg++;
+		split = bitlen(omin ^ omax) - lg;
+		if (split < 2) split = 0;
+	}
+	jb.split = split;
+	jb.gbase = split > 0 ? (int)(omin >> split) : 0;
+	jb.ngroups = split > 0 ? (int)(omax >> split) - jb.gbase + 1 : 1;
+	// buckets: the levels above split by level (34 .. split + 1: the order they are taken in does not matter for the layout), behind
+	// them (group, level <= split)
+	const int per = split + 1, nlow = jb.ngroups * per, NB = 35 + nlow;
+	jb.high_ptr.assign(36, 0);
+	jb.group_ptr.assign(nlow + 1, 0);
+	std::vector<int>& bucket = w.edge_lev; // per key: < 0 diagonal, 0 .. 34 a high level, 35 + (group, level) a low one
+	bucket.resize(nk);
+	// a stable counting sort over ranges of the keys (one per thread when this is the one large job of the level: chol_symbolic):
+	// every range counts per bucket, the running sums over (bucket, range) are every range's first places, every range writes in key order
+	const int T = (want_groups > 1 && nk >= 100000) ? std::max(1, want_groups / 2) : 1;
+	std::vector<int>& cnt = w.cdeg; // [T][NB]
+	cnt.assign((size_t)T * NB, 0);
+	const int kb = jb.kb, gbase = jb.gbase;
+	const std::function<void(int)> classify = [&](int t) {
+		const int e0 = (int)((long)nk * t / T), e1 = (int)((long)nk * (t + 1) / T);
+		int* c = cnt.data() + (size_t)t * NB;
+		for (int e = e0; e < e1; e++)
+		{
+			const unsigned long long k = keys[kb + e];
+			const int p = (int)(k >> 32), q = (int)(k & 0xffffffffull);
+			if (p == q) { bucket[e] = -1; continue; }
+			const int l = bitlen((unsigned)(origin[p] ^ origin[q]));
+			const int b = (l > split || split == 0) ? l : 35 + ((int)((unsigned)origin[p] >> split) - gbase) * per + l;
+			bucket[e] = b;
+			c[b]++;
+		}
+	};
+	if (T > 1) sym_pool().run(T, classify); else classify(0);
+	{
+		int run = 0;
+		for (int b = 0; b < NB; b++)
+		{
+			if (b < 35) jb.high_ptr[b] = run; else jb.group_ptr[b - 35] = run;
+			for (int t = 0; t < T; t++) { const int x = cnt[(size_t)t * NB + b]; cnt[(size_t)t * NB + b] = run; run += x; }
+			if (b == 34) jb.high_ptr[35] = run;
+		}
+		jb.group_ptr[nlow] = run;
+		jb.ne = run;
+	}
+	const double t1 = tm ? now() : 0;
+	const std::function<void(int)> place = [&](int t) {
+		const int e0 = (int)((long)nk * t / T), e1 = (int)((long)nk * (t + 1) / T);
+		int* pos = cnt.data() + (size_t)t * NB;
+		for (int e = e0; e < e1; e++)
+		{
+			const int b = bucket[e];
+			if (b < 0) continue;
+			const unsigned long long k = keys[kb + e];
+			const int at = pos[b]++;
+			jb.edge_a[at] = (int)(k >> 32); jb.edge_b[at] = (int)(k & 0xffffffffull);
+		}
+	};
+	if (T > 1) sym_pool().run(T, place); else place(0);
+	const double t2 = tm ? now() : 0;
+	for (int l = 33; l >= 1; l--)
+		if (l > split || split == 0) cover_level(l, jb, jb.high_ptr[l], jb.high_ptr[l + 1], sep, w, M);
+	if (tm && nk > 100000) fprintf(stderr, "[sym]     edges %.3f ms, buckets %.3f ms, top levels %.3f ms\n", t1 - t0, t2 - t1, now() - t2);
+}
+// the levels <= split of one group
+static void cover_group(const CoverJob& jb, int g, std::vector<int>& sep, int M)
+{
+	Workspace& w = workspace();
+	const int per = jb.split + 1;
+	for (int l = jb.split; l >= 1; l--) cover_level(l, jb, jb.group_ptr[g * per + l], jb.group_ptr[g * per + l + 1], sep, w, M);
 }
 
 void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, int M, CholSymbolic& ch, int block_maps)
@@ -229,9 +310,25 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double tprev = tnow();
 	auto tick = [&](const char* what) { if (sym_timing) { const double n = tnow(); fprintf(stderr, "[sym] %-28s %8.3f ms\n", what, n - tprev); tprev = n; } };
+	if (const char* dump = getenv("LSFM_SYM_DUMP"))
+	{
+		// diagnostic: the inputs of the analyses of large systems, for work on this function away from the device (tools/sym_bench.cpp)
+		if (nnzb >= 200000)
+		{
+			char path[512];
+			snprintf(path, sizeof path, "%s/sym_%d_%d.bin", dump, M, nnzb);
+			if (FILE* f = fopen(path, "wb"))
+			{
+				const int hdr[4] = { M, nnzb, block_maps, 0 };
+				fwrite(hdr, sizeof(int), 4, f);
+				fwrite(keys, sizeof(unsigned long long), (size_t)nnzb, f);
+				fwrite(origin, sizeof(int), (size_t)M, f);
+				fclose(f);
+			}
+		}
+	}
 	// ---- separators: greedy vertex cover of the crossing edges, top level first --------------------------------------
 	std::vector<int>& sep = w.sep;
-	sep.assign(M, 0);
 	sep.assign(M, 0);
 	// Independent systems of the level (no edge between them) are analysed side by side: the rows are cut where no key crosses into
 	// chunks of about equal numbers of keys, one host thread each for the vertex cover here and for the row sub-tree walks below
@@ -264,11 +361,37 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		if (nchunk == 1) { fn(0); return; }
 		sym_pool().run(nchunk, std::function<void(int)>([&fn](int c) { fn(c); }));
 	};
-	par_chunks([&](int c) {
-		const double t0 = sym_timing ? tnow() : 0;
-		cover_edges(keys, cut_key[c], cut_key[c + 1], origin, M, sep, workspace());
-		if (sym_timing) fprintf(stderr, "[sym]   chunk %d: rows %d..%d, %d keys, cover %.3f ms\n", c, cut_row[c], cut_row[c + 1], cut_key[c + 1] - cut_key[c], tnow() - t0);
-	});
+	{
+		// (the jobs keep their arrays between calls)
+		static thread_local std::vector<CoverJob> jobs_tl;
+		std::vector<CoverJob>& jobs = jobs_tl; // (a reference: the lambdas below run on other threads, whose own jobs_tl is not this one)
+		if ((int)jobs.size() < nchunk) jobs.resize(nchunk);
+		static const int max_threads = getenv("LSFM_SYM_THREADS") ? std::max(1, atoi(getenv("LSFM_SYM_THREADS"))) : 8;
+		const int threads = block_maps > 0 ? 1 : std::min<int>(max_threads, std::max(1u, std::thread::hardware_concurrency() / 2));
+		// twice as many pieces as threads between all the chunks: the groups of a job differ in work
+		const int want_groups = threads > 1 ? std::max(1, 2 * threads / nchunk) : 1;
+		par_chunks([&](int c) {
+			const double t0 = sym_timing ? tnow() : 0;
+			jobs[c].kb = cut_key[c]; jobs[c].ke = cut_key[c + 1];
+			cover_prepare(keys, origin, M, cut_row[c], cut_row[c + 1], sep, jobs[c], want_groups);
+			if (sym_timing) fprintf(stderr, "[sym]   chunk %d: rows %d..%d, %d keys, split at level %d into %d groups, top levels' cover %.3f ms\n", c, cut_row[c], cut_row[c + 1], cut_key[c + 1] - cut_key[c], jobs[c].split, jobs[c].ngroups, tnow() - t0);
+		});
+		tick("separators: top levels");
+		std::vector<std::pair<int, int>> tasks;
+		for (int c = 0; c < nchunk; c++)
+			if (jobs[c].split > 0)
+				for (int g = 0; g < jobs[c].ngroups; g++) tasks.emplace_back(c, g);
+		if (!tasks.empty())
+		{
+			const std::function<void(int)> fn = [&](int t) {
+				const double t0 = sym_timing ? tnow() : 0;
+				cover_group(jobs[tasks[t].first], tasks[t].second, sep, M);
+				if (sym_timing) fprintf(stderr, "[sym]   chunk %d group %d: %.3f ms\n", tasks[t].first, tasks[t].second, tnow() - t0);
+			};
+			if (tasks.size() == 1 || threads == 1) for (int t = 0; t < (int)tasks.size(); t++) fn(t);
+			else sym_pool().run((int)tasks.size(), fn);
+		}
+	}
 	tick("separators");
 	// ---- permutation: by separator level, original order inside a level (a stable counting sort) ---------------------
 	std::vector<int>&perm = ch.perm, &pinv = ch.pinv;
@@ -301,21 +424,67 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	}
 	// ---- strict lower adjacency by row, new numbering ------------------------------------------------------------------
 	std::vector<int>&rcnt = w.rcnt, &radj = w.radj, &fill = w.fill;
-	rcnt.assign(M + 1, 0);
-	for (int e = 0; e < nnzb; e++)
+	static const int max_threads_a = getenv("LSFM_SYM_THREADS") ? std::max(1, atoi(getenv("LSFM_SYM_THREADS"))) : 8;
+	const int athreads = (nnzb < 60000 || block_maps > 0) ? 1 : std::min<int>(max_threads_a, std::max(1u, std::thread::hardware_concurrency() / 2));
+	if (athreads > 1)
 	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p != q) rcnt[std::max(pinv[p], pinv[q]) + 1]++;
+		// a stable counting sort by row over ranges of the keys, one range per thread: every range counts its entries per row, the running
+		// sums over (row, range) give every range its first place in every row, every range writes its entries in key order -- the rows
+		// come out as the one-thread pass leaves them
+		const int T = athreads;
+		std::vector<int>& cnt = w.cfill; // [T][M]
+		cnt.assign((size_t)T * M, 0);
+		auto range = [&](int t, int& e0, int& e1) { e0 = (int)((long)nnzb * t / T); e1 = (int)((long)nnzb * (t + 1) / T); };
+		sym_pool().run(T, std::function<void(int)>([&](int t) {
+			int e0, e1;
+			range(t, e0, e1);
+			int* c = cnt.data() + (size_t)t * M;
+			for (int e = e0; e < e1; e++)
+			{
+				const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+				if (p != q) c[std::max(pinv[p], pinv[q])]++;
+			}
+		}));
+		rcnt.resize(M + 1);
+		int run = 0;
+		for (int i = 0; i < M; i++)
+		{
+			rcnt[i] = run;
+			for (int t = 0; t < T; t++) { const int x = cnt[(size_t)t * M + i]; cnt[(size_t)t * M + i] = run; run += x; }
+		}
+		rcnt[M] = run;
+		radj.resize(run);
+		sym_pool().run(T, std::function<void(int)>([&](int t) {
+			int e0, e1;
+			range(t, e0, e1);
+			int* c = cnt.data() + (size_t)t * M;
+			for (int e = e0; e < e1; e++)
+			{
+				const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+				if (p == q) continue;
+				const int a = std::min(pinv[p], pinv[q]), b = std::max(pinv[p], pinv[q]);
+				radj[c[b]++] = a;
+			}
+		}));
 	}
-	for (int i = 0; i < M; i++) rcnt[i + 1] += rcnt[i];
-	radj.resize(rcnt[M]);
-	fill.assign(M, 0);
-	for (int e = 0; e < nnzb; e++)
+	else
 	{
-		const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
-		if (p == q) continue;
-		const int a = std::min(pinv[p], pinv[q]), b = std::max(pinv[p], pinv[q]);
-		radj[rcnt[b] + fill[b]++] = a;
+		rcnt.assign(M + 1, 0);
+		for (int e = 0; e < nnzb; e++)
+		{
+			const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+			if (p != q) rcnt[std::max(pinv[p], pinv[q]) + 1]++;
+		}
+		for (int i = 0; i < M; i++) rcnt[i + 1] += rcnt[i];
+		radj.resize(rcnt[M]);
+		fill.assign(M, 0);
+		for (int e = 0; e < nnzb; e++)
+		{
+			const int p = (int)(keys[e] >> 32), q = (int)(keys[e] & 0xffffffffull);
+			if (p == q) continue;
+			const int a = std::min(pinv[p], pinv[q]), b = std::max(pinv[p], pinv[q]);
+			radj[rcnt[b] + fill[b]++] = a;
+		}
 	}
 	tick("perm + adjacency");
 	// ---- elimination tree (ancestor path compression), column counts, column patterns by row sub-tree walks ----------
@@ -343,18 +512,90 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		});
 	});
 	tick("etree");
-	mark.assign(M, -1); ccount.assign(M, 1);
-	par_chunks([&](int c) {
-		for_rows(c, [&](int k) {
+	// Column counts and column patterns: row k of L is the union of the tree paths from k's neighbours up to k (a row sub-tree walk
+	// with a mark per visited column).  The rows are cut into RANGES, taken by the host threads in any order -- a range needs the
+	// finished tree and a mark array of its own, nothing of another range: pass 1 counts what every range adds to every column
+	// (cnt[range][column]), the running sums over the ranges give every range the place of ITS first entry in every column, pass 2
+	// repeats the walk and writes -- the ranges ascend and so do the rows inside one, so a column's row indices come out ascending,
+	// exactly as the one-thread walk over all rows leaves them.  (One system of 16 386 poses, 2.07 M blocks of L: 9 of its
+	// analysis's 30 ms were these two walks on one thread.)
+	std::vector<int>&colptr = ch.colptr, &rowidx = ch.rowidx;
+	static const int max_threads_w = getenv("LSFM_SYM_THREADS") ? std::max(1, atoi(getenv("LSFM_SYM_THREADS"))) : 8;
+	const int wthreads = (nnzb < 60000 || block_maps > 0) ? 1 : std::min<int>(max_threads_w, std::max(1u, std::thread::hardware_concurrency() / 2));
+	if (wthreads > 1)
+	{
+		// ranges of about equal numbers of adjacency entries, four per thread (the paths of the last rows -- the top separators -- are the long ones)
+		const int R = 4 * wthreads;
+		std::vector<int> rb(1, 0);
+		{
+			const long total = rcnt[M];
+			for (int k = 0, r = 1; k < M && r < R; k++)
+				if ((long)rcnt[k + 1] * R >= total * r) { if (k + 1 > rb.back() && k + 1 < M) rb.push_back(k + 1); r++; }
+			rb.push_back(M);
+		}
+		const int nr = (int)rb.size() - 1;
+		std::vector<int>& cnt = w.cfill; // [nr][M]
+		cnt.assign((size_t)nr * M, 0);
+		const std::function<void(int)> count_fn = [&](int r) {
+			std::vector<int>& mk = workspace().mark;
+			mk.assign(M, -1);
+			int* c = cnt.data() + (size_t)r * M;
+			for (int k = rb[r]; k < rb[r + 1]; k++)
+			{
+				mk[k] = k;
+				for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+					for (int i = radj[t]; mk[i] != k; i = parent[i]) { c[i]++; mk[i] = k; }
+			}
+		};
+		sym_pool().run(nr, count_fn);
+		tick("column counts");
+		colptr.assign(M + 1, 0);
+		ccount.resize(M);
+		for (int j = 0; j < M; j++)
+		{
+			int run = 1; // (the pivot block first)
+			for (int r = 0; r < nr; r++) { const int x = cnt[(size_t)r * M + j]; cnt[(size_t)r * M + j] = run; run += x; }
+			ccount[j] = run;
+			colptr[j + 1] = colptr[j] + run;
+		}
+		rowidx.resize(colptr[M]);
+		for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
+		const std::function<void(int)> fill_fn = [&](int r) {
+			std::vector<int>& mk = workspace().mark;
+			mk.assign(M, -1);
+			int* c = cnt.data() + (size_t)r * M;
+			for (int k = rb[r]; k < rb[r + 1]; k++)
+			{
+				mk[k] = k;
+				for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+					for (int i = radj[t]; mk[i] != k; i = parent[i]) { rowidx[colptr[i] + c[i]++] = k; mk[i] = k; }
+			}
+		};
+		sym_pool().run(nr, fill_fn);
+	}
+	else
+	{
+		mark.assign(M, -1); ccount.assign(M, 1);
+		for (int k = 0; k < M; k++)
+		{
 			mark[k] = k;
 			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
 				for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
-		});
-	});
-	tick("column counts");
-	std::vector<int>&colptr = ch.colptr, &rowidx = ch.rowidx;
-	colptr.assign(M + 1, 0);
-	for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
+		}
+		tick("column counts");
+		colptr.assign(M + 1, 0);
+		for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
+		rowidx.resize(colptr[M]);
+		w.cfill.assign(M, 1);
+		for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
+		std::fill(mark.begin(), mark.end(), -1);
+		for (int k = 0; k < M; k++)
+		{
+			mark[k] = k;
+			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+				for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + w.cfill[i]++] = k; mark[i] = k; }
+		}
+	}
 	const int nnzL = colptr[M];
 	ch.work_total = ch.work_shared = 0;
 	for (int j = 0; j < M; j++)
@@ -363,17 +604,6 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		ch.work_total += w;
 		if (j >= ch.first_shared) ch.work_shared += w;
 	}
-	rowidx.resize(nnzL);
-	w.cfill.assign(M, 1);
-	for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
-	std::fill(mark.begin(), mark.end(), -1);
-	par_chunks([&](int c) {
-		for_rows(c, [&](int k) {
-			mark[k] = k;
-			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-				for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + w.cfill[i]++] = k; mark[i] = k; }
-		});
-	});
 	tick("column patterns");
 	// ---- level sets (height above the leaves); the narrow top (<= 2 columns per level) becomes the tail ---------------
 	std::vector<int>& lev = w.lev;

@@ -1,13 +1,14 @@
 # A/B of build variants on ONE box:  gpurun -- bash tools/ab_build.sh "<label>|<make flags>" ...   (first entry usually "default|")
+#   [CONFIG=<name> STEPS=<n> REPS=<n>]
 # every variant: rebuild the library in place, 2 x `bench.py --steps 20 --warmup 3` (analysing / repeat ms, K9 ms per level, stage times)
 ulimit -c 0
 D=gpurun_out/ab; mkdir -p $D
 for spec in "$@"; do
   label="${spec%%|*}"; flags="${spec#*|}"
-  touch linearsfm_amd/csrc/lsfm_solve.hpp
+  touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp
   ( cd linearsfm_amd/csrc && make -s -j16 $flags > /dev/null 2>&1 ) || { echo "$label: build failed"; continue; }
-  for rep in 1 2; do
-    timeout 300 python bench.py --cpu-baseline 0 --extras 0 --steps 20 --warmup 3 2>/dev/null | python -c "
+  for rep in $(seq 1 ${REPS:-2}); do
+    timeout 600 python bench.py --config ${CONFIG:-nc3500} --cpu-baseline 0 --extras 0 --steps ${STEPS:-20} --warmup 3 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -17,4 +18,4 @@ for l in sys.stdin:
   done
 done 2>&1 | tee $D/ab_$(date +%H%M%S).txt
 # leave the default build behind
-touch linearsfm_amd/csrc/lsfm_solve.hpp; ( cd linearsfm_amd/csrc && make -s -j16 > /dev/null 2>&1 )
+touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp; ( cd linearsfm_amd/csrc && make -s -j16 > /dev/null 2>&1 )

@@ -93,3 +93,31 @@ def test_symbolic_rejects_malformed_patterns():
         api.symbolic_analyse(np.array([0, 1, 2], np.int32), np.array([1, 1], np.int32))   # row 0 without its diagonal block
     with pytest.raises(api.LsfmError):
         api.symbolic_analyse(np.array([0, 2, 3], np.int32), np.array([0, 5, 1], np.int32))  # column out of range
+
+
+def test_symbolic_large_system_same_on_one_thread_and_many(tmp_path):
+    """One large system is analysed on several host threads (separator cover by origin groups, counting sorts over key ranges, row-range
+    walks for the column counts and patterns: lsfm_symbolic.cpp): every output must be what ONE thread produces.  The thread count is
+    read once per process (LSFM_SYM_THREADS), so either side runs in a process of its own."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, sys.argv[1])\n"
+        "from linearsfm_amd import api, synth\n"
+        "rowptr, colidx, _ = synth.schur_like_matrix(9000, 20, 16, seed=5)\n"
+        "assert rowptr[-1] >= 200000\n"
+        "r = api.symbolic_analyse(rowptr, colidx)\n"
+        "h = hashlib.sha256()\n"
+        "for k in ('perm', 'colptr', 'rowidx', 'info'): h.update(np.ascontiguousarray(r[k]).tobytes())\n"
+        "print(h.hexdigest(), int(r['info'][0]))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for label, threads in (("one", "1"), ("many", "8")):
+        env = dict(os.environ, LSFM_SYM_THREADS=threads)
+        out[label] = subprocess.check_output([sys.executable, str(script), root], env=env, text=True).split()
+    assert out["one"] == out["many"]
+    assert int(out["one"][1]) > 200000

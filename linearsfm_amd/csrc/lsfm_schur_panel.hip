@@ -50,6 +50,9 @@ namespace lsfm {
 #ifndef LSFM_K9_T32
 #define LSFM_K9_T32 512 /* threads of the 32-slot variant (512 | 1024) */
 #endif
+#ifndef LSFM_K9_OCC16
+#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
+#endif
 #ifndef LSFM_K9_OCC16W
 #define LSFM_K9_OCC16W 2 /* work-groups per CU of a 512-thread 16-slot variant: 2 = 128 registers a wave, 3 = 80 */
 #endif
@@ -123,6 +126,138 @@ struct PmShared {
 	static constexpr bool PLANNED = SMAX <= PM_SMAX;
 	int pslot[PLANNED ? SMAX * (SMAX + 1) / 2 : 1];
 };
+
+// The end of a tile, behind the barrier that ends its passes: every touched block of S leaves the work-group once (fixed point), the
+// right-hand side rows are summed per wave and then over the waves in their order.  `scratch`: the (now free) panel; wslot: the row
+// set of this wave's output tiles (0 .. NWV - 1).
+template <int T, int NWV, int THREADS, class SH>
+__device__ __forceinline__ void k9_tile_end(SH& sh, double* scratch, int ns, const v4d (&acc)[T], const int (&ti)[T], const int (&tj)[T], int wslot, bool fused, int ey,
+                                            const K9Out& o, const unsigned long long* __restrict__ tab, const int* __restrict__ val, unsigned long long mask,
+                                            unsigned char* __restrict__ fallback, int tile)
+{
+	const int tid = threadIdx.x, lane = tid & 63, rows = 6 * ns;
+	if (sh.bad)
+	{
+		if (tid == 0) fallback[tile] = 1;
+		return;
+	}
+	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair: planned at the tile's start, or now, in the
+	// (now free) panel ----
+	int* pslot = reinterpret_cast<int*>(scratch);
+	if constexpr (!SH::PLANNED)
+	{
+		for (int q = tid; q < ns * ns; q += THREADS)
+		{
+			const int si = q / ns, sj = q - si * ns;
+			pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
+		}
+	}
+	// ... and behind them the tile's right-hand side rows, one set per wave: a wave adds its output tiles' shares in the order it holds
+	// them, the waves' sets are added in their order below -- the same bits every run, no atomics, one conversion to the fixed point per row
+	double* wsum = scratch + ((ns * ns + 1) >> 1);
+	for (int q = tid; q < NWV * rows; q += THREADS) wsum[q] = 0.0;
+	__syncthreads();
+	bool bad = false;
+	// E_R -= sum_C (P P^T)_RC m_C: m_C = the estimate of pose scalar C; for the two columns behind the poses' (P z_End, P z_Cur)
+	// 1 on the rows of that side's poses.  Off the diagonal a tile stands for its mirror image too: E_C -= sum_R (P P^T)_RC x_R.
+	double* mine = wsum + (wslot < 0 ? 0 : wslot) * rows; // (a wave without output tiles -- wslot < 0 -- adds nothing)
+#pragma unroll
+	for (int t = 0; t < T; t++)
+	{
+		if (ti[t] < 0) continue; // (uniform)
+		const int C = 16 * tj[t] + (lane & 15), Rb = 16 * ti[t] + (lane >> 4);
+		if (!fused && 16 * tj[t] + 15 < rows) continue; // (uniform: without estimates only the tiles of the last strip count)
+		const double xc = C < rows ? sh.xs[C] : 0.0;
+		const int zc = C - rows;
+		const bool mirror = ti[t] != tj[t] && fused;
+		double rs[4], cs = 0.0;
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+		{
+			const int R = Rb + 4 * e;
+			const double v = acc[t][e];
+			double term = v * xc;
+			if (zc >= 0) term = (zc < 2 && R < rows && sh.side[R / 6] == zc) ? v : 0.0;
+			rs[e] = term;
+			if (mirror && C < rows) cs = fma(v, sh.xs[R], cs); // (xs is zero past the poses' rows)
+		}
+		// the four row sums over the 16 lanes of a row group in five exchanges: halves of the group trade the pair of sums they do not
+		// keep, quarters the one, then two plain steps -- lane bits (3, 2) of the group say whose sum a lane ends up with
+		{
+			const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+			const double s0 = b3 ? rs[0] : rs[2], s1 = b3 ? rs[1] : rs[3];
+			const double a0 = (b3 ? rs[2] : rs[0]) + __shfl_xor(s0, 8, 64), a1 = (b3 ? rs[3] : rs[1]) + __shfl_xor(s1, 8, 64);
+			double r = (b2 ? a1 : a0) + __shfl_xor(b2 ? a0 : a1, 4, 64);
+			r += __shfl_xor(r, 2, 64);
+			r += __shfl_xor(r, 1, 64);
+			const int R = Rb + 4 * ((b3 ? 2 : 0) + (b2 ? 1 : 0));
+			if ((lane & 3) == 0 && R < rows) mine[R] -= r;
+		}
+		if (mirror)
+		{
+			cs += __shfl_xor(cs, 16, 64);
+			cs += __shfl_xor(cs, 32, 64);
+			if (lane < 16 && C < rows) mine[C] -= cs; // (rows of another strip than the ones above: ti != tj)
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < T; t++)
+	{
+		if (ti[t] < 0) continue;
+		const int C = 16 * tj[t] + (lane & 15);
+		if (C >= rows) continue;
+		const int sj = C / 6, c = C - 6 * sj;
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+		{
+			// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+			const int R = 16 * ti[t] + (lane >> 4) + 4 * e;
+			const double v = acc[t][e];
+			if (R >= rows || !(v != 0.0)) continue; // exact zero: this pose pair shares no feature of the tile
+			const int si = R / 6, r = R - 6 * si;
+			if (si > sj) continue; // diagonal tile: the mirrored element covers it
+			int slot;
+			if constexpr (SH::PLANNED) slot = sh.pslot[sj * (sj + 1) / 2 + si];
+			else slot = pslot[si * ns + sj];
+			if (slot < 0) continue;
+			// order-independent: the entry in fixed point, units of 2^(sexp_R + sexp_C - 60) -- every partial sum of an entry of
+			// W V^-1 W^T is below sqrt(U_RR U_CC) < 2^(sexp_R + sexp_C - 2) (the joint information matrix is positive semi-definite)
+			long long* d = o.S + (size_t)slot * 36;
+			const long long q = to_fixed(v, 60 - sh.sexp[R] - sh.sexp[C], bad);
+			if (si == sj)
+			{
+				// a pose with itself is stored full; across a tile boundary only this half was computed
+				atomic_add_i64(d + r * 6 + c, q);
+				if (ti[t] != tj[t]) atomic_add_i64(d + c * 6 + r, q);
+			}
+			else
+			{
+				// stored orientation: rows = smaller pose index
+				const bool up = sh.pose_of[si] <= sh.pose_of[sj];
+				atomic_add_i64(d + (up ? r * 6 + c : c * 6 + r), q);
+			}
+		}
+	}
+	__syncthreads();
+	{
+		for (int row = tid; row < rows; row += THREADS)
+		{
+			double e = 0.0;
+#pragma unroll
+			for (int w = 0; w < NWV; w++) e += wsum[w * rows + row];
+			if (e != 0.0)
+			{
+				// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
+				long long hi, lo;
+				to_fixed2(e, 62 - sh.sexp[row] - ey, hi, lo, bad);
+				const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
+				atomic_add_i64(o.Ehi + at, hi);
+				if (lo) atomic_add_i64(o.Elo + at, lo);
+			}
+		}
+	}
+	if (bad) atomic_add_i64(o.poison, 1);
+}
 
 // T = 16x16 tiles per wave (the work-group's upper-triangle tiles are dealt q = wave + NW t over its NW waves; slots
 // past the last tile recompute tile (0,0) and are dropped)
@@ -324,129 +459,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	K9T(5);
 	__syncthreads();
 	K9T(1);
-	if (sh.bad)
-	{
-		if (tid == 0) fallback[tile] = 1;
-		return;
-	}
-	// ---- every touched block leaves the work-group once.  Slot of S for every slot pair: planned at the tile's start, or now, in the
-	// (now free) panel ----
-	int* pslot = reinterpret_cast<int*>(sh.P);
-	if constexpr (!PmShared<SMAX>::PLANNED)
-	{
-		for (int q = tid; q < ns * ns; q += THREADS)
-		{
-			const int si = q / ns, sj = q - si * ns;
-			pslot[q] = si <= sj ? pn_hash_find(tab, val, mask, sh.pose_of[si], sh.pose_of[sj]) : -1;
-		}
-	}
-	// ... and behind them the tile's right-hand side rows, one set per wave: a wave adds its output tiles' shares in the order it holds
-	// them, the waves' sets are added in their order below -- the same bits every run, no atomics, one conversion to the fixed point per row
-	constexpr int NWV = THREADS / 64;
-	double* wsum = sh.P + ((ns * ns + 1) >> 1);
-	for (int q = tid; q < NWV * rows; q += THREADS) wsum[q] = 0.0;
-	__syncthreads();
-	bool bad = false;
-	// E_R -= sum_C (P P^T)_RC m_C: m_C = the estimate of pose scalar C; for the two columns behind the poses' (P z_End, P z_Cur)
-	// 1 on the rows of that side's poses.  Off the diagonal a tile stands for its mirror image too: E_C -= sum_R (P P^T)_RC x_R.
-	double* mine = wsum + wave * rows;
-#pragma unroll
-	for (int t = 0; t < T; t++)
-	{
-		if (ti[t] < 0) continue; // (uniform)
-		const int C = 16 * tj[t] + (lane & 15), Rb = 16 * ti[t] + (lane >> 4);
-		if (!fused && 16 * tj[t] + 15 < rows) continue; // (uniform: without estimates only the tiles of the last strip count)
-		const double xc = C < rows ? sh.xs[C] : 0.0;
-		const int zc = C - rows;
-		const bool mirror = ti[t] != tj[t] && fused;
-		double rs[4], cs = 0.0;
-#pragma unroll
-		for (int e = 0; e < 4; e++)
-		{
-			const int R = Rb + 4 * e;
-			const double v = acc[t][e];
-			double term = v * xc;
-			if (zc >= 0) term = (zc < 2 && R < rows && sh.side[R / 6] == zc) ? v : 0.0;
-			rs[e] = term;
-			if (mirror && C < rows) cs = fma(v, sh.xs[R], cs); // (xs is zero past the poses' rows)
-		}
-		// the four row sums over the 16 lanes of a row group in five exchanges: halves of the group trade the pair of sums they do not
-		// keep, quarters the one, then two plain steps -- lane bits (3, 2) of the group say whose sum a lane ends up with
-		{
-			const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-			const double s0 = b3 ? rs[0] : rs[2], s1 = b3 ? rs[1] : rs[3];
-			const double a0 = (b3 ? rs[2] : rs[0]) + __shfl_xor(s0, 8, 64), a1 = (b3 ? rs[3] : rs[1]) + __shfl_xor(s1, 8, 64);
-			double r = (b2 ? a1 : a0) + __shfl_xor(b2 ? a0 : a1, 4, 64);
-			r += __shfl_xor(r, 2, 64);
-			r += __shfl_xor(r, 1, 64);
-			const int R = Rb + 4 * ((b3 ? 2 : 0) + (b2 ? 1 : 0));
-			if ((lane & 3) == 0 && R < rows) mine[R] -= r;
-		}
-		if (mirror)
-		{
-			cs += __shfl_xor(cs, 16, 64);
-			cs += __shfl_xor(cs, 32, 64);
-			if (lane < 16 && C < rows) mine[C] -= cs; // (rows of another strip than the ones above: ti != tj)
-		}
-	}
-	K9T(11);
-#pragma unroll
-	for (int t = 0; t < T; t++)
-	{
-		if (ti[t] < 0) continue;
-		const int C = 16 * tj[t] + (lane & 15);
-		if (C >= rows) continue;
-		const int sj = C / 6, c = C - 6 * sj;
-#pragma unroll
-		for (int e = 0; e < 4; e++)
-		{
-			// C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-			const int R = 16 * ti[t] + (lane >> 4) + 4 * e;
-			const double v = acc[t][e];
-			if (R >= rows || !(v != 0.0)) continue; // exact zero: this pose pair shares no feature of the tile
-			const int si = R / 6, r = R - 6 * si;
-			if (si > sj) continue; // diagonal tile: the mirrored element covers it
-			int slot;
-			if constexpr (PmShared<SMAX>::PLANNED) slot = sh.pslot[sj * (sj + 1) / 2 + si];
-			else slot = pslot[si * ns + sj];
-			if (slot < 0) continue;
-			// order-independent: the entry in fixed point, units of 2^(sexp_R + sexp_C - 60) -- every partial sum of an entry of
-			// W V^-1 W^T is below sqrt(U_RR U_CC) < 2^(sexp_R + sexp_C - 2) (the joint information matrix is positive semi-definite)
-			long long* d = o.S + (size_t)slot * 36;
-			const long long q = to_fixed(v, 60 - sh.sexp[R] - sh.sexp[C], bad);
-			if (si == sj)
-			{
-				// a pose with itself is stored full; across a tile boundary only this half was computed
-				atomic_add_i64(d + r * 6 + c, q);
-				if (ti[t] != tj[t]) atomic_add_i64(d + c * 6 + r, q);
-			}
-			else
-			{
-				// stored orientation: rows = smaller pose index
-				const bool up = sh.pose_of[si] <= sh.pose_of[sj];
-				atomic_add_i64(d + (up ? r * 6 + c : c * 6 + r), q);
-			}
-		}
-	}
-	__syncthreads();
-	{
-		for (int row = tid; row < rows; row += THREADS)
-		{
-			double e = 0.0;
-#pragma unroll
-			for (int w = 0; w < NWV; w++) e += wsum[w * rows + row];
-			if (e != 0.0)
-			{
-				// |any partial sum of (W V^-1 eb)_row| <= sqrt(U_row,row) |L^T eb| < 2^(sexp_row + ey - 1): two limbs below that
-				long long hi, lo;
-				to_fixed2(e, 62 - sh.sexp[row] - ey, hi, lo, bad);
-				const size_t at = (size_t)sh.pose_of[row / 6] * 6 + row % 6;
-				atomic_add_i64(o.Ehi + at, hi);
-				if (lo) atomic_add_i64(o.Elo + at, lo);
-			}
-		}
-	}
-	if (bad) atomic_add_i64(o.poison, 1);
+	k9_tile_end<T, THREADS / 64, THREADS>(sh, sh.P, ns, acc, ti, tj, wave, fused, ey, o, tab, val, mask, fallback, tile);
 	K9T(6);
 	K9T_FLUSH(1, 8);
 	K9T_FLUSH(11, 13);
@@ -660,9 +673,6 @@ __global__ void __launch_bounds__(256) k_schur_lists(int ntiles, K9Cache kc)
 	}
 }
 
-#ifndef LSFM_K9_OCC16
-#define LSFM_K9_OCC16 3 /* work-groups per CU of the 16-slot variant: 3 = 170 registers a wave (22 spilled), 2 = 256 (none) */
-#endif
 template <int SMAX, int THREADS>
 constexpr int k9_waves_per_simd() { return THREADS == 256 ? (SMAX <= 8 ? 4 : LSFM_K9_OCC16) : (SMAX <= 16 ? LSFM_K9_OCC16W * (THREADS / 256) : THREADS / 256 / 2); }
 

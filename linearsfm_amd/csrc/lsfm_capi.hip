@@ -370,6 +370,7 @@ int lsfm_tree_run(lsfm_context* ctx, lsfm_tree* t, lsfm_stats* stats)
 				}
 				// what the warm levels left in the device accumulators instead of stopping for it
 				RunStatsDev rs;
+				LSFM_CHECK_HIP(hipStreamSynchronize(ctx->stream2)); // (the side stream's share of the record: k_sum_run_squares)
 				LSFM_CHECK_HIP(hipMemcpy(&rs, ctx->d_run, sizeof rs, hipMemcpyDeviceToHost));
 				if (ctx->comm)
 				{

@@ -1405,8 +1405,14 @@ void build_schur_values(lsfm_context* ctx, const SolveIO& io, SchurSystem& sy)
 			// (the W part of the right-hand sides, when K9 takes it along: eF += W^T x_p and eP += W x_f, 36 multiply-adds a block,
 			// and the estimates they read -- until round 5 a pass of its own, k_join_rhs_w)
 			if (io.rhs) { ctx->stats->schur_flops += (double)io.NW * 72.0; ctx->stats->schur_bytes += (double)io.NF * (48 + 24) + (double)io.M * 48; }
+			// (on the side stream, behind the 16-slot variant and its event: a number for the run's statistics has no place in the
+			// chain of the main stream -- 9 us per level; lsfm_tree_run waits for that stream before it reads the record)
 			if (ctx->in_tree_run && ctx->d_run)
-				hipLaunchKernelGGL(k_sum_run_squares, dim3(std::min((NF + 255) / 256, 512)), dim3(256), 0, s, NF, io.fptr, &ctx->d_run->k2);
+			{
+				LSFM_CHECK_HIP(hipEventRecord(ctx->ev_k9[0], s)); // (the run pointers are final at this point of the main stream)
+				LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_k9[0], 0));
+				hipLaunchKernelGGL(k_sum_run_squares, dim3(std::min((NF + 255) / 256, 512)), dim3(256), 0, ctx->stream2, NF, io.fptr, &ctx->d_run->k2);
+			}
 		}
 	}
 	if (ctx->comm) ctx->comm->allreduce(s, sy.acc, 1 + (size_t)cnt * 36, LSFM_DTYPE_I64);

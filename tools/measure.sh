@@ -32,13 +32,15 @@ for c in nc3500 synth16k rs468; do
   if [ $c = nc3500 ]; then a="--steps 5 --warmup 2"; elif [ $c = synth16k ]; then a="--steps 2 --warmup 1"; else a="--steps 5 --warmup 2"; fi
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D/$c/stats -o run -- python3 bench.py --config $c $a --cpu-baseline 0 --extras 0 > $D/bench_prof_$c.log 2>/dev/null
   rm -f $D/$c/stats/*kernel_trace.csv $D/$c/stats/*/*kernel_trace.csv   # tens of MB: the per-kernel statistics are what is kept
+  # (synth16k: one timed step -- the counter collection of a longer run of it crashed the profiler on this pool)
+  if [ $c = synth16k ]; then ps=1; trees=5; else ps=2; trees=7; fi
   for m in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $m --output-format csv -d $D/$c/pmc_$m -o run -- python3 bench.py --config $c --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 > $D/pmc_${m}_$c.log 2>&1
+    timeout 900 rocprofv3 --pmc $m --output-format csv -d $D/$c/pmc_$m -o run -- python3 bench.py --config $c --steps $ps --warmup 1 --cpu-baseline 0 --extras 0 > $D/pmc_${m}_$c.log 2>&1
   done
-  # the summaries are made HERE (trees in a --steps 2 --warmup 1 run: first + 1 warm-up + 2 timed + 3 of the other mode = 7); the raw
-  # per-dispatch counter files (5-10 MB each) travel back for nc3500 only
+  # the summaries are made HERE (trees in a --steps 2 --warmup 1 run: first + 1 warm-up + 2 timed + 3 of the other mode = 7; --steps 1: 5);
+  # the raw per-dispatch counter files (5-10 MB each) travel back for nc3500 only
   if [ $c = nc3500 ]; then kr=1; else kr=0; fi
-  PROFILES_DIR=$D/profiles KEEP_RAW=$kr python tools/refresh_profiles.py $D/$c $TAG $c 7 > $D/refresh_$c.txt 2>&1
+  PROFILES_DIR=$D/profiles KEEP_RAW=$kr python tools/refresh_profiles.py $D/$c $TAG $c $trees > $D/refresh_$c.txt 2>&1
   rm -rf $D/$c/pmc_FETCH_SIZE $D/$c/pmc_WRITE_SIZE
 done
 touch linearsfm_amd/csrc/lsfm_pcg.hip linearsfm_amd/csrc/lsfm_schur_panel.hip linearsfm_amd/csrc/lsfm_transform.hip

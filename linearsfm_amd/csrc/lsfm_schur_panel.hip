@@ -341,6 +341,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	// adds to): loaded behind the first pass's rows, not in front of them -- one memory round trip of a tile's three less in the open;
 	// visible to the passes through the barrier at the top of the first one
 	if (q0 == 0) fill();
+	K9T(0); // (with the header loads of the kernel: "poses -> slots")
 	const int ey = *o.ey;
 	for (int p0 = f0; p0 < f1; p0 += PM_PASS)
 	{
@@ -461,7 +462,7 @@ __device__ __forceinline__ void pm_body(PmShared<SMAX>& sh, int ns, int f0, int 
 	K9T(1);
 	k9_tile_end<T, THREADS / 64, THREADS>(sh, sh.P, ns, acc, ti, tj, wave, fused, ey, o, tab, val, mask, fallback, tile);
 	K9T(6);
-	K9T_FLUSH(1, 8);
+	K9T_FLUSH(0, 8);
 	K9T_FLUSH(11, 13);
 	K9T_COUNT(ns, T);
 }

@@ -426,7 +426,7 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	std::vector<int>&rcnt = w.rcnt, &radj = w.radj, &fill = w.fill;
 	static const int max_threads_a = getenv("LSFM_SYM_THREADS") ? std::max(1, atoi(getenv("LSFM_SYM_THREADS"))) : 8;
 	const int athreads = (nnzb < 60000 || block_maps > 0) ? 1 : std::min<int>(max_threads_a, std::max(1u, std::thread::hardware_concurrency() / 2));
-	if (athreads > 1)
+	if (athreads > 1 && nnzb >= 400000)
 	{
 		// a stable counting sort by row over ranges of the keys, one range per thread: every range counts its entries per row, the running
 		// sums over (row, range) give every range its first place in every row, every range writes its entries in key order -- the rows
@@ -522,7 +522,9 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	std::vector<int>&colptr = ch.colptr, &rowidx = ch.rowidx;
 	static const int max_threads_w = getenv("LSFM_SYM_THREADS") ? std::max(1, atoi(getenv("LSFM_SYM_THREADS"))) : 8;
 	const int wthreads = (nnzb < 60000 || block_maps > 0) ? 1 : std::min<int>(max_threads_w, std::max(1u, std::thread::hardware_concurrency() / 2));
-	if (wthreads > 1)
+	// (a level of many independent systems is cut into chunks of whole systems instead, one thread each, below: no counters per range,
+	// no sums over them -- 16 384 columns x 32 ranges of those cost a level of small systems more than its walks)
+	if (wthreads > 1 && nchunk < 4)
 	{
 		// ranges of about equal numbers of adjacency entries, four per thread (the paths of the last rows -- the top separators -- are the long ones)
 		const int R = 4 * wthreads;
@@ -551,13 +553,16 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		tick("column counts");
 		colptr.assign(M + 1, 0);
 		ccount.resize(M);
-		for (int j = 0; j < M; j++)
-		{
-			int run = 1; // (the pivot block first)
-			for (int r = 0; r < nr; r++) { const int x = cnt[(size_t)r * M + j]; cnt[(size_t)r * M + j] = run; run += x; }
-			ccount[j] = run;
-			colptr[j + 1] = colptr[j] + run;
-		}
+		sym_pool().run(wthreads, std::function<void(int)>([&](int t) {
+			const int j0 = (int)((long)M * t / wthreads), j1 = (int)((long)M * (t + 1) / wthreads);
+			for (int r = 0; r < nr; r++)
+			{
+				int* c = cnt.data() + (size_t)r * M;
+				if (r == 0) for (int j = j0; j < j1; j++) { const int x = c[j]; c[j] = 1; ccount[j] = 1 + x; } // (the pivot block first)
+				else for (int j = j0; j < j1; j++) { const int x = c[j]; c[j] = ccount[j]; ccount[j] += x; }
+			}
+		}));
+		for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
 		rowidx.resize(colptr[M]);
 		for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
 		const std::function<void(int)> fill_fn = [&](int r) {
@@ -575,13 +580,15 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 	}
 	else
 	{
+		// (a row only ever touches columns of its own system: the chunks share mark, ccount and cfill without meeting)
 		mark.assign(M, -1); ccount.assign(M, 1);
-		for (int k = 0; k < M; k++)
-		{
-			mark[k] = k;
-			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-				for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
-		}
+		par_chunks([&](int c) {
+			for_rows(c, [&](int k) {
+				mark[k] = k;
+				for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+					for (int i = radj[t]; mark[i] != k; i = parent[i]) { ccount[i]++; mark[i] = k; }
+			});
+		});
 		tick("column counts");
 		colptr.assign(M + 1, 0);
 		for (int j = 0; j < M; j++) colptr[j + 1] = colptr[j] + ccount[j];
@@ -589,12 +596,13 @@ void chol_symbolic(const unsigned long long* keys, int nnzb, const int* origin, 
 		w.cfill.assign(M, 1);
 		for (int j = 0; j < M; j++) rowidx[colptr[j]] = j;
 		std::fill(mark.begin(), mark.end(), -1);
-		for (int k = 0; k < M; k++)
-		{
-			mark[k] = k;
-			for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
-				for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + w.cfill[i]++] = k; mark[i] = k; }
-		}
+		par_chunks([&](int c) {
+			for_rows(c, [&](int k) {
+				mark[k] = k;
+				for (int t = rcnt[k]; t < rcnt[k + 1]; t++)
+					for (int i = radj[t]; mark[i] != k; i = parent[i]) { rowidx[colptr[i] + w.cfill[i]++] = k; mark[i] = k; }
+			});
+		});
 	}
 	const int nnzL = colptr[M];
 	ch.work_total = ch.work_shared = 0;

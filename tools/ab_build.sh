@@ -8,7 +8,7 @@ for spec in "$@"; do
   touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp
   ( cd linearsfm_amd/csrc && make -s -j16 $flags > /dev/null 2>&1 ) || { echo "$label: build failed"; continue; }
   for rep in $(seq 1 ${REPS:-2}); do
-    timeout 600 python bench.py --config ${CONFIG:-nc3500} --cpu-baseline 0 --extras 0 --steps ${STEPS:-20} --warmup 3 2>/dev/null | python -c "
+    timeout 600 python bench.py --config ${CONFIG:-nc3500} ${MAPS:+--maps $MAPS} --cpu-baseline 0 --extras 0 --steps ${STEPS:-20} --warmup 3 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -29,7 +29,7 @@ def main():
     ctx.tree_run(t)
     L.lsfm_debug_k9(out, 0)
     v = np.array(list(out), dtype=np.float64).reshape(4, 16)
-    names = ["poses -> slots", "barrier (pass consumed)", "zero panel, y", "stage P = W L", "barrier (staged)", "MFMA", "scatter to S", "wait for the prefetch"]
+    names = ["header + poses -> slots", "barrier (pass consumed)", "zero panel, y", "stage P = W L", "barrier (staged)", "MFMA", "tile end (rhs, scatter)", "wait for the prefetch"]
     for k, smax in enumerate((8, 16, 32, 48)):
         tiles = v[k, 8]
         if not tiles:
@@ -39,7 +39,6 @@ def main():
               f"{tot / tiles:.0f} clocks per tile")
         for n, x in zip(names, v[k, :8]):
             print(f"    {n:26s} {100 * x / tot:5.1f} %   {x / tiles:9.0f} clocks per tile")
-        print(f"    {'right-hand side at tile end':26s} {100 * v[k, 11] / (tot + v[k, 11] + v[k, 12]):5.1f} %   {v[k, 11] / tiles:9.0f} clocks per tile (on top of the 100 % above)")
         print(f"    {'prefetch issue':26s} {100 * v[k, 12] / (tot + v[k, 11] + v[k, 12]):5.1f} %   {v[k, 12] / tiles:9.0f} clocks per tile (on top of the 100 % above)")
     ctx.tree_free(t)
     ctx.close()

@@ -286,13 +286,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_wall = []  # wall ms of every tree of the last timed() call: how far single steps scatter around `value` (their mean)
+
     def timed(steps):
         """`steps` whole trees between two barrier + synchronize points: (seconds, summed stats, last stats, worst rc)"""
         barrier()
         t0 = time.perf_counter()
         acc, last, worst = {}, None, 0
+        del step_wall[:]
         for _ in range(steps):
+            t1 = time.perf_counter()
             last, rc = tree.run()
+            step_wall.append(1e3 * (time.perf_counter() - t1))  # (a run returns when its tree is done: no extra synchronisation)
             worst = max(worst, rc)
             for k, v in (last or {}).items():
                 if isinstance(v, (int, float)):
@@ -310,6 +315,8 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         tree.run()
     elapsed, acc, stats, worst = timed(args.steps)
+    sw = sorted(step_wall)
+    step_spread = {"min": sw[0], "median": sw[len(sw) // 2], "max": sw[-1]} if sw else None
     rdev = "cpu" if os.environ.get("LSFM_BENCH_ONE_GPU") else "cuda"
     tm = torch.tensor([elapsed, first_s], dtype=torch.float64, device=rdev)
     if world > 1:
@@ -374,6 +381,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_ms_spread": step_spread,
             "higher_is_better": False,
             "scaling": "strong",
             "vs_baseline": None,

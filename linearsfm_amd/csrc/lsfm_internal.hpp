@@ -326,6 +326,7 @@ struct lsfm_context {
 	// refinement steps of the level being run: step_hint > 0 = what an earlier run of this tree needed here (the steps are then
 	// enqueued without asking the device after each one; whether they sufficed is read at the end of the run), steps_used = what
 	// a level that did ask needed
+	bool level_syncs = false;                    // the level under way waits for the device at its end anyway (a Mono level that analyses): a hinted refinement may ask once
 	int step_hint = 0, steps_used = 0;           // lsfm_tree_run: errors of a level may be left in d_run and read at the end of the run
 	hipEvent_t evC = nullptr;
 	lsfm_stats* stats = nullptr; // optional sink during a tree run

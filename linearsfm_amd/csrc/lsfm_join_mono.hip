@@ -610,7 +610,11 @@ void join_batch_mono(lsfm_context* ctx, Arena& ar, const DevBatch& in, DevBatch&
 		io.seed = &seed;
 	}
 	ctx->solved_keys = nullptr; ctx->solved_nnzb = 0;
-	int rc = solve_batch(ctx, io);
+	ctx->level_syncs = !warm; // (this level waits for the device below: its refinement may ask once instead of guessing a margin)
+	int rc;
+	try { rc = solve_batch(ctx, io); }
+	catch (...) { ctx->level_syncs = false; throw; }
+	ctx->level_syncs = false;
 	if (!warm && ctx->in_tree_run && ctx->solved_keys && ctx->solved_nnzb > 0 && !ctx->comm)
 	{
 		// ... and this level's pattern stays with its output for the level above

@@ -2708,9 +2708,15 @@ small_tail:
 	// for its count to vary from run to run -- one synth-16k run in
 	// eight asked for one more than the run before and had to be repeated as a whole: such levels get one step of margin; systems
 	// that are done are frozen on the device, the extra step costs them the launches only)
+	// A hinted level whose caller waits for the device at its end anyway (ctx->level_syncs: a Mono level that analyses) needs neither the
+	// margin nor the repeat: it enqueues the steps the run before needed, asks ONCE whether every system is done, and goes on asking
+	// step by step if not -- one synth-16k analysing run in eight to twenty was repeated as a whole (twice its time) until round 6.
+	const bool ask_after = hinted && ctx->level_syncs && !ctx->comm;
 	const int base_steps = hinted ? ctx->step_hint : (planned_run ? sp->its : maxit);
-	const int planned = (planned_run && base_steps >= (mixed ? 3 : 2)) ? std::min(base_steps + 1, maxit) : base_steps;
-	while ((planned_run ? its < planned : (ndone < nseg && its < maxit)))
+	const int planned = (planned_run && !ask_after && base_steps >= (mixed ? 3 : 2)) ? std::min(base_steps + 1, maxit) : base_steps;
+	bool counting = planned_run; // (the steps are enqueued without asking)
+	bool extended = false;
+	while ((counting ? its < planned : (ndone < nseg && its < maxit)))
 	{
 		const int cur = its & 1;
 		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
@@ -2722,7 +2728,17 @@ small_tail:
 		// the test comes before the preconditioner: the apply for a residual that already passed would be wasted
 		hipLaunchKernelGGL(k_pcg_check, dim3(nbs), dim3(128), 0, s, nseg, seg, d_misc + 1);
 		its++;
-		if (planned_run) { if (its >= planned) break; }
+		if (counting)
+		{
+			if (its >= planned)
+			{
+				if (!ask_after) break;
+				ndone = d2h_int(ctx, d_misc + 1);
+				if (ndone >= nseg || its >= maxit) break;
+				counting = false; // (a system needs more than the run before did: from here on like a run without a hint)
+				extended = true;
+			}
+		}
 		else
 		{
 			ctx->mark("cg_enq");
@@ -2805,7 +2821,7 @@ small_tail:
 		st->spmv_bytes += nsample * spmv_bytes(sy);
 		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
 	}
-	ctx->steps_used = planned_run ? 0 : std::max(its, 1);
+	ctx->steps_used = (planned_run && !extended) ? 0 : std::max(its, 1);
 	if (deferred)
 	{
 		if (warm && !planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt

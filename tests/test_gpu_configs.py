@@ -459,3 +459,37 @@ def test_mono_pattern_from_the_level_below_equals_the_joint_maps(ctx, oracle, mo
     assert orc == 0
     _same_structure(got, exp)
     assert pose_param_err(got["stVal"], exp["stVal"], exp["stno"]) < TREE_TOL
+
+
+def test_hinted_mono_refinement_asks_once_when_the_hint_is_short(ctx, oracle):
+    """A run that analyses enqueues, per level, the refinement steps the run before needed.  A Mono level waits for the device at its end
+    anyway, so when that count turns out short it asks ONCE and goes on step by step (lsfm_pcg.hip, `ask_after`) -- until round 6 the whole
+    run was joined again.  Forced here: the first runs leave the step counts of the fp64 preconditioner (one step per level), then the
+    preconditioner is switched to fp32, which needs two -- the next run's hints are short at every level above the dense path's, it
+    must still converge in ONE attempt, and its map must be the oracle's."""
+    typ, maps = synth.make_config("rs468", 200)
+    assert typ == "Monocular"
+    dicts = [oracle.localmap_to_dict(m) for m in maps]
+    c = ctx
+    t = None
+    try:
+        t = c.tree_upload(dicts, True)
+        c.tree_set_plans(t, False)
+        for _ in range(2):
+            s0, rc = c.tree_run(t)
+            assert rc == 0 and s0["attempts"] == 1
+        c.set_precision(True)
+        s1, rc = c.tree_run(t)
+        assert rc == 0 and s1["attempts"] == 1 and s1["not_converged"] == 0, s1
+        assert s1["pcg_iterations"] > s0["pcg_iterations"], (s0["pcg_iterations"], s1["pcg_iterations"])
+        assert s1["max_rel_residual"] < 1e-9, s1
+        got = c.tree_download(t)
+    finally:
+        c.set_precision(False)  # (the session's context: back to the library's default)
+        if t is not None:
+            c.tree_free(t)
+    exp, _, orc = oracle.divide_conquer(dicts, True, match_hash=True)
+    assert orc == 0
+    ep = pose_param_err(got["stVal"], exp["stVal"], exp["stno"])
+    print(f"steps per tree {s0['pcg_iterations']} (fp64 preconditioner) -> {s1['pcg_iterations']} (fp32, hints of the fp64 runs), one attempt; pose parameters vs oracle {ep:.2e}")
+    assert ep < TREE_TOL

@@ -40,6 +40,8 @@ CHAINS = {
     # name: (type, generator keyword arguments) -- laps that return to their start: the upper joins close loops
     "chain_stereo_n512": ("Stereo", dict(n_maps=512, new_per_frame=16, vis=5, seed=31, lap=60, home=8, revisit=0.4)),
     "chain_mono_n200": ("Monocular", dict(n_maps=200, new_per_frame=10, vis=4, seed=32, **synth.SPIRAL)),
+    # the same path at 768 maps: 10 levels, the top systems past the dense path and the leaf tasks of the device's factorisation
+    "chain_mono_n768": ("Monocular", dict(n_maps=768, new_per_frame=10, vis=4, seed=34, **synth.SPIRAL)),
     # the NC3500-like path (laps of 120 frames through one place, synth.FLOWER) at 2 048 maps: 2 048 poses, 11 levels, the top
     # systems as wide as the device's 32-slot Schur panels and supernode groups see them on the headline set
     "chain_stereo_n2048": ("Stereo", dict(n_maps=2048, new_per_frame=24, vis=5, seed=33, **synth.FLOWER)),
@@ -137,4 +139,4 @@ if __name__ == "__main__":
     po.build()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     for nm in (sys.argv[1:] or ["stereo", "mono"]):
-        run({"stereo": "chain_stereo_n512", "mono": "chain_mono_n200", "stereo2048": "chain_stereo_n2048"}.get(nm, nm))
+        run({"stereo": "chain_stereo_n512", "mono": "chain_mono_n200", "stereo2048": "chain_stereo_n2048", "mono768": "chain_mono_n768"}.get(nm, nm))

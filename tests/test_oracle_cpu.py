@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import GOLD_MID, GOLD_SMALL, GOLD_WIDE, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden, pose_param_err, ref_map, rel_err
+from common import CHAIN_FLOOR, GOLD_CHAIN, GOLD_MID, GOLD_SMALL, GOLD_WIDE, assert_maps_close, dense_reference_solve, feat_param_err, get_map, golden_system, load_golden, pose_param_err, ref_map, rel_err
 from linearsfm_amd import synth
 from refdump import dense_info
 
@@ -497,14 +497,15 @@ def test_schur_reference_solve_is_the_dense_expected_value(name):
         assert np.max(np.abs(x - d) / np.maximum(1, np.abs(d))) < (1e-9 if mono else 1e-12), (name, j)
 
 
-@pytest.mark.parametrize("name", ["chain_stereo_n512", "chain_mono_n200", "chain_stereo_n2048"])
+@pytest.mark.parametrize("name", GOLD_CHAIN)
 def test_oracle_whole_tree_vs_reference_chain(oracle, name):
     """The oracle's WHOLE tree -- transforms, assemblies, Schur complements, sparse Cholesky, back-substitutions, 9 / 8 levels, systems of up
     to 512 / 202 / 2 048 poses with lap closures -- against the same tree evaluated by the REAL reference (every transform and assembly:
     oracle/_ref/ref_dump) with every solve replaced by the exact solution of the reference-assembled system (make_chain_golden.py): the
-    chain holds no arithmetic of the oracle.  Measured 6.8e-10 (512 Stereo) / 3.4e-8 (Mono) / 2.5e-8 (2 048 Stereo) on the pose parameters; the long-double twin of the
-    oracle's solves lands at the same distance -- what is left is the rounding of the state between the levels, not a solver's."""
-    from common import chain_set
+    chain holds no arithmetic of the oracle.  Measured 6.8e-10 (512 Stereo) / 3.4e-8 (200 Mono) / 2.5e-8 (2 048 Stereo) on the pose parameters; the long-double twin of the
+    oracle's solves lands at the same distance -- what is left is the rounding of the state between the levels, not a solver's.  On the
+    768-map Mono chain that rounding alone is 1e-6 .. 3e-6 (common.CHAIN_FLOOR): the fixture shows where BASELINE.json's 1e-6 meets fp64."""
+    from common import chain_bar, chain_set
     typ, mono, maps, z = chain_set(name)
     d = [oracle.localmap_to_dict(m) for m in maps]
     G, _, rc = oracle.divide_conquer(d, mono, match_hash=True)
@@ -513,7 +514,17 @@ def test_oracle_whole_tree_vs_reference_chain(oracle, name):
     for k in ("Ref", "FRef") + (("ScaP", "Fix", "Sign") if mono else ()):
         assert int(G[k]) == int(z[f"result.{k}"]), k
     ep, ef = pose_param_err(G["stVal"], z["result.stVal"], z["result.stno"]), feat_param_err(G["stVal"], z["result.stVal"], z["result.stno"])
-    assert ep < 1e-7 and ef < 1e-7, (ep, ef)
+    bar = chain_bar(name, 1e-7)
+    print(f"{name}: oracle vs the reference chain: pose parameters {ep:.2e}, features {ef:.2e} (bar {bar:.1e})")
+    assert ep < bar and ef < bar, (ep, ef)
+    if name in CHAIN_FLOOR:
+        # (the spread really is fp64's, not the oracle's: its long-double twin is as far from the chain, and from the oracle)
+        T, _, rc = oracle.divide_conquer(d, mono, match_hash=True, extended=True)
+        assert rc == 0
+        tp = pose_param_err(T["stVal"], z["result.stVal"], z["result.stno"])
+        ot = pose_param_err(G["stVal"], T["stVal"], z["result.stno"])
+        print(f"{name}: long-double twin vs the chain {tp:.2e}, oracle vs its twin {ot:.2e}")
+        assert 1e-7 < tp < bar and 1e-7 < ot < bar, (tp, ot)
 
 
 def test_generator_visibility_index_equals_a_pass_over_all_points():

@@ -314,6 +314,7 @@ struct lsfm_context {
 	hipEvent_t ev_solve_end = nullptr; // (LSFM_LEVEL_GAPS=1: the event behind the last solve, against the next level's first)
 	double dbg_gap_ms = 0.0;
 	hipEvent_t evY = nullptr, evP = nullptr; // joint index arrays of the level final (main stream) / prefetch complete (stream3)
+	hipEvent_t evU = nullptr;                // the transform's U stage may start: everything it reads is final, the block kernel of the features has not begun
 	hipEvent_t evK = nullptr;                // the level's Schur assembly (K9) has left the main stream: the chain of the factorisation starts
 	const unsigned long long* solved_keys = nullptr; // left by solve_batch: sorted upper pattern of the system it just solved (scratch arena)
 	int solved_nnzb = 0;

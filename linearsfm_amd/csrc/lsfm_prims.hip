@@ -487,6 +487,7 @@ int lsfm_context_create(int device, size_t arena_bytes, lsfm_context** out)
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evY, lsfm::order_event_flags()));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evP, lsfm::order_event_flags()));
 		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evK, lsfm::order_event_flags()));
+		LSFM_CHECK_HIP(hipEventCreateWithFlags(&c->evU, lsfm::order_event_flags()));
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 4096));
 		c->stage_size = (size_t)64 << 20;
 		LSFM_CHECK_HIP(hipHostMalloc((void**)&c->h_stage, c->stage_size));
@@ -543,6 +544,7 @@ void lsfm_context_destroy(lsfm_context* c)
 	if (c->evY) (void)hipEventDestroy(c->evY);
 	if (c->evP) (void)hipEventDestroy(c->evP);
 	if (c->evK) (void)hipEventDestroy(c->evK);
+	if (c->evU) (void)hipEventDestroy(c->evU);
 	c->pre.reset();
 	c->sarena[0].destroy(); c->sarena[1].destroy();
 	c->early.reset();

@@ -1001,7 +1001,9 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 {
 	hipStream_t s = ctx->stream;
 	const int M = in.M;
-	bool ev_entries = false;
+	bool ev_entries = false, u_early = false;
+	static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
+	static const bool early_u = !getenv("LSFM_U_STAGE_LATE");
 	if (!in.NF && hook) (void)(*hook)(out); // nothing to redirect, but the consumer still lays out its container
 	if (in.NF)
 	{
@@ -1016,6 +1018,19 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 		TrRedirect rd;
 		if (hook) rd = (*hook)(out);
 		if (!rd.W) { rd = TrRedirect(); rd.wbase = out.fptr; rd.W = out.W; rd.photo = out.photo; rd.feature = out.feature; }
+		// The U blocks' kernel reads nothing the feature kernels write (U, the poses' Jacobians, the kept-block ranks) and ADDS to the pose
+		// rows of G like they do: it goes to the side stream HERE, beside the block kernel of the features, not behind it -- one lane per
+		// 6x6 block with a few hundred dependent multiply-adds each, it takes 160-190 us whatever the level's size, and behind the
+		// block kernel the main stream waited 60 us per level for it (k_tr_diag needs the U stage).  Only the poses' kernel, which
+		// reads the finished rows, still waits for the block kernel.  LSFM_U_STAGE_LATE=1: as until round 6.
+		if (side && early_u && !ctx->comm && in.NU)
+		{
+			LSFM_CHECK_HIP(hipEventRecord(ctx->evU, s));
+			LSFM_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evU, 0));
+			hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, ctx->stream2, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
+			                   Dp, Cp, out.U, out.Ui, out.Uj, Gpose);
+			u_early = true;
+		}
 		hipEvent_t e0 = nullptr, e1 = nullptr; // the events bracket k_tr_entries alone; read at the end of the run
 		if (ctx->stats) { e0 = ctx->pool_event(); e1 = ctx->pool_event(); LSFM_REC_T(e0, s); }
 		hipLaunchKernelGGL(k_tr_entries<NH>, dim3((in.NF + TRE_TILE - 1) / TRE_TILE), dim3(TRE_ROUND), 0, s, in.NF, M, finfo, in.fptr, in.W,
@@ -1038,15 +1053,14 @@ static void launch_stage(lsfm_context* ctx, const DevBatch& in, DevBatch& out, c
 			                         nf_act * 18 * NH * 8 + nw_pass * (4 + 8 + (out.W_alias ? 0 : 288)) + (double)(in.NF - nf_act) * (16 + 4);
 		}
 	}
-	// U stage: needs the pose rows of G (complete after k_tr_entries) but nothing of the feature epilogue, which runs
-	// on the main stream meanwhile; k_tr_diag needs both
-	static const bool side = !getenv("LSFM_NO_SIDE_STREAM");
+	// U stage: its second kernel needs the pose rows of G (complete after k_tr_entries and k_tr_ublocks) but nothing of the feature
+	// epilogue, which runs on the main stream meanwhile; k_tr_diag needs both
 	// feature-sharded run: what the features of this rank's slice added to the pose rows of G (k_tr_entries) and to the hub-hub
 	// blocks (k_tr_feat_post) becomes the sum over all slices before the pose kernels read and extend it
 	if (ctx->comm) ctx->comm->allreduce(s, Gpose, (size_t)M * 36 * NH + (size_t)in.B * 3 * 36, LSFM_DTYPE_F64);
 	hipStream_t su = (side && ev_entries && !ctx->comm) ? ctx->stream2 : s;
 	if (su != s) LSFM_CHECK_HIP(hipStreamWaitEvent(su, ctx->evA, 0));
-	if (in.NU)
+	if (in.NU && !u_early)
 		hipLaunchKernelGGL(k_tr_ublocks<NH>, dim3((in.NU + 127) / 128), dim3(128), 0, su, in.NU, M, d_tm, in.pose_map, in.U, in.Ui, in.Uj, KU,
 		                   Dp, Cp, out.U, out.Ui, out.Uj, Gpose);
 	if (M)

@@ -2716,7 +2716,12 @@ small_tail:
 	const int planned = (planned_run && !ask_after && base_steps >= (mixed ? 3 : 2)) ? std::min(base_steps + 1, maxit) : base_steps;
 	bool counting = planned_run; // (the steps are enqueued without asking)
 	bool extended = false;
-	while ((counting ? its < planned : (ndone < nseg && its < maxit)))
+	// (an extension is for the run that needs ONE step more than the run before -- the counts scatter by one or two; a system that is
+	// still not done three steps on has stalled where its true residual stops shrinking, and steps do not cure that: the run is
+	// joined again, as before, which does -- the rounding falls differently.  Nor does an extension raise the hint: it would stay
+	// raised, and every later run would pay for the one that stalled)
+	int cap = maxit;
+	while ((counting ? its < planned : (ndone < nseg && its < cap)))
 	{
 		const int cur = its & 1;
 		launch_spmv(ctx, sy, p, Ap, io.d_fixed, p, io.d_pose_seg, &seg[0].pAp, SEG_STRIDE);
@@ -2737,6 +2742,7 @@ small_tail:
 				if (ndone >= nseg || its >= maxit) break;
 				counting = false; // (a system needs more than the run before did: from here on like a run without a hint)
 				extended = true;
+				cap = std::min(maxit, planned + 3);
 			}
 		}
 		else
@@ -2821,7 +2827,8 @@ small_tail:
 		st->spmv_bytes += nsample * spmv_bytes(sy);
 		st->spmv_nnzb_upper_last = sy.nnzb; st->spmv_rows_last = M;
 	}
-	ctx->steps_used = (planned_run && !extended) ? 0 : std::max(its, 1);
+	ctx->steps_used = planned_run ? 0 : std::max(its, 1);
+	(void)extended;
 	if (deferred)
 	{
 		if (warm && !planned_run) { sp->its = std::max(its, 1); sp->mixed = mixed; sp->rel_tol = ctx->pcg.rel_tol; } // precision / tolerance changed: the count was re-learnt

@@ -67,7 +67,10 @@ struct SmallShared {
 };
 
 template <int NTR>
-__global__ void __launch_bounds__(SM_THREADS, NTR >= 6 ? 1 : 2) // (the prefetched super-pass is ~45 registers: three waves a SIMD would spill 160)
+#ifndef LSFM_SMALL_OCC
+#define LSFM_SMALL_OCC 2 /* work-groups per CU of the 2- and 5-pose instances (levels 0 and 1 of a Stereo tree): 3 = 168 registers, 76-104 bytes spilled */
+#endif
+__global__ void __launch_bounds__(SM_THREADS, NTR >= 6 ? 1 : (NTR <= 2 ? LSFM_SMALL_OCC : 2)) // (the prefetched super-pass is ~45 registers: three waves a SIMD would spill 160)
 k_small_solve(SmallArgs a)
 {
 	constexpr int R = 16 * NTR, LD = R + 1;

@@ -5,7 +5,7 @@ ulimit -c 0
 D=gpurun_out/ab; mkdir -p $D
 for spec in "$@"; do
   label="${spec%%|*}"; flags="${spec#*|}"
-  touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp
+  touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp linearsfm_amd/csrc/lsfm_small.hip
   ( cd linearsfm_amd/csrc && make -s -j16 $flags > /dev/null 2>&1 ) || { echo "$label: build failed"; continue; }
   for rep in $(seq 1 ${REPS:-2}); do
     timeout 600 python bench.py --config ${CONFIG:-nc3500} ${MAPS:+--maps $MAPS} --cpu-baseline 0 --extras 0 --steps ${STEPS:-20} --warmup 3 2>/dev/null | python -c "
@@ -18,4 +18,4 @@ for l in sys.stdin:
   done
 done 2>&1 | tee $D/ab_$(date +%H%M%S).txt
 # leave the default build behind
-touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp; ( cd linearsfm_amd/csrc && make -s -j16 > /dev/null 2>&1 )
+touch linearsfm_amd/csrc/lsfm_solve.hpp linearsfm_amd/csrc/lsfm_symbolic.hpp linearsfm_amd/csrc/lsfm_small.hip; ( cd linearsfm_amd/csrc && make -s -j16 > /dev/null 2>&1 )

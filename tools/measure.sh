@@ -1,6 +1,6 @@
 # Everything profiles/<tag>_* is made from, in ONE gpurun call (about 45 GPU-minutes):
 #     gpurun --timeout 3300 -- bash tools/measure.sh r06
-# then, here:  cp gpurun_out/$TAG/profiles/* profiles/   and the bench lines / text files that are to be kept
+# then, here:  python tools/collect_profiles.py gpurun_out/$TAG r06
 # Parts: the GPU suite; the bench line of every configuration; rocprofv3 --kernel-trace --stats of the bench command (nc3500, synth16k,
 # rs468); HBM traffic from SEPARATE --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command (never combined with a trace domain);
 # run-to-run stability with LSFM_FACTOR_DIGEST=1; the multi-rank logic runs on ONE GPU over gloo (structure, not times); the Gauss-Newton

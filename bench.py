@@ -54,6 +54,17 @@ def pmc_traffic(config):
         return None
 
 
+def pmc_mfma_busy(config):
+    """The matrix cores' busy share of the SIMD cycles per kernel, from THIS round's counter pass of this command
+    (profiles/<ROUND>_pmc_mfma_busy_<config>.json: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)); None when the round has none."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_mfma_busy_{config}.json")
+    try:
+        k = json.load(open(path))["kernels"]
+        return {"source": os.path.relpath(path, ROOT), "share_of_simd_cycles": {n: v["mfma_busy_share_of_simd_cycles"] for n, v in k.items() if n.startswith("k_schur_panel")}}
+    except Exception:
+        return None
+
+
 def rocprof_kernel_avg(config, prefixes):
     """Per-launch average (us) and total of the kernels whose names start with one of `prefixes`, from THIS round's committed
     `rocprofv3 --kernel-trace --stats` summary of this command (profiles/<ROUND>_bench_<config>_kernel_stats.csv): the line carries it
@@ -447,6 +458,7 @@ def main():
                                        "frac_of_hbm_peak": kern[dom]["gbs"] / HBM_PEAK_GBS},
                           "launches_per_step": kern[dom]["launches_per_step"], "traffic_note": traffic_note,
                           "rocprof": rocprof_kernel_avg(args.config, ("k_schur_panel", "k_schur_w", "k_schur_slots", "k_schur_lists")),
+                          "mfma_busy": pmc_mfma_busy(args.config),
                           "rocprof_note": "per-variant averages of the committed rocprofv3 --kernel-trace --stats summary of this command; the variants of a "
                                           "level run beside each other on two streams, so their SUM (total_us / trees profiled) is above the event "
                                           "bracket avg_launch_ms x launches_per_step that `achieved` is computed from",

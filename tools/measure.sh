@@ -42,6 +42,12 @@ for c in nc3500 synth16k rs468; do
   if [ $c = nc3500 ]; then kr=1; else kr=0; fi
   PROFILES_DIR=$D/profiles KEEP_RAW=$kr python tools/refresh_profiles.py $D/$c $TAG $c $trees > $D/refresh_$c.txt 2>&1
   rm -rf $D/$c/pmc_FETCH_SIZE $D/$c/pmc_WRITE_SIZE
+  if [ $c = nc3500 ]; then
+    # the matrix cores' busy share per kernel (counters alone, like the passes above)
+    timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $D/$c/pmc_mfma -o run -- python3 bench.py --config $c --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 > $D/pmc_mfma_$c.log 2>&1
+    PROFILES_DIR=$D/profiles python tools/mfma_busy.py $(ls $D/$c/pmc_mfma/*counter_collection.csv $D/$c/pmc_mfma/*/*counter_collection.csv 2>/dev/null | head -1) $TAG $c > $D/mfma_busy_$c.txt 2>&1
+    rm -rf $D/$c/pmc_mfma
+  fi
 done
 touch linearsfm_amd/csrc/lsfm_pcg.hip linearsfm_amd/csrc/lsfm_schur_panel.hip linearsfm_amd/csrc/lsfm_transform.hip
 make -s -C linearsfm_amd/csrc K9_TIMING=1 -j16 > $D/build_timing.log 2>&1
